@@ -1,0 +1,512 @@
+"""CPU oracle for the DGDM guided-sampling hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module.  Nothing under ``dgdm_amd/`` does: the product path is the HIP
+library and fails loudly when it is missing.
+
+What this is: a plain PyTorch-CPU fp32 restatement, in functional form over flat
+``state_dict``s carrying the reference's key names, of every function on the path
+(SURVEY.md §8(a)).  It deliberately keeps the reference's *as-written* dataflow - the
+R-row replicated inputs of ``cond_fn``, the ``sub_bs`` loop with gradient accumulation,
+PointNet++ evaluated on every replica, ``torch.autograd.grad`` for the guidance gradient,
+the CPU-generator ``torch.randint`` FPS starts - so that it is an independent check of the
+de-duplicated HIP dataflow.  Each function cites the reference lines it follows
+(paths relative to /root/reference).
+
+Pinning: the reference has no tests or golden vectors.  The model
+arithmetic (a4-a12) is pinned by ``tests/golden/*.npz``, produced here by
+``tests/golden/make_golden.py`` from the reference's own modules (``generator/diffusion.py``
+imported through third-party stubs) and compared with this file in
+``tests/test_oracle_golden.py``.  The DDIM scheduler (a13) lives in un-vendored
+``diffusers==0.11.1`` (requirements.txt:1) which is absent from this image: that part is
+restated from the published algorithm and is **parity unpinned**; it is anchored only on
+the reference's call sites and the closed forms / probe values recorded in SURVEY.md §8(a13,c).
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+SD = Dict[str, torch.Tensor]
+
+# generator/diffusion.py:30-33
+SCALE_2D, SCALE_2D_CONV, SCALE_3D, SCALE_3D_CONV = 0.001, 10.0, 0.5, 0.8
+
+
+# =========================================================================== a13  DDIM
+class DDIM:
+    """diffusers 0.11.1 ``DDIMScheduler`` as the reference constructs it
+    (generator/train.py:83: squaredcos_cap_v2, clip_sample=True, epsilon prediction;
+    ``step`` is called with the default eta=0 at generator/diffusion.py:201,256,576,647)."""
+
+    def __init__(self, num_train_timesteps: int):
+        T = num_train_timesteps
+
+        def abar(s: float) -> float:
+            return math.cos((s + 0.008) / 1.008 * math.pi / 2) ** 2
+
+        betas = [min(1.0 - abar((i + 1) / T) / abar(i / T), 0.999) for i in range(T)]  # python float64
+        self.betas = torch.tensor(betas, dtype=torch.float32)
+        self.alphas_cumprod = torch.cumprod(1.0 - self.betas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0)      # set_alpha_to_one=True (default)
+        self.num_train_timesteps = T
+        self.num_inference_steps: Optional[int] = None
+        self.timesteps = torch.from_numpy(np.arange(0, T)[::-1].copy().astype(np.int64))
+
+    def set_timesteps(self, n: int) -> None:
+        self.num_inference_steps = n
+        ratio = self.num_train_timesteps // n
+        self.timesteps = torch.from_numpy((np.arange(0, n) * ratio).round()[::-1].copy().astype(np.int64))
+
+    def add_noise(self, x0: torch.Tensor, noise: torch.Tensor, timesteps: torch.Tensor) -> torch.Tensor:
+        a = self.alphas_cumprod[timesteps]
+        sa = (a ** 0.5).flatten()
+        sb = ((1 - a) ** 0.5).flatten()
+        while sa.dim() < x0.dim():
+            sa, sb = sa.unsqueeze(-1), sb.unsqueeze(-1)
+        return sa * x0 + sb * noise
+
+    def step(self, eps: torch.Tensor, t: int, x: torch.Tensor) -> torch.Tensor:
+        t = int(t)
+        prev = t - self.num_train_timesteps // self.num_inference_steps
+        a_t = self.alphas_cumprod[t]
+        a_p = self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha_cumprod
+        x0 = (x - (1 - a_t) ** 0.5 * eps) / a_t ** 0.5
+        x0 = torch.clamp(x0, -1, 1)                         # clip_sample=True
+        return a_p ** 0.5 * x0 + (1 - a_p) ** 0.5 * eps     # eta = 0: no variance term
+
+
+# =========================================================================== a7  U-Net
+def _conv_gn_mish(sd: SD, p: str, x: torch.Tensor, groups: int = 8) -> torch.Tensor:
+    # generator/diffusion_utils.py:57-72
+    w = sd[p + ".block.0.weight"]
+    x = F.conv1d(x, w, sd[p + ".block.0.bias"], padding=w.shape[-1] // 2)
+    x = F.group_norm(x, groups, sd[p + ".block.1.weight"], sd[p + ".block.1.bias"])
+    return F.mish(x)
+
+
+def _film_res_block(sd: SD, p: str, x: torch.Tensor, cond: torch.Tensor) -> torch.Tensor:
+    # generator/diffusion_utils.py:101-120
+    out = _conv_gn_mish(sd, p + ".blocks.0", x)
+    e = F.linear(F.mish(cond), sd[p + ".cond_encoder.1.weight"], sd[p + ".cond_encoder.1.bias"])
+    c = out.shape[1]
+    out = e[:, :c, None] * out + e[:, c:, None]
+    out = _conv_gn_mish(sd, p + ".blocks.1", out)
+    if p + ".residual_conv.weight" in sd:
+        x = F.conv1d(x, sd[p + ".residual_conv.weight"], sd[p + ".residual_conv.bias"])
+    return out + x
+
+
+def unet1d_forward(sd: SD, sample: torch.Tensor, timestep: torch.Tensor) -> torch.Tensor:
+    """``ConditionalUnet1D.forward`` (generator/diffusion_utils.py:238-285); sample (B,L,C), timestep (B,)."""
+    x = sample.transpose(1, 2)
+    dsed = sd["diffusion_step_encoder.1.weight"].shape[1]
+    half = dsed // 2
+    fr = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1)))     # :30-37
+    arg = timestep.expand(x.shape[0])[:, None] * fr[None, :]
+    g = torch.cat((arg.sin(), arg.cos()), dim=-1)
+    g = F.linear(g, sd["diffusion_step_encoder.1.weight"], sd["diffusion_step_encoder.1.bias"])
+    g = F.linear(F.mish(g), sd["diffusion_step_encoder.3.weight"], sd["diffusion_step_encoder.3.bias"])
+    n_down = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("down_modules."))
+    n_up = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("up_modules."))
+    skips: List[torch.Tensor] = []
+    for lvl in range(n_down):                                                 # :265-269
+        x = _film_res_block(sd, f"down_modules.{lvl}.0", x, g)
+        x = _film_res_block(sd, f"down_modules.{lvl}.1", x, g)
+        skips.append(x)
+        if f"down_modules.{lvl}.2.conv.weight" in sd:
+            x = F.conv1d(x, sd[f"down_modules.{lvl}.2.conv.weight"], sd[f"down_modules.{lvl}.2.conv.bias"],
+                         stride=2, padding=1)
+    for i in range(2):                                                        # :271-272
+        x = _film_res_block(sd, f"mid_modules.{i}", x, g)
+    for lvl in range(n_up):                                                   # :274-278
+        x = torch.cat((x, skips.pop()), dim=1)
+        x = _film_res_block(sd, f"up_modules.{lvl}.0", x, g)
+        x = _film_res_block(sd, f"up_modules.{lvl}.1", x, g)
+        if f"up_modules.{lvl}.2.conv.weight" in sd:
+            x = F.conv_transpose1d(x, sd[f"up_modules.{lvl}.2.conv.weight"], sd[f"up_modules.{lvl}.2.conv.bias"],
+                                   stride=2, padding=1)
+    x = _conv_gn_mish(sd, "final_conv.0", x)                                  # :280
+    x = F.conv1d(x, sd["final_conv.1.weight"], sd["final_conv.1.bias"])
+    return x.transpose(1, 2)
+
+
+# =========================================================================== a8  2-D dynamics
+def nerf_embed(x: torch.Tensor, nfreq: int = 4) -> torch.Tensor:
+    """``get_embedder(d, 4)``: [x, sin(2^k x), cos(2^k x)] k=0..3 (dynamics/profile_forward_2d.py:10-56)."""
+    parts = [x]
+    for f in 2.0 ** torch.linspace(0.0, nfreq - 1, steps=nfreq):
+        parts += [torch.sin(x * f), torch.cos(x * f)]
+    return torch.cat(parts, -1)
+
+
+def timestep_embedding(t: torch.Tensor, dim: int, max_period: int = 10000) -> torch.Tensor:
+    """dynamics/profile_forward_2d.py:58-76 ([cos | sin], frequencies exp(-ln(P) i / half))."""
+    half = dim // 2
+    fr = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)
+    a = t[:, None].float() * fr[None]
+    return torch.cat([torch.cos(a), torch.sin(a)], dim=-1)
+
+
+def _mlp2(sd: SD, p: str, x: torch.Tensor, act: Callable) -> torch.Tensor:
+    x = act(F.linear(x, sd[p + ".0.weight"], sd[p + ".0.bias"]))
+    return F.linear(x, sd[p + ".2.weight"], sd[p + ".2.bias"])
+
+
+def _trunk(sd: SD, x: torch.Tensor) -> torch.Tensor:
+    # Linear -> BatchNorm1d(eval) -> ReLU x8, then Linear (profile_forward_2d.py:109-135,154-155)
+    i = 0
+    while f"linears.{3 * i}.weight" in sd:
+        x = F.linear(x, sd[f"linears.{3 * i}.weight"], sd[f"linears.{3 * i}.bias"])
+        b = f"linears.{3 * i + 1}"
+        x = F.batch_norm(x, sd[b + ".running_mean"], sd[b + ".running_var"], sd[b + ".weight"], sd[b + ".bias"],
+                         training=False, eps=1e-5)
+        x = F.relu(x)
+        i += 1
+    return F.linear(x, sd["output.weight"], sd["output.bias"])
+
+
+def dyn2d_forward(sd: SD, x_ctrl, x_ori, x_pos, timesteps, object_vertices) -> torch.Tensor:
+    """``ProfileForward2DModel.forward`` (dynamics/profile_forward_2d.py:137-156)."""
+    g = _mlp2(sd, "gripper_encoder", x_ctrl, F.relu)
+    pose = torch.cat([nerf_embed(x_ori), nerf_embed(x_pos)], dim=1)
+    o = _mlp2(sd, "object_encoder", object_vertices, F.relu)
+    W = sd["time_encoder.2.weight"].shape[0]
+    te = _mlp2(sd, "time_encoder", timestep_embedding(timesteps, W // 2), F.silu)
+    return _trunk(sd, torch.cat([o, g, pose, te], dim=1))
+
+
+# =========================================================================== a10-a12  PointNet++
+class StartLog:
+    """FPS start indices.  ``draw`` takes them from the torch CPU generator exactly as
+    dynamics/models/pointnet2_utils.py:83 does and records them, so that the HIP path can be
+    fed the identical indices; ``replay`` hands back previously recorded/forced ones."""
+
+    def __init__(self, forced: Optional[List[torch.Tensor]] = None):
+        self.log: List[torch.Tensor] = []
+        self._forced = list(forced) if forced is not None else None
+
+    def draw(self, n_points: int, rows: int) -> torch.Tensor:
+        if self._forced is not None:
+            s = self._forced.pop(0)
+            assert s.shape == (rows,)
+        else:
+            s = torch.randint(0, n_points, (rows,), dtype=torch.long)
+        self.log.append(s.clone())
+        return s
+
+
+def square_distance(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    # pointnet2_utils.py:27-48: the expanded form, in this operation order
+    d = -2 * torch.matmul(src, dst.permute(0, 2, 1))
+    d += torch.sum(src ** 2, -1)[:, :, None]
+    d += torch.sum(dst ** 2, -1)[:, None, :]
+    return d
+
+
+def farthest_point_sample(xyz: torch.Tensor, npoint: int, start: torch.Tensor) -> torch.Tensor:
+    # pointnet2_utils.py:71-92; first-max tie-break comes from torch.max
+    B, N, _ = xyz.shape
+    out = torch.zeros(B, npoint, dtype=torch.long)
+    dist = torch.ones(B, N) * 1e10
+    far = start
+    rows = torch.arange(B)
+    for i in range(npoint):
+        out[:, i] = far
+        c = xyz[rows, far, :].view(B, 1, 3)
+        d = torch.sum((xyz - c) ** 2, -1)
+        dist = torch.where(d < dist, d, dist)
+        far = torch.max(dist, -1)[1]
+    return out
+
+
+def _gather(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    # index_points, pointnet2_utils.py:51-68
+    B = points.shape[0]
+    bi = torch.arange(B).view([B] + [1] * (idx.dim() - 1)).expand_as(idx)
+    return points[bi, idx, :]
+
+
+def query_ball_point(radius: float, nsample: int, xyz: torch.Tensor, new_xyz: torch.Tensor) -> torch.Tensor:
+    # pointnet2_utils.py:95-115: first `nsample` in-radius indices in ascending order, padded with the first
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    idx = torch.arange(N).view(1, 1, N).repeat(B, S, 1)
+    idx[square_distance(new_xyz, xyz) > radius ** 2] = N
+    idx = idx.sort(dim=-1)[0][:, :, :nsample]
+    first = idx[:, :, :1].expand(-1, -1, nsample)
+    return torch.where(idx == N, first, idx)
+
+
+def set_abstraction(sd: SD, p: str, xyz: torch.Tensor, points: Optional[torch.Tensor], npoint, radius, nsample,
+                    starts: Optional[StartLog]):
+    """``PointNetSetAbstraction.forward`` (pointnet2_utils.py:184-210); xyz (B,3,N), points (B,D,N)."""
+    xyz = xyz.permute(0, 2, 1)
+    if points is not None:
+        points = points.permute(0, 2, 1)
+    B, N, C = xyz.shape
+    if npoint is None:                                    # sample_and_group_all :149-166
+        new_xyz = torch.zeros(B, 1, C)
+        feat = xyz.view(B, 1, N, C)
+        if points is not None:
+            feat = torch.cat([feat, points.view(B, 1, N, -1)], dim=-1)
+    else:                                                 # sample_and_group :118-146
+        fps = farthest_point_sample(xyz, npoint, starts.draw(N, B))
+        new_xyz = _gather(xyz, fps)
+        idx = query_ball_point(radius, nsample, xyz, new_xyz)
+        feat = _gather(xyz, idx) - new_xyz.view(B, npoint, 1, C)
+        if points is not None:
+            feat = torch.cat([feat, _gather(points, idx)], dim=-1)
+    feat = feat.permute(0, 3, 2, 1)                       # (B, C+D, nsample, npoint)
+    i = 0
+    while f"{p}.mlp_convs.{i}.weight" in sd:
+        feat = F.conv2d(feat, sd[f"{p}.mlp_convs.{i}.weight"], sd[f"{p}.mlp_convs.{i}.bias"])
+        b = f"{p}.mlp_bns.{i}"
+        feat = F.batch_norm(feat, sd[b + ".running_mean"], sd[b + ".running_var"], sd[b + ".weight"], sd[b + ".bias"],
+                            training=False, eps=1e-5)
+        feat = F.relu(feat)
+        i += 1
+    return new_xyz.permute(0, 2, 1), torch.max(feat, 2)[0]
+
+
+def pointnet2_forward(sd: SD, xyz: torch.Tensor, starts: Optional[StartLog] = None, prefix: str = "") -> torch.Tensor:
+    """``PointNet2.forward`` (dynamics/models/pointnet2.py:21-32); xyz (B,3,N) -> (B,256)."""
+    starts = starts or StartLog()
+    l1x, l1p = set_abstraction(sd, prefix + "sa1", xyz, None, 512, 0.2, 32, starts)
+    l2x, l2p = set_abstraction(sd, prefix + "sa2", l1x, l1p, 128, 0.4, 64, starts)
+    _, l3p = set_abstraction(sd, prefix + "sa3", l2x, l2p, None, None, None, None)
+    return l3p.reshape(xyz.shape[0], -1)
+
+
+def dyn3d_forward(sd: SD, x_ctrl, x_ori, x_pos, timesteps, object_vertices, starts: Optional[StartLog] = None):
+    """``ProfileForward3DModel.forward`` (dynamics/profile_forward_3d.py:67-86): channel 1 of x_ctrl only,
+    raw 256-d timestep embedding (``time_encoder`` is never called)."""
+    g = _mlp2(sd, "gripper_encoder", x_ctrl[:, 1, :], F.relu)
+    pose = torch.cat([nerf_embed(x_ori), nerf_embed(x_pos)], dim=1)
+    o = pointnet2_forward(sd, object_vertices, starts, prefix="object_encoder.")
+    W = sd["gripper_encoder.2.weight"].shape[0]
+    te = timestep_embedding(timesteps, W)
+    return _trunk(sd, torch.cat([o, g, pose, te], dim=1))
+
+
+# =========================================================================== a5/a6  objectives
+def slicer(a: torch.Tensor, lower: int, upper: int) -> torch.Tensor:
+    # dynamics/metrics.py:32-38
+    if lower < 0:
+        return torch.cat((a[lower:], a[:upper]))
+    if upper > len(a):
+        return torch.cat((a[lower:], a[:upper - len(a)]))
+    return a[lower:upper]
+
+
+_LINEAR_OBJ = {  # generator/diffusion.py:433-468: coefficient of (dtheta, dx, dy)
+    'rotate_clockwise': (-1, 0, 0), 'rotate_counterclockwise': (1, 0, 0), 'shift_up': (0, -1, 0),
+    'shift_down': (0, 1, 0), 'shift_left': (0, 0, -1), 'shift_right': (0, 0, 1),
+    'clockwise_up': (-1, -1, 0), 'clockwise_down': (-1, 1, 0), 'clockwise_left': (-1, 0, -1),
+    'clockwise_right': (-1, 0, 1), 'counterclockwise_up': (1, -1, 0), 'counterclockwise_down': (1, 1, 0),
+    'counterclockwise_left': (1, 0, -1), 'counterclockwise_right': (1, 0, 1),
+}
+
+
+def deltas_to_objective(deltas: torch.Tensor, opt_obj: str, centers=None, grid_size: int = 360, num_pos: int = 5):
+    """``Diffusion.deltas_to_objective`` (generator/diffusion.py:430-471)."""
+    if opt_obj == 'rotate':
+        return deltas[..., 0] ** 2
+    if opt_obj in _LINEAR_OBJ:
+        c = _LINEAR_OBJ[opt_obj]
+        out = None
+        for j in range(3):
+            if c[j]:
+                term = deltas[..., j] if c[j] > 0 else -deltas[..., j]
+                out = term if out is None else out + term
+        return out
+    if opt_obj == 'convergence':
+        cells = grid_size * num_pos ** 2
+        half = (grid_size // 2) * num_pos ** 2
+        parts = []
+        for i, c in enumerate(centers):
+            c = int(c)
+            dth = deltas[i * cells:(i + 1) * cells, 0]
+            parts.append(slicer(dth, c * num_pos ** 2 - half, c * num_pos ** 2))
+            parts.append(slicer(-dth, c * num_pos ** 2, c * num_pos ** 2 + half))
+        return torch.cat(parts, dim=0)
+    raise ValueError('opt obj not supported')
+
+
+def convergence_mode(profile: torch.Tensor):
+    # dynamics/metrics.py:4-21
+    profile = torch.where(profile > 0, 1.0, 0.0)
+    n = len(profile)
+    if torch.all(profile == 0):
+        return torch.tensor([n]), torch.tensor([0])
+    if torch.all(profile == 1):
+        return torch.tensor([n]), torch.tensor([n - 1])
+    profile = torch.cat((profile, profile), dim=0)
+    diff = torch.diff(profile)
+    conv = torch.where(diff < 0)[0]
+    conv = conv[conv < n]
+    start = torch.where(diff > 0)[0]
+    lengths = torch.diff(torch.cat((torch.tensor([0]), start[start > conv[0]], torch.tensor([2 * n]))))
+    return lengths[:len(conv)], conv
+
+
+def convergence_mode_three_class(profile: torch.Tensor):
+    # dynamics/metrics.py:23-30
+    ids = torch.where(profile != 1)[0]
+    if len(ids) == 0:
+        return torch.tensor([0]), torch.tensor([0])
+    lengths, pts = convergence_mode(profile[profile != 1])
+    return lengths, ids[pts]
+
+
+# =========================================================================== a4  cond_fn (as written)
+class Setup:
+    """What ``Diffusion.__init__`` keeps for the guided path (generator/diffusion.py:88-118)."""
+
+    def __init__(self, mode: str, unet: SD, dyn: SD, sched: DDIM, num_points: int, grid_size: int, num_pos: int,
+                 sub_batch_size: int = 1024):
+        self.mode, self.unet, self.dyn, self.sched = mode, unet, dyn, sched
+        self.num_points, self.grid_size, self.num_pos, self.sub_batch_size = num_points, grid_size, num_pos, sub_batch_size
+        if mode == 'point_3d':
+            thr, std = torch.tensor([0.02, 0.001, 0.001]), torch.tensor([0.0312, 0.0016, 0.0026])
+        else:
+            thr, std = torch.tensor([0.03, 0.002, 0.003]), torch.tensor([0.0565, 0.0026, 0.0047])
+        self.threshold_std = thr / std
+
+
+def _pose_grid(s: Setup, B: int, ori_range):
+    # generator/diffusion.py:478-482: 'ij' meshgrid, every cell value repeated B times -> row r = cell*B + b
+    o, px, py = torch.meshgrid(torch.linspace(ori_range[0], ori_range[1], s.grid_size),
+                               torch.linspace(-1, 1, s.num_pos), torch.linspace(-1, 1, s.num_pos), indexing='ij')
+    ori = o.reshape(-1).repeat_interleave(B).reshape(-1, 1)
+    pos = torch.stack([px.reshape(-1).repeat_interleave(B), py.reshape(-1).repeat_interleave(B)], dim=-1)
+    return ori, pos
+
+
+def _pts3d(s: Setup, x: torch.Tensor) -> torch.Tensor:
+    # generator/diffusion.py:489: channels [linspace ; x ; linspace]; only channel 1 reaches the model
+    B = x.shape[0]
+    lin = torch.linspace(-1.0, 1.0, s.num_points // 2).repeat(B * 2, 1).reshape(B, 1, -1)
+    return torch.cat([lin, x.transpose(-1, -2), lin], dim=1)
+
+
+def cond_fn(s: Setup, x: torch.Tensor, t: torch.Tensor, opt_obj: str, object_vertices: torch.Tensor,
+            ori_range=(-1.0, 1.0), centers=None, starts: Optional[StartLog] = None) -> torch.Tensor:
+    """``Diffusion.cond_fn`` (generator/diffusion.py:473-504)."""
+    T = s.sched.num_train_timesteps
+    with torch.enable_grad():
+        x = x.detach().requires_grad_(True)
+        B = x.shape[0]
+        cells = s.grid_size * s.num_pos ** 2
+        ori, pos = _pose_grid(s, B, ori_range)
+        tt = t.repeat(cells).float() / T
+        kw = dict(centers=centers, grid_size=s.grid_size, num_pos=s.num_pos)
+        if s.mode == 'point':
+            pts = x.repeat(cells, 1, 1).reshape(B * cells, -1)
+            obj = object_vertices.reshape(1, -1).expand(B * cells, -1)
+            logits = dyn2d_forward(s.dyn, pts, ori, pos, tt, obj)
+            return torch.autograd.grad(deltas_to_objective(logits, opt_obj, **kw).sum(), x)[0]
+        if s.mode == 'point_3d':
+            pts = _pts3d(s, x).repeat(cells, 1, 1)
+            obj = object_vertices.t().unsqueeze(0)            # (1,3,N), replicated per sub-batch below
+            grad = 0.0
+            for i in range(0, B * cells, s.sub_batch_size):
+                j = min(i + s.sub_batch_size, B * cells)
+                logits = dyn3d_forward(s.dyn, pts[i:j], ori[i:j], pos[i:j], tt[i:j], obj.expand(j - i, -1, -1), starts)
+                grad = grad + torch.autograd.grad(deltas_to_objective(logits, opt_obj, **kw).sum(), x)[0]
+            return grad
+        raise ValueError('model type not supported')
+
+
+def get_convergence_centers(s: Setup, unguided: torch.Tensor, object_vertices: torch.Tensor, ori_range=(-1.0, 1.0),
+                            starts: Optional[StartLog] = None) -> torch.Tensor:
+    """``Diffusion.get_convergence_centers`` (generator/diffusion.py:506-539)."""
+    B = unguided.shape[0]
+    G = s.grid_size
+    with torch.no_grad():
+        ori = torch.linspace(ori_range[0], ori_range[1], G).repeat_interleave(B).reshape(-1, 1)
+        pos = torch.zeros(B * G, 2)
+        tt = torch.zeros(B * G)
+        if s.mode == 'point':
+            pts = unguided.repeat(G, 1, 1).reshape(B * G, -1)
+            logits = dyn2d_forward(s.dyn, pts, ori, pos, tt, object_vertices.reshape(1, -1).expand(B * G, -1))
+        else:
+            pts = _pts3d(s, unguided).repeat(G, 1, 1)
+            obj = object_vertices.t().unsqueeze(0)
+            chunks = []
+            for i in range(0, B * G, s.sub_batch_size):
+                j = min(i + s.sub_batch_size, B * G)
+                chunks.append(dyn3d_forward(s.dyn, pts[i:j], ori[i:j], pos[i:j], tt[i:j], obj.expand(j - i, -1, -1), starts))
+            logits = torch.cat(chunks, dim=0)
+    th = s.threshold_std[0]
+    d0 = logits[..., 0]
+    prof = torch.where(d0 > th, 2.0, torch.where(d0 < -th, 0.0, 1.0))                        # :532
+    out = []
+    for i in range(B):
+        lengths, cs = convergence_mode_three_class(prof[torch.arange(i, B * G, B)])
+        out.append(cs[torch.argmax(lengths)])
+    return torch.stack(out, dim=0)
+
+
+# =========================================================================== a1-a3  denoise loops
+def classifier_scale(mode: str, opt_obj: str, multi: bool = False) -> float:
+    # generator/diffusion.py:549-560 and :631-636 (the multi-object loop never uses the *_CONV scales)
+    if mode == 'point':
+        return SCALE_2D_CONV if (opt_obj == 'convergence' and not multi) else SCALE_2D
+    if mode == 'point_3d':
+        return SCALE_3D_CONV if (opt_obj == 'convergence' and not multi) else SCALE_3D
+    return 0.001
+
+
+def unguided_sample(s: Setup, x: torch.Tensor) -> torch.Tensor:
+    """Loop bodies of generator/diffusion.py:193-201 and :249-256 (bookkeeping dropped)."""
+    B = x.shape[0]
+    x = x.clone()
+    for t in s.sched.timesteps:
+        with torch.no_grad():
+            eps = unet1d_forward(s.unet, x, t * torch.ones(B, dtype=torch.int64))
+        x = s.sched.step(eps, t, x)
+    return x
+
+
+def guided_sample(s: Setup, noise: torch.Tensor, object_vertices: torch.Tensor, opt_obj: str, ori_range=(-1.0, 1.0),
+                  unguided: Optional[torch.Tensor] = None, starts: Optional[StartLog] = None,
+                  trace: Optional[list] = None) -> torch.Tensor:
+    """One object of ``Diffusion.guided_sample`` (generator/diffusion.py:561-576)."""
+    B = noise.shape[0]
+    centers = get_convergence_centers(s, unguided, object_vertices, ori_range, starts) if opt_obj == 'convergence' else None
+    scale = classifier_scale(s.mode, opt_obj)
+    x = noise.clone().detach()
+    for t in s.sched.timesteps:
+        ts = t * torch.ones(B, dtype=torch.int64)
+        with torch.no_grad():
+            eps = unet1d_forward(s.unet, x, ts)
+        g = cond_fn(s, x, ts, opt_obj, object_vertices, ori_range, centers, starts)
+        if trace is not None:
+            trace.append((eps.clone(), g.clone()))
+        eps = eps - (1 - s.sched.alphas_cumprod[t]).sqrt() * g * scale
+        x = s.sched.step(eps, t, x)
+    return x
+
+
+def guided_sample_multi_object(s: Setup, noise: torch.Tensor, objects: Sequence[torch.Tensor], opt_obj: str,
+                               ori_range=(-1.0, 1.0), starts: Optional[StartLog] = None) -> torch.Tensor:
+    """``Diffusion.guided_sample_multi_object`` loop (generator/diffusion.py:637-647)."""
+    B = noise.shape[0]
+    scale = classifier_scale(s.mode, opt_obj, multi=True)
+    x = noise.clone().detach()
+    for t in s.sched.timesteps:
+        ts = t * torch.ones(B, dtype=torch.int64)
+        with torch.no_grad():
+            eps = unet1d_forward(s.unet, x, ts)
+        g = 0.0
+        for ov in objects:
+            g = g + cond_fn(s, x, ts, opt_obj, ov, ori_range, None, starts)
+        g = g / len(objects)
+        eps = eps - (1 - s.sched.alphas_cumprod[t]).sqrt() * g * scale
+        x = s.sched.step(eps, t, x)
+    return x

@@ -1,0 +1,419 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE's own modules.
+
+Runs only in the build container (it imports /root/reference, which does not exist on the
+GPU box); its *outputs* - small .npz files holding inputs, FPS start indices and the
+reference's results - are what is committed.  Nothing of the reference's text is stored.
+
+How the reference is executed:
+* ``generator.diffusion_utils``, ``dynamics.profile_forward_{2d,3d}``, ``dynamics.models.*``,
+  ``dynamics.metrics`` import as they are.
+* ``generator/diffusion.py`` needs wandb / pytorch_lightning / diffusers / MuJoCo-side modules
+  that this image lacks.  They are replaced by inert stand-ins in ``sys.modules`` *for this
+  process only*: ``LightningModule`` = ``nn.Module`` + ``device``/``log*``; ``DDIMScheduler`` = the
+  oracle's restatement (diffusers itself is absent - this is the "parity unpinned" boundary);
+  ``sim_test_batch{,_3d}`` = a recorder that keeps the final samples it is handed.
+  With that the reference's own ``Diffusion.cond_fn`` / ``get_convergence_centers`` /
+  ``guided_sample`` / ``guided_sample_multi_object`` run unmodified on CPU.
+* Weights: ``dgdm_amd.synth`` fills the reference modules' ``state_dict`` deterministically, so
+  fixtures carry seeds, not weights.  The key/shape specs are asserted against the modules.
+
+Usage:  python tests/golden/make_golden.py   (from the repo root, takes ~2 min)
+"""
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+warnings.filterwarnings("ignore")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+from dgdm_amd import synth                      # noqa: E402
+from oracle import dgdm_oracle as orc           # noqa: E402  (only its DDIM restatement is used here)
+
+RECORDED = []
+
+
+def _install_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class LightningModule(nn.Module):
+        current_epoch = 0
+        on_validation_batch_start = True
+        logger = types.SimpleNamespace(save_dir="/tmp/dgdm_golden", log_table=lambda *a, **k: None)
+
+        @property
+        def device(self):
+            return torch.device("cpu")
+
+        def log(self, *a, **k):
+            pass
+
+        def log_dict(self, *a, **k):
+            pass
+
+    class _Out:
+        def __init__(self, prev):
+            self.prev_sample = prev
+
+    class DDIMScheduler(orc.DDIM):
+        def __init__(self, num_train_timesteps=1000, **kw):
+            super().__init__(num_train_timesteps)
+            self.config = types.SimpleNamespace(num_train_timesteps=num_train_timesteps)
+
+        def step(self, model_output, timestep, sample):
+            return _Out(super().step(model_output, timestep, sample))
+
+        def add_noise(self, original_samples, noise, timesteps):
+            return super().add_noise(original_samples, noise, timesteps)
+
+    class EMAModel:
+        def __init__(self, model=None, **kw):
+            self.averaged_model = model
+
+    def recorder(samples, *a, **k):
+        RECORDED.append(np.array(samples, copy=True))
+        return [], [], [], [], [], [], [], []
+
+    mod("wandb", Image=lambda *a, **k: None, Video=lambda *a, **k: None)
+    mod("pytorch_lightning", LightningModule=LightningModule)
+    mod("diffusers", UNet2DModel=object)
+    mod("diffusers.schedulers")
+    mod("diffusers.schedulers.scheduling_ddim", DDIMScheduler=DDIMScheduler, DDIMSchedulerOutput=_Out)
+    mod("diffusers.schedulers.scheduling_ddpm", DDPMScheduler=DDIMScheduler, DDPMSchedulerOutput=_Out)
+    mod("diffusers.training_utils", EMAModel=EMAModel)
+    mod("dynamics.sim_test_mj", sim_test_batch=recorder)
+    mod("dynamics.sim_test_mj_3d", sim_test_batch_3d=recorder)
+    plt = types.ModuleType("matplotlib.pyplot")
+    plt.__getattr__ = lambda name: (lambda *a, **k: types.SimpleNamespace(
+        add_subplot=lambda *a, **k: types.SimpleNamespace(set=lambda *a, **k: None, scatter=lambda *a, **k: None)))
+    sys.modules["matplotlib.pyplot"] = plt
+    return DDIMScheduler
+
+
+DDIMScheduler = _install_stubs()
+from generator.diffusion_utils import ConditionalUnet1D            # noqa: E402  (reference)
+from dynamics.profile_forward_2d import ProfileForward2DModel      # noqa: E402
+from dynamics.profile_forward_3d import ProfileForward3DModel      # noqa: E402
+from dynamics.models import pointnet2_utils as ref_pn              # noqa: E402
+from dynamics.models.pointnet2 import PointNet2                    # noqa: E402
+from dynamics import metrics as ref_metrics                        # noqa: E402
+from generator.diffusion import Diffusion                          # noqa: E402
+
+UNET_SEED, DYN2D_SEED, DYN3D_SEED = 11, 22, 33
+
+
+def load_checked(module: nn.Module, spec, seed):
+    ref_sd = module.state_dict()
+    assert sorted(ref_sd.keys()) == sorted(k for k, _ in spec), "spec keys differ from the reference module"
+    for k, shp in spec:
+        assert tuple(ref_sd[k].shape) == tuple(shp), (k, ref_sd[k].shape, shp)
+    module.load_state_dict(synth.synth_state_dict(spec, seed))
+    return module.eval()
+
+
+def make_unet():
+    return load_checked(ConditionalUnet1D(input_dim=1, global_cond_dim=0, down_dims=[128, 256],
+                                          diffusion_step_embed_dim=32), synth.unet_spec(), UNET_SEED)
+
+
+def make_dyn2d(object_ch):
+    return load_checked(ProfileForward2DModel(output_ch=3, params_ch=14, object_ch=object_ch),
+                        synth.dyn2d_spec(14, object_ch), DYN2D_SEED)
+
+
+def make_dyn3d():
+    return load_checked(ProfileForward3DModel(output_ch=3, params_ch=42), synth.dyn3d_spec(42), DYN3D_SEED)
+
+
+class _Wrap(nn.Module):   # stands in for nn.DataParallel: only `.module`-free call semantics are needed
+    def __init__(self, m):
+        super().__init__()
+        self.module = m
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)
+
+
+def make_diffusion(mode, unet, dyn, T, S, L, G, P, objects, sub_bs):
+    sched = DDIMScheduler(num_train_timesteps=T)
+    d = Diffusion(noise_pred_net=unet, noise_scheduler=sched, num_inference_steps=S, mode=mode, input_dim=1,
+                  num_points=L, class_cond=True, classifier_model=_Wrap(dyn), grid_size=G, num_pos=P,
+                  object_vertices=objects, object_ids=list(range(len(objects))), sub_batch_size=sub_bs, seed=0)
+    return d.eval()
+
+
+class RandintSpy:
+    """Records every torch.randint call made by the reference's FPS (pointnet2_utils.py:83)."""
+
+    def __enter__(self):
+        self.calls = []
+        self._orig = torch.randint
+
+        def spy(*a, **k):
+            r = self._orig(*a, **k)
+            self.calls.append(r.clone())
+            return r
+        torch.randint = spy
+        return self
+
+    def __exit__(self, *exc):
+        torch.randint = self._orig
+
+    def packed(self):
+        """(flat int64 array, lengths) of all draws, in call order."""
+        if not self.calls:
+            return np.zeros(0, np.int64), np.zeros(0, np.int64)
+        return (torch.cat(self.calls).numpy().astype(np.int64),
+                np.array([len(c) for c in self.calls], np.int64))
+
+
+def run_chain(fn):
+    RECORDED.clear()
+    try:
+        with torch.no_grad():   # Lightning's validate loop wraps validation_step in no_grad (train.py:152-155)
+            fn()
+    except (IndexError, ValueError, KeyError, AttributeError):
+        pass    # the wandb/metric bookkeeping after the loop has nothing to chew on
+    assert RECORDED, "chain produced no samples"
+    return [r.copy() for r in RECORDED]
+
+
+def g2_unet():
+    unet = make_unet()
+    out = {}
+    for L in (14, 42):
+        x = synth.synth_noise(100 + L, 4, L)
+        out[f"x_L{L}"] = x.numpy()
+        for t in (0, 3, 12, 999):
+            with torch.no_grad():
+                out[f"y_L{L}_t{t}"] = unet(x, torch.full((4,), t, dtype=torch.int64)).numpy()
+    np.savez_compressed(os.path.join(OUT, "g2_unet.npz"), seed=UNET_SEED, **out)
+
+
+from tests.golden.make_golden_names import OBJ16     # noqa: E402
+
+
+def g3_dyn2d():
+    nv = 10
+    dyn = make_dyn2d(2 * nv)
+    unet = make_unet()
+    obj = synth.synth_object_2d(0, nv)
+    B, G, P, L, T, S = 2, 4, 2, 14, 15, 5
+    d = make_diffusion('point', unet, dyn, T, S, L, G, P, obj[None], 1024)
+    out = dict(obj=obj.numpy(), dims=np.array([B, G, P, L, T, S, nv]))
+    # plain forward on arbitrary rows
+    rs = np.random.RandomState(5)
+    rows = 37
+    xc, xo, xp = rs.uniform(-1, 1, (rows, L)), rs.uniform(-1, 1, (rows, 1)), rs.uniform(-1, 1, (rows, 2))
+    tt, ov = rs.uniform(0, 1, (rows,)), rs.uniform(-1, 1, (rows, 2 * nv))
+    f32 = lambda a: torch.from_numpy(a.astype(np.float32))
+    with torch.no_grad():
+        out["fwd_logits"] = dyn(f32(xc), f32(xo), f32(xp), f32(tt), f32(ov)).numpy()
+    out.update(fwd_xc=xc.astype(np.float32), fwd_xo=xo.astype(np.float32), fwd_xp=xp.astype(np.float32),
+               fwd_t=tt.astype(np.float32), fwd_obj=ov.astype(np.float32))
+    x = synth.synth_noise(7, B, L)
+    t = torch.full((B,), 9, dtype=torch.int64)
+    out["x"] = x.numpy()
+    centers = torch.tensor([1, 3])
+    out["centers"] = centers.numpy()
+    for o in OBJ16:
+        for rng_name, rng in (("full", [-1.0, 1.0]), ("half", [-0.5, 0.25])):
+            g = d.cond_fn(x, t, opt_obj=o, object_vertices=obj, ori_range=rng,
+                          convergence_centers=centers if o == 'convergence' else None)
+            out[f"grad_{o}_{rng_name}"] = g.detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "g3_dyn2d.npz"), seed=DYN2D_SEED, **out)
+
+
+def _dup_cloud(seed, n=512):
+    pts = synth.synth_object_3d(seed, n).clone()
+    pts[5] = pts[200]          # exact duplicates -> exact FPS ties and zero distances
+    pts[77] = pts[200]
+    pts[300] = pts[301]
+    return pts
+
+
+def g4_pointnet():
+    out = {}
+    dyn = make_dyn3d()
+    pn = dyn.object_encoder
+    clouds = torch.stack([synth.synth_object_3d(0), synth.synth_object_3d(1), _dup_cloud(2), synth.synth_object_3d(0)])
+    out["clouds"] = clouds.numpy()
+    torch.manual_seed(1234)
+    with RandintSpy() as spy, torch.no_grad():
+        emb, _ = pn(clouds.permute(0, 2, 1))
+    out["emb"] = emb.numpy()
+    out["starts"], out["start_lens"] = spy.packed()
+    # raw FPS / ball-query indices (incl. the duplicate cloud)
+    xyz = clouds
+    st = torch.tensor([3, 500, 200, 77])
+    orig = torch.randint
+    torch.randint = lambda *a, **k: st.clone()
+    try:
+        fps512 = ref_pn.farthest_point_sample(xyz, 512)
+        fps128 = ref_pn.farthest_point_sample(xyz, 128)
+    finally:
+        torch.randint = orig
+    out["fps_start"] = st.numpy()
+    out["fps512"] = fps512.numpy().astype(np.int32)
+    out["fps128"] = fps128.numpy().astype(np.int32)
+    new_xyz = ref_pn.index_points(xyz, fps128)
+    out["ball_r02_n32"] = ref_pn.query_ball_point(0.2, 32, xyz, new_xyz).numpy().astype(np.int32)
+    out["ball_r04_n64"] = ref_pn.query_ball_point(0.4, 64, xyz, new_xyz).numpy().astype(np.int32)
+    np.savez_compressed(os.path.join(OUT, "g4_pointnet.npz"), seed=DYN3D_SEED, **out)
+
+
+def g5_dyn3d():
+    dyn = make_dyn3d()
+    unet = make_unet()
+    obj = synth.synth_object_3d(4)
+    B, G, P, L, T, S = 2, 3, 2, 42, 15, 5
+    out = dict(obj=obj.numpy(), dims=np.array([B, G, P, L, T, S]))
+    x = synth.synth_noise(8, B, L)
+    out["x"] = x.numpy()
+    t = torch.full((B,), 6, dtype=torch.int64)
+    # plain forward on distinct clouds / rows
+    rs = np.random.RandomState(6)
+    rows = 5
+    f32 = lambda a: torch.from_numpy(a.astype(np.float32))
+    xc, xo, xp, tt = rs.uniform(-1, 1, (rows, 3, L)), rs.uniform(-1, 1, (rows, 1)), rs.uniform(-1, 1, (rows, 2)), rs.uniform(0, 1, rows)
+    clouds = torch.stack([synth.synth_object_3d(10 + i) for i in range(rows)])
+    torch.manual_seed(77)
+    with RandintSpy() as spy, torch.no_grad():
+        out["fwd_logits"] = dyn(f32(xc), f32(xo), f32(xp), f32(tt), clouds.permute(0, 2, 1)).numpy()
+    out["fwd_starts"], out["fwd_start_lens"] = spy.packed()
+    out.update(fwd_xc=xc.astype(np.float32), fwd_xo=xo.astype(np.float32), fwd_xp=xp.astype(np.float32),
+               fwd_t=tt.astype(np.float32), fwd_clouds=clouds.numpy())
+    for sub in (7, 512):
+        d = make_diffusion('point_3d', unet, dyn, T, S, L, G, P, obj[None], sub)
+        for o in ('rotate', 'clockwise_left', 'convergence'):
+            torch.manual_seed(99)
+            with RandintSpy() as spy:
+                g = d.cond_fn(x, t, opt_obj=o, object_vertices=obj, ori_range=[-1.0, 1.0],
+                              convergence_centers=torch.tensor([1, 0]) if o == 'convergence' else None)
+            out[f"grad_{o}_sub{sub}"] = g.detach().numpy()
+            out[f"starts_{o}_sub{sub}"], out[f"start_lens_{o}_sub{sub}"] = spy.packed()
+    np.savez_compressed(os.path.join(OUT, "g5_dyn3d.npz"), seed=DYN3D_SEED, **out)
+
+
+def g6_chains():
+    out = {}
+    unet = make_unet()
+    # ---- 2-D
+    nv = 10
+    dyn2 = make_dyn2d(2 * nv)
+    objs2 = torch.stack([synth.synth_object_2d(i, nv) for i in range(2)])
+    B, G, P, L, T, S = 3, 6, 2, 14, 15, 5
+    out["dims2d"] = np.array([B, G, P, L, T, S, nv])
+    out["objs2d"] = objs2.numpy()
+    noise = synth.synth_noise(0, B, L)
+    d = make_diffusion('point', unet, dyn2, T, S, L, G, P, objs2, 1024)
+    # unguided chain from pure noise (diffusion.py:249-256), through the reference scheduler stub + its U-Net
+    xs = noise.clone()
+    for t in d.noise_scheduler.timesteps:
+        with torch.no_grad():
+            e = d.noise_pred_net(xs, t * torch.ones(B, dtype=torch.int64))
+        xs = d.noise_scheduler.step(e, t, xs).prev_sample
+    out["unguided2d"] = xs.numpy()
+    for o in ('rotate', 'shift_left', 'counterclockwise_up', 'convergence'):
+        for oi in range(2):
+            d.object_vertices, d.object_ids = objs2[oi:oi + 1], [oi]
+            res = run_chain(lambda: d.guided_sample(0, B, noise, "/tmp/dgdm_golden", opt_obj=o, ori_range=[-1.0, 1.0],
+                                                    unguided_sample=xs))
+            out[f"guided2d_{o}_obj{oi}"] = res[0]
+    d.object_vertices, d.object_ids = objs2, [0, 1]
+    res = run_chain(lambda: d.guided_sample_multi_object(0, B, noise, "/tmp/dgdm_golden", opt_obj='rotate_clockwise',
+                                                         ori_range=[-1.0, 1.0]))
+    out["multi2d_rotate_clockwise"] = np.concatenate(res, axis=0)
+    # ---- 3-D
+    dyn3 = make_dyn3d()
+    objs3 = torch.stack([synth.synth_object_3d(20 + i) for i in range(2)])
+    B, G, P, L, T, S = 2, 3, 2, 42, 15, 5
+    out["dims3d"] = np.array([B, G, P, L, T, S])
+    out["objs3d"] = objs3.numpy()
+    noise = synth.synth_noise(0, B, L)
+    d = make_diffusion('point_3d', unet, dyn3, T, S, L, G, P, objs3, 5)
+    xs = noise.clone()
+    for t in d.noise_scheduler.timesteps:
+        with torch.no_grad():
+            e = d.noise_pred_net(xs, t * torch.ones(B, dtype=torch.int64))
+        xs = d.noise_scheduler.step(e, t, xs).prev_sample
+    out["unguided3d"] = xs.numpy()
+    for o in ('rotate', 'convergence'):
+        d.object_vertices, d.object_ids = objs3[:1], [0]
+        torch.manual_seed(0)
+        with RandintSpy() as spy:
+            res = run_chain(lambda: d.guided_sample(0, B, noise, "/tmp/dgdm_golden", opt_obj=o, ori_range=[-1.0, 1.0],
+                                                    unguided_sample=xs))
+        out[f"guided3d_{o}"] = res[0]
+        out[f"guided3d_{o}_starts"], out[f"guided3d_{o}_start_lens"] = spy.packed()
+    d.object_vertices, d.object_ids = objs3, [0, 1]
+    torch.manual_seed(0)
+    with RandintSpy() as spy:
+        res = run_chain(lambda: d.guided_sample_multi_object(0, B, noise, "/tmp/dgdm_golden", opt_obj='shift_up',
+                                                             ori_range=[-1.0, 1.0]))
+    out["multi3d_shift_up"] = np.concatenate(res, axis=0)
+    out["multi3d_shift_up_starts"], out["multi3d_shift_up_start_lens"] = spy.packed()
+    np.savez_compressed(os.path.join(OUT, "g6_chains.npz"), unet_seed=UNET_SEED, dyn2d_seed=DYN2D_SEED,
+                        dyn3d_seed=DYN3D_SEED, **out)
+
+
+def g7_convergence():
+    out = {}
+    cases = {
+        "all0": [0] * 8, "all2": [2] * 8, "all1": [1] * 6, "wrap": [0, 0, 2, 2, 1, 2, 0, 0, 2],
+        "mixed": [2, 2, 0, 1, 0, 2, 1, 1, 0, 0, 2, 2, 2, 0], "single": [2, 0], "ones_between": [1, 2, 1, 1, 0, 1, 2, 0],
+    }
+    for k, v in cases.items():
+        p = torch.tensor(v, dtype=torch.float32)
+        l, c = ref_metrics.convergence_mode_three_class(p)
+        out[f"{k}_profile"], out[f"{k}_lengths"], out[f"{k}_centers"] = p.numpy(), l.numpy(), c.numpy()
+    a = torch.arange(10.0)
+    for i, (lo, hi) in enumerate([(-3, 4), (6, 13), (2, 7), (-12, 3), (0, 0), (8, 25)]):
+        out[f"slicer_{i}_args"] = np.array([lo, hi])
+        out[f"slicer_{i}"] = ref_metrics.slicer(a, lo, hi).numpy()
+    # get_convergence_centers through the reference's Diffusion, 2-D and 3-D
+    unet = make_unet()
+    nv = 10
+    dyn2 = make_dyn2d(2 * nv)
+    obj2 = synth.synth_object_2d(3, nv)
+    B, G, P = 3, 24, 2
+    d = make_diffusion('point', unet, dyn2, 15, 5, 14, G, P, obj2[None], 1024)
+    ug = synth.synth_noise(3, B, 14).clamp(-1, 1)
+    out["cc2d_unguided"], out["cc2d_obj"], out["cc2d_dims"] = ug.numpy(), obj2.numpy(), np.array([B, G, P, nv])
+    out["cc2d_centers"] = d.get_convergence_centers(ug, obj2, B, ori_range=[-1.0, 1.0]).numpy()
+    dyn3 = make_dyn3d()
+    obj3 = synth.synth_object_3d(5)
+    B, G, P = 2, 9, 2
+    d = make_diffusion('point_3d', unet, dyn3, 15, 5, 42, G, P, obj3[None], 4)
+    ug = synth.synth_noise(4, B, 42).clamp(-1, 1)
+    torch.manual_seed(5)
+    with RandintSpy() as spy:
+        out["cc3d_centers"] = d.get_convergence_centers(ug, obj3, B, ori_range=[-1.0, 1.0]).numpy()
+    out["cc3d_starts"], out["cc3d_start_lens"] = spy.packed()
+    out["cc3d_unguided"], out["cc3d_obj"], out["cc3d_dims"] = ug.numpy(), obj3.numpy(), np.array([B, G, P])
+    np.savez_compressed(os.path.join(OUT, "g7_convergence.npz"), dyn2d_seed=DYN2D_SEED, dyn3d_seed=DYN3D_SEED, **out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    os.makedirs("/tmp/dgdm_golden", exist_ok=True)
+    only = sys.argv[1:]
+    for name, fn in (("g2", g2_unet), ("g3", g3_dyn2d), ("g4", g4_pointnet), ("g5", g5_dyn3d), ("g6", g6_chains),
+                     ("g7", g7_convergence)):
+        if only and name not in only:
+            continue
+        fn()
+        print("wrote", name, flush=True)

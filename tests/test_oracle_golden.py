@@ -1,0 +1,155 @@
+"""The oracle against the golden vectors captured from the reference (tests/golden/make_golden.py).
+
+This is what pins oracle/dgdm_oracle.py: same seeds, same FPS start indices -> same numbers as the
+reference's own modules, to float32 round-off (torch CPU kernels are identical here, so most are exact).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dgdm_oracle as orc
+from tests import util
+from tests.golden.make_golden_names import OBJ16
+
+TOL = 2e-6
+
+
+def test_ddim_closed_forms():
+    # SURVEY.md §8(a13,c): the only anchors that exist for the un-vendored scheduler (parity unpinned)
+    s = orc.DDIM(15)
+    s.set_timesteps(5)
+    assert s.timesteps.tolist() == [12, 9, 6, 3, 0]
+    assert abs(float(s.alphas_cumprod[0]) - 0.98668) < 1e-5
+    assert abs(float(s.alphas_cumprod[14]) / 1.0756e-5 - 1) < 1e-3
+    assert bool((s.alphas_cumprod[1:] < s.alphas_cumprod[:-1]).all())
+    assert float(s.betas.max()) <= 0.999 + 1e-7
+    x = torch.randn(3, 14, 1)
+    e = torch.randn(3, 14, 1)
+    last = s.step(e, 0, x)          # prev_t < 0 -> alpha_prev = 1 -> returns clamp(x0)
+    a0 = s.alphas_cumprod[0]
+    assert torch.allclose(last, ((x - (1 - a0) ** 0.5 * e) / a0 ** 0.5).clamp(-1, 1))
+    s2 = orc.DDIM(1000)
+    s2.set_timesteps(100)
+    assert s2.timesteps[:3].tolist() == [990, 980, 970] and len(s2.timesteps) == 100
+    n = s.add_noise(x, e, torch.tensor([5, 5, 5]))
+    assert torch.allclose(n, s.alphas_cumprod[5] ** 0.5 * x + (1 - s.alphas_cumprod[5]) ** 0.5 * e)
+
+
+def test_unet_matches_reference():
+    g = util.load("g2_unet.npz")
+    sd = util.unet_sd(g["seed"])
+    for L in (14, 42):
+        x = torch.from_numpy(g[f"x_L{L}"])
+        for t in (0, 3, 12, 999):
+            y = orc.unet1d_forward(sd, x, torch.full((4,), t, dtype=torch.int64))
+            assert util.rel_l2(y, g[f"y_L{L}_t{t}"]) < TOL
+
+
+def test_dyn2d_forward_and_grads():
+    g = util.load("g3_dyn2d.npz")
+    B, G, P, L, T, S, nv = g["dims"]
+    sd = util.dyn2d_sd(g["seed"], nv)
+    f = lambda k: torch.from_numpy(g[k])
+    y = orc.dyn2d_forward(sd, f("fwd_xc"), f("fwd_xo"), f("fwd_xp"), f("fwd_t"), f("fwd_obj"))
+    assert util.rel_l2(y, g["fwd_logits"]) < TOL
+    s = util.setup('point', None, sd, T, S, L, G, P)
+    x, obj = f("x"), f("obj")
+    t = torch.full((int(B),), 9, dtype=torch.int64)
+    for o in OBJ16:
+        for name, rng in (("full", (-1.0, 1.0)), ("half", (-0.5, 0.25))):
+            gr = orc.cond_fn(s, x, t, o, obj, rng, centers=f("centers") if o == 'convergence' else None)
+            assert util.rel_l2(gr, g[f"grad_{o}_{name}"]) < 1e-5, (o, name)
+
+
+def test_pointnet_indices_and_embedding():
+    g = util.load("g4_pointnet.npz")
+    sd = util.dyn3d_sd(g["seed"])
+    clouds = torch.from_numpy(g["clouds"])
+    st = torch.from_numpy(g["fps_start"])
+    assert np.array_equal(orc.farthest_point_sample(clouds, 512, st).numpy(), g["fps512"])
+    f128 = orc.farthest_point_sample(clouds, 128, st)
+    assert np.array_equal(f128.numpy(), g["fps128"])
+    new = orc._gather(clouds, f128)
+    assert np.array_equal(orc.query_ball_point(0.2, 32, clouds, new).numpy(), g["ball_r02_n32"])
+    assert np.array_equal(orc.query_ball_point(0.4, 64, clouds, new).numpy(), g["ball_r04_n64"])
+    log = orc.StartLog(util.unpack_starts(g["starts"], g["start_lens"]))
+    emb = orc.pointnet2_forward(sd, clouds.permute(0, 2, 1), log, prefix="object_encoder.")
+    assert util.rel_l2(emb, g["emb"]) < TOL
+
+
+def test_dyn3d_forward_and_grads():
+    g = util.load("g5_dyn3d.npz")
+    B, G, P, L, T, S = g["dims"]
+    sd = util.dyn3d_sd(g["seed"])
+    f = lambda k: torch.from_numpy(g[k])
+    log = orc.StartLog(util.unpack_starts(g["fwd_starts"], g["fwd_start_lens"]))
+    y = orc.dyn3d_forward(sd, f("fwd_xc"), f("fwd_xo"), f("fwd_xp"), f("fwd_t"), f("fwd_clouds").permute(0, 2, 1), log)
+    assert util.rel_l2(y, g["fwd_logits"]) < TOL
+    x, obj = f("x"), f("obj")
+    t = torch.full((int(B),), 6, dtype=torch.int64)
+    for sub in (7, 512):
+        s = util.setup('point_3d', None, sd, T, S, L, G, P, sub)
+        for o in ('rotate', 'clockwise_left', 'convergence'):
+            log = orc.StartLog(util.unpack_starts(g[f"starts_{o}_sub{sub}"], g[f"start_lens_{o}_sub{sub}"]))
+            gr = orc.cond_fn(s, x, t, o, obj, (-1.0, 1.0), centers=torch.tensor([1, 0]) if o == 'convergence' else None,
+                             starts=log)
+            assert util.rel_l2(gr, g[f"grad_{o}_sub{sub}"]) < 1e-5, (o, sub)
+    # same seed -> the oracle's own torch.randint draws reproduce the reference's (pointnet2_utils.py:83)
+    s = util.setup('point_3d', None, sd, T, S, L, G, P, 7)
+    torch.manual_seed(99)
+    log = orc.StartLog()
+    orc.cond_fn(s, x, t, 'rotate', obj, (-1.0, 1.0), starts=log)
+    assert np.array_equal(torch.cat(log.log).numpy(), g["starts_rotate_sub7"])
+
+
+def test_full_chains():
+    g = util.load("g6_chains.npz")
+    unet = util.unet_sd(g["unet_seed"])
+    from dgdm_amd import synth
+    # 2-D
+    B, G, P, L, T, S, nv = g["dims2d"]
+    s = util.setup('point', unet, util.dyn2d_sd(g["dyn2d_seed"], nv), T, S, L, G, P)
+    noise = synth.synth_noise(0, int(B), int(L))
+    ug = orc.unguided_sample(s, noise)
+    assert util.rel_l2(ug, g["unguided2d"]) < 1e-5
+    objs = torch.from_numpy(g["objs2d"])
+    for o in ('rotate', 'shift_left', 'counterclockwise_up', 'convergence'):
+        for oi in range(2):
+            out = orc.guided_sample(s, noise, objs[oi], o, (-1.0, 1.0), unguided=ug)
+            assert util.rel_l2(out, g[f"guided2d_{o}_obj{oi}"]) < 1e-4, (o, oi)
+    out = orc.guided_sample_multi_object(s, noise, list(objs), 'rotate_clockwise')
+    assert util.rel_l2(out, g["multi2d_rotate_clockwise"]) < 1e-4
+    # 3-D
+    B, G, P, L, T, S = g["dims3d"]
+    s = util.setup('point_3d', unet, util.dyn3d_sd(g["dyn3d_seed"]), T, S, L, G, P, 5)
+    noise = synth.synth_noise(0, int(B), int(L))
+    ug = orc.unguided_sample(s, noise)
+    assert util.rel_l2(ug, g["unguided3d"]) < 1e-5
+    objs = torch.from_numpy(g["objs3d"])
+    for o in ('rotate', 'convergence'):
+        log = orc.StartLog(util.unpack_starts(g[f"guided3d_{o}_starts"], g[f"guided3d_{o}_start_lens"]))
+        out = orc.guided_sample(s, noise, objs[0], o, (-1.0, 1.0), unguided=ug, starts=log)
+        assert util.rel_l2(out, g[f"guided3d_{o}"]) < 1e-4, o
+    log = orc.StartLog(util.unpack_starts(g["multi3d_shift_up_starts"], g["multi3d_shift_up_start_lens"]))
+    out = orc.guided_sample_multi_object(s, noise, list(objs), 'shift_up', starts=log)
+    assert util.rel_l2(out, g["multi3d_shift_up"]) < 1e-4
+
+
+def test_convergence_helpers():
+    g = util.load("g7_convergence.npz")
+    for k in ("all0", "all2", "all1", "wrap", "mixed", "single", "ones_between"):
+        l, c = orc.convergence_mode_three_class(torch.from_numpy(g[f"{k}_profile"]))
+        assert np.array_equal(l.numpy(), g[f"{k}_lengths"]) and np.array_equal(c.numpy(), g[f"{k}_centers"]), k
+    a = torch.arange(10.0)
+    for i in range(6):
+        lo, hi = g[f"slicer_{i}_args"]
+        assert np.array_equal(orc.slicer(a, int(lo), int(hi)).numpy(), g[f"slicer_{i}"])
+    B, G, P, nv = g["cc2d_dims"]
+    s = util.setup('point', None, util.dyn2d_sd(g["dyn2d_seed"], nv), 15, 5, 14, G, P)
+    c = orc.get_convergence_centers(s, torch.from_numpy(g["cc2d_unguided"]), torch.from_numpy(g["cc2d_obj"]))
+    assert np.array_equal(c.numpy(), g["cc2d_centers"])
+    B, G, P = g["cc3d_dims"]
+    s = util.setup('point_3d', None, util.dyn3d_sd(g["dyn3d_seed"]), 15, 5, 42, G, P, 4)
+    log = orc.StartLog(util.unpack_starts(g["cc3d_starts"], g["cc3d_start_lens"]))
+    c = orc.get_convergence_centers(s, torch.from_numpy(g["cc3d_unguided"]), torch.from_numpy(g["cc3d_obj"]), starts=log)
+    assert np.array_equal(c.numpy(), g["cc3d_centers"])

@@ -1,0 +1,47 @@
+"""Shared helpers for the parity tests."""
+import os
+
+import numpy as np
+import torch
+
+from dgdm_amd import synth
+from oracle import dgdm_oracle as orc
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def unpack_starts(flat, lens):
+    """Inverse of make_golden.RandintSpy.packed: list of per-call index tensors."""
+    out, o = [], 0
+    for n in lens:
+        out.append(torch.from_numpy(np.asarray(flat[o:o + int(n)], dtype=np.int64)))
+        o += int(n)
+    return out
+
+
+def rel_l2(a, b):
+    a = torch.as_tensor(a, dtype=torch.float64).reshape(-1)
+    b = torch.as_tensor(b, dtype=torch.float64).reshape(-1)
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def unet_sd(seed):
+    return synth.synth_state_dict(synth.unet_spec(), int(seed))
+
+
+def dyn2d_sd(seed, nv):
+    return synth.synth_state_dict(synth.dyn2d_spec(14, 2 * int(nv)), int(seed))
+
+
+def dyn3d_sd(seed):
+    return synth.synth_state_dict(synth.dyn3d_spec(42), int(seed))
+
+
+def setup(mode, unet, dyn, T, S, L, G, P, sub=1024):
+    sch = orc.DDIM(int(T))
+    sch.set_timesteps(int(S))
+    return orc.Setup(mode, unet, dyn, sch, int(L), int(G), int(P), int(sub))
