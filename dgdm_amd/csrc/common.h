@@ -1,0 +1,87 @@
+// Shared host/device helpers for libdgdm_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include <map>
+
+#include "../../include/dgdm_hip.h"
+
+#define DGDM_MAX_CHAINS 256
+
+namespace dgdm {
+
+void set_error(const char *fmt, ...);
+
+#define DGDM_HIP_CHECK(expr)                                                              \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            dgdm::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return DGDM_EHIP;                                                             \
+        }                                                                                 \
+    } while (0)
+
+#define DGDM_REQUIRE(cond, code, ...)                                                     \
+    do {                                                                                  \
+        if (!(cond)) {                                                                    \
+            dgdm::set_error(__VA_ARGS__);                                                 \
+            return (code);                                                                \
+        }                                                                                 \
+    } while (0)
+
+// Device buffer owned by a model/guidance handle.
+struct DevBuf {
+    void  *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) {
+        if (p && bytes >= n) return DGDM_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        if (n == 0) return DGDM_OK;
+        DGDM_HIP_CHECK(hipMalloc(&p, n));
+        bytes = n;
+        return DGDM_OK;
+    }
+    int upload(const void *host, size_t n) {
+        int rc = alloc(n);
+        if (rc) return rc;
+        DGDM_HIP_CHECK(hipMemcpy(p, host, n, hipMemcpyHostToDevice));
+        return DGDM_OK;
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// state_dict lookup
+struct StateDict {
+    std::map<std::string, const DgdmTensor *> m;
+    StateDict(const DgdmTensor *t, int n) { for (int i = 0; i < n; ++i) m[t[i].name] = &t[i]; }
+    const float *f32(const std::string &k, int64_t numel) const;   // nullptr + error when missing / wrong size
+    bool has(const std::string &k) const { return m.count(k) != 0; }
+};
+
+// Linear weight [out][in] with an optional eval-mode BatchNorm folded in (double precision fold):
+//   y = s*(W x + b - mean) + beta,  s = gamma / sqrt(var + eps)
+struct Folded {
+    int out = 0, in = 0;
+    std::vector<float> w;   // [out][in]
+    std::vector<float> b;   // [out]
+};
+int fold_linear(const StateDict &sd, const std::string &lin, const std::string &bn /* "" = none */, int out, int in,
+                Folded *dst);
+
+// ---- MFMA-chain weight image (see mfma_chain.h).  src is [M][K] row-major, M,K multiples of 32.
+//   img[((op*KB + o)*4 + q)*64 + lane][0..3] = src[32 op + (lane&31)][32 o + 8 q + 4 (lane>>5) + 0..3]
+std::vector<float> pack_chain(const float *src, int M, int K);
+std::vector<float> transpose(const float *src, int rows, int cols);   // -> [cols][rows]
+
+// profiling of the dominant kernel
+void prof_begin(hipStream_t s);
+void prof_end(hipStream_t s, double flops);
+
+}  // namespace dgdm

@@ -1,0 +1,408 @@
+// Diffusion.cond_fn / get_convergence_centers (generator/diffusion.py:473-539) for batches of chains,
+// and the PointNet++-backed forward entry points.
+#include "common.h"
+#include "models.h"
+#include <algorithm>
+#include <cstring>
+#include <unordered_map>
+
+using namespace dgdm;
+
+namespace {
+
+// torch.linspace(start, end, steps) for float32 on CPU: symmetric evaluation around the midpoint
+std::vector<float> linspace_f32(float start, float end, int steps) {
+    std::vector<float> v(steps);
+    if (steps == 1) { v[0] = start; return v; }
+    const float step = (end - start) / (float)(steps - 1);
+    const int half = steps / 2;
+    for (int i = 0; i < steps; ++i) v[i] = i < half ? start + step * (float)i : end - step * (float)(steps - i - 1);
+    return v;
+}
+
+struct ObjectTables {       // 3-D, per object
+    DevBuf xyz;             // [N][3]
+    DevBuf fps1;            // [N][512] int
+    DevBuf Z;               // [N][N][256]
+};
+
+}  // namespace
+
+struct DgdmGuidance {
+    DgdmDynamics *m = nullptr;
+    DgdmGuidanceConfig cfg{};
+    int C = 0, G = 0, B = 0, tiles_per_b = 0, sweep_tiles_per_b = 0;
+    int64_t R = 0, Rs = 0;                       // rows per chain: cond_fn grid, orientation sweep
+    DevBuf ptab, ptab_sweep;                     // [C][W1], [G][W1]
+    DevBuf objpart;                              // 2-D: [max_objects][W1]
+    std::vector<std::unique_ptr<ObjectTables>> tables;   // 3-D
+    DevBuf tmpF1, tmpU, tmpY, tmpL2, vlist;      // 3-D table-build temporaries
+    DevBuf V, genc, atab, chainbias, timepart, ttmp, partial, objdev, objidx, xobj, starts, xchains;
+    int n_objects = 0;
+    void *pinned = nullptr; size_t pinned_bytes = 0; hipEvent_t pinned_ev = nullptr;
+    ~DgdmGuidance() {
+        if (pinned) (void)hipHostFree(pinned);
+        if (pinned_ev) (void)hipEventDestroy(pinned_ev);
+    }
+    int build_pose_table(const std::vector<float> &ori, const std::vector<float> &pos, DevBuf *dst, hipStream_t s);
+    int common_pre(const float *x_dev, float t_scaled, const int *objidx_host, int n_chains, hipStream_t s);
+    int upload_starts(const int64_t *starts_host, int n_chains, int64_t rows, hipStream_t s);
+    int build_object(int oi, const float *xyz_dev, hipStream_t s);
+    int run_xobj(const int *objidx_host, int n_chains, int64_t rows, hipStream_t s);
+};
+
+int DgdmGuidance::build_pose_table(const std::vector<float> &ori, const std::vector<float> &pos, DevBuf *dst, hipStream_t s) {
+    const int n = (int)ori.size(), W1 = m->W1;
+    DevBuf d_ori, d_pos, d_emb;
+    int rc;
+    if ((rc = d_ori.upload(ori.data(), sizeof(float) * n))) return rc;
+    if ((rc = d_pos.upload(pos.data(), sizeof(float) * 2 * n))) return rc;
+    if ((rc = d_emb.alloc(sizeof(float) * 27 * n))) return rc;
+    if ((rc = dst->alloc(sizeof(float) * (size_t)W1 * n))) return rc;
+    if ((rc = pose_embed(d_ori.as<float>(), d_pos.as<float>(), d_emb.as<float>(), n, s))) return rc;
+    if ((rc = linear(d_emb.as<float>(), 27, m->blob.at(m->off.w1p_wt), nullptr, nullptr, 1, dst->as<float>(), W1, n, 27, W1, ACT_NONE, false, s))) return rc;
+    DGDM_HIP_CHECK(hipStreamSynchronize(s));     // temporaries die here
+    return DGDM_OK;
+}
+
+extern "C" int dgdm_guidance_create(DgdmGuidance **out, DgdmDynamics *model, const DgdmGuidanceConfig *cfg) {
+    DGDM_REQUIRE(out && model && cfg, DGDM_EINVAL, "dgdm_guidance_create: null argument");
+    DGDM_REQUIRE(cfg->batch > 0 && cfg->grid_size > 0 && cfg->num_pos > 0 && cfg->max_chains > 0 && cfg->num_train_timesteps > 0,
+                 DGDM_EINVAL, "dgdm_guidance_create: bad config");
+    DGDM_REQUIRE(cfg->max_chains <= DGDM_MAX_CHAINS, DGDM_EINVAL, "max_chains %d > %d", cfg->max_chains, DGDM_MAX_CHAINS);
+    if (model->kind == 3) {
+        DGDM_REQUIRE(cfg->sub_batch_size > 0, DGDM_EINVAL, "3-D guidance needs sub_batch_size (it partitions the FPS start draws)");
+        DGDM_REQUIRE(cfg->num_object_points > 0 && cfg->num_object_points <= 1024, DGDM_EINVAL, "object clouds of %d points unsupported (1..1024)", cfg->num_object_points);
+    } else {
+        DGDM_REQUIRE(2 * cfg->num_object_points == model->object_ch, DGDM_EINVAL, "2*num_object_points (%d) != object_ch (%d)", 2 * cfg->num_object_points, model->object_ch);
+    }
+    std::unique_ptr<DgdmGuidance> g(new DgdmGuidance());
+    g->m = model; g->cfg = *cfg;
+    g->B = cfg->batch; g->G = cfg->grid_size;
+    const int P = cfg->num_pos;
+    g->C = g->G * P * P;
+    g->R = (int64_t)g->B * g->C; g->Rs = (int64_t)g->B * g->G;
+    g->tiles_per_b = (g->C + 31) / 32; g->sweep_tiles_per_b = (g->G + 31) / 32;
+    // pose grid: torch.meshgrid(linspace(ori), linspace(-1,1,P), linspace(-1,1,P)) 'ij' -> cell = (g*P + px)*P + py  (diffusion.py:478)
+    const std::vector<float> lo = linspace_f32(cfg->ori_lo, cfg->ori_hi, g->G), lp = linspace_f32(-1.f, 1.f, P);
+    std::vector<float> ori(g->C), pos(2 * (size_t)g->C);
+    for (int gi = 0; gi < g->G; ++gi)
+        for (int a = 0; a < P; ++a)
+            for (int b = 0; b < P; ++b) {
+                const int c = (gi * P + a) * P + b;
+                ori[c] = lo[gi]; pos[2 * c] = lp[a]; pos[2 * c + 1] = lp[b];
+            }
+    int rc;
+    if ((rc = g->build_pose_table(ori, pos, &g->ptab, nullptr))) return rc;
+    std::vector<float> pos0(2 * (size_t)g->G, 0.f);                       // get_convergence_centers: pos = 0 (:511)
+    if ((rc = g->build_pose_table(lo, pos0, &g->ptab_sweep, nullptr))) return rc;
+    const int W1 = model->W1, nc = cfg->max_chains;
+    const size_t rows = (size_t)nc * g->B;
+    if ((rc = g->V.alloc(rows * 256 * 4)) || (rc = g->genc.alloc(rows * 256 * 4)) || (rc = g->atab.alloc(rows * W1 * 4)) ||
+        (rc = g->chainbias.alloc((size_t)nc * W1 * 4)) || (rc = g->timepart.alloc((size_t)W1 * 4)) || (rc = g->ttmp.alloc(768 * 4)) ||
+        (rc = g->partial.alloc(rows * g->tiles_per_b * W1 * 4)) || (rc = g->objdev.alloc(sizeof(TrunkObjective) * nc)) ||
+        (rc = g->objidx.alloc(sizeof(int) * nc)))
+        return rc;
+    if (model->kind == 2) {
+        if ((rc = g->objpart.alloc((size_t)std::max(1, cfg->max_objects) * W1 * 4))) return rc;
+    } else {
+        if ((rc = g->xobj.alloc((size_t)nc * g->R * 256 * 4)) || (rc = g->starts.alloc((size_t)nc * g->R * 2 * sizeof(int))) ||
+            (rc = g->xchains.alloc(sizeof(XobjChain) * nc)))
+            return rc;
+        g->pinned_bytes = (size_t)nc * g->R * 2 * sizeof(int);
+        DGDM_HIP_CHECK(hipHostMalloc(&g->pinned, g->pinned_bytes, hipHostMallocDefault));
+        DGDM_HIP_CHECK(hipEventCreateWithFlags(&g->pinned_ev, hipEventDisableTiming));
+    }
+    *out = g.release();
+    return DGDM_OK;
+}
+
+extern "C" void dgdm_guidance_destroy(DgdmGuidance *g) { delete g; }
+extern "C" int64_t dgdm_guidance_rows(const DgdmGuidance *g) { return g ? g->R : 0; }
+extern "C" int64_t dgdm_guidance_starts_per_call(const DgdmGuidance *g) { return (g && g->m->kind == 3) ? 2 * g->R : 0; }
+
+// ------------------------------------------------------------------------------------------------ objects
+int DgdmGuidance::build_object(int oi, const float *xyz_dev, hipStream_t s) {
+    const int N = cfg.num_object_points;
+    ObjectTables &t = *tables[oi];
+    const PnWeights w = m->pn();
+    int rc;
+    if ((rc = t.xyz.alloc((size_t)N * 3 * 4)) || (rc = t.fps1.alloc((size_t)N * 512 * sizeof(int))) || (rc = t.Z.alloc((size_t)N * N * 256 * 4)))
+        return rc;
+    if ((rc = tmpF1.alloc((size_t)N * 128 * 4)) || (rc = tmpU.alloc((size_t)N * 128 * 4)) || (rc = tmpY.alloc((size_t)N * N * 256 * 4)) ||
+        (rc = tmpL2.alloc((size_t)N * N * 256 * 4)))
+        return rc;
+    if (vlist.bytes < (size_t)N * sizeof(int)) {
+        std::vector<int> v(N);
+        for (int i = 0; i < N; ++i) v[i] = i;
+        if ((rc = vlist.upload(v.data(), sizeof(int) * N))) return rc;
+    }
+    DGDM_HIP_CHECK(hipMemcpyAsync(t.xyz.p, xyz_dev, (size_t)N * 3 * 4, hipMemcpyDeviceToDevice, s));
+    const float *xyz = t.xyz.as<float>();
+    if ((rc = pn_fps_table(xyz, N, N, 512, t.fps1.as<int>(), s))) return rc;                                   // T1
+    if ((rc = pn_sa1(xyz, N, w, tmpF1.as<float>(), s))) return rc;                                             // T2
+    if ((rc = linear(tmpF1.as<float>(), 128, w.sa2_wf_t, w.sa2_b0, nullptr, 1, tmpU.as<float>(), 128, N, 128, 128, ACT_NONE, false, s))) return rc;  // T3
+    if ((rc = pn_pairs(xyz, N, tmpU.as<float>(), w, tmpY.as<float>(), s))) return rc;                          // T4
+    if ((rc = pn_l2(xyz, N, w, t.fps1.as<int>(), vlist.as<int>(), N, tmpY.as<float>(), tmpL2.as<float>(), s))) return rc;   // T5
+    return pn_z(xyz, N, N, w, tmpL2.as<float>(), t.Z.as<float>(), s);                                          // T6
+}
+
+extern "C" int dgdm_guidance_set_objects(DgdmGuidance *g, const float *objects_dev, int n_objects, void *stream) {
+    DGDM_REQUIRE(g && objects_dev && n_objects > 0, DGDM_EINVAL, "dgdm_guidance_set_objects: bad argument");
+    DGDM_REQUIRE(n_objects <= std::max(1, g->cfg.max_objects), DGDM_EINVAL, "%d objects > max_objects %d", n_objects, g->cfg.max_objects);
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (g->m->kind == 2) {
+        DevBuf tmp;
+        if ((rc = tmp.alloc((size_t)n_objects * 512 * 4))) return rc;
+        if ((rc = g->m->object_part_2d(objects_dev, tmp.as<float>(), g->objpart.as<float>(), n_objects, false, s))) return rc;
+        DGDM_HIP_CHECK(hipStreamSynchronize(s));
+    } else {
+        while ((int)g->tables.size() < n_objects) g->tables.emplace_back(new ObjectTables());
+        const int N = g->cfg.num_object_points;
+        for (int i = 0; i < n_objects; ++i)
+            if ((rc = g->build_object(i, objects_dev + (size_t)i * N * 3, s))) return rc;
+    }
+    g->n_objects = n_objects;
+    return DGDM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ shared front end
+// V/genc from x, timepart(t), chain bias (2-D: object part + time part), A table.
+int DgdmGuidance::common_pre(const float *x_dev, float t_scaled, const int *objidx_host, int n_chains, hipStream_t s) {
+    const int rows = n_chains * B, W1 = m->W1;
+    int rc;
+    if ((rc = m->gripper_forward(x_dev, m->L, V.as<float>(), genc.as<float>(), rows, s))) return rc;
+    if ((rc = m->time_part(nullptr, t_scaled, ttmp.as<float>(), timepart.as<float>(), 1, s))) return rc;
+    if (m->kind == 2) {
+        for (int i = 0; i < n_chains; ++i)
+            DGDM_REQUIRE(objidx_host[i] >= 0 && objidx_host[i] < n_objects, DGDM_EINVAL, "chain %d refers to object %d of %d", i, objidx_host[i], n_objects);
+        DGDM_HIP_CHECK(hipMemcpyAsync(objidx.p, objidx_host, sizeof(int) * n_chains, hipMemcpyHostToDevice, s));   // pageable: staged before return
+        if ((rc = gather_add(objpart.as<float>(), objidx.as<int>(), timepart.as<float>(), chainbias.as<float>(), n_chains, W1, s))) return rc;
+        return linear(genc.as<float>(), 256, m->blob.at(m->off.w1c_wt), nullptr, chainbias.as<float>(), B, atab.as<float>(), W1, rows, 256, W1, ACT_NONE, false, s);
+    }
+    return linear(genc.as<float>(), 256, m->blob.at(m->off.w1c_wt), timepart.as<float>(), nullptr, 1, atab.as<float>(), W1, rows, 256, W1, ACT_NONE, false, s);
+}
+
+// Reference draw order per chain: for each sub-batch i, sa1's torch.randint(rows_i) then sa2's  ->  device [chain][row][2]
+int DgdmGuidance::upload_starts(const int64_t *starts_host, int n_chains, int64_t rows, hipStream_t s) {
+    const int N = cfg.num_object_points;
+    const int64_t sb = cfg.sub_batch_size;
+    DGDM_REQUIRE((size_t)n_chains * rows * 2 * sizeof(int) <= pinned_bytes, DGDM_EINVAL, "starts staging too small");
+    DGDM_HIP_CHECK(hipEventSynchronize(pinned_ev));            // previous copy out of the staging buffer has finished
+    int *dst = static_cast<int *>(pinned);
+    for (int c = 0; c < n_chains; ++c) {
+        const int64_t *src = starts_host + (size_t)c * 2 * rows;
+        int *d = dst + (size_t)c * 2 * rows;
+        for (int64_t r0 = 0; r0 < rows; r0 += sb) {
+            const int64_t n = std::min(sb, rows - r0);
+            const int64_t *s1 = src + 2 * r0, *s2 = s1 + n;
+            for (int64_t k = 0; k < n; ++k) {
+                const int64_t a = s1[k], b = s2[k];
+                DGDM_REQUIRE(a >= 0 && a < N && b >= 0 && b < 512, DGDM_EINVAL, "FPS start out of range (sa1 %lld of %d, sa2 %lld of 512)", (long long)a, N, (long long)b);
+                d[2 * (r0 + k)] = (int)a; d[2 * (r0 + k) + 1] = (int)b;
+            }
+        }
+    }
+    DGDM_HIP_CHECK(hipMemcpyAsync(starts.p, pinned, (size_t)n_chains * rows * 2 * sizeof(int), hipMemcpyHostToDevice, s));
+    DGDM_HIP_CHECK(hipEventRecord(pinned_ev, s));
+    return DGDM_OK;
+}
+
+int DgdmGuidance::run_xobj(const int *objidx_host, int n_chains, int64_t rows, hipStream_t s) {
+    std::vector<XobjChain> ch(n_chains);
+    for (int i = 0; i < n_chains; ++i) {
+        DGDM_REQUIRE(objidx_host[i] >= 0 && objidx_host[i] < n_objects, DGDM_EINVAL, "chain %d refers to object %d of %d", i, objidx_host[i], n_objects);
+        const ObjectTables &t = *tables[objidx_host[i]];
+        ch[i].xyz = t.xyz.as<float>(); ch[i].fps1 = t.fps1.as<int>(); ch[i].slot_of_start = nullptr; ch[i].Z = t.Z.as<float>();
+        ch[i].N = cfg.num_object_points; ch[i].pad = 0;
+    }
+    DGDM_HIP_CHECK(hipMemcpyAsync(xchains.p, ch.data(), sizeof(XobjChain) * n_chains, hipMemcpyHostToDevice, s));
+    XobjParams xp{};
+    xp.chains = xchains.as<XobjChain>(); xp.starts = starts.as<int>(); xp.xobj = xobj.as<float>();
+    xp.R = rows; xp.total_rows = rows * n_chains;
+    return pn_xobj(xp, s);
+}
+
+static int guidance_grad(DgdmGuidance *g, int kind, const float *x_dev, int timestep, const DgdmObjective *objectives, const float *rowcoef_dev,
+                         const int64_t *starts_host, int n_chains, float *grad_dev, hipStream_t s) {
+    DGDM_REQUIRE(g && x_dev && objectives && grad_dev, DGDM_EINVAL, "guidance_grad: null argument");
+    if (g->m->kind != kind) { set_error("model type not supported: %d-D entry point on a %d-D model", kind, g->m->kind); return DGDM_EMODE; }
+    DGDM_REQUIRE(n_chains > 0 && n_chains <= g->cfg.max_chains, DGDM_EINVAL, "n_chains %d outside 1..%d", n_chains, g->cfg.max_chains);
+    DGDM_REQUIRE(g->n_objects > 0, DGDM_EINVAL, "dgdm_guidance_set_objects has not been called");
+    std::vector<int> oidx(n_chains);
+    std::vector<TrunkObjective> tob(n_chains);
+    for (int i = 0; i < n_chains; ++i) {
+        oidx[i] = objectives[i].object;
+        for (int j = 0; j < 3; ++j) { tob[i].lin[j] = objectives[i].lin[j]; tob[i].quad[j] = objectives[i].quad[j]; }
+        tob[i].use_rowcoef = objectives[i].use_rowcoef; tob[i].pad = 0;
+        DGDM_REQUIRE(!tob[i].use_rowcoef || rowcoef_dev, DGDM_EINVAL, "chain %d uses rowcoef but rowcoef_dev is null", i);
+    }
+    const float t_scaled = (float)timestep / (float)g->cfg.num_train_timesteps;      // timesteps.float() / T  (diffusion.py:487,496)
+    int rc;
+    if ((rc = g->common_pre(x_dev, t_scaled, oidx.data(), n_chains, s))) return rc;
+    DGDM_HIP_CHECK(hipMemcpyAsync(g->objdev.p, tob.data(), sizeof(TrunkObjective) * n_chains, hipMemcpyHostToDevice, s));
+    TrunkParams p;
+    g->m->fill_trunk(&p);
+    if (kind == 3) {
+        DGDM_REQUIRE(starts_host, DGDM_EINVAL, "3-D guidance needs the FPS start indices");
+        if ((rc = g->upload_starts(starts_host, n_chains, g->R, s))) return rc;
+        if ((rc = g->run_xobj(oidx.data(), n_chains, g->R, s))) return rc;
+        p.xobj = g->xobj.as<float>();
+    }
+    p.Atab = g->atab.as<float>(); p.Ptab = g->ptab.as<float>(); p.obj = g->objdev.as<TrunkObjective>(); p.rowcoef = rowcoef_dev;
+    p.partial = g->partial.as<float>();
+    p.B = g->B; p.C = g->C; p.tiles_per_b = g->tiles_per_b; p.ntiles = n_chains * g->B * g->tiles_per_b; p.R = g->R;
+    if ((rc = trunk_launch(kind, false, false, p, s))) return rc;
+    return dyn_post(g->m->W1, g->partial.as<float>(), g->tiles_per_b, g->m->blob.at(g->m->off.w1c_w), g->m->blob.at(g->m->off.g2_w),
+                    g->m->blob.at(g->m->off.g0_w), g->V.as<float>(), grad_dev, n_chains * g->B, g->m->L, s);
+}
+
+extern "C" int dgdm_dyn2d_guidance_grad(DgdmGuidance *g, const float *x_dev, int timestep, const DgdmObjective *objectives,
+                                        const float *rowcoef_dev, int n_chains, float *grad_dev, void *stream) {
+    return guidance_grad(g, 2, x_dev, timestep, objectives, rowcoef_dev, nullptr, n_chains, grad_dev, (hipStream_t)stream);
+}
+
+extern "C" int dgdm_dyn3d_guidance_grad(DgdmGuidance *g, const float *x_dev, int timestep, const DgdmObjective *objectives,
+                                        const float *rowcoef_dev, const int64_t *starts_host, int n_chains, float *grad_dev, void *stream) {
+    return guidance_grad(g, 3, x_dev, timestep, objectives, rowcoef_dev, starts_host, n_chains, grad_dev, (hipStream_t)stream);
+}
+
+extern "C" int dgdm_guidance_orientation_sweep(DgdmGuidance *g, const float *x_dev, const int32_t *object_of_chain, const int64_t *starts_host,
+                                               int n_chains, float *logits_dev, void *stream) {
+    DGDM_REQUIRE(g && x_dev && object_of_chain && logits_dev, DGDM_EINVAL, "dgdm_guidance_orientation_sweep: null argument");
+    DGDM_REQUIRE(n_chains > 0 && n_chains <= g->cfg.max_chains, DGDM_EINVAL, "n_chains %d outside 1..%d", n_chains, g->cfg.max_chains);
+    DGDM_REQUIRE(g->n_objects > 0, DGDM_EINVAL, "dgdm_guidance_set_objects has not been called");
+    hipStream_t s = (hipStream_t)stream;
+    const int kind = g->m->kind;
+    int rc;
+    if ((rc = g->common_pre(x_dev, 0.f, object_of_chain, n_chains, s))) return rc;       // timesteps = zeros (:515,521)
+    TrunkParams p;
+    g->m->fill_trunk(&p);
+    if (kind == 3) {
+        DGDM_REQUIRE(starts_host, DGDM_EINVAL, "3-D sweep needs the FPS start indices");
+        if ((rc = g->upload_starts(starts_host, n_chains, g->Rs, s))) return rc;
+        if ((rc = g->run_xobj(object_of_chain, n_chains, g->Rs, s))) return rc;
+        p.xobj = g->xobj.as<float>();
+    }
+    p.Atab = g->atab.as<float>(); p.Ptab = g->ptab_sweep.as<float>(); p.logits = logits_dev;
+    p.B = g->B; p.C = g->G; p.tiles_per_b = g->sweep_tiles_per_b; p.ntiles = n_chains * g->B * g->sweep_tiles_per_b; p.R = g->Rs;
+    return trunk_launch(kind, false, true, p, s);
+}
+
+// ================================================================================================ PointNet++ on arbitrary rows
+namespace {
+
+struct CloudGroup { std::vector<int> rows; };
+
+// Runs the table pipeline for every distinct cloud among `rows` clouds and writes emb_dev [rows][256].
+int pointnet_rows(DgdmDynamics *m, const float *xyz_dev /*[rows][3][N]*/, const int64_t *s1, const int64_t *s2, float *emb_dev, int rows,
+                  int N, hipStream_t s) {
+    DGDM_REQUIRE(N > 0 && N <= 1024, DGDM_EINVAL, "clouds of %d points unsupported (1..1024)", N);
+    std::vector<float> host((size_t)rows * 3 * N);
+    DGDM_HIP_CHECK(hipMemcpyAsync(host.data(), xyz_dev, host.size() * 4, hipMemcpyDeviceToHost, s));
+    DGDM_HIP_CHECK(hipStreamSynchronize(s));
+    // group bit-identical clouds (cond_fn hands 512 replicas of one cloud per call, diffusion.py:491)
+    std::unordered_map<std::string, int> seen;
+    std::vector<CloudGroup> groups;
+    std::vector<int> rep;
+    for (int r = 0; r < rows; ++r) {
+        std::string key(reinterpret_cast<const char *>(host.data() + (size_t)r * 3 * N), (size_t)3 * N * 4);
+        auto it = seen.find(key);
+        int gid;
+        if (it == seen.end()) {
+            gid = (int)groups.size();
+            seen.emplace(std::move(key), gid);
+            groups.emplace_back();
+            rep.push_back(r);
+        } else {
+            gid = it->second;
+        }
+        groups[gid].rows.push_back(r);
+    }
+    const PnWeights w = m->pn();
+    DevBuf xyz, fps1, F1, U, Y, L2, Z, vlist, slotmap, starts, chains, out;
+    int rc;
+    if ((rc = xyz.alloc((size_t)N * 12)) || (rc = fps1.alloc((size_t)N * 512 * 4)) || (rc = F1.alloc((size_t)N * 512)) || (rc = U.alloc((size_t)N * 512)) ||
+        (rc = Y.alloc((size_t)N * N * 1024)) || (rc = chains.alloc(sizeof(XobjChain))))
+        return rc;
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+        const std::vector<int> &rws = groups[gi].rows;
+        std::vector<float> pts((size_t)N * 3);
+        const float *src = host.data() + (size_t)rep[gi] * 3 * N;
+        for (int i = 0; i < N; ++i) { pts[3 * i] = src[i]; pts[3 * i + 1] = src[N + i]; pts[3 * i + 2] = src[2 * N + i]; }
+        std::vector<int> slot_of(N, -1), vl, st(2 * rws.size());
+        for (size_t k = 0; k < rws.size(); ++k) {
+            const int64_t a = s1[rws[k]], b = s2[rws[k]];
+            DGDM_REQUIRE(a >= 0 && a < N && b >= 0 && b < 512, DGDM_EINVAL, "FPS start out of range");
+            if (slot_of[a] < 0) { slot_of[a] = (int)vl.size(); vl.push_back((int)a); }
+            st[2 * k] = (int)a; st[2 * k + 1] = (int)b;
+        }
+        const int nv = (int)vl.size();
+        if ((rc = xyz.upload(pts.data(), pts.size() * 4)) || (rc = vlist.upload(vl.data(), vl.size() * 4)) ||
+            (rc = slotmap.upload(slot_of.data(), slot_of.size() * 4)) || (rc = starts.upload(st.data(), st.size() * 4)) ||
+            (rc = L2.alloc((size_t)nv * N * 1024)) || (rc = Z.alloc((size_t)nv * N * 1024)) || (rc = out.alloc(rws.size() * 1024)))
+            return rc;
+        const float *x = xyz.as<float>();
+        if ((rc = pn_fps_table(x, N, N, 512, fps1.as<int>(), s))) return rc;
+        if ((rc = pn_sa1(x, N, w, F1.as<float>(), s))) return rc;
+        if ((rc = linear(F1.as<float>(), 128, w.sa2_wf_t, w.sa2_b0, nullptr, 1, U.as<float>(), 128, N, 128, 128, ACT_NONE, false, s))) return rc;
+        if ((rc = pn_pairs(x, N, U.as<float>(), w, Y.as<float>(), s))) return rc;
+        if ((rc = pn_l2(x, N, w, fps1.as<int>(), vlist.as<int>(), nv, Y.as<float>(), L2.as<float>(), s))) return rc;
+        if ((rc = pn_z(x, N, nv, w, L2.as<float>(), Z.as<float>(), s))) return rc;
+        XobjChain ch{};
+        ch.xyz = x; ch.fps1 = fps1.as<int>(); ch.slot_of_start = slotmap.as<int>(); ch.Z = Z.as<float>(); ch.N = N;
+        DGDM_HIP_CHECK(hipMemcpyAsync(chains.p, &ch, sizeof ch, hipMemcpyHostToDevice, s));
+        XobjParams xp{};
+        xp.chains = chains.as<XobjChain>(); xp.starts = starts.as<int>(); xp.xobj = out.as<float>(); xp.R = (int64_t)rws.size(); xp.total_rows = xp.R;
+        if ((rc = pn_xobj(xp, s))) return rc;
+        // scatter the group's rows back
+        bool contiguous = true;
+        for (size_t k = 1; k < rws.size(); ++k) contiguous = contiguous && rws[k] == rws[k - 1] + 1;
+        if (contiguous) {
+            DGDM_HIP_CHECK(hipMemcpyAsync(emb_dev + (size_t)rws[0] * 256, out.p, rws.size() * 1024, hipMemcpyDeviceToDevice, s));
+        } else {
+            for (size_t k = 0; k < rws.size(); ++k)
+                DGDM_HIP_CHECK(hipMemcpyAsync(emb_dev + (size_t)rws[k] * 256, out.as<float>() + k * 256, 1024, hipMemcpyDeviceToDevice, s));
+        }
+        DGDM_HIP_CHECK(hipStreamSynchronize(s));     // per-group buffers are reused by the next group
+    }
+    return DGDM_OK;
+}
+
+}  // namespace
+
+extern "C" int dgdm_pointnet2_forward(DgdmDynamics *m, const float *xyz_dev, const int64_t *start_sa1_host, const int64_t *start_sa2_host,
+                                      float *emb_dev, int rows, int N, void *stream) {
+    DGDM_REQUIRE(m && xyz_dev && start_sa1_host && start_sa2_host && emb_dev && rows >= 0, DGDM_EINVAL, "dgdm_pointnet2_forward: bad argument");
+    if (m->kind != 3) { set_error("model type not supported: PointNet++ belongs to the 3-D model"); return DGDM_EMODE; }
+    if (rows == 0) return DGDM_OK;
+    return pointnet_rows(m, xyz_dev, start_sa1_host, start_sa2_host, emb_dev, rows, N, (hipStream_t)stream);
+}
+
+extern "C" int dgdm_dyn3d_forward(DgdmDynamics *m, const float *x_ctrl, const float *x_ori, const float *x_pos, const float *t,
+                                  const float *xyz, const int64_t *start_sa1_host, const int64_t *start_sa2_host, float *logits, int rows,
+                                  int N, void *stream) {
+    DGDM_REQUIRE(m && x_ctrl && x_ori && x_pos && t && xyz && start_sa1_host && start_sa2_host && logits && rows >= 0, DGDM_EINVAL,
+                 "dgdm_dyn3d_forward: bad argument");
+    if (m->kind != 3) { set_error("model type not supported: dgdm_dyn3d_forward on a 2-D model"); return DGDM_EMODE; }
+    if (rows == 0) return DGDM_OK;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    // workspace: V, GENC [rows][256] | pose [rows][32] | tmp [rows][768] | z1 [rows][512] | xobj [rows][256]
+    const size_t need = (size_t)rows * (256 + 256 + 32 + 768 + 512 + 256) * sizeof(float);
+    if ((rc = m->ws.alloc(need))) return rc;
+    float *V = m->ws.as<float>(), *genc = V + (size_t)rows * 256, *pose = genc + (size_t)rows * 256, *tmp = pose + (size_t)rows * 32,
+          *z1 = tmp + (size_t)rows * 768, *xo = z1 + (size_t)rows * 512;
+    if ((rc = pointnet_rows(m, xyz, start_sa1_host, start_sa2_host, xo, rows, N, s))) return rc;
+    if ((rc = m->time_part(t, 0.f, tmp, z1, rows, s))) return rc;
+    // x_ctrl[:, 1, :]  (profile_forward_3d.py:78): rows of length L at stride 3L, offset L
+    if ((rc = m->gripper_forward(x_ctrl + m->L, 3 * m->L, V, genc, rows, s))) return rc;
+    if ((rc = linear(genc, 256, m->blob.at(m->off.w1c_wt), nullptr, nullptr, 1, z1, 512, rows, 256, 512, ACT_NONE, true, s))) return rc;
+    if ((rc = pose_embed(x_ori, x_pos, pose, rows, s))) return rc;
+    if ((rc = linear(pose, 27, m->blob.at(m->off.w1p_wt), nullptr, nullptr, 1, z1, 512, rows, 27, 512, ACT_NONE, true, s))) return rc;
+    TrunkParams p;
+    m->fill_trunk(&p);
+    p.Atab = z1; p.xobj = xo; p.logits = logits; p.C = rows; p.R = rows; p.B = 1; p.tiles_per_b = 1; p.ntiles = (rows + 31) / 32;
+    return trunk_launch(3, true, true, p, s);
+}

@@ -1,0 +1,208 @@
+// Register-resident MLP chains on v_mfma_f32_32x32x2_f32 (gfx950).
+//
+// One wave owns 32 batch rows.  An activation matrix H [F features x 32 rows] lives in
+// F/32 blocks of 16 VGPRs in the MFMA C/D layout:
+//
+//   block o, register r, lane l (n = l & 31, h = l >> 5)   <->   H[32 o + rho(r,h)][row n],
+//   rho(r,h) = (r & 3) + 8 (r >> 2) + 4 h
+//
+// A layer is computed transposed, D[out x rows] += W[out x in] * H[in x rows], with the weights as
+// the MFMA A operand and the activations as the B operand.  B of 32x32x2 wants lane (n,h) to supply
+// H[k_h][n] for the two k of the step - and register (o,r) of that lane already holds
+// H[32 o + rho(r,0)][n] in the lower half-wave and H[32 o + rho(r,1)][n] in the upper one.  So the
+// K-step (o,r) contracts over exactly that feature pair: the previous layer's accumulators ARE the
+// next layer's B operands.  Activations never leave the VGPRs, there is no LDS traffic and no
+// barrier between layers; only the weights stream (L2-resident, one coalesced 1 KiB load per 4 MFMAs).
+//
+// Weight image (host side: dgdm::pack_chain): for A, lane (i = l & 31, h) needs W[32 o' + i][32 o + rho(r,h)].
+// Registers r = 4q..4q+3 are four consecutive input features, so one float4 per lane serves 4 MFMAs:
+//   img[((o' * KB + o) * 4 + q) * 64 + l] = W[32 o' + i][32 o + 8 q + 4 h + {0,1,2,3}]
+//
+// The same image format with W^T gives the input-gradient pass G_in = W^T G_out.
+// Numerics: every output is a k-ordered float32 fma chain (exact f32, no reduced precision).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dgdm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// float4 holding features 32 o + 8 q + 4 h + {0..3} of a row-major feature vector
+__device__ __forceinline__ float4 feat4(const float *__restrict__ row, int o, int q, int h4) {
+    return *reinterpret_cast<const float4 *>(row + 32 * o + 8 * q + h4);
+}
+
+// Depth of the software prefetch ring on the weight stream: one float4 per lane feeds 4 MFMAs
+// (256 cycles), so DEPTH entries cover DEPTH*256 cycles of L2 latency with one wave per SIMD.
+#ifndef DGDM_CHAIN_DEPTH
+#define DGDM_CHAIN_DEPTH 8
+#endif
+
+// Weight images are read through a buffer descriptor (wave-uniform base in SGPRs, per-lane byte
+// offset lane*16 in ONE VGPR, entry offset as scalar/immediate): no 64-bit per-load address math in
+// VGPRs, which is what lets the compiler keep a deep prefetch ring beside 128 operand registers.
+typedef __amdgpu_buffer_rsrc_t wrsrc_t;
+
+__device__ __forceinline__ wrsrc_t weight_rsrc(const float4 *base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(base), 0, (int)bytes, 0x00020000);
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 wload(wrsrc_t rs, int voff, int soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    float4 f;
+    f.x = __builtin_bit_cast(float, v.x); f.y = __builtin_bit_cast(float, v.y);
+    f.z = __builtin_bit_cast(float, v.z); f.w = __builtin_bit_cast(float, v.w);
+    return f;
+}
+
+// Streams `TOTAL` consecutive float4-per-lane weight entries (1 KiB apart) starting at byte offset
+// `base_off` of the image and feeds them to `body(i, a)` in order, keeping DGDM_CHAIN_DEPTH loads in flight.
+template <int TOTAL, class Body>
+__device__ __forceinline__ void stream_weights(wrsrc_t rs, int voff, int base_off, Body &&body) {
+    constexpr int D = DGDM_CHAIN_DEPTH < TOTAL ? DGDM_CHAIN_DEPTH : TOTAL;
+    float4 ring[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) ring[i] = wload(rs, voff, base_off + i * 1024);
+#pragma unroll
+    for (int i = 0; i < TOTAL; ++i) {
+        const float4 a = ring[i % D];
+        if (i + D < TOTAL) ring[i % D] = wload(rs, voff, base_off + (i + D) * 1024);
+        body(i, a);
+        // pin the step: [wait entry i | 4 MFMA | issue entry i+D].  Left alone, hipcc's scheduler
+        // sinks the loads next to their uses over long stretches (vmcnt(1) instead of vmcnt(D-1)).
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+enum { CHAIN_ZERO = 0, CHAIN_BIAS = 1, CHAIN_KEEP = 2 };
+
+// out[MB] (+)= W * in[KB].  Wp: chain image of W [32 MB x 32 KB]; INIT selects the accumulator start:
+// zero, the bias vector [32 MB], or whatever the caller already put into out[].
+template <int KB, int MB, int INIT>
+__device__ __forceinline__ void chain_layer(const float4 *__restrict__ Wp, const float *__restrict__ bias,
+                                            const f32x16 (&in)[KB], f32x16 (&out)[MB], int lane) {
+    const int h4 = (lane >> 5) * 4;
+    if (INIT != CHAIN_KEEP) {
+#pragma unroll
+        for (int op = 0; op < MB; ++op) {
+            if (INIT == CHAIN_BIAS) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b4 = feat4(bias, op, q, h4);
+                    out[op][4 * q + 0] = b4.x; out[op][4 * q + 1] = b4.y; out[op][4 * q + 2] = b4.z; out[op][4 * q + 3] = b4.w;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) out[op][r] = 0.f;
+            }
+        }
+    }
+    stream_weights<MB * KB * 4>(weight_rsrc(Wp, MB * KB * 4 * 1024), lane * 16, 0, [&](int i, const float4 a) {
+        const int op = i / (KB * 4), o = (i / 4) % KB, q = i % 4;
+        out[op] = mfma32(a.x, in[o][4 * q + 0], out[op]);
+        out[op] = mfma32(a.y, in[o][4 * q + 1], out[op]);
+        out[op] = mfma32(a.z, in[o][4 * q + 2], out[op]);
+        out[op] = mfma32(a.w, in[o][4 * q + 3], out[op]);
+    });
+}
+
+// One output block only (used when a wide layer is streamed block by block).
+template <int KB, bool BIAS>
+__device__ __forceinline__ f32x16 chain_block(const float4 *__restrict__ Wp_block, const float *__restrict__ bias_block,
+                                              const f32x16 (&in)[KB], int lane) {
+    const int h4 = (lane >> 5) * 4;
+    f32x16 acc;
+    if (BIAS) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 b4 = feat4(bias_block, 0, q, h4);
+            acc[4 * q + 0] = b4.x; acc[4 * q + 1] = b4.y; acc[4 * q + 2] = b4.z; acc[4 * q + 3] = b4.w;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    }
+    stream_weights<KB * 4>(weight_rsrc(Wp_block, KB * 4 * 1024), lane * 16, 0, [&](int i, const float4 a) {
+        const int o = i / 4, q = i % 4;
+        acc = mfma32(a.x, in[o][4 * q + 0], acc);
+        acc = mfma32(a.y, in[o][4 * q + 1], acc);
+        acc = mfma32(a.z, in[o][4 * q + 2], acc);
+        acc = mfma32(a.w, in[o][4 * q + 3], acc);
+    });
+    return acc;
+}
+
+// acc[MB] += W[:, block kb] * x   for one 32-feature input block x (16 K-steps).
+// Wp is the image of the full [32 MB x 32 KBtot] matrix; kb selects the input block.
+template <int MB>
+__device__ __forceinline__ void chain_accumulate_block(const float4 *__restrict__ Wp, int KBtot, int kb, const f32x16 &x,
+                                                       f32x16 (&acc)[MB], int lane) {
+    const wrsrc_t rs = weight_rsrc(Wp, (uint32_t)MB * KBtot * 4 * 1024);
+    const int voff = lane * 16;
+    float4 a[MB * 4];
+#pragma unroll
+    for (int op = 0; op < MB; ++op)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[op * 4 + q] = wload(rs, voff, ((op * KBtot + kb) * 4 + q) * 1024);
+#pragma unroll
+    for (int op = 0; op < MB; ++op) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 w = a[op * 4 + q];
+            acc[op] = mfma32(w.x, x[4 * q + 0], acc[op]);
+            acc[op] = mfma32(w.y, x[4 * q + 1], acc[op]);
+            acc[op] = mfma32(w.z, x[4 * q + 2], acc[op]);
+            acc[op] = mfma32(w.w, x[4 * q + 3], acc[op]);
+        }
+    }
+}
+
+// ReLU in place; returns the sign bits (bit r set <=> x[r] > 0), torch's relu'(0) = 0.
+__device__ __forceinline__ uint32_t relu_bits(f32x16 &x) {
+    uint32_t bits = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const bool pos = x[r] > 0.f;
+        bits |= pos ? (1u << r) : 0u;
+        x[r] = pos ? x[r] : 0.f;
+    }
+    return bits;
+}
+
+__device__ __forceinline__ void apply_bits(f32x16 &g, uint32_t bits) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g[r] = ((bits >> r) & 1u) ? g[r] : 0.f;
+}
+
+template <int NB>
+__device__ __forceinline__ void relu_mask(f32x16 (&x)[NB], uint32_t (&m)[NB / 2]) {
+#pragma unroll
+    for (int o = 0; o < NB; o += 2) m[o / 2] = relu_bits(x[o]) | (relu_bits(x[o + 1]) << 16);
+}
+
+template <int NB>
+__device__ __forceinline__ void apply_mask(f32x16 (&g)[NB], const uint32_t (&m)[NB / 2]) {
+#pragma unroll
+    for (int o = 0; o < NB; o += 2) {
+        apply_bits(g[o], m[o / 2] & 0xffffu);
+        apply_bits(g[o + 1], m[o / 2] >> 16);
+    }
+}
+
+// Sum over the 32 rows of the tile: afterwards every lane of a half-wave holds sum_n x[.][n].
+__device__ __forceinline__ float rows_sum(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 16);
+    return v;
+}
+
+}  // namespace dgdm

@@ -1,0 +1,39 @@
+#pragma once
+#include "common.h"
+#include "blob.h"
+#include "unet.h"
+#include "trunk.h"
+#include "pointnet.h"
+#include "smallnet.h"
+#include <memory>
+
+struct DgdmUnet1d {
+    dgdm::Blob blob;
+    dgdm::UnetParams p;
+};
+
+namespace dgdm {
+struct DynOff {   // offsets (floats) into the blob
+    size_t g0_wt, g0_b, g0_w, g2_wt, g2_b, g2_w;
+    size_t w1c_wt, w1c_w, w1p_wt, w1t_wt, b1, w1o_wt, w1o_img;
+    size_t w2f_img, b2, w2b_img;
+    size_t wf[8], bf[8], wb[8];
+    size_t wout, bout;
+    size_t te0_wt, te0_b, te2_wt, te2_b, oe0_wt, oe0_b, oe2_wt, oe2_b, tfreq;
+    size_t sa1_w0t, sa1_b0, sa1_w1, sa1_b1, sa2_wf_t, sa2_b0, sa2_vx, sa2_w1_img, sa2_b1, sa3_w_img, sa3_wx, sa3_b;
+};
+}  // namespace dgdm
+
+struct DgdmDynamics {
+    int kind = 0, L = 0, object_ch = 0, W1 = 256, n_mid = 7, thalf = 64;
+    dgdm::Blob blob;
+    dgdm::DynOff off{};
+    dgdm::DevBuf ws;        // grow-only workspace of the plain forward entry points
+    dgdm::DevBuf ws2;
+
+    void fill_trunk(dgdm::TrunkParams *p) const;
+    dgdm::PnWeights pn() const;
+    int gripper_forward(const float *x, int ldx, float *V, float *genc, int rows, hipStream_t s) const;
+    int time_part(const float *t_dev, float t_scalar, float *tmp, float *out, int rows, hipStream_t s) const;
+    int object_part_2d(const float *obj, float *tmp, float *out, int n, bool accumulate, hipStream_t s) const;
+};

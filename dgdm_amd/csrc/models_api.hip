@@ -1,0 +1,316 @@
+// Model handles: weight packing/upload and the plain forward entry points of the C-ABI.
+#include "common.h"
+#include "blob.h"
+#include "models.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+using namespace dgdm;
+
+// ================================================================================================ U-Net
+namespace {
+
+// torch Conv1d weight [Cout][Cin][KW] -> [(ci*KW + k)*Cout + co]
+std::vector<float> conv_ckn(const float *w, int cout, int cin, int kw) {
+    std::vector<float> o((size_t)cout * cin * kw);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int k = 0; k < kw; ++k) o[((size_t)ci * kw + k) * cout + co] = w[((size_t)co * cin + ci) * kw + k];
+    return o;
+}
+
+// torch ConvTranspose1d weight [Cin][Cout][KW] -> [(ci*KW + k)*Cout + co]
+std::vector<float> convT_ckn(const float *w, int cin, int cout, int kw) {
+    std::vector<float> o((size_t)cout * cin * kw);
+    for (int ci = 0; ci < cin; ++ci)
+        for (int co = 0; co < cout; ++co)
+            for (int k = 0; k < kw; ++k) o[((size_t)ci * kw + k) * cout + co] = w[((size_t)ci * cout + co) * kw + k];
+    return o;
+}
+
+struct ResOff { size_t c0w, c0b, g0w, g0b, c1w, c1b, g1w, g1b, cw, cb, rw, rb; bool has_res; int cin, cout; };
+
+int pack_res(const StateDict &sd, Blob &bl, const std::string &p, int cin, int cout, int cond, int kw, ResOff *o) {
+    auto vec = [&](const std::string &k, int64_t n, size_t *off) -> int {
+        const float *d = sd.f32(k, n);
+        if (!d) return DGDM_EKEY;
+        *off = bl.add(d, (size_t)n);
+        return DGDM_OK;
+    };
+    o->cin = cin; o->cout = cout;
+    const float *w;
+    if (!(w = sd.f32(p + ".blocks.0.block.0.weight", (int64_t)cout * cin * kw))) return DGDM_EKEY;
+    o->c0w = bl.add(conv_ckn(w, cout, cin, kw));
+    if (!(w = sd.f32(p + ".blocks.1.block.0.weight", (int64_t)cout * cout * kw))) return DGDM_EKEY;
+    o->c1w = bl.add(conv_ckn(w, cout, cout, kw));
+    int rc;
+    if ((rc = vec(p + ".blocks.0.block.0.bias", cout, &o->c0b))) return rc;
+    if ((rc = vec(p + ".blocks.0.block.1.weight", cout, &o->g0w))) return rc;
+    if ((rc = vec(p + ".blocks.0.block.1.bias", cout, &o->g0b))) return rc;
+    if ((rc = vec(p + ".blocks.1.block.0.bias", cout, &o->c1b))) return rc;
+    if ((rc = vec(p + ".blocks.1.block.1.weight", cout, &o->g1w))) return rc;
+    if ((rc = vec(p + ".blocks.1.block.1.bias", cout, &o->g1b))) return rc;
+    if (!(w = sd.f32(p + ".cond_encoder.1.weight", (int64_t)2 * cout * cond))) return DGDM_EKEY;
+    o->cw = bl.add(transpose(w, 2 * cout, cond));
+    if ((rc = vec(p + ".cond_encoder.1.bias", 2 * cout, &o->cb))) return rc;
+    o->has_res = cin != cout;
+    if (o->has_res) {
+        if (!(w = sd.f32(p + ".residual_conv.weight", (int64_t)cout * cin))) return DGDM_EKEY;
+        o->rw = bl.add(conv_ckn(w, cout, cin, 1));
+        if ((rc = vec(p + ".residual_conv.bias", cout, &o->rb))) return rc;
+    }
+    return DGDM_OK;
+}
+
+}  // namespace
+
+extern "C" int dgdm_unet1d_create(DgdmUnet1d **out, const DgdmTensor *tensors, int n_tensors, const int32_t *down_dims, int n_down,
+                                  int dsed, int kernel_size, int n_groups) {
+    DGDM_REQUIRE(out && tensors && down_dims, DGDM_EINVAL, "dgdm_unet1d_create: null argument");
+    DGDM_REQUIRE(n_down == 2, DGDM_EINVAL, "only two-level U-Nets (len(down_dims) == 2, as generator/train.py:80 builds) are supported, got %d", n_down);
+    DGDM_REQUIRE(kernel_size == 5, DGDM_EINVAL, "kernel_size %d unsupported (reference uses 5)", kernel_size);
+    const int d0 = down_dims[0], d1 = down_dims[1];
+    DGDM_REQUIRE(d0 % n_groups == 0 && d1 % n_groups == 0 && dsed % 2 == 0 && dsed >= 4, DGDM_EINVAL, "bad U-Net dims");
+    StateDict sd(tensors, n_tensors);
+    std::unique_ptr<DgdmUnet1d> m(new DgdmUnet1d());
+    Blob &bl = m->blob;
+    ResOff ro[8];
+    const struct { const char *name; int cin, cout; } spec[8] = {
+        {"down_modules.0.0", 1, d0}, {"down_modules.0.1", d0, d0}, {"down_modules.1.0", d0, d1}, {"down_modules.1.1", d1, d1},
+        {"mid_modules.0", d1, d1}, {"mid_modules.1", d1, d1}, {"up_modules.0.0", 2 * d1, d0}, {"up_modules.0.1", d0, d0}};
+    int rc;
+    for (int i = 0; i < 8; ++i)
+        if ((rc = pack_res(sd, bl, spec[i].name, spec[i].cin, spec[i].cout, dsed, kernel_size, &ro[i]))) return rc;
+    const float *w, *b;
+    // diffusion_step_encoder
+    std::vector<float> fr(dsed / 2);
+    {   // SinusoidalPosEmb (diffusion_utils.py:32-34): exp(arange(half) * -(log(10000)/(half-1))) in float32
+        const int half = dsed / 2;
+        const float e = -(float)(std::log(10000.0) / (half - 1));
+        for (int i = 0; i < half; ++i) fr[i] = expf((float)i * e);
+    }
+    const size_t o_fr = bl.add(fr);
+    if (!(w = sd.f32("diffusion_step_encoder.1.weight", (int64_t)4 * dsed * dsed)) || !(b = sd.f32("diffusion_step_encoder.1.bias", 4 * dsed))) return DGDM_EKEY;
+    const size_t o_s1w = bl.add(transpose(w, 4 * dsed, dsed)), o_s1b = bl.add(b, 4 * dsed);
+    if (!(w = sd.f32("diffusion_step_encoder.3.weight", (int64_t)4 * dsed * dsed)) || !(b = sd.f32("diffusion_step_encoder.3.bias", dsed))) return DGDM_EKEY;
+    const size_t o_s3w = bl.add(transpose(w, dsed, 4 * dsed)), o_s3b = bl.add(b, dsed);
+    if (!(w = sd.f32("down_modules.0.2.conv.weight", (int64_t)d0 * d0 * 3)) || !(b = sd.f32("down_modules.0.2.conv.bias", d0))) return DGDM_EKEY;
+    const size_t o_dw = bl.add(conv_ckn(w, d0, d0, 3)), o_db = bl.add(b, d0);
+    if (!(w = sd.f32("up_modules.0.2.conv.weight", (int64_t)d0 * d0 * 4)) || !(b = sd.f32("up_modules.0.2.conv.bias", d0))) return DGDM_EKEY;
+    const size_t o_uw = bl.add(convT_ckn(w, d0, d0, 4)), o_ub = bl.add(b, d0);
+    if (!(w = sd.f32("final_conv.0.block.0.weight", (int64_t)d0 * d0 * kernel_size)) || !(b = sd.f32("final_conv.0.block.0.bias", d0))) return DGDM_EKEY;
+    const size_t o_fw = bl.add(conv_ckn(w, d0, d0, kernel_size)), o_fb = bl.add(b, d0);
+    const float *gw, *gb;
+    if (!(gw = sd.f32("final_conv.0.block.1.weight", d0)) || !(gb = sd.f32("final_conv.0.block.1.bias", d0))) return DGDM_EKEY;
+    const size_t o_fgw = bl.add(gw, d0), o_fgb = bl.add(gb, d0);
+    if (!(w = sd.f32("final_conv.1.weight", d0)) || !(b = sd.f32("final_conv.1.bias", 1))) return DGDM_EKEY;
+    const size_t o_ow = bl.add(w, d0), o_ob = bl.add(b, 1);
+    if ((rc = bl.upload())) return rc;
+
+    UnetParams &p = m->p;
+    memset(&p, 0, sizeof p);
+    p.d0 = d0; p.d1 = d1; p.dsed = dsed; p.groups = n_groups; p.cmax = std::max(d0, d1);
+    p.freqs = bl.at(o_fr);
+    p.se1_wt = bl.at(o_s1w); p.se1_b = bl.at(o_s1b); p.se3_wt = bl.at(o_s3w); p.se3_b = bl.at(o_s3b);
+    for (int i = 0; i < 8; ++i) {
+        UnetRes &r = p.res[i];
+        r.cin = ro[i].cin; r.cout = ro[i].cout;
+        r.c0_w = bl.at(ro[i].c0w); r.c0_b = bl.at(ro[i].c0b); r.g0_w = bl.at(ro[i].g0w); r.g0_b = bl.at(ro[i].g0b);
+        r.c1_w = bl.at(ro[i].c1w); r.c1_b = bl.at(ro[i].c1b); r.g1_w = bl.at(ro[i].g1w); r.g1_b = bl.at(ro[i].g1b);
+        r.cond_wt = bl.at(ro[i].cw); r.cond_b = bl.at(ro[i].cb);
+        r.res_w = ro[i].has_res ? bl.at(ro[i].rw) : nullptr;
+        r.res_b = ro[i].has_res ? bl.at(ro[i].rb) : nullptr;
+    }
+    p.down_w = bl.at(o_dw); p.down_b = bl.at(o_db); p.up_w = bl.at(o_uw); p.up_b = bl.at(o_ub);
+    p.fin_w = bl.at(o_fw); p.fin_b = bl.at(o_fb); p.fin_gw = bl.at(o_fgw); p.fin_gb = bl.at(o_fgb);
+    p.out_w = bl.at(o_ow); p.out_b = bl.at(o_ob);
+    *out = m.release();
+    return DGDM_OK;
+}
+
+extern "C" void dgdm_unet1d_destroy(DgdmUnet1d *m) { delete m; }
+
+extern "C" int dgdm_unet1d_forward(DgdmUnet1d *m, const float *sample_dev, const int32_t *timestep_dev, float *eps_dev, int B, int L,
+                                   void *stream) {
+    DGDM_REQUIRE(m && sample_dev && timestep_dev && eps_dev && B >= 0 && L > 0, DGDM_EINVAL, "dgdm_unet1d_forward: bad argument");
+    return unet_launch(m->p, sample_dev, timestep_dev, eps_dev, B, L, (hipStream_t)stream);
+}
+
+// ================================================================================================ dynamics
+namespace {
+
+// columns [c0, c0+n) of a row-major [rows][cols] matrix -> row-major [rows][n]
+std::vector<float> cols(const std::vector<float> &w, int rows, int ncols, int c0, int n) {
+    std::vector<float> o((size_t)rows * n);
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < n; ++c) o[(size_t)r * n + c] = w[(size_t)r * ncols + c0 + c];
+    return o;
+}
+
+std::vector<float> tfreqs(int half) {
+    // timestep_embedding (profile_forward_2d.py:68-71): exp(-log(10000) * arange(half, f32) / half), float32 ops
+    std::vector<float> f(half);
+    const float l = -(float)std::log(10000.0);
+    for (int i = 0; i < half; ++i) f[i] = expf(l * (float)i / (float)half);
+    return f;
+}
+
+}  // namespace
+
+extern "C" int dgdm_dynamics_create(DgdmDynamics **out, int kind, const DgdmTensor *tensors, int n_tensors, int params_ch, int object_ch) {
+    DGDM_REQUIRE(out && tensors, DGDM_EINVAL, "dgdm_dynamics_create: null argument");
+    if (kind != 2 && kind != 3) { set_error("model type not supported: kind %d", kind); return DGDM_EMODE; }
+    DGDM_REQUIRE(params_ch > 0 && params_ch <= 256, DGDM_EINVAL, "params_ch %d unsupported", params_ch);
+    StateDict sd(tensors, n_tensors);
+    std::unique_ptr<DgdmDynamics> m(new DgdmDynamics());
+    m->kind = kind; m->L = params_ch; m->object_ch = object_ch; m->W1 = kind == 3 ? 512 : 256;
+    const int W = 256, W1 = m->W1, IN1 = 3 * W + 27;
+    Blob &bl = m->blob;
+    int rc;
+    Folded g0, g2, l1, lout;
+    if ((rc = fold_linear(sd, "gripper_encoder.0", "", W, params_ch, &g0))) return rc;
+    if ((rc = fold_linear(sd, "gripper_encoder.2", "", W, W, &g2))) return rc;
+    if ((rc = fold_linear(sd, "linears.0", "linears.1", W1, IN1, &l1))) return rc;
+    if ((rc = fold_linear(sd, "output", "", 3, W, &lout))) return rc;
+    DynOff &o = m->off;
+    o.g0_wt = bl.add(transpose(g0.w.data(), W, params_ch)); o.g0_b = bl.add(g0.b); o.g0_w = bl.add(g0.w);
+    o.g2_wt = bl.add(transpose(g2.w.data(), W, W)); o.g2_b = bl.add(g2.b); o.g2_w = bl.add(g2.w);
+    // first trunk layer: concat order [x_object | x_ctrl | x_pose | time_emb]  (profile_forward_2d.py:154, _3d.py:84)
+    const std::vector<float> w1o = cols(l1.w, W1, IN1, 0, W), w1c = cols(l1.w, W1, IN1, W, W), w1p = cols(l1.w, W1, IN1, 2 * W, 27),
+                             w1t = cols(l1.w, W1, IN1, 2 * W + 27, W);
+    o.w1c_wt = bl.add(transpose(w1c.data(), W1, W)); o.w1c_w = bl.add(w1c);
+    o.w1p_wt = bl.add(transpose(w1p.data(), W1, 27));
+    o.w1t_wt = bl.add(transpose(w1t.data(), W1, W));
+    o.b1 = bl.add(l1.b);
+    o.wout = bl.add(lout.w); o.bout = bl.add(lout.b);
+    int first_mid = 1;
+    if (kind == 2) {
+        o.w1o_wt = bl.add(transpose(w1o.data(), W1, W));
+        Folded t0, t2, e0, e2;
+        if ((rc = fold_linear(sd, "time_encoder.0", "", W, W / 2, &t0))) return rc;
+        if ((rc = fold_linear(sd, "time_encoder.2", "", W, W, &t2))) return rc;
+        if ((rc = fold_linear(sd, "object_encoder.0", "", W, object_ch, &e0))) return rc;
+        if ((rc = fold_linear(sd, "object_encoder.2", "", W, W, &e2))) return rc;
+        o.te0_wt = bl.add(transpose(t0.w.data(), W, W / 2)); o.te0_b = bl.add(t0.b);
+        o.te2_wt = bl.add(transpose(t2.w.data(), W, W)); o.te2_b = bl.add(t2.b);
+        o.oe0_wt = bl.add(transpose(e0.w.data(), W, object_ch)); o.oe0_b = bl.add(e0.b);
+        o.oe2_wt = bl.add(transpose(e2.w.data(), W, W)); o.oe2_b = bl.add(e2.b);
+        o.tfreq = bl.add(tfreqs(W / 4));
+        m->thalf = W / 4;
+    } else {
+        o.w1o_img = bl.add(pack_chain(w1o.data(), W1, W));
+        Folded l2;
+        if ((rc = fold_linear(sd, "linears.3", "linears.4", W, W1, &l2))) return rc;
+        o.w2f_img = bl.add(pack_chain(l2.w.data(), W, W1));
+        o.b2 = bl.add(l2.b);
+        o.w2b_img = bl.add(pack_chain(transpose(l2.w.data(), W, W1).data(), W1, W));
+        o.tfreq = bl.add(tfreqs(W / 2));
+        m->thalf = W / 2;
+        first_mid = 2;
+        // PointNet++ (pointnet2.py:17-19); Conv2d 1x1 weights are [out][in][1][1]
+        Folded a0, a1, b0, b1, c0;
+        if ((rc = fold_linear(sd, "object_encoder.sa1.mlp_convs.0", "object_encoder.sa1.mlp_bns.0", 64, 3, &a0))) return rc;
+        if ((rc = fold_linear(sd, "object_encoder.sa1.mlp_convs.1", "object_encoder.sa1.mlp_bns.1", 128, 64, &a1))) return rc;
+        if ((rc = fold_linear(sd, "object_encoder.sa2.mlp_convs.0", "object_encoder.sa2.mlp_bns.0", 128, 131, &b0))) return rc;
+        if ((rc = fold_linear(sd, "object_encoder.sa2.mlp_convs.1", "object_encoder.sa2.mlp_bns.1", 256, 128, &b1))) return rc;
+        if ((rc = fold_linear(sd, "object_encoder.sa3.mlp_convs.0", "object_encoder.sa3.mlp_bns.0", 256, 259, &c0))) return rc;
+        o.sa1_w0t = bl.add(transpose(a0.w.data(), 64, 3)); o.sa1_b0 = bl.add(a0.b);
+        o.sa1_w1 = bl.add(a1.w); o.sa1_b1 = bl.add(a1.b);
+        o.sa2_wf_t = bl.add(transpose(cols(b0.w, 128, 131, 3, 128).data(), 128, 128)); o.sa2_b0 = bl.add(b0.b);
+        o.sa2_vx = bl.add(transpose(cols(b0.w, 128, 131, 0, 3).data(), 128, 3));
+        o.sa2_w1_img = bl.add(pack_chain(b1.w.data(), 256, 128)); o.sa2_b1 = bl.add(b1.b);
+        o.sa3_w_img = bl.add(pack_chain(cols(c0.w, 256, 259, 3, 256).data(), 256, 256));
+        o.sa3_wx = bl.add(transpose(cols(c0.w, 256, 259, 0, 3).data(), 256, 3)); o.sa3_b = bl.add(c0.b);
+    }
+    m->n_mid = 8 - first_mid;
+    for (int i = 0; i < m->n_mid; ++i) {
+        const int li = 3 * (first_mid + i);
+        Folded f;
+        if ((rc = fold_linear(sd, "linears." + std::to_string(li), "linears." + std::to_string(li + 1), W, W, &f))) return rc;
+        o.wf[i] = bl.add(pack_chain(f.w.data(), W, W));
+        o.bf[i] = bl.add(f.b);
+        o.wb[i] = bl.add(pack_chain(transpose(f.w.data(), W, W).data(), W, W));
+    }
+    if ((rc = bl.upload())) return rc;
+    *out = m.release();
+    return DGDM_OK;
+}
+
+extern "C" void dgdm_dynamics_destroy(DgdmDynamics *m) { delete m; }
+
+void DgdmDynamics::fill_trunk(TrunkParams *p) const {
+    memset(p, 0, sizeof *p);
+    for (int i = 0; i < n_mid; ++i) { p->Wf[i] = blob.at4(off.wf[i]); p->bf[i] = blob.at(off.bf[i]); p->Wb[i] = blob.at4(off.wb[i]); }
+    p->n_mid = n_mid;
+    p->Wout = blob.at(off.wout); p->bout = blob.at(off.bout);
+    if (kind == 3) {
+        p->W1o = blob.at4(off.w1o_img); p->W2f = blob.at4(off.w2f_img); p->b2 = blob.at(off.b2); p->W2b = blob.at4(off.w2b_img);
+    }
+}
+
+PnWeights DgdmDynamics::pn() const {
+    PnWeights w{};
+    w.r1sq = (float)(0.2 * 0.2);     // `radius ** 2` is a Python double; torch compares it with float32 distances as float32
+    w.r2sq = (float)(0.4 * 0.4);
+    w.sa1_w0t = blob.at(off.sa1_w0t); w.sa1_b0 = blob.at(off.sa1_b0); w.sa1_w1 = blob.at(off.sa1_w1); w.sa1_b1 = blob.at(off.sa1_b1);
+    w.sa2_wf_t = blob.at(off.sa2_wf_t); w.sa2_b0 = blob.at(off.sa2_b0); w.sa2_vx = blob.at(off.sa2_vx);
+    w.sa2_w1_img = blob.at4(off.sa2_w1_img); w.sa2_b1 = blob.at(off.sa2_b1);
+    w.sa3_w_img = blob.at4(off.sa3_w_img); w.sa3_wx = blob.at(off.sa3_wx); w.sa3_b = blob.at(off.sa3_b);
+    return w;
+}
+
+// gripper encoder forward on `rows` fingers: V = relu(g0 x + b), GENC = g2 V + b   (profile_forward_2d.py:103-107,148)
+int DgdmDynamics::gripper_forward(const float *x, int ldx, float *V, float *genc, int rows, hipStream_t s) const {
+    int rc;
+    if ((rc = linear(x, ldx, blob.at(off.g0_wt), blob.at(off.g0_b), nullptr, 1, V, 256, rows, L, 256, ACT_RELU, false, s))) return rc;
+    return linear(V, 256, blob.at(off.g2_wt), blob.at(off.g2_b), nullptr, 1, genc, 256, rows, 256, 256, ACT_NONE, false, s);
+}
+
+// out[rows][W1] = W1'[:, time part] * time_feature(t) + b1'.  t_dev per row, or the scalar t_scalar for one row.
+int DgdmDynamics::time_part(const float *t_dev, float t_scalar, float *tmp /*rows*768*/, float *out, int rows, hipStream_t s) const {
+    int rc;
+    float *emb = tmp, *h = tmp + (size_t)rows * 256, *enc = tmp + (size_t)rows * 512;
+    if ((rc = time_embed(t_dev, t_scalar, blob.at(off.tfreq), emb, rows, thalf, s))) return rc;
+    const float *feat = emb;
+    if (kind == 2) {       // time_encoder: Linear -> SiLU -> Linear (profile_forward_2d.py:92-96,153); the 3-D model feeds the raw embedding (_3d.py:83)
+        if ((rc = linear(emb, 2 * thalf, blob.at(off.te0_wt), blob.at(off.te0_b), nullptr, 1, h, 256, rows, 2 * thalf, 256, ACT_SILU, false, s))) return rc;
+        if ((rc = linear(h, 256, blob.at(off.te2_wt), blob.at(off.te2_b), nullptr, 1, enc, 256, rows, 256, 256, ACT_NONE, false, s))) return rc;
+        feat = enc;
+    }
+    return linear(feat, 256, blob.at(off.w1t_wt), blob.at(off.b1), nullptr, 1, out, W1, rows, 256, W1, ACT_NONE, false, s);
+}
+
+// 2-D object encoder + first-layer object part: out[n][W1] = W1'[:, object part] * oenc(obj)
+int DgdmDynamics::object_part_2d(const float *obj, float *tmp /*n*512*/, float *out, int n, bool accumulate, hipStream_t s) const {
+    int rc;
+    float *h = tmp, *e = tmp + (size_t)n * 256;
+    if ((rc = linear(obj, object_ch, blob.at(off.oe0_wt), blob.at(off.oe0_b), nullptr, 1, h, 256, n, object_ch, 256, ACT_RELU, false, s))) return rc;
+    if ((rc = linear(h, 256, blob.at(off.oe2_wt), blob.at(off.oe2_b), nullptr, 1, e, 256, n, 256, 256, ACT_NONE, false, s))) return rc;
+    return linear(e, 256, blob.at(off.w1o_wt), nullptr, nullptr, 1, out, W1, n, 256, W1, ACT_NONE, accumulate, s);
+}
+
+// ProfileForward2DModel.forward on arbitrary rows
+extern "C" int dgdm_dyn2d_forward(DgdmDynamics *m, const float *x_ctrl, const float *x_ori, const float *x_pos, const float *t,
+                                  const float *object, float *logits, int rows, void *stream) {
+    DGDM_REQUIRE(m && x_ctrl && x_ori && x_pos && t && object && logits && rows >= 0, DGDM_EINVAL, "dgdm_dyn2d_forward: bad argument");
+    if (m->kind != 2) { set_error("model type not supported: dgdm_dyn2d_forward on a 3-D model"); return DGDM_EMODE; }
+    if (rows == 0) return DGDM_OK;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    // workspace: V, GENC [rows][256] | pose [rows][27 -> 32] | tmp [rows][768] | z1 [rows][256]
+    const size_t need = (size_t)rows * (256 + 256 + 32 + 768 + 256) * sizeof(float);
+    if ((rc = m->ws.alloc(need))) return rc;
+    float *V = m->ws.as<float>(), *genc = V + (size_t)rows * 256, *pose = genc + (size_t)rows * 256, *tmp = pose + (size_t)rows * 32,
+          *z1 = tmp + (size_t)rows * 768;
+    if ((rc = m->time_part(t, 0.f, tmp, z1, rows, s))) return rc;                          // z1 = W1t' te + b1'
+    if ((rc = m->object_part_2d(object, tmp, z1, rows, true, s))) return rc;               // += W1o' oenc
+    if ((rc = m->gripper_forward(x_ctrl, m->L, V, genc, rows, s))) return rc;
+    if ((rc = linear(genc, 256, m->blob.at(m->off.w1c_wt), nullptr, nullptr, 1, z1, 256, rows, 256, 256, ACT_NONE, true, s))) return rc;
+    if ((rc = pose_embed(x_ori, x_pos, pose, rows, s))) return rc;
+    if ((rc = linear(pose, 27, m->blob.at(m->off.w1p_wt), nullptr, nullptr, 1, z1, 256, rows, 27, 256, ACT_NONE, true, s))) return rc;
+    TrunkParams p;
+    m->fill_trunk(&p);
+    p.Atab = z1; p.logits = logits; p.C = rows; p.R = rows; p.B = 1; p.tiles_per_b = 1; p.ntiles = (rows + 31) / 32;
+    return trunk_launch(2, true, true, p, s);
+}

@@ -1,0 +1,46 @@
+#pragma once
+#include "common.h"
+
+namespace dgdm {
+
+// PointNet2 weights, BatchNorm folded (device pointers)
+struct PnWeights {
+    float r1sq, r2sq;             // float32(0.2**2), float32(0.4**2): what `sqrdists > radius ** 2` compares against
+    const float *sa1_w0t;         // [3][64]    sa1.mlp_convs.0 (kn)
+    const float *sa1_b0;          // [64]
+    const float *sa1_w1;          // [128][64]  sa1.mlp_convs.1 row-major
+    const float *sa1_b1;          // [128]
+    const float *sa2_wf_t;        // [128][128] sa2.mlp_convs.0[:, 3:] (kn)  -> U = F1 * wf_t + b
+    const float *sa2_b0;          // [128]
+    const float *sa2_vx;          // [3][128]   sa2.mlp_convs.0[:, 0:3] (kn)
+    const float4 *sa2_w1_img;     // chain image of sa2.mlp_convs.1 [256 x 128]
+    const float *sa2_b1;          // [256]
+    const float4 *sa3_w_img;      // chain image of sa3.mlp_convs.0[:, 3:] [256 x 256]
+    const float *sa3_wx;          // [3][256]   sa3.mlp_convs.0[:, 0:3] (kn)
+    const float *sa3_b;           // [256]
+};
+
+struct XobjChain {
+    const float *xyz;             // [N][3]
+    const int   *fps1;            // [N][512]
+    const int   *slot_of_start;   // [N] start index -> table slot, or null (slot = start)
+    const float *Z;               // [nv][N][256]
+    int          N;
+    int          pad;
+};
+
+struct XobjParams {
+    const XobjChain *chains;      // device array [nchain]
+    const int       *starts;      // [nchain][R][2]  (s1, s2) per reference row
+    float           *xobj;        // [nchain][R][256]
+    int64_t          R, total_rows;
+};
+
+int pn_fps_table(const float *xyz, int N, int nv, int npoint, int *out, hipStream_t s);
+int pn_sa1(const float *xyz, int N, const PnWeights &w, float *F1, hipStream_t s);
+int pn_pairs(const float *xyz, int N, const float *U, const PnWeights &w, float *Y, hipStream_t s);
+int pn_l2(const float *xyz, int N, const PnWeights &w, const int *fps1, const int *vlist, int nv, const float *Y, float *L2, hipStream_t s);
+int pn_z(const float *xyz, int N, int nv, const PnWeights &w, const float *L2, float *Z, hipStream_t s);
+int pn_xobj(const XobjParams &p, hipStream_t s);
+
+}  // namespace dgdm

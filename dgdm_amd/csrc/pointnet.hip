@@ -1,0 +1,364 @@
+// PointNet++ SSG object encoder (dynamics/models/pointnet2.py:11-32, pointnet2_utils.py:27-210)
+// restructured around what Diffusion.cond_fn actually feeds it: R replicas of ONE cloud that differ
+// only in the two random FPS start indices (s1 for sa1, s2 for sa2) drawn per row
+// (pointnet2_utils.py:83 via generator/diffusion.py:491-496).
+//
+// Facts used (DESIGN.md §4 derives them; all are exact, no approximation):
+//  * sa1 samples npoint = 512 of N points: FPS from start s1 yields an ordering fps1[s1][0..511] of
+//    point ids ("variant" s1).  The sa1 feature of a centre depends on the centre POINT only
+//    (ball query scans the original order), so F1[p] is computed once per cloud.
+//  * sa2 works on the cloud re-ordered by fps1[s1].  Its ball query keeps the first 64 in-radius
+//    neighbours IN THAT ORDER, so the sa2 feature of a centre depends on (variant, centre point):
+//    L2[v][c] = max over those <=64 neighbours k of Y[c][k], where Y[c][k] is the two-layer pointwise
+//    MLP on the pair (centre c, neighbour k) - a function of the two POINTS only.
+//  * sa3 (group_all) applies a pointwise layer to [xyz_c | L2[v][c]] and takes the max over the 128
+//    centres FPS selected from start s2: Z[v][c] once per (variant, point), then per row only
+//    FPS(128) on the re-ordered cloud and a max over 128 rows of Z[v].
+// The first sa2 conv is linear in [xyz_k - xyz_c | F1[k]] (pointnet2_utils.py:136-140), so its
+// feature part U[k] = W[:,3:] F1[k] + b is computed once per point.
+//
+// Distances replicate the reference's float32 operation order, without fma contraction:
+//   FPS   : (dx*dx + dy*dy) + dz*dz                         (pointnet2_utils.py:88)
+//   balls : ((-2 * (a.b)) + |a|^2) + |b|^2  >  r^2           (pointnet2_utils.py:45-47,110)
+#include "common.h"
+#include "mfma_chain.h"
+#include "pointnet.h"
+
+namespace dgdm {
+
+__device__ __forceinline__ float sq3(float x, float y, float z) {
+    return __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+}
+
+// square_distance(src = centre, dst = candidate) in the reference's expanded form
+__device__ __forceinline__ float sqdist_expanded(float cx, float cy, float cz, float cn, float px, float py, float pz, float pn) {
+    const float dot = fmaf(cz, pz, fmaf(cy, py, __fmul_rn(cx, px)));
+    return __fadd_rn(__fadd_rn(__fmul_rn(-2.f, dot), cn), pn);
+}
+
+// wave-wide argmax, first index wins ties (torch.max semantics, pointnet2_utils.py:91)
+__device__ __forceinline__ void wave_argmax(float &v, int &i) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(v, off);
+        const int oi = __shfl_xor(i, off);
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+}
+
+// farthest_point_sample (pointnet2_utils.py:71-92) by one wave over M <= 64*PPL points whose
+// coordinates sit in LDS (SoA lx/ly/lz, M entries).  Writes npoint indices to out (LDS or global).
+template <int PPL>
+__device__ void fps_wave(const float *lx, const float *ly, const float *lz, int M, int start, int npoint, int *out, int lane) {
+    float px[PPL], py[PPL], pz[PPL], dist[PPL];
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        const int j = lane + 64 * i;
+        const bool ok = j < M;
+        px[i] = ok ? lx[j] : 0.f; py[i] = ok ? ly[j] : 0.f; pz[i] = ok ? lz[j] : 0.f;
+        dist[i] = ok ? 1e10f : -1.f;                 // padding can never be the farthest point
+    }
+    int far = start;
+    for (int it = 0; it < npoint; ++it) {
+        if (lane == 0) out[it] = far;
+        const float cx = lx[far], cy = ly[far], cz = lz[far];
+        float bv = -2.f;
+        int bi = 0;
+#pragma unroll
+        for (int i = 0; i < PPL; ++i) {
+            const float d = sq3(px[i] - cx, py[i] - cy, pz[i] - cz);
+            if (d < dist[i]) dist[i] = d;
+            if (dist[i] > bv) { bv = dist[i]; bi = lane + 64 * i; }
+        }
+        wave_argmax(bv, bi);
+        far = bi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ T1
+// fps1[v][0..npoint) for v = 0..nv-1 (start index v) on cloud xyz [N][3]
+__global__ __launch_bounds__(256) void fps_table_kernel(const float *__restrict__ xyz, int N, int nv, int npoint, int *__restrict__ out) {
+    extern __shared__ float lds[];
+    float *lx = lds, *ly = lds + N, *lz = lds + 2 * N;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) { lx[i] = xyz[3 * i]; ly[i] = xyz[3 * i + 1]; lz[i] = xyz[3 * i + 2]; }
+    __syncthreads();
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= nv) return;
+    if (N <= 512) fps_wave<8>(lx, ly, lz, N, v, npoint, out + (size_t)v * npoint, threadIdx.x & 63);
+    else fps_wave<16>(lx, ly, lz, N, v, npoint, out + (size_t)v * npoint, threadIdx.x & 63);
+}
+
+// ------------------------------------------------------------------------------------------------ T2
+// sa1 feature of every point p as a centre: first 32 in-radius (r=0.2) points in index order, padded with
+// the first; Conv(3->64)+BN+ReLU, Conv(64->128)+BN+ReLU, max  (pointnet2.py:17, pointnet2_utils.py:95-146,203-208)
+__global__ __launch_bounds__(128) void sa1_kernel(const float *__restrict__ xyz, int N, float r2, const float *__restrict__ w0t /*[3][64]*/,
+                                                  const float *__restrict__ b0, const float *__restrict__ w1 /*[128][64]*/,
+                                                  const float *__restrict__ b1, float *__restrict__ F1 /*[N][128]*/) {
+    __shared__ int nbr[32];
+    __shared__ __attribute__((aligned(16))) float h1[32][64];
+    const int t = threadIdx.x, lane = t & 63;
+    float wrow[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) wrow[k] = w1[t * 64 + k];
+    const float bias1 = b1[t];
+    for (int p = blockIdx.x; p < N; p += gridDim.x) {
+        const float cx = xyz[3 * p], cy = xyz[3 * p + 1], cz = xyz[3 * p + 2];
+        const float cn = sq3(cx, cy, cz);
+        if (t < 64) {      // wave 0: ordered compaction of in-radius indices
+            int cnt = 0;
+            for (int base = 0; base < N && cnt < 32; base += 64) {
+                const int k = base + lane;
+                bool in = false;
+                if (k < N) {
+                    const float x = xyz[3 * k], y = xyz[3 * k + 1], z = xyz[3 * k + 2];
+                    in = !(sqdist_expanded(cx, cy, cz, cn, x, y, z, sq3(x, y, z)) > r2);
+                }
+                const unsigned long long m = __ballot(in);
+                const int rank = cnt + __popcll(m & ((1ull << lane) - 1ull));
+                if (in && rank < 32) nbr[rank] = k;
+                cnt += __popcll(m);
+            }
+            cnt = min(cnt, 32);
+            __builtin_amdgcn_wave_barrier();
+            if (lane >= cnt && lane < 32) nbr[lane] = (cnt > 0) ? nbr[0] : p;   // pad with the first (:112-114)
+        }
+        __syncthreads();
+        for (int i = t; i < 32 * 64; i += 128) {          // layer 0 on the relative coordinates
+            const int s = i >> 6, c = i & 63, k = nbr[s];
+            const float dx = xyz[3 * k] - cx, dy = xyz[3 * k + 1] - cy, dz = xyz[3 * k + 2] - cz;
+            const float v = fmaf(w0t[128 + c], dz, fmaf(w0t[64 + c], dy, fmaf(w0t[c], dx, 0.f))) + b0[c];
+            h1[s][c] = fmaxf(v, 0.f);
+        }
+        __syncthreads();
+        float best = 0.f;                                  // ReLU outputs are >= 0 and the group is never empty
+        for (int s = 0; s < 32; ++s) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 64; k += 4) {
+                const float4 h = *reinterpret_cast<const float4 *>(&h1[s][k]);
+                acc = fmaf(wrow[k + 3], h.w, fmaf(wrow[k + 2], h.z, fmaf(wrow[k + 1], h.y, fmaf(wrow[k], h.x, acc))));
+            }
+            best = fmaxf(best, fmaxf(acc + bias1, 0.f));
+        }
+        F1[(size_t)p * 128 + t] = best;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ T4
+// Y[c][k][256] = ReLU(W2b' ReLU(U[k] + Vx (xyz_k - xyz_c)) + b2b') for all ordered pairs of points.
+// One wave = centre c x 32 consecutive k.  Layer 128 -> 256 on the MFMA chain.
+__global__ __launch_bounds__(256, 1) void pair_kernel(const float *__restrict__ xyz, int N, const float *__restrict__ U /*[N][128]*/,
+                                                      const float *__restrict__ vx /*[3][128]*/, const float4 *__restrict__ Wimg,
+                                                      const float *__restrict__ bias, float *__restrict__ Y) {
+    const int lane = threadIdx.x & 63, n = lane & 31, h4 = (lane >> 5) * 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kt = (N + 31) / 32;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= N * kt) return;
+    const int c = tile / kt, k0 = (tile - c * kt) * 32;
+    const int k = min(k0 + n, N - 1);
+    const float dx = xyz[3 * k] - xyz[3 * c], dy = xyz[3 * k + 1] - xyz[3 * c + 1], dz = xyz[3 * k + 2] - xyz[3 * c + 2];
+    f32x16 in[4], out[8];
+    const float *urow = U + (size_t)k * 128;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 u = feat4(urow, o, q, h4);
+            const float4 a = feat4(vx, o, q, h4), b = feat4(vx + 128, o, q, h4), d = feat4(vx + 256, o, q, h4);
+            in[o][4 * q + 0] = fmaxf(fmaf(d.x, dz, fmaf(b.x, dy, fmaf(a.x, dx, u.x))), 0.f);
+            in[o][4 * q + 1] = fmaxf(fmaf(d.y, dz, fmaf(b.y, dy, fmaf(a.y, dx, u.y))), 0.f);
+            in[o][4 * q + 2] = fmaxf(fmaf(d.z, dz, fmaf(b.z, dy, fmaf(a.z, dx, u.z))), 0.f);
+            in[o][4 * q + 3] = fmaxf(fmaf(d.w, dz, fmaf(b.w, dy, fmaf(a.w, dx, u.w))), 0.f);
+        }
+    }
+    chain_layer<4, 8, CHAIN_BIAS>(Wimg, bias, in, out, lane);
+    if (k0 + n < N) {
+        float *dst = Y + ((size_t)c * N + k) * 256;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 v;
+                v.x = fmaxf(out[o][4 * q + 0], 0.f); v.y = fmaxf(out[o][4 * q + 1], 0.f);
+                v.z = fmaxf(out[o][4 * q + 2], 0.f); v.w = fmaxf(out[o][4 * q + 3], 0.f);
+                *reinterpret_cast<float4 *>(dst + 32 * o + 8 * q + h4) = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ T5
+// L2[slot][c][256] = max over the first 64 in-radius (r=0.4) positions of variant vlist[slot] of Y[c][point].
+// grid (c, slot-group): consecutive waves share the centre so its Y slab stays cache resident.
+__global__ __launch_bounds__(256) void l2_kernel(const float *__restrict__ xyz, int N, float r2, const int *__restrict__ fps1 /*[N][512]*/,
+                                                 const int *__restrict__ vlist, int nv, const float *__restrict__ Y,
+                                                 float *__restrict__ L2 /*[nv][N][256]*/) {
+    __shared__ int sel[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.y;
+    const int slot = blockIdx.x * 4 + wave;
+    if (slot >= nv) return;
+    const int *perm = fps1 + (size_t)vlist[slot] * 512;
+    const float cx = xyz[3 * c], cy = xyz[3 * c + 1], cz = xyz[3 * c + 2];
+    const float cn = sq3(cx, cy, cz);
+    int cnt = 0;
+    for (int base = 0; base < 512 && cnt < 64; base += 64) {
+        const int pk = perm[base + lane];
+        const float x = xyz[3 * pk], y = xyz[3 * pk + 1], z = xyz[3 * pk + 2];
+        const bool in = !(sqdist_expanded(cx, cy, cz, cn, x, y, z, sq3(x, y, z)) > r2);
+        const unsigned long long m = __ballot(in);
+        const int rank = cnt + __popcll(m & ((1ull << lane) - 1ull));
+        if (in && rank < 64) sel[wave][rank] = pk;
+        cnt += __popcll(m);
+    }
+    cnt = min(cnt, 64);
+    __builtin_amdgcn_wave_barrier();
+    const float *slab = Y + (size_t)c * N * 256 + lane * 4;
+    float4 best = make_float4(0.f, 0.f, 0.f, 0.f);       // Y >= 0 (ReLU); an empty ball cannot happen for a centre of the set,
+                                                         // and a centre outside the variant's set is never read
+    int i = 0;
+    for (; i + 4 <= cnt; i += 4) {
+        const float4 a = *reinterpret_cast<const float4 *>(slab + (size_t)sel[wave][i] * 256);
+        const float4 b = *reinterpret_cast<const float4 *>(slab + (size_t)sel[wave][i + 1] * 256);
+        const float4 d = *reinterpret_cast<const float4 *>(slab + (size_t)sel[wave][i + 2] * 256);
+        const float4 e = *reinterpret_cast<const float4 *>(slab + (size_t)sel[wave][i + 3] * 256);
+        best.x = fmaxf(fmaxf(best.x, fmaxf(a.x, b.x)), fmaxf(d.x, e.x));
+        best.y = fmaxf(fmaxf(best.y, fmaxf(a.y, b.y)), fmaxf(d.y, e.y));
+        best.z = fmaxf(fmaxf(best.z, fmaxf(a.z, b.z)), fmaxf(d.z, e.z));
+        best.w = fmaxf(fmaxf(best.w, fmaxf(a.w, b.w)), fmaxf(d.w, e.w));
+    }
+    for (; i < cnt; ++i) {
+        const float4 a = *reinterpret_cast<const float4 *>(slab + (size_t)sel[wave][i] * 256);
+        best.x = fmaxf(best.x, a.x); best.y = fmaxf(best.y, a.y); best.z = fmaxf(best.z, a.z); best.w = fmaxf(best.w, a.w);
+    }
+    *reinterpret_cast<float4 *>(L2 + ((size_t)slot * N + c) * 256 + lane * 4) = best;
+}
+
+// ------------------------------------------------------------------------------------------------ T6
+// Z[row][256] = ReLU(W3'[:,3:] L2[row] + W3'[:,0:3] xyz_c + b3'),  row = slot*N + c   (sa3, pointnet2.py:19)
+__global__ __launch_bounds__(256, 1) void z_kernel(const float *__restrict__ xyz, int N, int64_t rows, const float *__restrict__ L2,
+                                                   const float4 *__restrict__ Wimg, const float *__restrict__ w3x /*[3][256]*/,
+                                                   const float *__restrict__ bias, float *__restrict__ Z) {
+    const int lane = threadIdx.x & 63, n = lane & 31, h4 = (lane >> 5) * 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    if (tile * 32 >= rows) return;
+    const int64_t row = min(tile * 32 + n, rows - 1);
+    const int c = (int)(row % N);
+    const float x = xyz[3 * c], y = xyz[3 * c + 1], z = xyz[3 * c + 2];
+    f32x16 in[8], out[8];
+    const float *lrow = L2 + (size_t)row * 256;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = feat4(lrow, o, q, h4);
+            in[o][4 * q + 0] = v.x; in[o][4 * q + 1] = v.y; in[o][4 * q + 2] = v.z; in[o][4 * q + 3] = v.w;
+            const float4 b = feat4(bias, o, q, h4);
+            const float4 a0 = feat4(w3x, o, q, h4), a1 = feat4(w3x + 256, o, q, h4), a2 = feat4(w3x + 512, o, q, h4);
+            out[o][4 * q + 0] = fmaf(a2.x, z, fmaf(a1.x, y, fmaf(a0.x, x, b.x)));
+            out[o][4 * q + 1] = fmaf(a2.y, z, fmaf(a1.y, y, fmaf(a0.y, x, b.y)));
+            out[o][4 * q + 2] = fmaf(a2.z, z, fmaf(a1.z, y, fmaf(a0.z, x, b.z)));
+            out[o][4 * q + 3] = fmaf(a2.w, z, fmaf(a1.w, y, fmaf(a0.w, x, b.w)));
+        }
+    }
+    chain_layer<8, 8, CHAIN_KEEP>(Wimg, nullptr, in, out, lane);
+    if (tile * 32 + n < rows) {
+        float *dst = Z + (size_t)row * 256;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 v;
+                v.x = fmaxf(out[o][4 * q + 0], 0.f); v.y = fmaxf(out[o][4 * q + 1], 0.f);
+                v.z = fmaxf(out[o][4 * q + 2], 0.f); v.w = fmaxf(out[o][4 * q + 3], 0.f);
+                *reinterpret_cast<float4 *>(dst + 32 * o + 8 * q + h4) = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ per row
+// xobj[row][256] = max over the 128 centres FPS picks (start s2) on the cloud re-ordered by variant s1 of
+// Z[slot(s1)][point].  One wave per row.   (sa2's FPS + sa3's max, pointnet2_utils.py:132,208)
+__global__ __launch_bounds__(256) void xobj_kernel(const XobjParams p) {
+    __shared__ float coords[4][3][512];
+    __shared__ int centres[4][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t w = (int64_t)blockIdx.x * 4 + wave;
+    if (w >= p.total_rows) return;
+    const int chain = (int)(w / p.R);
+    const int64_t r = w - (int64_t)chain * p.R;
+    const XobjChain ch = p.chains[chain];
+    const int *st = p.starts + (size_t)chain * 2 * p.R;
+    const int s1 = st[2 * r], s2 = st[2 * r + 1];
+    const int slot = ch.slot_of_start ? ch.slot_of_start[s1] : s1;
+    const int *perm = ch.fps1 + (size_t)s1 * 512;
+    float *lx = coords[wave][0], *ly = coords[wave][1], *lz = coords[wave][2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int j = lane + 64 * i, pid = perm[j];
+        lx[j] = ch.xyz[3 * pid]; ly[j] = ch.xyz[3 * pid + 1]; lz[j] = ch.xyz[3 * pid + 2];
+    }
+    __builtin_amdgcn_wave_barrier();
+    fps_wave<8>(lx, ly, lz, 512, s2, 128, centres[wave], lane);
+    __builtin_amdgcn_wave_barrier();
+    const float *zt = ch.Z + (size_t)slot * ch.N * 256 + lane * 4;
+    float4 best = make_float4(0.f, 0.f, 0.f, 0.f);      // Z >= 0 (ReLU)
+    for (int i = 0; i < 128; i += 4) {
+        const float4 a = *reinterpret_cast<const float4 *>(zt + (size_t)perm[centres[wave][i]] * 256);
+        const float4 b = *reinterpret_cast<const float4 *>(zt + (size_t)perm[centres[wave][i + 1]] * 256);
+        const float4 d = *reinterpret_cast<const float4 *>(zt + (size_t)perm[centres[wave][i + 2]] * 256);
+        const float4 e = *reinterpret_cast<const float4 *>(zt + (size_t)perm[centres[wave][i + 3]] * 256);
+        best.x = fmaxf(fmaxf(best.x, fmaxf(a.x, b.x)), fmaxf(d.x, e.x));
+        best.y = fmaxf(fmaxf(best.y, fmaxf(a.y, b.y)), fmaxf(d.y, e.y));
+        best.z = fmaxf(fmaxf(best.z, fmaxf(a.z, b.z)), fmaxf(d.z, e.z));
+        best.w = fmaxf(fmaxf(best.w, fmaxf(a.w, b.w)), fmaxf(d.w, e.w));
+    }
+    *reinterpret_cast<float4 *>(p.xobj + (size_t)w * 256 + lane * 4) = best;
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+int pn_fps_table(const float *xyz, int N, int nv, int npoint, int *out, hipStream_t s) {
+    hipLaunchKernelGGL(fps_table_kernel, dim3((nv + 3) / 4), dim3(256), (size_t)3 * N * sizeof(float), s, xyz, N, nv, npoint, out);
+    DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
+}
+
+int pn_sa1(const float *xyz, int N, const PnWeights &w, float *F1, hipStream_t s) {
+    hipLaunchKernelGGL(sa1_kernel, dim3(std::min(N, 1024)), dim3(128), 0, s, xyz, N, w.r1sq, w.sa1_w0t, w.sa1_b0, w.sa1_w1, w.sa1_b1, F1);
+    DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
+}
+
+int pn_pairs(const float *xyz, int N, const float *U, const PnWeights &w, float *Y, hipStream_t s) {
+    const int tiles = N * ((N + 31) / 32);
+    hipLaunchKernelGGL(pair_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, xyz, N, U, w.sa2_vx, w.sa2_w1_img, w.sa2_b1, Y);
+    DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
+}
+
+int pn_l2(const float *xyz, int N, const PnWeights &w, const int *fps1, const int *vlist, int nv, const float *Y, float *L2, hipStream_t s) {
+    hipLaunchKernelGGL(l2_kernel, dim3((nv + 3) / 4, N), dim3(256), 0, s, xyz, N, w.r2sq, fps1, vlist, nv, Y, L2);
+    DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
+}
+
+int pn_z(const float *xyz, int N, int nv, const PnWeights &w, const float *L2, float *Z, hipStream_t s) {
+    const int64_t rows = (int64_t)nv * N;
+    const int64_t tiles = (rows + 31) / 32;
+    hipLaunchKernelGGL(z_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, xyz, N, rows, L2, w.sa3_w_img, w.sa3_wx, w.sa3_b, Z);
+    DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
+}
+
+int pn_xobj(const XobjParams &p, hipStream_t s) {
+    if (p.total_rows <= 0) return DGDM_OK;
+    hipLaunchKernelGGL(xobj_kernel, dim3((unsigned)((p.total_rows + 3) / 4)), dim3(256), 0, s, p);
+    DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
+}
+
+}  // namespace dgdm

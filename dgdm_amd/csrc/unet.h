@@ -1,0 +1,30 @@
+#pragma once
+#include "common.h"
+
+namespace dgdm {
+
+// One ConditionalResidualBlock1D (generator/diffusion_utils.py:75-120), device pointers.
+// Conv weights are stored [(ci*KW + k)*Cout + co]; Linear weights [in][out].
+struct UnetRes {
+    int cin, cout;
+    const float *c0_w, *c0_b, *g0_w, *g0_b;      // blocks.0: Conv1d k5, GroupNorm
+    const float *c1_w, *c1_b, *g1_w, *g1_b;      // blocks.1
+    const float *cond_wt, *cond_b;               // cond_encoder.1: Linear(cond_dim, 2*cout)
+    const float *res_w, *res_b;                  // residual_conv (1x1) or null
+};
+
+struct UnetParams {
+    int d0, d1, dsed, groups, cmax;
+    int bufA, bufS;                              // LDS buffer sizes in floats (set per launch from L)
+    const float *freqs;                          // SinusoidalPosEmb frequencies [dsed/2]
+    const float *se1_wt, *se1_b, *se3_wt, *se3_b;
+    UnetRes res[8];                              // down0.0 down0.1 down1.0 down1.1 mid0 mid1 up0.0 up0.1
+    const float *down_w, *down_b;                // Downsample1d conv k3 s2
+    const float *up_w, *up_b;                    // Upsample1d ConvTranspose1d k4 s2, stored [(ci*4+k)*C + co]
+    const float *fin_w, *fin_b, *fin_gw, *fin_gb;// final_conv.0
+    const float *out_w, *out_b;                  // final_conv.1 (d0 -> 1)
+};
+
+int unet_launch(const UnetParams &p, const float *sample, const int *timestep, float *eps, int B, int L, hipStream_t s);
+
+}  // namespace dgdm

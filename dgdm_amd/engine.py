@@ -1,0 +1,191 @@
+"""Python handles over the C-ABI objects of libdgdm_hip.so.
+
+PyTorch supplies device memory and the stream; every computation is a HIP kernel behind
+``include/dgdm_hip.h``.  These classes are what the reference-shaped modules in
+``dgdm_amd.generator`` / ``dgdm_amd.dynamics`` delegate to.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, dptr, lib, stream_ptr
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(dtype=torch.float32).contiguous()
+
+
+class Unet1d:
+    """``ConditionalUnet1D`` weights packed on the device (generator/diffusion_utils.py:123-285)."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], down_dims: Sequence[int] = (128, 256), step_embed_dim: int = 32,
+                 kernel_size: int = 5, n_groups: int = 8):
+        packed = _lib.PackedStateDict(state_dict)
+        dd = (C.c_int32 * len(down_dims))(*down_dims)
+        h = C.c_void_p()
+        check(lib().dgdm_unet1d_create(C.byref(h), packed.array, packed.n, dd, len(down_dims), step_embed_dim, kernel_size, n_groups))
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().dgdm_unet1d_destroy(self._h)
+            self._h = None
+
+    def forward(self, sample: torch.Tensor, timestep: torch.Tensor) -> torch.Tensor:
+        """sample (B, L, 1) float32 cuda, timestep (B,) integer -> eps (B, L, 1)."""
+        assert sample.dim() == 3 and sample.shape[-1] == 1, "input_dim must be 1 (generator/train.py:76)"
+        x = _f32(sample)
+        B, L, _ = x.shape
+        t = timestep.to(device=x.device, dtype=torch.int32).expand(B).contiguous()
+        out = torch.empty_like(x)
+        check(lib().dgdm_unet1d_forward(self._h, dptr(x), dptr(t), dptr(out), B, L, stream_ptr()))
+        return out
+
+
+class Dynamics:
+    """``ProfileForward2DModel`` (kind 2) / ``ProfileForward3DModel`` (kind 3) on the device."""
+
+    def __init__(self, kind: int, state_dict: Dict[str, torch.Tensor], params_ch: int, object_ch: int = 0):
+        packed = _lib.PackedStateDict(state_dict)
+        h = C.c_void_p()
+        check(lib().dgdm_dynamics_create(C.byref(h), kind, packed.array, packed.n, params_ch, object_ch))
+        self._h, self.kind, self.params_ch, self.object_ch = h, kind, params_ch, object_ch
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().dgdm_dynamics_destroy(self._h)
+            self._h = None
+
+    def forward2d(self, x_ctrl, x_ori, x_pos, timesteps, object_vertices) -> torch.Tensor:
+        rows = x_ctrl.shape[0]
+        a = [_f32(v) for v in (x_ctrl, x_ori, x_pos, timesteps, object_vertices)]
+        out = torch.empty((rows, 3), dtype=torch.float32, device=a[0].device)
+        check(lib().dgdm_dyn2d_forward(self._h, *[dptr(v) for v in a], dptr(out), rows, stream_ptr()))
+        return out
+
+    @staticmethod
+    def _starts(s: torch.Tensor) -> np.ndarray:
+        return np.ascontiguousarray(s.detach().cpu().numpy().astype(np.int64))
+
+    def pointnet2(self, xyz: torch.Tensor, start_sa1: torch.Tensor, start_sa2: torch.Tensor) -> torch.Tensor:
+        """xyz (rows, 3, N) -> (rows, 256)."""
+        x = _f32(xyz)
+        rows, _, N = x.shape
+        s1, s2 = self._starts(start_sa1), self._starts(start_sa2)
+        out = torch.empty((rows, 256), dtype=torch.float32, device=x.device)
+        check(lib().dgdm_pointnet2_forward(self._h, dptr(x), s1.ctypes.data, s2.ctypes.data, dptr(out), rows, N, stream_ptr()))
+        return out
+
+    def forward3d(self, x_ctrl, x_ori, x_pos, timesteps, xyz, start_sa1, start_sa2) -> torch.Tensor:
+        rows, _, N = xyz.shape
+        a = [_f32(v) for v in (x_ctrl, x_ori, x_pos, timesteps, xyz)]
+        s1, s2 = self._starts(start_sa1), self._starts(start_sa2)
+        out = torch.empty((rows, 3), dtype=torch.float32, device=a[0].device)
+        check(lib().dgdm_dyn3d_forward(self._h, *[dptr(v) for v in a], s1.ctypes.data, s2.ctypes.data, dptr(out), rows, N, stream_ptr()))
+        return out
+
+
+def make_objective(name: str, object_index: int = 0) -> _lib.Objective:
+    o = _lib.Objective()
+    o.object = object_index
+    check(lib().dgdm_objective_from_name(name.encode(), C.byref(o)))
+    return o
+
+
+class Guidance:
+    """State of ``Diffusion.cond_fn`` for up to ``max_chains`` chains (generator/diffusion.py:473-504)."""
+
+    def __init__(self, dyn: Dynamics, batch: int, grid_size: int, num_pos: int, ori_range: Sequence[float], max_chains: int,
+                 num_train_timesteps: int, num_object_points: int, sub_batch_size: int = 0, max_objects: int = 8):
+        cfg = _lib.GuidanceConfig(batch, grid_size, num_pos, float(ori_range[0]), float(ori_range[1]), max_chains,
+                                  num_train_timesteps, sub_batch_size, num_object_points, max_objects)
+        h = C.c_void_p()
+        check(lib().dgdm_guidance_create(C.byref(h), dyn._h, C.byref(cfg)))
+        self._h, self.dyn, self.cfg = h, dyn, cfg
+        self.rows = int(lib().dgdm_guidance_rows(h))
+        self.starts_per_call = int(lib().dgdm_guidance_starts_per_call(h))
+        self.sweep_rows = batch * grid_size
+        self.n_objects = 0
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().dgdm_guidance_destroy(self._h)
+            self._h = None
+
+    def set_objects(self, objects: torch.Tensor) -> None:
+        """2-D: (n, V, 2); 3-D: (n, N, 3)."""
+        o = _f32(objects)
+        check(lib().dgdm_guidance_set_objects(self._h, dptr(o), o.shape[0], stream_ptr()))
+        torch.cuda.current_stream().synchronize()     # `o` may be a temporary
+        self.n_objects = o.shape[0]
+
+    def rowcoef(self, centers: torch.Tensor) -> np.ndarray:
+        """'convergence' row coefficients of one chain (deltas_to_objective :445-452 applied per cond_fn call)."""
+        c = np.ascontiguousarray(centers.detach().cpu().numpy().astype(np.int64))
+        out = np.empty(self.rows, dtype=np.float32)
+        sub = self.cfg.sub_batch_size if self.dyn.kind == 3 else 0
+        check(lib().dgdm_convergence_rowcoef(c.ctypes.data, len(c), self.cfg.grid_size, self.cfg.num_pos, self.rows, sub, out.ctypes.data))
+        return out
+
+    def grad(self, x: torch.Tensor, timestep: int, objectives: Sequence[_lib.Objective], rowcoef: Optional[torch.Tensor] = None,
+             starts: Optional[np.ndarray] = None) -> torch.Tensor:
+        """x (n_chains, B, L) -> d sum(objective)/dx (n_chains, B, L)."""
+        x = _f32(x)
+        nc = x.shape[0]
+        assert nc == len(objectives)
+        arr = (_lib.Objective * nc)(*objectives)
+        out = torch.empty_like(x)
+        rc_ptr = dptr(rowcoef) if rowcoef is not None else None
+        if self.dyn.kind == 2:
+            check(lib().dgdm_dyn2d_guidance_grad(self._h, dptr(x), int(timestep), arr, rc_ptr, nc, dptr(out), stream_ptr()))
+        else:
+            assert starts is not None and starts.dtype == np.int64 and starts.size == nc * self.starts_per_call
+            starts = np.ascontiguousarray(starts)
+            check(lib().dgdm_dyn3d_guidance_grad(self._h, dptr(x), int(timestep), arr, rc_ptr, starts.ctypes.data, nc, dptr(out), stream_ptr()))
+        return out
+
+    def sweep(self, x: torch.Tensor, object_of_chain: Sequence[int], starts: Optional[np.ndarray] = None) -> torch.Tensor:
+        """Orientation sweep of get_convergence_centers (:506-531): logits (n_chains, B*G, 3), row = g*B + b."""
+        x = _f32(x)
+        nc = x.shape[0]
+        oc = (C.c_int32 * nc)(*object_of_chain)
+        out = torch.empty((nc, self.sweep_rows, 3), dtype=torch.float32, device=x.device)
+        sp = None
+        if self.dyn.kind == 3:
+            assert starts is not None and starts.dtype == np.int64 and starts.size == nc * 2 * self.sweep_rows
+            starts = np.ascontiguousarray(starts)
+            sp = starts.ctypes.data
+        check(lib().dgdm_guidance_orientation_sweep(self._h, dptr(x), oc, sp, nc, dptr(out), stream_ptr()))
+        return out
+
+
+def ddim_guided_step(x: torch.Tensor, eps: torch.Tensor, grad: Optional[torch.Tensor], n_grad: int, coef: Tuple[float, float, float, float],
+                     scale: float) -> torch.Tensor:
+    """grad: None or (n_grad, *x.shape) stacked gradients whose mean guides the step."""
+    x, eps = _f32(x), _f32(eps)
+    out = torch.empty_like(x)
+    g = _f32(grad) if grad is not None else None
+    check(lib().dgdm_ddim_guided_step(dptr(x), dptr(eps), dptr(g), n_grad, dptr(out), x.numel(), *[float(c) for c in coef], float(scale), stream_ptr()))
+    return out
+
+
+def ddim_add_noise(x0: torch.Tensor, noise: torch.Tensor, sqrt_abar: float, sqrt_1m_abar: float) -> torch.Tensor:
+    x0, noise = _f32(x0), _f32(noise)
+    out = torch.empty_like(x0)
+    check(lib().dgdm_ddim_add_noise(dptr(x0), dptr(noise), dptr(out), x0.numel(), float(sqrt_abar), float(sqrt_1m_abar), stream_ptr()))
+    return out
+
+
+def prof_enable(on: bool) -> None:
+    check(lib().dgdm_prof_enable(int(on)))
+
+
+def prof_read() -> Tuple[int, float, float]:
+    n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
+    check(lib().dgdm_prof_read(C.byref(n), C.byref(ms), C.byref(fl)))
+    return n.value, ms.value, fl.value

@@ -1,0 +1,163 @@
+"""Denoise loops of ``generator/diffusion.py`` (:193-201, :249-256, :570-576, :637-647) on the HIP path.
+
+Independent chains - the (object, objective) pairs ``Diffusion.guided_sample`` walks through one after
+the other (:561) - are advanced together as an extra batch axis: one U-Net launch, one guidance
+launch sequence and one scheduler launch per denoise step for all of them.  The chains do not
+interact, so the results equal the reference's sequential evaluation; what has to be preserved is
+the order in which the reference consumes the torch CPU generator for the FPS starts
+(dynamics/models/pointnet2_utils.py:83), which ``StartStream`` replays.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import engine
+from .engine import Guidance, Unet1d, make_objective
+from .scheduler import DDIMScheduler
+
+SCALE_2D, SCALE_2D_CONV, SCALE_3D, SCALE_3D_CONV = 0.001, 10.0, 0.5, 0.8      # generator/diffusion.py:30-33
+
+
+def classifier_scale(mode: str, opt_obj: str, multi: bool = False) -> float:
+    """generator/diffusion.py:549-560 (per-object loop) and :631-636 (multi-object loop)."""
+    if mode == 'point':
+        return SCALE_2D_CONV if (opt_obj == 'convergence' and not multi) else SCALE_2D
+    if mode == 'point_3d':
+        return SCALE_3D_CONV if (opt_obj == 'convergence' and not multi) else SCALE_3D
+    return 0.001
+
+
+class StartStream:
+    """FPS start indices in the reference's draw order.
+
+    One classifier call on ``rows`` rows with sub-batch size ``sub`` draws, per sub-batch, ``torch.randint(0, N, (n,))``
+    for sa1 and ``torch.randint(0, 512, (n,))`` for sa2 from the global CPU generator
+    (pointnet2_utils.py:83 reached via generator/diffusion.py:495-498 and :524-526)."""
+
+    def __init__(self, num_points: int, sub_batch_size: int, forced: Optional[Sequence[torch.Tensor]] = None):
+        self.N, self.sub = int(num_points), int(sub_batch_size)
+        self._forced = list(forced) if forced is not None else None
+
+    def _draw(self, high: int, n: int) -> np.ndarray:
+        if self._forced is not None:
+            s = self._forced.pop(0)
+            assert s.shape == (n,), (s.shape, n)
+            return s.numpy().astype(np.int64)
+        return torch.randint(0, high, (n,), dtype=torch.long).numpy()
+
+    def call(self, rows: int) -> np.ndarray:
+        """The 2*rows indices one classifier call over `rows` rows consumes."""
+        out = np.empty(2 * rows, dtype=np.int64)
+        for r0 in range(0, rows, self.sub):
+            n = min(self.sub, rows - r0)
+            out[2 * r0:2 * r0 + n] = self._draw(self.N, n)
+            out[2 * r0 + n:2 * r0 + 2 * n] = self._draw(512, n)
+        return out
+
+
+def unguided_sample(unet: Unet1d, sched: DDIMScheduler, x: torch.Tensor) -> torch.Tensor:
+    """S x [eps-net ; DDIM step]  (generator/diffusion.py:193-201, :249-256)."""
+    B = x.shape[0]
+    x = x.clone()
+    for t in sched.timesteps:
+        ts = torch.full((B,), int(t), dtype=torch.int32, device=x.device)
+        eps = unet.forward(x, ts)
+        x = engine.ddim_guided_step(x, eps, None, 0, sched.coefficients(int(t)), 0.0)
+    return x
+
+
+def convergence_centers(guid: Guidance, mode: str, unguided: torch.Tensor, objects_of_chain: Sequence[int],
+                        starts: Optional[np.ndarray] = None) -> torch.Tensor:
+    """``Diffusion.get_convergence_centers`` (:506-539) for several objects at once -> (n_chains, B) int64."""
+    from .dynamics import metrics
+    nc, B = len(objects_of_chain), unguided.shape[0]
+    x = unguided.reshape(1, B, -1).expand(nc, -1, -1).contiguous()
+    logits = guid.sweep(x, objects_of_chain, starts).cpu()                       # (nc, B*G, 3), row = g*B + b
+    if mode == 'point_3d':
+        thr = torch.tensor(0.02) / torch.tensor(0.0312)                          # threshold/std (:116-118)
+    else:
+        thr = torch.tensor(0.03) / torch.tensor(0.0565)
+    G = guid.cfg.grid_size
+    out = torch.zeros((nc, B), dtype=torch.int64)
+    for c in range(nc):
+        d0 = logits[c, :, 0]
+        prof = torch.where(d0 > thr, 2.0, torch.where(d0 < -thr, 0.0, 1.0))      # :532
+        for i in range(B):
+            lengths, centers = metrics.convergence_mode_three_class(prof[torch.arange(i, B * G, B)])
+            out[c, i] = centers[torch.argmax(lengths)]
+    return out
+
+
+def guided_chains(unet: Unet1d, guid: Guidance, sched: DDIMScheduler, mode: str, noise: torch.Tensor,
+                  chains: Sequence[Tuple[int, str]], unguided: Optional[torch.Tensor] = None,
+                  starts: Optional[StartStream] = None, trace: Optional[list] = None) -> torch.Tensor:
+    """``Diffusion.guided_sample`` loop bodies (:561-576) for the chains [(object index, opt_obj), ...].
+
+    noise (B, L, 1) is shared by all chains (:570).  Returns (n_chains, B, L, 1)."""
+    nc, (B, L, _) = len(chains), noise.shape
+    dev = noise.device
+    is3d = mode == 'point_3d'
+    S = len(sched.timesteps)
+    objectives = [make_objective(o, oi) for oi, o in chains]
+    # --- replay of the reference's RNG consumption: chain after chain; inside a chain the centre sweep, then the steps
+    sweep_starts: List[Optional[np.ndarray]] = [None] * nc
+    step_starts = np.zeros((S, nc, guid.starts_per_call), dtype=np.int64) if is3d else None
+    if is3d:
+        starts = starts or StartStream(guid.cfg.num_object_points, guid.cfg.sub_batch_size)
+        for c, (_, o) in enumerate(chains):
+            if o == 'convergence':
+                sweep_starts[c] = starts.call(guid.sweep_rows)
+            for si in range(S):
+                step_starts[si, c] = starts.call(guid.rows)
+    # --- 'convergence' chains: centres from the unguided sample, then row coefficients
+    rowcoef = None
+    conv = [c for c, (_, o) in enumerate(chains) if o == 'convergence']
+    if conv:
+        assert unguided is not None, "opt_obj='convergence' needs the unguided sample (generator/diffusion.py:563)"
+        st = np.concatenate([sweep_starts[c] for c in conv]) if is3d else None
+        centers = convergence_centers(guid, mode, unguided, [chains[c][0] for c in conv], st)
+        rc = np.zeros((nc, guid.rows), dtype=np.float32)
+        for k, c in enumerate(conv):
+            rc[c] = guid.rowcoef(centers[k])
+        rowcoef = torch.from_numpy(rc).to(dev)
+    scales = [classifier_scale(mode, o) for _, o in chains]
+    x = noise.reshape(1, B, L).expand(nc, -1, -1).contiguous().to(torch.float32)
+    for si, t in enumerate(sched.timesteps):
+        t = int(t)
+        ts = torch.full((nc * B,), t, dtype=torch.int32, device=dev)
+        eps = unet.forward(x.reshape(nc * B, L, 1), ts).reshape(nc, B, L)
+        g = guid.grad(x, t, objectives, rowcoef, step_starts[si].reshape(-1) if is3d else None)
+        if trace is not None:
+            trace.append((eps.clone(), g.clone()))
+        coef = sched.coefficients(t)
+        if len(set(scales)) == 1:
+            x = engine.ddim_guided_step(x, eps, g, 1, coef, scales[0])
+        else:
+            x = torch.stack([engine.ddim_guided_step(x[c], eps[c], g[c], 1, coef, scales[c]) for c in range(nc)])
+    return x.reshape(nc, B, L, 1)
+
+
+def guided_multi_object(unet: Unet1d, guid: Guidance, sched: DDIMScheduler, mode: str, noise: torch.Tensor,
+                        object_indices: Sequence[int], opt_obj: str, starts: Optional[StartStream] = None) -> torch.Tensor:
+    """``Diffusion.guided_sample_multi_object`` loop (:637-647): one chain, gradient = mean over the objects."""
+    n_obj, (B, L, _) = len(object_indices), noise.shape
+    dev = noise.device
+    is3d = mode == 'point_3d'
+    objectives = [make_objective(opt_obj, oi) for oi in object_indices]
+    if opt_obj == 'convergence':
+        raise ValueError("the reference never runs the multi-object loop with 'convergence' (generator/diffusion.py:337)")
+    if is3d:
+        starts = starts or StartStream(guid.cfg.num_object_points, guid.cfg.sub_batch_size)
+    scale = classifier_scale(mode, opt_obj, multi=True)
+    x = noise.reshape(B, L).contiguous().to(torch.float32)
+    for t in sched.timesteps:
+        t = int(t)
+        ts = torch.full((B,), t, dtype=torch.int32, device=dev)
+        eps = unet.forward(x.reshape(B, L, 1), ts).reshape(B, L)
+        st = np.concatenate([starts.call(guid.rows) for _ in object_indices]) if is3d else None      # object after object (:641-643)
+        g = guid.grad(x.reshape(1, B, L).expand(n_obj, -1, -1).contiguous(), t, objectives, None, st)
+        x = engine.ddim_guided_step(x, eps, g, n_obj, sched.coefficients(t), scale)
+    return x.reshape(B, L, 1)

@@ -1,0 +1,187 @@
+/*
+ * dgdm_hip.h - C-ABI of the MI355X (gfx950) guided-sampling library, libdgdm_hip.so.
+ *
+ * The reference (real-stanford/dgdm @ 2024_08_07) has no FFI layer: its hot path is Python
+ * calling torch.nn modules.  This header is the boundary the replacement sits behind.  Each
+ * entry point names the reference interface it stands in for (paths relative to the
+ * reference tree); INTEGRATION.md shows the ctypes binding a maintainer adds on the
+ * reference side.  Plain C types only: device pointers, sizes, a hipStream_t passed as void*.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative DGDM_E* code otherwise;
+ *    dgdm_last_error() gives the message (thread-local).  The Python shim turns the codes into
+ *    the reference's exceptions (ValueError('opt obj not supported'), ...).
+ *  - "dev" pointers are HIP device memory owned by the caller; "host" pointers are ordinary
+ *    memory.  Model handles own their packed weights and workspaces in device memory.
+ *  - all floating point is IEEE binary32; timesteps / point indices are int64 on the host side
+ *    (as in the reference) and int32 on the device side.
+ *  - launches go to the stream given; nothing here synchronises unless documented.
+ */
+#ifndef DGDM_HIP_H
+#define DGDM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGDM_OK            0
+#define DGDM_EINVAL       -1   /* bad argument / unsupported shape                          */
+#define DGDM_EKEY         -2   /* state_dict key missing or wrong size                      */
+#define DGDM_EHIP         -3   /* HIP runtime error (message carries hipGetErrorString)     */
+#define DGDM_EOBJECTIVE   -4   /* 'opt obj not supported'   (generator/diffusion.py:470)    */
+#define DGDM_EMODE        -5   /* 'model type not supported' (generator/diffusion.py:502)   */
+#define DGDM_ENODEVICE    -6   /* no gfx950 device visible                                  */
+
+/* One host tensor of a reference-format state_dict (torch layout, contiguous). */
+typedef struct DgdmTensor {
+    const char *name;     /* e.g. "linears.3.weight", "module."-prefix already stripped     */
+    const void *data;     /* host memory                                                    */
+    int64_t     numel;
+    int32_t     dtype;    /* 0 = float32, 1 = int64                                         */
+} DgdmTensor;
+
+typedef struct DgdmUnet1d   DgdmUnet1d;    /* generator/diffusion_utils.py:123 ConditionalUnet1D        */
+typedef struct DgdmDynamics DgdmDynamics;  /* dynamics/profile_forward_{2d,3d}.py ProfileForward{2,3}DModel */
+typedef struct DgdmGuidance DgdmGuidance;  /* state of Diffusion.cond_fn for a batch of chains           */
+
+/* Objective of Diffusion.deltas_to_objective (generator/diffusion.py:430-471) in gradient form:
+ *   d objective / d delta_j = lin[j] + 2*quad[j]*delta_j                     (all but 'convergence')
+ * 'convergence' sets use_rowcoef: d objective / d delta_0 of reference row r is rowcoef[r],
+ * the signed multiplicity of r in the slicer() windows (dynamics/metrics.py:32-38), built by
+ * dgdm_convergence_rowcoef().                                                                   */
+typedef struct DgdmObjective {
+    float   lin[3];
+    float   quad[3];
+    int32_t use_rowcoef;
+    int32_t object;       /* index into the object bank given to dgdm_guidance_set_objects      */
+} DgdmObjective;
+
+/* ------------------------------------------------------------------ library */
+int         dgdm_version(void);
+const char *dgdm_last_error(void);
+/* 0 when device `ordinal` exists and is gfx950; selects it for this thread. */
+int         dgdm_device_init(int ordinal);
+/* Fills *out (lin/quad/use_rowcoef) for a reference objective name; DGDM_EOBJECTIVE otherwise. */
+int         dgdm_objective_from_name(const char *opt_obj, DgdmObjective *out);
+
+/* ------------------------------------------------------------------ a7: noise-prediction net
+ * ConditionalUnet1D(input_dim=1, global_cond_dim=0, down_dims, diffusion_step_embed_dim,
+ * kernel_size=5, n_groups=8)  (generator/diffusion_utils.py:124-236).                          */
+int dgdm_unet1d_create(DgdmUnet1d **out, const DgdmTensor *state_dict, int n_tensors,
+                       const int32_t *down_dims, int n_down, int step_embed_dim, int kernel_size, int n_groups);
+void dgdm_unet1d_destroy(DgdmUnet1d *m);
+/* ConditionalUnet1D.forward (diffusion_utils.py:238-285): sample_dev [B][L] (input_dim 1),
+ * timestep_dev [B] int32 (one per sample), eps_dev [B][L].                                      */
+int dgdm_unet1d_forward(DgdmUnet1d *m, const float *sample_dev, const int32_t *timestep_dev, float *eps_dev,
+                        int B, int L, void *stream);
+
+/* ------------------------------------------------------------------ a13/a14: scheduler step
+ * noise_pred - sqrt(1-abar_t)*grad*scale  (generator/diffusion.py:575,645) followed by
+ * DDIMScheduler.step(eta=0, clip_sample=True).prev_sample (diffusers 0.11.1; call sites
+ * diffusion.py:201,256,576,647).  grad_dev may be NULL (unguided loops :193-201, :249-256).
+ * grad_dev holds n_grad stacked gradients [n_grad][n]; their mean is used
+ * (guided_sample_multi_object :640-644).  The four square roots are float32 values computed
+ * by the host scheduler exactly as the reference computes them.                                 */
+int dgdm_ddim_guided_step(const float *x_dev, const float *eps_dev, const float *grad_dev, int n_grad,
+                          float *x_next_dev, int64_t n, float sqrt_abar_t, float sqrt_1m_abar_t,
+                          float sqrt_abar_prev, float sqrt_1m_abar_prev, float guidance_scale, void *stream);
+/* DDIMScheduler.add_noise (diffusion.py:145,185): out = sqrt_abar*x0 + sqrt_1m_abar*noise */
+int dgdm_ddim_add_noise(const float *x0_dev, const float *noise_dev, float *out_dev, int64_t n,
+                        float sqrt_abar, float sqrt_1m_abar, void *stream);
+
+/* ------------------------------------------------------------------ a8-a12: dynamics models
+ * kind 2: ProfileForward2DModel(W=256, params_ch, object_ch) (dynamics/profile_forward_2d.py:78-135)
+ * kind 3: ProfileForward3DModel(W=256, params_ch)            (dynamics/profile_forward_3d.py:13-65)
+ * BatchNorm layers are folded with their running statistics (the reference runs the classifier
+ * in eval mode with frozen parameters: generator/train.py:91-92).                 */
+int dgdm_dynamics_create(DgdmDynamics **out, int kind, const DgdmTensor *state_dict, int n_tensors,
+                         int params_ch, int object_ch);
+void dgdm_dynamics_destroy(DgdmDynamics *m);
+
+/* ProfileForward2DModel.forward (profile_forward_2d.py:137-156) on `rows` arbitrary rows:
+ * x_ctrl [rows][params_ch], x_ori [rows][1], x_pos [rows][2], t [rows] (already divided by
+ * num_train_timesteps, as cond_fn passes it), object [rows][object_ch] -> logits [rows][3].     */
+int dgdm_dyn2d_forward(DgdmDynamics *m, const float *x_ctrl_dev, const float *x_ori_dev, const float *x_pos_dev,
+                       const float *t_dev, const float *object_dev, float *logits_dev, int rows, void *stream);
+
+/* PointNet2.forward (dynamics/models/pointnet2.py:21-32): xyz_dev [rows][3][N] (channel-major, as
+ * the reference passes it), FPS start indices of sa1 and sa2 for every row (the values
+ * torch.randint draws at pointnet2_utils.py:83) in host memory -> emb_dev [rows][256].
+ * Rows holding bit-identical clouds share the per-cloud work.                                   */
+int dgdm_pointnet2_forward(DgdmDynamics *m, const float *xyz_dev, const int64_t *start_sa1_host,
+                           const int64_t *start_sa2_host, float *emb_dev, int rows, int N, void *stream);
+
+/* ProfileForward3DModel.forward (profile_forward_3d.py:67-86): x_ctrl [rows][3][params_ch]
+ * (only channel 1 is read, :78), object xyz [rows][3][N], FPS starts as above.                  */
+int dgdm_dyn3d_forward(DgdmDynamics *m, const float *x_ctrl_dev, const float *x_ori_dev, const float *x_pos_dev,
+                       const float *t_dev, const float *xyz_dev, const int64_t *start_sa1_host,
+                       const int64_t *start_sa2_host, float *logits_dev, int rows, int N, void *stream);
+
+/* ------------------------------------------------------------------ a4-a6: guidance gradient
+ * One DgdmGuidance serves up to max_chains independent chains (object x objective pairs) that
+ * share B fingers, the (grid_size, num_pos, ori_range) pose grid and the timestep; each chain
+ * has its own x [B][L].  This is Diffusion.cond_fn (generator/diffusion.py:473-504) with the
+ * R = B*grid_size*num_pos^2 replicated rows evaluated without materialising them.              */
+typedef struct DgdmGuidanceConfig {
+    int32_t batch;            /* B fingers per chain                                            */
+    int32_t grid_size;        /* G  (--grid_size)                                               */
+    int32_t num_pos;          /* P  (--num_pos)                                                 */
+    float   ori_lo, ori_hi;   /* ori_range                                                      */
+    int32_t max_chains;
+    int32_t num_train_timesteps;
+    int32_t sub_batch_size;   /* 3-D: --sub_bs; it fixes which rows share a torch.randint call  */
+    int32_t num_object_points;/* 3-D: N points per object cloud; 2-D: vertices per contour      */
+    int32_t max_objects;
+} DgdmGuidanceConfig;
+
+int  dgdm_guidance_create(DgdmGuidance **out, DgdmDynamics *model, const DgdmGuidanceConfig *cfg);
+void dgdm_guidance_destroy(DgdmGuidance *g);
+/* Objects the chains refer to.  2-D: objects_dev [n][num_vertices][2] (flattened to object_ch as
+ * cond_fn does, diffusion.py:485).  3-D: objects_dev [n][N][3]; builds the per-object PointNet++
+ * tables on `stream`.                                                            */
+int  dgdm_guidance_set_objects(DgdmGuidance *g, const float *objects_dev, int n_objects, void *stream);
+/* Rows of the pose grid per chain: R = B * G * P * P (reference row r = cell*B + b). */
+int64_t dgdm_guidance_rows(const DgdmGuidance *g);
+/* 3-D only: number of int64 FPS start indices one cond_fn call consumes per chain (= 2*R:
+ * for every sub-batch, sa1's draw then sa2's, pointnet2_utils.py:83 via diffusion.py:495-498). */
+int64_t dgdm_guidance_starts_per_call(const DgdmGuidance *g);
+
+/* Diffusion.cond_fn for n_chains chains at once.
+ *   x_dev        [n_chains][B][L]       current samples
+ *   timestep     the (shared) integer diffusion timestep t; the model sees t/num_train_timesteps
+ *   objectives   [n_chains] host array (objective + object index per chain)
+ *   rowcoef_dev  [n_chains][R] or NULL  (only read for chains with use_rowcoef)
+ *   starts_host  3-D: [n_chains][starts_per_call] int64 in the order the reference draws them;
+ *                2-D: NULL
+ *   grad_dev     [n_chains][B][L]       d sum(objective) / d x                                 */
+int dgdm_dyn2d_guidance_grad(DgdmGuidance *g, const float *x_dev, int timestep, const DgdmObjective *objectives,
+                             const float *rowcoef_dev, int n_chains, float *grad_dev, void *stream);
+int dgdm_dyn3d_guidance_grad(DgdmGuidance *g, const float *x_dev, int timestep, const DgdmObjective *objectives,
+                             const float *rowcoef_dev, const int64_t *starts_host, int n_chains, float *grad_dev,
+                             void *stream);
+
+/* Forward-only sweep of Diffusion.get_convergence_centers (diffusion.py:506-531): G orientations,
+ * pos = 0, t = 0, rows r = g*B + b.  logits_dev [n_chains][B*G][3].  starts_host (3-D) holds
+ * 2*B*G indices per chain in draw order with the sub_batch_size partition of :524-526.           */
+int dgdm_guidance_orientation_sweep(DgdmGuidance *g, const float *x_dev, const int32_t *object_of_chain,
+                                    const int64_t *starts_host, int n_chains, float *logits_dev, void *stream);
+
+/* Host helper for 'convergence': rowcoef_host[r] for one chain from its centers [B]
+ * (deltas_to_objective :445-452 + slicer; `rows_in_call` is R for 2-D and the sub-batch
+ * partition is applied for 3-D exactly as cond_fn :494-499 does).                               */
+int dgdm_convergence_rowcoef(const int64_t *centers_host, int n_centers, int grid_size, int num_pos,
+                             int64_t total_rows, int64_t sub_batch_size /* 0 = no sub-batching */, float *rowcoef_host);
+
+/* ------------------------------------------------------------------ measurement hooks
+ * When enabled, every launch of the trunk kernel (the dominant kernel) is
+ * bracketed by hipEvents on its own stream.  dgdm_prof_read synchronises those events and
+ * returns launches, total milliseconds and the algorithmic FLOPs they covered.                  */
+int dgdm_prof_enable(int on);
+int dgdm_prof_read(int64_t *launches, double *total_ms, double *total_flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGDM_HIP_H */

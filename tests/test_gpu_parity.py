@@ -1,0 +1,222 @@
+"""GPU parity tests: the HIP path (through the C-ABI of libdgdm_hip.so) against
+(a) the golden vectors captured from the reference and (b) the CPU oracle on seeded inputs.
+
+Tolerances (float32 path; north_star asks for finger-profile L2 error < 1e-4):
+  * forward passes / gradients: relative L2 <= 2e-5 (summation order and folded BatchNorm differ from torch's)
+  * final samples of a chain:   absolute L2 per finger <= 1e-4
+"""
+import numpy as np
+import pytest
+import torch
+
+from dgdm_amd import engine, sampler, synth
+from dgdm_amd.scheduler import DDIMScheduler
+from oracle import dgdm_oracle as orc
+from tests import util
+from tests.golden.make_golden_names import OBJ16
+
+pytestmark = pytest.mark.gpu
+REL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from dgdm_amd import _lib
+    _lib.device_init(0)
+    return torch.device("cuda:0")
+
+
+def sched(T, S):
+    s = DDIMScheduler(num_train_timesteps=int(T))
+    s.set_timesteps(int(S))
+    return s
+
+
+def finger_l2(a, b):
+    a = torch.as_tensor(a, dtype=torch.float64).reshape(-1, a.shape[-2] * a.shape[-1])
+    b = torch.as_tensor(b, dtype=torch.float64).reshape(a.shape)
+    return float((a - b).norm(dim=1).max())
+
+
+# ------------------------------------------------------------------------------------------------ a7 / a13
+def test_unet_golden(dev):
+    g = util.load("g2_unet.npz")
+    net = engine.Unet1d(util.unet_sd(g["seed"]))
+    for L in (14, 42):
+        x = torch.from_numpy(g[f"x_L{L}"]).to(dev)
+        for t in (0, 3, 12, 999):
+            y = net.forward(x, torch.full((4,), t, device=dev))
+            assert util.rel_l2(y.cpu(), g[f"y_L{L}_t{t}"]) < REL, (L, t)
+
+
+def test_unet_mixed_timesteps_and_batch(dev):
+    sd = util.unet_sd(5)
+    net = engine.Unet1d(sd)
+    x = torch.randn(37, 42, 1, generator=torch.Generator().manual_seed(1))
+    t = torch.randint(0, 1000, (37,), generator=torch.Generator().manual_seed(2))
+    y = net.forward(x.to(dev), t.to(dev))
+    assert util.rel_l2(y.cpu(), orc.unet1d_forward(sd, x, t)) < REL
+
+
+def test_ddim_step_and_unguided_chain(dev):
+    sd = util.unet_sd(11)
+    net = engine.Unet1d(sd)
+    for T, S, B, L in ((15, 5, 3, 14), (1000, 100, 2, 42)):
+        s = sched(T, S)
+        so = orc.DDIM(T)
+        so.set_timesteps(S)
+        assert torch.equal(s.timesteps, so.timesteps) and torch.equal(s.alphas_cumprod, so.alphas_cumprod)
+        x = synth.synth_noise(3, B, L)
+        e = synth.synth_noise(4, B, L)
+        for t in (int(s.timesteps[0]), int(s.timesteps[-1])):
+            got = s.step(e.to(dev), t, x.to(dev)).prev_sample.cpu()
+            assert util.rel_l2(got, so.step(e, t, x)) < 1e-6
+        n = s.add_noise(x.to(dev), e.to(dev), torch.full((B,), S, dtype=torch.int64)).cpu()
+        assert util.rel_l2(n, so.add_noise(x, e, torch.full((B,), S, dtype=torch.int64))) < 1e-6
+        out = sampler.unguided_sample(net, s, x.to(dev)).cpu()
+        ref = orc.unguided_sample(util.setup('point', sd, None, T, S, L, 1, 1), x)
+        assert finger_l2(out, ref) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ a8 / a4 (2-D)
+def test_dyn2d_forward_golden(dev):
+    g = util.load("g3_dyn2d.npz")
+    nv = int(g["dims"][6])
+    dyn = engine.Dynamics(2, util.dyn2d_sd(g["seed"], nv), 14, 2 * nv)
+    f = lambda k: torch.from_numpy(g[k]).to(dev)
+    y = dyn.forward2d(f("fwd_xc"), f("fwd_xo"), f("fwd_xp"), f("fwd_t"), f("fwd_obj"))
+    assert util.rel_l2(y.cpu(), g["fwd_logits"]) < REL
+
+
+def _guid2d(dyn, B, G, P, rng, T, nv, objs, dev, max_chains=4):
+    gd = engine.Guidance(dyn, B, G, P, rng, max_chains, T, nv, 0, max_objects=max(1, len(objs)))
+    gd.set_objects(torch.stack(list(objs)).to(dev))
+    return gd
+
+
+def test_dyn2d_cond_fn_golden(dev):
+    g = util.load("g3_dyn2d.npz")
+    B, G, P, L, T, S, nv = [int(v) for v in g["dims"]]
+    dyn = engine.Dynamics(2, util.dyn2d_sd(g["seed"], nv), 14, 2 * nv)
+    x = torch.from_numpy(g["x"]).to(dev).reshape(1, B, L)
+    obj = torch.from_numpy(g["obj"])
+    centers = torch.from_numpy(g["centers"])
+    for name, rng in (("full", (-1.0, 1.0)), ("half", (-0.5, 0.25))):
+        gd = _guid2d(dyn, B, G, P, rng, T, nv, [obj], dev)
+        rc = torch.from_numpy(gd.rowcoef(centers)).to(dev).reshape(1, -1)
+        for o in OBJ16:
+            gr = gd.grad(x, 9, [engine.make_objective(o, 0)], rc if o == 'convergence' else None)
+            assert util.rel_l2(gr.cpu().reshape(B, L, 1), g[f"grad_{o}_{name}"]) < REL, (o, name)
+
+
+def test_dyn2d_cond_fn_oracle_multichain(dev):
+    """Several chains with different objects/objectives in one launch; ragged last cell tile (C = 7*9 = 63)."""
+    nv, B, G, P, L, T = 100, 5, 7, 3, 14, 15
+    sd = util.dyn2d_sd(77, nv)
+    dyn = engine.Dynamics(2, sd, L, 2 * nv)
+    objs = [synth.synth_object_2d(i, nv) for i in range(3)]
+    gd = _guid2d(dyn, B, G, P, (-1.0, 1.0), T, nv, objs, dev, max_chains=6)
+    s = util.setup('point', None, sd, T, 5, L, G, P)
+    chains = [(0, 'rotate'), (1, 'shift_left'), (2, 'clockwise_up'), (1, 'rotate'), (0, 'convergence'), (2, 'rotate_counterclockwise')]
+    xs = torch.stack([synth.synth_noise(50 + i, B, L).clamp(-1, 1) for i in range(len(chains))])
+    centers = torch.tensor([2, 0, 6, 3, 1])
+    rc = np.zeros((len(chains), gd.rows), np.float32)
+    rc[4] = gd.rowcoef(centers)
+    gr = gd.grad(xs.reshape(len(chains), B, L).to(dev), 6, [engine.make_objective(o, oi) for oi, o in chains], torch.from_numpy(rc).to(dev)).cpu()
+    for c, (oi, o) in enumerate(chains):
+        ref = orc.cond_fn(s, xs[c], torch.full((B,), 6, dtype=torch.int64), o, objs[oi], (-1.0, 1.0), centers if o == 'convergence' else None)
+        assert util.rel_l2(gr[c].reshape(B, L, 1), ref) < REL, (c, o)
+
+
+# ------------------------------------------------------------------------------------------------ a9-a12 (3-D)
+def test_pointnet_golden(dev):
+    g = util.load("g4_pointnet.npz")
+    dyn = engine.Dynamics(3, util.dyn3d_sd(g["seed"]), 42)
+    clouds = torch.from_numpy(g["clouds"]).permute(0, 2, 1).contiguous().to(dev)
+    st = util.unpack_starts(g["starts"], g["start_lens"])
+    emb = dyn.pointnet2(clouds, st[0], st[1])
+    assert util.rel_l2(emb.cpu(), g["emb"]) < REL
+
+
+def test_dyn3d_forward_golden(dev):
+    g = util.load("g5_dyn3d.npz")
+    dyn = engine.Dynamics(3, util.dyn3d_sd(g["seed"]), 42)
+    f = lambda k: torch.from_numpy(g[k]).to(dev)
+    st = util.unpack_starts(g["fwd_starts"], g["fwd_start_lens"])
+    y = dyn.forward3d(f("fwd_xc"), f("fwd_xo"), f("fwd_xp"), f("fwd_t"), f("fwd_clouds").permute(0, 2, 1).contiguous(), st[0], st[1])
+    assert util.rel_l2(y.cpu(), g["fwd_logits"]) < REL
+
+
+def test_dyn3d_cond_fn_golden(dev):
+    g = util.load("g5_dyn3d.npz")
+    B, G, P, L, T, S = [int(v) for v in g["dims"]]
+    dyn = engine.Dynamics(3, util.dyn3d_sd(g["seed"]), 42)
+    x = torch.from_numpy(g["x"]).to(dev).reshape(1, B, L)
+    obj = torch.from_numpy(g["obj"])
+    for sub in (7, 512):
+        gd = engine.Guidance(dyn, B, G, P, (-1.0, 1.0), 2, T, 512, sub, max_objects=1)
+        gd.set_objects(obj[None].to(dev))
+        rc = torch.from_numpy(gd.rowcoef(torch.tensor([1, 0]))).to(dev).reshape(1, -1)
+        for o in ('rotate', 'clockwise_left', 'convergence'):
+            starts = g[f"starts_{o}_sub{sub}"].astype(np.int64)
+            gr = gd.grad(x, 6, [engine.make_objective(o, 0)], rc if o == 'convergence' else None, starts)
+            assert util.rel_l2(gr.cpu().reshape(B, L, 1), g[f"grad_{o}_sub{sub}"]) < REL, (o, sub)
+
+
+# ------------------------------------------------------------------------------------------------ a1-a3, a6: chains
+def test_chains_golden_2d(dev):
+    g = util.load("g6_chains.npz")
+    B, G, P, L, T, S, nv = [int(v) for v in g["dims2d"]]
+    net = engine.Unet1d(util.unet_sd(g["unet_seed"]))
+    dyn = engine.Dynamics(2, util.dyn2d_sd(g["dyn2d_seed"], nv), L, 2 * nv)
+    objs = torch.from_numpy(g["objs2d"])
+    gd = _guid2d(dyn, B, G, P, (-1.0, 1.0), T, nv, list(objs), dev, max_chains=8)
+    s = sched(T, S)
+    noise = synth.synth_noise(0, B, L).to(dev)
+    ug = sampler.unguided_sample(net, s, noise)
+    assert finger_l2(ug.cpu(), g["unguided2d"]) < 1e-4
+    names = ('rotate', 'shift_left', 'counterclockwise_up', 'convergence')
+    chains = [(oi, o) for o in names for oi in range(2)]
+    out = sampler.guided_chains(net, gd, s, 'point', noise, chains, unguided=ug).cpu()
+    for c, (oi, o) in enumerate(chains):
+        assert finger_l2(out[c], g[f"guided2d_{o}_obj{oi}"]) < 1e-4, (o, oi)
+    m = sampler.guided_multi_object(net, gd, s, 'point', noise, [0, 1], 'rotate_clockwise').cpu()
+    assert finger_l2(m, g["multi2d_rotate_clockwise"]) < 1e-4
+
+
+def test_chains_golden_3d(dev):
+    g = util.load("g6_chains.npz")
+    B, G, P, L, T, S = [int(v) for v in g["dims3d"]]
+    net = engine.Unet1d(util.unet_sd(g["unet_seed"]))
+    dyn = engine.Dynamics(3, util.dyn3d_sd(g["dyn3d_seed"]), L)
+    objs = torch.from_numpy(g["objs3d"])
+    gd = engine.Guidance(dyn, B, G, P, (-1.0, 1.0), 2, T, 512, 5, max_objects=2)
+    gd.set_objects(objs.to(dev))
+    s = sched(T, S)
+    noise = synth.synth_noise(0, B, L).to(dev)
+    ug = sampler.unguided_sample(net, s, noise)
+    assert finger_l2(ug.cpu(), g["unguided3d"]) < 1e-4
+    for o in ('rotate', 'convergence'):
+        st = sampler.StartStream(512, 5, util.unpack_starts(g[f"guided3d_{o}_starts"], g[f"guided3d_{o}_start_lens"]))
+        out = sampler.guided_chains(net, gd, s, 'point_3d', noise, [(0, o)], unguided=ug, starts=st).cpu()
+        assert finger_l2(out[0], g[f"guided3d_{o}"]) < 1e-4, o
+    st = sampler.StartStream(512, 5, util.unpack_starts(g["multi3d_shift_up_starts"], g["multi3d_shift_up_start_lens"]))
+    m = sampler.guided_multi_object(net, gd, s, 'point_3d', noise, [0, 1], 'shift_up', starts=st).cpu()
+    assert finger_l2(m, g["multi3d_shift_up"]) < 1e-4
+
+
+def test_convergence_centers_golden(dev):
+    g = util.load("g7_convergence.npz")
+    B, G, P, nv = [int(v) for v in g["cc2d_dims"]]
+    dyn = engine.Dynamics(2, util.dyn2d_sd(g["dyn2d_seed"], nv), 14, 2 * nv)
+    gd = _guid2d(dyn, B, G, P, (-1.0, 1.0), 15, nv, [torch.from_numpy(g["cc2d_obj"])], dev)
+    c = sampler.convergence_centers(gd, 'point', torch.from_numpy(g["cc2d_unguided"]).to(dev), [0])
+    assert np.array_equal(c[0].numpy(), g["cc2d_centers"])
+    B, G, P = [int(v) for v in g["cc3d_dims"]]
+    dyn = engine.Dynamics(3, util.dyn3d_sd(g["dyn3d_seed"]), 42)
+    gd = engine.Guidance(dyn, B, G, P, (-1.0, 1.0), 1, 15, 512, 4, max_objects=1)
+    gd.set_objects(torch.from_numpy(g["cc3d_obj"])[None].to(dev))
+    st = sampler.StartStream(512, 4, util.unpack_starts(g["cc3d_starts"], g["cc3d_start_lens"]))
+    c = sampler.convergence_centers(gd, 'point_3d', torch.from_numpy(g["cc3d_unguided"]).to(dev), [0], st.call(B * G))
+    assert np.array_equal(c[0].numpy(), g["cc3d_centers"])
