@@ -1,0 +1,41 @@
+// Unit-test hook for the MFMA chain: Y[256 x 32] = W[256 x 256] * X[256 x 32] for one tile.
+// X, Y are row-major [32 rows][256 features] (as every feature table in this library).
+#include "common.h"
+#include "mfma_chain.h"
+
+namespace dgdm {
+__global__ __launch_bounds__(64, 1) void debug_chain_kernel(const float4 *__restrict__ Wimg, const float *__restrict__ bias,
+                                                           const float *__restrict__ X, float *__restrict__ Y) {
+    const int lane = threadIdx.x & 63, n = lane & 31, h4 = (lane >> 5) * 4;
+    f32x16 in[8], out[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = feat4(X + n * 256, o, q, h4);
+            in[o][4 * q + 0] = v.x; in[o][4 * q + 1] = v.y; in[o][4 * q + 2] = v.z; in[o][4 * q + 3] = v.w;
+        }
+    chain_layer<8, 8, CHAIN_BIAS>(Wimg, bias, in, out, lane);
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 v;
+            v.x = out[o][4 * q + 0]; v.y = out[o][4 * q + 1]; v.z = out[o][4 * q + 2]; v.w = out[o][4 * q + 3];
+            *reinterpret_cast<float4 *>(Y + n * 256 + 32 * o + 8 * q + h4) = v;
+        }
+}
+}  // namespace dgdm
+
+// W_host [256][256] row-major, bias_host [256], X_dev/Y_dev [32][256]
+extern "C" int dgdm_debug_chain_layer(const float *W_host, const float *bias_host, const float *X_dev, float *Y_dev, void *stream) {
+    using namespace dgdm;
+    std::vector<float> img = pack_chain(W_host, 256, 256);
+    DevBuf dw, db;
+    int rc;
+    if ((rc = dw.upload(img.data(), img.size() * 4)) || (rc = db.upload(bias_host, 256 * 4))) return rc;
+    hipLaunchKernelGGL(debug_chain_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dw.as<float4>(), db.as<float>(), X_dev, Y_dev);
+    DGDM_HIP_CHECK(hipGetLastError());
+    DGDM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return DGDM_OK;
+}

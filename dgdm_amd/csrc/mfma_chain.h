@@ -46,19 +46,25 @@ __device__ __forceinline__ float4 feat4(const float *__restrict__ row, int o, in
 // Weight images are read through a buffer descriptor (wave-uniform base in SGPRs, per-lane byte
 // offset lane*16 in ONE VGPR, entry offset as scalar/immediate): no 64-bit per-load address math in
 // VGPRs, which is what lets the compiler keep a deep prefetch ring beside 128 operand registers.
-typedef __amdgpu_buffer_rsrc_t wrsrc_t;
+// (hipcc 7.2's __builtin_amdgcn_raw_buffer_load_b128 lowers to a ONE-dword load splatted over the vector -
+// checked in the .s - so the LLVM intrinsic is bound directly, the way composable_kernel does.)
+typedef int wrsrc_t __attribute__((ext_vector_type(4)));
+typedef float v4f32 __attribute__((ext_vector_type(4)));
+__device__ v4f32 llvm_amdgcn_raw_buffer_load_v4f32(wrsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 
 __device__ __forceinline__ wrsrc_t weight_rsrc(const float4 *base, uint32_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(base), 0, (int)bytes, 0x00020000);
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    wrsrc_t rs;
+    rs.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    rs.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)((a >> 32) & 0xffffu));     // stride 0, no swizzle
+    rs.z = (int)bytes;
+    rs.w = 0x00020000;
+    return rs;
 }
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 wload(wrsrc_t rs, int voff, int soff) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
-    float4 f;
-    f.x = __builtin_bit_cast(float, v.x); f.y = __builtin_bit_cast(float, v.y);
-    f.z = __builtin_bit_cast(float, v.z); f.w = __builtin_bit_cast(float, v.w);
-    return f;
+    const v4f32 v = llvm_amdgcn_raw_buffer_load_v4f32(rs, voff, soff, 0);
+    return make_float4(v.x, v.y, v.z, v.w);
 }
 
 // Streams `TOTAL` consecutive float4-per-lane weight entries (1 KiB apart) starting at byte offset

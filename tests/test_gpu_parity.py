@@ -74,9 +74,20 @@ def test_ddim_step_and_unguided_chain(dev):
             assert util.rel_l2(got, so.step(e, t, x)) < 1e-6
         n = s.add_noise(x.to(dev), e.to(dev), torch.full((B,), S, dtype=torch.int64)).cpu()
         assert util.rel_l2(n, so.add_noise(x, e, torch.full((B,), S, dtype=torch.int64))) < 1e-6
-        out = sampler.unguided_sample(net, s, x.to(dev)).cpu()
-        ref = orc.unguided_sample(util.setup('point', sd, None, T, S, L, 1, 1), x)
-        assert finger_l2(out, ref) < 1e-4
+        # Random-init nets make long chains chaotic: on the CPU oracle itself a 1e-7 relative change of the start noise moves
+        # the end of the 100-step chain by 5e-3 (finger L2) but the 5-step chain by 5e-6.  So the shipped 5-step chain is
+        # compared end to end, and long chains step by step along the oracle's trajectory (teacher forcing).
+        if S <= 10:
+            out = sampler.unguided_sample(net, s, x.to(dev)).cpu()
+            ref = orc.unguided_sample(util.setup('point', sd, None, T, S, L, 1, 1), x)
+            assert finger_l2(out, ref) < 1e-4
+        xo = x.clone()
+        for t in so.timesteps:
+            ts = torch.full((B,), int(t), dtype=torch.int64)
+            nxt = so.step(orc.unet1d_forward(sd, xo, ts), t, xo)
+            got = s.step(net.forward(xo.to(dev), ts.to(dev)), int(t), xo.to(dev)).prev_sample.cpu()
+            assert finger_l2(got, nxt) < 2e-5, int(t)
+            xo = nxt
 
 
 # ------------------------------------------------------------------------------------------------ a8 / a4 (2-D)
