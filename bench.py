@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Benchmark of the guided-sampling hot path (BASELINE.json metric: guided samples/sec over the full DDIM chain,
+plus ms per denoise step) on MI355X.
+
+Workload (default, BASELINE config 3 shape; config 4 at N = 8): 3-D dynamics-guided sampling.  One *step* of this
+benchmark is one batch of `--pairs` independent (object x objective) pairs per GPU, each a complete guided chain of
+B = 32 fingers: PointNet++ object tables, then S = 5 x [eps-net, cond_fn over R = 32*45*25 = 36 000 replicated rows with
+sub_bs = 512 FPS-start partition, guidance combine, DDIM step].  Every pair has its own synthetic 512-point object, so
+nothing is shared between pairs; the tables are rebuilt inside the timed region for every pair.  The FPS start
+indices (the torch.randint draws of pointnet2_utils.py:83) are the path's random input: they are drawn on the host
+in the reference's order by a background thread one step ahead and handed over as host buffers, so the timed region
+contains their host->device copy but not the Mersenne-Twister draw.
+`--workload 2d` runs BASELINE config 2 (B = 64, G = 360, P = 5, R = 576 000 rows per pair, 100-vertex contours).
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; one rank per GPU (RANK/LOCAL_RANK/WORLD_SIZE from the
+environment when N > 1); W untimed steps, exactly K timed steps between barrier + synchronize; rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from dgdm_amd import _lib, engine, sampler, synth          # noqa: E402
+from dgdm_amd.scheduler import DDIMScheduler               # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=4)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--workload", choices=["3d", "2d"], default="3d")
+    p.add_argument("--pairs", type=int, default=0, help="(object x objective) pairs per GPU per step (default 32 for 3d, 4 for 2d)")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-extra", action="store_true", help="skip the secondary workload summary")
+    return p.parse_args()
+
+
+class Workload:
+    def __init__(self, kind, pairs, dev, rank):
+        self.kind, self.dev = kind, dev
+        if kind == "3d":
+            self.mode, self.B, self.G, self.P, self.L, self.N, self.sub = 'point_3d', 32, 45, 5, 42, 512, 512
+        else:
+            self.mode, self.B, self.G, self.P, self.L, self.N, self.sub = 'point', 64, 360, 5, 14, 100, 0
+        self.T, self.S, self.pairs = 15, 5, pairs
+        self.unet_sd = synth.synth_state_dict(synth.unet_spec(), 11)
+        if kind == "3d":
+            self.dyn_sd = synth.synth_state_dict(synth.dyn3d_spec(self.L), 33)
+            self.dyn = engine.Dynamics(3, self.dyn_sd, self.L)
+        else:
+            self.dyn_sd = synth.synth_state_dict(synth.dyn2d_spec(self.L, 2 * self.N), 22)
+            self.dyn = engine.Dynamics(2, self.dyn_sd, self.L, 2 * self.N)
+        self.net = engine.Unet1d(self.unet_sd)
+        self.guid = engine.Guidance(self.dyn, self.B, self.G, self.P, (-1.0, 1.0), pairs, self.T, self.N, self.sub, max_objects=pairs)
+        self.sched = DDIMScheduler(num_train_timesteps=self.T)
+        self.sched.set_timesteps(self.S)
+        self.noise = synth.synth_noise(0, self.B, self.L).to(dev)
+        self.rank = rank
+        objectives = [o for o in synth.OBJECTIVES_12 if o != 'convergence']     # 'convergence' needs the sim-side unguided pass
+        self.chains = lambda step: [(i, objectives[(step * pairs + i) % len(objectives)]) for i in range(pairs)]
+        self.rows = self.guid.rows
+
+    def objects(self, step):
+        """Synthetic objects of this step's pairs (distinct for every pair, rank and step), already on the device."""
+        base = (self.rank * 100_000 + step) * self.pairs
+        mk = synth.synth_object_3d if self.kind == "3d" else synth.synth_object_2d
+        return torch.stack([mk(base + i, self.N) for i in range(self.pairs)]).to(self.dev)
+
+    def draw(self, step):
+        if self.kind != "3d":
+            return None
+        return sampler.draw_chain_starts(self.guid, self.chains(step), self.S)
+
+    def run(self, step, objs, predrawn):
+        self.guid.set_objects(objs)                      # 3-D: builds the PointNet++ tables of every pair (timed)
+        return sampler.guided_chains(self.net, self.guid, self.sched, self.mode, self.noise, self.chains(step), predrawn=predrawn)
+
+
+def timed_loop(wl, steps, warmup, dist):
+    """Returns (seconds for `steps` steps, last output).  Inputs of step k+1 are prepared while step k runs."""
+    total = warmup + steps
+    prepared = {}
+
+    def prepare(k):
+        prepared[k] = (wl.objects(k), wl.draw(k))
+
+    prepare(0)
+    out = None
+    t0 = None
+    for k in range(total):
+        if k == warmup:
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        th = None
+        if k + 1 < total:
+            th = threading.Thread(target=prepare, args=(k + 1,))
+            th.start()
+        objs, pre = prepared.pop(k)
+        out = wl.run(k, objs, pre)
+        if dist is not None and dist.get_world_size() > 1:
+            gathered = [torch.empty_like(out) for _ in range(dist.get_world_size())]
+            dist.all_gather(gathered, out)                # the path's only collective: final samples
+        if th is not None:
+            th.join()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, out
+
+
+def cpu_baseline(wl):
+    """The CPU oracle (a restatement of the reference's as-written dataflow) on this box's host cores, bounded sample."""
+    from oracle import dgdm_oracle as orc
+    # torch CPU kernels on these small/medium tensors get slower beyond a few dozen threads (256 threads: >10x slower
+    # than 32 on the MI355X host), so the baseline uses at most 32 - the count is reported in `cores`
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    cores = torch.get_num_threads()
+    so = orc.DDIM(wl.T)
+    so.set_timesteps(wl.S)
+    B, L = wl.B, wl.L
+    x = wl.noise.cpu()
+    ts = torch.full((B,), int(so.timesteps[0]), dtype=torch.int64)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        orc.unet1d_forward(wl.unet_sd, x, ts)
+    t_unet = time.perf_counter() - t0
+    cells = wl.G * wl.P * wl.P
+    if wl.kind == "3d":
+        # one full 512-row sub-batch of cond_fn (fwd + autograd), as generator/diffusion.py:495-498 runs 71 of per step
+        s = orc.Setup('point_3d', wl.unet_sd, wl.dyn_sd, so, L, wl.G, wl.P, wl.sub)
+        obj = synth.synth_object_3d(0, wl.N)
+        xr = x.clone().requires_grad_(True)
+        ori, pos = orc._pose_grid(s, B, (-1.0, 1.0))
+        n = 128                                          # a quarter of one 512-row sub-batch; cost is linear in rows
+        t0 = time.perf_counter()
+        with torch.enable_grad():
+            pts = orc._pts3d(s, xr).repeat(cells, 1, 1)[:n]
+            logits = orc.dyn3d_forward(wl.dyn_sd, pts, ori[:n], pos[:n], ts.repeat(cells)[:n].float() / wl.T,
+                                       obj.t().unsqueeze(0).expand(n, -1, -1), None)
+            torch.autograd.grad(orc.deltas_to_objective(logits, 'rotate').sum(), xr)
+        t_rows = (time.perf_counter() - t0) / n
+        chain = wl.S * (B * cells * t_rows + t_unet)
+        sample = (f"{n} of the {B * cells} replicated rows of one cond_fn call (PointNet++ + trunk forward, autograd backward) + 1 eps-net "
+                  f"forward, extrapolated to {B * cells} rows x {wl.S} steps")
+    else:
+        s = orc.Setup('point', wl.unet_sd, wl.dyn_sd, so, L, wl.G, wl.P)
+        obj = synth.synth_object_2d(0, wl.N)
+        Bs = 4                                          # 4 of 64 fingers against the full 9000-cell grid (36 000 rows)
+        t0 = time.perf_counter()
+        orc.cond_fn(s, x[:Bs], ts[:Bs], 'rotate', obj)
+        t_c = (time.perf_counter() - t0) * (B / Bs)
+        chain = wl.S * (t_c + t_unet)
+        sample = f"cond_fn on {Bs} of {B} fingers x all {cells} cells (36000 rows) + 1 eps-net forward, extrapolated x{B // Bs} x{wl.S} steps"
+    return {"value": B / chain, "unit": "guided samples/s", "cores": cores, "kind": "port", "sample": sample,
+            "ms_per_denoise_step": chain / wl.S * 1e3}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if a.gpus > 1 or world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    _lib.device_init(local)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    torch.manual_seed(1234 + rank)
+    pairs = a.pairs or (32 if a.workload == "3d" else 4)
+    wl = Workload(a.workload, pairs, dev, rank)
+
+    engine.prof_enable(False)
+    secs, _ = timed_loop(wl, a.steps, a.warmup, dist)
+    if dist is not None:
+        tmax = torch.tensor([secs], device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        secs = float(tmax.item())
+    # second pass, rank 0 only: HIP events around every launch of the dominant kernel (the fused trunk)
+    roof = None
+    if rank == 0:
+        engine.prof_enable(True)
+        objs, pre = wl.objects(0), wl.draw(0)
+        torch.cuda.synchronize()
+        wl.run(0, objs, pre)
+        torch.cuda.synchronize()
+        n, ms, flops = engine.prof_read()
+        engine.prof_enable(False)
+        if n:
+            ach = flops / (ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "trunk_kernel (fused dynamics trunk fwd+bwd)", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None, "launches": n, "avg_launch_ms": ms / n,
+                    "algorithmic_flops_per_launch": flops / n, "share_of_step": (ms * 1e-3) / (secs / a.steps)}
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    samples = wl.B * pairs * world * a.steps
+    line = {
+        "metric": "guided samples/sec (full DDIM chain)", "value": samples / secs, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": secs / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic (random-init checkpoints, synthetic objects, seeded noise; SURVEY.md §8(d))",
+        "config": {"workload": ("3-D dynamics-guided sampling (BASELINE configs[2]; configs[3] at 8 GPUs): per GPU and step %d (object x objective) "
+                                "pairs x B=32 fingers, G=45, P=5 -> R=36000 rows per cond_fn, sub_bs=512, 512-point objects, T=15/S=5"
+                                if a.workload == "3d" else
+                                "2-D dynamics-guided sampling (BASELINE configs[1]): per GPU and step %d (object x objective) pairs x B=64 fingers, "
+                                "G=360, P=5 -> R=576000 rows per cond_fn, 100-vertex objects, T=15/S=5") % pairs,
+                   "pairs_per_gpu_per_step": pairs, "fingers_per_pair": wl.B, "denoise_steps": wl.S, "rows_per_cond_fn": wl.rows},
+        "ms_per_denoise_step": secs / a.steps / wl.S * 1e3,
+        "ms_per_denoise_step_per_pair": secs / a.steps / wl.S / pairs * 1e3,
+    }
+    if roof:
+        line["roofline"] = roof
+    if world == 1 and not a.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(wl)
+        line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
+    if world == 1 and not a.no_extra:
+        other = "2d" if a.workload == "3d" else "3d"
+        del wl
+        torch.cuda.empty_cache()
+        w2 = Workload(other, 4 if other == "2d" else 32, dev, rank)
+        s2, _ = timed_loop(w2, 2, 1, None)
+        line["extra"] = {"workload": other, "samples_per_s": w2.B * w2.pairs * 2 / s2, "ms_per_denoise_step_per_pair": s2 / 2 / w2.S / w2.pairs * 1e3}
+    print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

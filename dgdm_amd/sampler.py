@@ -49,7 +49,12 @@ class StartStream:
         return torch.randint(0, high, (n,), dtype=torch.long).numpy()
 
     def call(self, rows: int) -> np.ndarray:
-        """The 2*rows indices one classifier call over `rows` rows consumes."""
+        """The 2*rows indices one classifier call over `rows` rows consumes, in draw order:
+        [sub-batch 0: sa1 x n0, sa2 x n0 | sub-batch 1: ...] - the layout dgdm_dyn3d_guidance_grad takes."""
+        if self._forced is None and self.N == 512:
+            # same range for both layers: consecutive randint calls on the CPU generator concatenate
+            # (tests/test_host_logic.py::test_start_stream_matches_reference_draws), so one call does it
+            return torch.randint(0, 512, (2 * rows,), dtype=torch.long).numpy()
         out = np.empty(2 * rows, dtype=np.int64)
         for r0 in range(0, rows, self.sub):
             n = min(self.sub, rows - r0)
@@ -91,9 +96,24 @@ def convergence_centers(guid: Guidance, mode: str, unguided: torch.Tensor, objec
     return out
 
 
+def draw_chain_starts(guid: Guidance, chains: Sequence[Tuple[int, str]], n_steps: int, starts: Optional[StartStream] = None):
+    """FPS starts of a batch of 3-D chains in the order the reference's sequential loops consume the generator:
+    chain after chain (generator/diffusion.py:561); inside a chain the centre sweep (:563) and then every step's cond_fn (:574)."""
+    nc = len(chains)
+    starts = starts or StartStream(guid.cfg.num_object_points, guid.cfg.sub_batch_size)
+    sweep: List[Optional[np.ndarray]] = [None] * nc
+    step = np.zeros((n_steps, nc, guid.starts_per_call), dtype=np.int64)
+    for c, (_, o) in enumerate(chains):
+        if o == 'convergence':
+            sweep[c] = starts.call(guid.sweep_rows)
+        for si in range(n_steps):
+            step[si, c] = starts.call(guid.rows)
+    return sweep, step
+
+
 def guided_chains(unet: Unet1d, guid: Guidance, sched: DDIMScheduler, mode: str, noise: torch.Tensor,
                   chains: Sequence[Tuple[int, str]], unguided: Optional[torch.Tensor] = None,
-                  starts: Optional[StartStream] = None, trace: Optional[list] = None) -> torch.Tensor:
+                  starts: Optional[StartStream] = None, trace: Optional[list] = None, predrawn=None) -> torch.Tensor:
     """``Diffusion.guided_sample`` loop bodies (:561-576) for the chains [(object index, opt_obj), ...].
 
     noise (B, L, 1) is shared by all chains (:570).  Returns (n_chains, B, L, 1)."""
@@ -104,14 +124,9 @@ def guided_chains(unet: Unet1d, guid: Guidance, sched: DDIMScheduler, mode: str,
     objectives = [make_objective(o, oi) for oi, o in chains]
     # --- replay of the reference's RNG consumption: chain after chain; inside a chain the centre sweep, then the steps
     sweep_starts: List[Optional[np.ndarray]] = [None] * nc
-    step_starts = np.zeros((S, nc, guid.starts_per_call), dtype=np.int64) if is3d else None
+    step_starts = None
     if is3d:
-        starts = starts or StartStream(guid.cfg.num_object_points, guid.cfg.sub_batch_size)
-        for c, (_, o) in enumerate(chains):
-            if o == 'convergence':
-                sweep_starts[c] = starts.call(guid.sweep_rows)
-            for si in range(S):
-                step_starts[si, c] = starts.call(guid.rows)
+        sweep_starts, step_starts = predrawn if predrawn is not None else draw_chain_starts(guid, chains, S, starts)
     # --- 'convergence' chains: centres from the unguided sample, then row coefficients
     rowcoef = None
     conv = [c for c, (_, o) in enumerate(chains) if o == 'convergence']
