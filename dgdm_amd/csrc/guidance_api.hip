@@ -24,6 +24,9 @@ struct ObjectTables {       // 3-D, per object
     DevBuf xyz;             // [N][3]
     DevBuf fps1;            // [N][512] int
     DevBuf Z;               // [N][N][256]
+    DevBuf fps2;            // [N][128] int: FPS(128) sequence by start point
+    DevBuf flags;           // [N] int: that sequence is order-dependent (exact distance tie / coordinates exhausted)
+    bool   fast_ok = false; // no flag set: rows can take their centres from fps2 instead of running FPS
 };
 
 }  // namespace
@@ -37,8 +40,9 @@ struct DgdmGuidance {
     DevBuf objpart;                              // 2-D: [max_objects][W1]
     std::vector<std::unique_ptr<ObjectTables>> tables;   // 3-D
     DevBuf tmpF1, tmpU, tmpY, tmpL2, vlist;      // 3-D table-build temporaries
-    DevBuf V, genc, atab, chainbias, timepart, ttmp, partial, objdev, objidx, xobj, starts, xchains;
+    DevBuf V, genc, atab, chainbias, timepart, ttmp, partial, objdev, objidx, xobj, starts, order, xchains;
     int n_objects = 0;
+    bool force_slow_xobj = false;   // test hook: always run the per-row FPS kernel
     void *pinned = nullptr; size_t pinned_bytes = 0; hipEvent_t pinned_ev = nullptr;
     ~DgdmGuidance() {
         if (pinned) (void)hipHostFree(pinned);
@@ -107,9 +111,9 @@ extern "C" int dgdm_guidance_create(DgdmGuidance **out, DgdmDynamics *model, con
         if ((rc = g->objpart.alloc((size_t)std::max(1, cfg->max_objects) * W1 * 4))) return rc;
     } else {
         if ((rc = g->xobj.alloc((size_t)nc * g->R * 256 * 4)) || (rc = g->starts.alloc((size_t)nc * g->R * 2 * sizeof(int))) ||
-            (rc = g->xchains.alloc(sizeof(XobjChain) * nc)))
+            (rc = g->order.alloc((size_t)nc * g->R * sizeof(int))) || (rc = g->xchains.alloc(sizeof(XobjChain) * nc)))
             return rc;
-        g->pinned_bytes = (size_t)nc * g->R * 2 * sizeof(int);
+        g->pinned_bytes = (size_t)nc * g->R * 3 * sizeof(int);
         DGDM_HIP_CHECK(hipHostMalloc(&g->pinned, g->pinned_bytes, hipHostMallocDefault));
         DGDM_HIP_CHECK(hipEventCreateWithFlags(&g->pinned_ev, hipEventDisableTiming));
     }
@@ -118,6 +122,14 @@ extern "C" int dgdm_guidance_create(DgdmGuidance **out, DgdmDynamics *model, con
 }
 
 extern "C" void dgdm_guidance_destroy(DgdmGuidance *g) { delete g; }
+
+extern "C" int dgdm_guidance_debug_fps_path(DgdmGuidance *g, int force_per_row, int32_t *out_fast_ok) {
+    DGDM_REQUIRE(g, DGDM_EINVAL, "dgdm_guidance_debug_fps_path: null handle");
+    g->force_slow_xobj = force_per_row != 0;
+    if (out_fast_ok)
+        for (int i = 0; i < g->n_objects && i < (int)g->tables.size(); ++i) out_fast_ok[i] = g->tables[i]->fast_ok ? 1 : 0;
+    return DGDM_OK;
+}
 extern "C" int64_t dgdm_guidance_rows(const DgdmGuidance *g) { return g ? g->R : 0; }
 extern "C" int64_t dgdm_guidance_starts_per_call(const DgdmGuidance *g) { return (g && g->m->kind == 3) ? 2 * g->R : 0; }
 
@@ -127,7 +139,8 @@ int DgdmGuidance::build_object(int oi, const float *xyz_dev, hipStream_t s) {
     ObjectTables &t = *tables[oi];
     const PnWeights w = m->pn();
     int rc;
-    if ((rc = t.xyz.alloc((size_t)N * 3 * 4)) || (rc = t.fps1.alloc((size_t)N * 512 * sizeof(int))) || (rc = t.Z.alloc((size_t)N * N * 256 * 4)))
+    if ((rc = t.xyz.alloc((size_t)N * 3 * 4)) || (rc = t.fps1.alloc((size_t)N * 512 * sizeof(int))) || (rc = t.Z.alloc((size_t)N * N * 256 * 4)) ||
+        (rc = t.fps2.alloc((size_t)N * 128 * sizeof(int))) || (rc = t.flags.alloc((size_t)N * sizeof(int))))
         return rc;
     if ((rc = tmpF1.alloc((size_t)N * 128 * 4)) || (rc = tmpU.alloc((size_t)N * 128 * 4)) || (rc = tmpY.alloc((size_t)N * N * 256 * 4)) ||
         (rc = tmpL2.alloc((size_t)N * N * 256 * 4)))
@@ -139,7 +152,8 @@ int DgdmGuidance::build_object(int oi, const float *xyz_dev, hipStream_t s) {
     }
     DGDM_HIP_CHECK(hipMemcpyAsync(t.xyz.p, xyz_dev, (size_t)N * 3 * 4, hipMemcpyDeviceToDevice, s));
     const float *xyz = t.xyz.as<float>();
-    if ((rc = pn_fps_table(xyz, N, N, 512, t.fps1.as<int>(), s))) return rc;                                   // T1
+    if ((rc = pn_fps_table(xyz, N, N, 512, t.fps1.as<int>(), nullptr, s))) return rc;                          // T1
+    if ((rc = pn_fps_table(xyz, N, N, 128, t.fps2.as<int>(), t.flags.as<int>(), s))) return rc;
     if ((rc = pn_sa1(xyz, N, w, tmpF1.as<float>(), s))) return rc;                                             // T2
     if ((rc = linear(tmpF1.as<float>(), 128, w.sa2_wf_t, w.sa2_b0, nullptr, 1, tmpU.as<float>(), 128, N, 128, 128, ACT_NONE, false, s))) return rc;  // T3
     if ((rc = pn_pairs(xyz, N, tmpU.as<float>(), w, tmpY.as<float>(), s))) return rc;                          // T4
@@ -162,6 +176,16 @@ extern "C" int dgdm_guidance_set_objects(DgdmGuidance *g, const float *objects_d
         const int N = g->cfg.num_object_points;
         for (int i = 0; i < n_objects; ++i)
             if ((rc = g->build_object(i, objects_dev + (size_t)i * N * 3, s))) return rc;
+        // which objects may use the table of FPS(128) sequences (no order-dependent selection anywhere)
+        std::vector<int> fl((size_t)n_objects * N);
+        for (int i = 0; i < n_objects; ++i)
+            DGDM_HIP_CHECK(hipMemcpyAsync(fl.data() + (size_t)i * N, g->tables[i]->flags.p, sizeof(int) * N, hipMemcpyDeviceToHost, s));
+        DGDM_HIP_CHECK(hipStreamSynchronize(s));
+        for (int i = 0; i < n_objects; ++i) {
+            bool ok = N >= 128;
+            for (int k = 0; k < N; ++k) ok = ok && fl[(size_t)i * N + k] == 0;
+            g->tables[i]->fast_ok = ok;
+        }
     }
     g->n_objects = n_objects;
     return DGDM_OK;
@@ -188,7 +212,7 @@ int DgdmGuidance::common_pre(const float *x_dev, float t_scaled, const int *obji
 int DgdmGuidance::upload_starts(const int64_t *starts_host, int n_chains, int64_t rows, hipStream_t s) {
     const int N = cfg.num_object_points;
     const int64_t sb = cfg.sub_batch_size;
-    DGDM_REQUIRE((size_t)n_chains * rows * 2 * sizeof(int) <= pinned_bytes, DGDM_EINVAL, "starts staging too small");
+    DGDM_REQUIRE((size_t)n_chains * rows * 3 * sizeof(int) <= pinned_bytes, DGDM_EINVAL, "starts staging too small");
     DGDM_HIP_CHECK(hipEventSynchronize(pinned_ev));            // previous copy out of the staging buffer has finished
     int *dst = static_cast<int *>(pinned);
     for (int c = 0; c < n_chains; ++c) {
@@ -204,7 +228,19 @@ int DgdmGuidance::upload_starts(const int64_t *starts_host, int n_chains, int64_
             }
         }
     }
+    // rows of every chain sorted by s1 (counting sort): rows of one variant gather from the same Z slab
+    int *ord = dst + (size_t)n_chains * 2 * rows;
+    std::vector<int> cnt(N + 1);
+    for (int c = 0; c < n_chains; ++c) {
+        const int *d = dst + (size_t)c * 2 * rows;
+        int *o = ord + (size_t)c * rows;
+        std::fill(cnt.begin(), cnt.end(), 0);
+        for (int64_t r = 0; r < rows; ++r) ++cnt[d[2 * r] + 1];
+        for (int k = 0; k < N; ++k) cnt[k + 1] += cnt[k];
+        for (int64_t r = 0; r < rows; ++r) o[cnt[d[2 * r]]++] = (int)r;
+    }
     DGDM_HIP_CHECK(hipMemcpyAsync(starts.p, pinned, (size_t)n_chains * rows * 2 * sizeof(int), hipMemcpyHostToDevice, s));
+    DGDM_HIP_CHECK(hipMemcpyAsync(order.p, ord, (size_t)n_chains * rows * sizeof(int), hipMemcpyHostToDevice, s));
     DGDM_HIP_CHECK(hipEventRecord(pinned_ev, s));
     return DGDM_OK;
 }
@@ -215,12 +251,12 @@ int DgdmGuidance::run_xobj(const int *objidx_host, int n_chains, int64_t rows, h
         DGDM_REQUIRE(objidx_host[i] >= 0 && objidx_host[i] < n_objects, DGDM_EINVAL, "chain %d refers to object %d of %d", i, objidx_host[i], n_objects);
         const ObjectTables &t = *tables[objidx_host[i]];
         ch[i].xyz = t.xyz.as<float>(); ch[i].fps1 = t.fps1.as<int>(); ch[i].slot_of_start = nullptr; ch[i].Z = t.Z.as<float>();
-        ch[i].N = cfg.num_object_points; ch[i].pad = 0;
+        ch[i].fps2 = t.fps2.as<int>(); ch[i].flags = t.flags.as<int>(); ch[i].N = cfg.num_object_points;
     }
     DGDM_HIP_CHECK(hipMemcpyAsync(xchains.p, ch.data(), sizeof(XobjChain) * n_chains, hipMemcpyHostToDevice, s));
     XobjParams xp{};
-    xp.chains = xchains.as<XobjChain>(); xp.starts = starts.as<int>(); xp.xobj = xobj.as<float>();
-    xp.R = rows; xp.total_rows = rows * n_chains;
+    xp.chains = xchains.as<XobjChain>(); xp.starts = starts.as<int>(); xp.order = order.as<int>(); xp.xobj = xobj.as<float>();
+    xp.R = rows; xp.total_rows = rows * n_chains; xp.use_table = force_slow_xobj ? 0 : 1;
     return pn_xobj(xp, s);
 }
 
@@ -344,14 +380,14 @@ int pointnet_rows(DgdmDynamics *m, const float *xyz_dev /*[rows][3][N]*/, const 
             (rc = L2.alloc((size_t)nv * N * 1024)) || (rc = Z.alloc((size_t)nv * N * 1024)) || (rc = out.alloc(rws.size() * 1024)))
             return rc;
         const float *x = xyz.as<float>();
-        if ((rc = pn_fps_table(x, N, N, 512, fps1.as<int>(), s))) return rc;
+        if ((rc = pn_fps_table(x, N, N, 512, fps1.as<int>(), nullptr, s))) return rc;
         if ((rc = pn_sa1(x, N, w, F1.as<float>(), s))) return rc;
         if ((rc = linear(F1.as<float>(), 128, w.sa2_wf_t, w.sa2_b0, nullptr, 1, U.as<float>(), 128, N, 128, 128, ACT_NONE, false, s))) return rc;
         if ((rc = pn_pairs(x, N, U.as<float>(), w, Y.as<float>(), s))) return rc;
         if ((rc = pn_l2(x, N, w, fps1.as<int>(), vlist.as<int>(), nv, Y.as<float>(), L2.as<float>(), s))) return rc;
         if ((rc = pn_z(x, N, nv, w, L2.as<float>(), Z.as<float>(), s))) return rc;
         XobjChain ch{};
-        ch.xyz = x; ch.fps1 = fps1.as<int>(); ch.slot_of_start = slotmap.as<int>(); ch.Z = Z.as<float>(); ch.N = N;
+        ch.xyz = x; ch.fps1 = fps1.as<int>(); ch.slot_of_start = slotmap.as<int>(); ch.Z = Z.as<float>(); ch.fps2 = nullptr; ch.flags = nullptr; ch.N = N;
         DGDM_HIP_CHECK(hipMemcpyAsync(chains.p, &ch, sizeof ch, hipMemcpyHostToDevice, s));
         XobjParams xp{};
         xp.chains = chains.as<XobjChain>(); xp.starts = starts.as<int>(); xp.xobj = out.as<float>(); xp.R = (int64_t)rws.size(); xp.total_rows = xp.R;

@@ -25,18 +25,21 @@ struct XobjChain {
     const int   *fps1;            // [N][512]
     const int   *slot_of_start;   // [N] start index -> table slot, or null (slot = start)
     const float *Z;               // [nv][N][256]
+    const int   *fps2;            // [N][128] FPS(128) sequences by start POINT, or null
+    const int   *flags;           // [N] 1 = the sequence from this start point is order-dependent: run FPS for the row
     int          N;
-    int          pad;
 };
 
 struct XobjParams {
     const XobjChain *chains;      // device array [nchain]
     const int       *starts;      // [nchain][R][2]  (s1, s2) per reference row
+    const int       *order;       // [nchain][R] row ids of each chain sorted by s1, or null (natural order)
     float           *xobj;        // [nchain][R][256]
     int64_t          R, total_rows;
+    int              use_table;   // 0: always run the per-row FPS (test hook)
 };
 
-int pn_fps_table(const float *xyz, int N, int nv, int npoint, int *out, hipStream_t s);
+int pn_fps_table(const float *xyz, int N, int nv, int npoint, int *out, int *flags, hipStream_t s);
 int pn_sa1(const float *xyz, int N, const PnWeights &w, float *F1, hipStream_t s);
 int pn_pairs(const float *xyz, int N, const float *U, const PnWeights &w, float *Y, hipStream_t s);
 int pn_l2(const float *xyz, int N, const PnWeights &w, const int *fps1, const int *vlist, int nv, const float *Y, float *L2, hipStream_t s);

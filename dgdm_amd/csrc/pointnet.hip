@@ -48,8 +48,13 @@ __device__ __forceinline__ void wave_argmax(float &v, int &i) {
 
 // farthest_point_sample (pointnet2_utils.py:71-92) by one wave over M <= 64*PPL points whose
 // coordinates sit in LDS (SoA lx/ly/lz, M entries).  Writes npoint indices to out (LDS or global).
-template <int PPL>
-__device__ void fps_wave(const float *lx, const float *ly, const float *lz, int M, int start, int npoint, int *out, int lane) {
+// With TIES the return value tells whether the selection was ever order-dependent: two candidates
+// with DIFFERENT coordinates shared the maximal distance, or every remaining distance was 0 (all
+// distinct coordinates used up, so the reference falls back to position 0 of its own ordering).
+// A sequence without such an event is the same for every ordering of the cloud, up to which of
+// several bit-identical points represents a coordinate.
+template <int PPL, bool TIES>
+__device__ bool fps_wave(const float *lx, const float *ly, const float *lz, int M, int start, int npoint, int *out, int lane) {
     float px[PPL], py[PPL], pz[PPL], dist[PPL];
 #pragma unroll
     for (int i = 0; i < PPL; ++i) {
@@ -59,6 +64,7 @@ __device__ void fps_wave(const float *lx, const float *ly, const float *lz, int 
         dist[i] = ok ? 1e10f : -1.f;                 // padding can never be the farthest point
     }
     int far = start;
+    bool ambiguous = false;
     for (int it = 0; it < npoint; ++it) {
         if (lane == 0) out[it] = far;
         const float cx = lx[far], cy = ly[far], cz = lz[far];
@@ -72,20 +78,36 @@ __device__ void fps_wave(const float *lx, const float *ly, const float *lz, int 
         }
         wave_argmax(bv, bi);
         far = bi;
+        if (TIES && it + 1 < npoint) {
+            const float wx = lx[far], wy = ly[far], wz = lz[far];
+            bool t = bv == 0.f;
+#pragma unroll
+            for (int i = 0; i < PPL; ++i) t = t || (dist[i] == bv && (px[i] != wx || py[i] != wy || pz[i] != wz));
+            ambiguous = ambiguous || t;
+        }
     }
+    return TIES ? (__ballot(ambiguous) != 0ull) : false;
 }
 
 // ------------------------------------------------------------------------------------------------ T1
-// fps1[v][0..npoint) for v = 0..nv-1 (start index v) on cloud xyz [N][3]
-__global__ __launch_bounds__(256) void fps_table_kernel(const float *__restrict__ xyz, int N, int nv, int npoint, int *__restrict__ out) {
+// fps[v][0..npoint) for v = 0..nv-1 (start index v) on cloud xyz [N][3]; flags[v] (optional) = selection was order-dependent
+__global__ __launch_bounds__(256) void fps_table_kernel(const float *__restrict__ xyz, int N, int nv, int npoint, int *__restrict__ out,
+                                                        int *__restrict__ flags) {
     extern __shared__ float lds[];
     float *lx = lds, *ly = lds + N, *lz = lds + 2 * N;
     for (int i = threadIdx.x; i < N; i += blockDim.x) { lx[i] = xyz[3 * i]; ly[i] = xyz[3 * i + 1]; lz[i] = xyz[3 * i + 2]; }
     __syncthreads();
-    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (v >= nv) return;
-    if (N <= 512) fps_wave<8>(lx, ly, lz, N, v, npoint, out + (size_t)v * npoint, threadIdx.x & 63);
-    else fps_wave<16>(lx, ly, lz, N, v, npoint, out + (size_t)v * npoint, threadIdx.x & 63);
+    bool amb;
+    if (flags) {
+        amb = N <= 512 ? fps_wave<8, true>(lx, ly, lz, N, v, npoint, out + (size_t)v * npoint, lane)
+                       : fps_wave<16, true>(lx, ly, lz, N, v, npoint, out + (size_t)v * npoint, lane);
+        if (lane == 0) flags[v] = amb ? 1 : 0;
+    } else {
+        if (N <= 512) fps_wave<8, false>(lx, ly, lz, N, v, npoint, out + (size_t)v * npoint, lane);
+        else fps_wave<16, false>(lx, ly, lz, N, v, npoint, out + (size_t)v * npoint, lane);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ T2
@@ -283,35 +305,57 @@ __global__ __launch_bounds__(256, 1) void z_kernel(const float *__restrict__ xyz
 // ------------------------------------------------------------------------------------------------ per row
 // xobj[row][256] = max over the 128 centres FPS picks (start s2) on the cloud re-ordered by variant s1 of
 // Z[slot(s1)][point].  One wave per row.   (sa2's FPS + sa3's max, pointnet2_utils.py:132,208)
+// The centres come from the per-object table fps2[start point] whenever that sequence is order-independent.
+// Work item -> row: workgroups are dealt round-robin to the 8 XCDs, so block b takes the (b/8)-th block of XCD (b%8)'s
+// contiguous share of the (chain, s1)-sorted rows; rows that gather from the same Z[variant] slab then meet in one L2.
+__device__ __forceinline__ int64_t xcd_contiguous(int64_t block, int64_t nblocks) {
+    const int64_t q = nblocks / 8, rem = nblocks % 8, x = block % 8, i = block / 8;
+    return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + i;
+}
+
 __global__ __launch_bounds__(256) void xobj_kernel(const XobjParams p) {
     __shared__ float coords[4][3][512];
     __shared__ int centres[4][128];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t w = (int64_t)blockIdx.x * 4 + wave;
+    int64_t w = xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wave;
     if (w >= p.total_rows) return;
+    if (p.order) w = (w / p.R) * p.R + p.order[w];
     const int chain = (int)(w / p.R);
     const int64_t r = w - (int64_t)chain * p.R;
     const XobjChain ch = p.chains[chain];
     const int *st = p.starts + (size_t)chain * 2 * p.R;
-    const int s1 = st[2 * r], s2 = st[2 * r + 1];
+    const int s1 = __builtin_amdgcn_readfirstlane(st[2 * r]), s2 = __builtin_amdgcn_readfirstlane(st[2 * r + 1]);
     const int slot = ch.slot_of_start ? ch.slot_of_start[s1] : s1;
     const int *perm = ch.fps1 + (size_t)s1 * 512;
-    float *lx = coords[wave][0], *ly = coords[wave][1], *lz = coords[wave][2];
+    int idA, idB;                                       // the 128 centre POINT ids, two per lane
+    const int q = __builtin_amdgcn_readfirstlane(perm[s2]);      // start point of sa2's FPS
+    if (p.use_table && ch.fps2 && ch.flags[q] == 0) {
+        // the FPS(128) sequence from start point q is the same for every ordering of the cloud (fps_wave TIES clear)
+        idA = ch.fps2[(size_t)q * 128 + lane];
+        idB = ch.fps2[(size_t)q * 128 + 64 + lane];
+    } else {
+        // order-dependent selection (exact distance tie) or no table: run FPS on the cloud as re-ordered by variant s1
+        float *lx = coords[wave][0], *ly = coords[wave][1], *lz = coords[wave][2];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int j = lane + 64 * i, pid = perm[j];
-        lx[j] = ch.xyz[3 * pid]; ly[j] = ch.xyz[3 * pid + 1]; lz[j] = ch.xyz[3 * pid + 2];
+        for (int i = 0; i < 8; ++i) {
+            const int j = lane + 64 * i, pid = perm[j];
+            lx[j] = ch.xyz[3 * pid]; ly[j] = ch.xyz[3 * pid + 1]; lz[j] = ch.xyz[3 * pid + 2];
+        }
+        __builtin_amdgcn_wave_barrier();
+        fps_wave<8, false>(lx, ly, lz, 512, s2, 128, centres[wave], lane);
+        __builtin_amdgcn_wave_barrier();
+        idA = perm[centres[wave][lane]];
+        idB = perm[centres[wave][64 + lane]];
     }
-    __builtin_amdgcn_wave_barrier();
-    fps_wave<8>(lx, ly, lz, 512, s2, 128, centres[wave], lane);
-    __builtin_amdgcn_wave_barrier();
     const float *zt = ch.Z + (size_t)slot * ch.N * 256 + lane * 4;
     float4 best = make_float4(0.f, 0.f, 0.f, 0.f);      // Z >= 0 (ReLU)
-    for (int i = 0; i < 128; i += 4) {
-        const float4 a = *reinterpret_cast<const float4 *>(zt + (size_t)perm[centres[wave][i]] * 256);
-        const float4 b = *reinterpret_cast<const float4 *>(zt + (size_t)perm[centres[wave][i + 1]] * 256);
-        const float4 d = *reinterpret_cast<const float4 *>(zt + (size_t)perm[centres[wave][i + 2]] * 256);
-        const float4 e = *reinterpret_cast<const float4 *>(zt + (size_t)perm[centres[wave][i + 3]] * 256);
+#pragma unroll 4
+    for (int i = 0; i < 64; i += 2) {
+        const int c0 = __shfl(idA, i), c1 = __shfl(idA, i + 1), c2 = __shfl(idB, i), c3 = __shfl(idB, i + 1);
+        const float4 a = *reinterpret_cast<const float4 *>(zt + (size_t)c0 * 256);
+        const float4 b = *reinterpret_cast<const float4 *>(zt + (size_t)c1 * 256);
+        const float4 d = *reinterpret_cast<const float4 *>(zt + (size_t)c2 * 256);
+        const float4 e = *reinterpret_cast<const float4 *>(zt + (size_t)c3 * 256);
         best.x = fmaxf(fmaxf(best.x, fmaxf(a.x, b.x)), fmaxf(d.x, e.x));
         best.y = fmaxf(fmaxf(best.y, fmaxf(a.y, b.y)), fmaxf(d.y, e.y));
         best.z = fmaxf(fmaxf(best.z, fmaxf(a.z, b.z)), fmaxf(d.z, e.z));
@@ -321,8 +365,8 @@ __global__ __launch_bounds__(256) void xobj_kernel(const XobjParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-int pn_fps_table(const float *xyz, int N, int nv, int npoint, int *out, hipStream_t s) {
-    hipLaunchKernelGGL(fps_table_kernel, dim3((nv + 3) / 4), dim3(256), (size_t)3 * N * sizeof(float), s, xyz, N, nv, npoint, out);
+int pn_fps_table(const float *xyz, int N, int nv, int npoint, int *out, int *flags, hipStream_t s) {
+    hipLaunchKernelGGL(fps_table_kernel, dim3((nv + 3) / 4), dim3(256), (size_t)3 * N * sizeof(float), s, xyz, N, nv, npoint, out, flags);
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
 }

@@ -124,6 +124,12 @@ class Guidance:
         torch.cuda.current_stream().synchronize()     # `o` may be a temporary
         self.n_objects = o.shape[0]
 
+    def debug_fps_path(self, force_per_row: bool):
+        """Test hook: force the per-row FPS kernel; returns which objects are admissible for the table path."""
+        ok = (C.c_int32 * max(1, self.n_objects))()
+        check(lib().dgdm_guidance_debug_fps_path(self._h, int(force_per_row), ok))
+        return [bool(v) for v in ok][:self.n_objects]
+
     def rowcoef(self, centers: torch.Tensor) -> np.ndarray:
         """'convergence' row coefficients of one chain (deltas_to_objective :445-452 applied per cond_fn call)."""
         c = np.ascontiguousarray(centers.detach().cpu().numpy().astype(np.int64))

@@ -179,6 +179,10 @@ int dgdm_convergence_rowcoef(const int64_t *centers_host, int n_centers, int gri
  * bracketed by hipEvents on its own stream.  dgdm_prof_read synchronises those events and
  * returns launches, total milliseconds and the algorithmic FLOPs they covered.                  */
 int dgdm_prof_enable(int on);
+/* Test hook (3-D): when on, every row runs its own FPS(128) instead of reading the per-object table of
+ * order-independent sequences; results must be identical.  Also reports, per object of the
+ * bank, whether the table path is admissible (out_fast_ok[n_objects], may be NULL).                   */
+int dgdm_guidance_debug_fps_path(DgdmGuidance *g, int force_per_row, int32_t *out_fast_ok);
 int dgdm_prof_read(int64_t *launches, double *total_ms, double *total_flops);
 
 #ifdef __cplusplus

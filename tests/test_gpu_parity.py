@@ -231,3 +231,35 @@ def test_convergence_centers_golden(dev):
     st = sampler.StartStream(512, 4, util.unpack_starts(g["cc3d_starts"], g["cc3d_start_lens"]))
     c = sampler.convergence_centers(gd, 'point_3d', torch.from_numpy(g["cc3d_unguided"]).to(dev), [0], st.call(B * G))
     assert np.array_equal(c[0].numpy(), g["cc3d_centers"])
+
+
+# ------------------------------------------------------------------------------------------------ larger shapes vs the oracle
+def test_dyn3d_cond_fn_oracle_fps_paths(dev):
+    """3-D cond_fn on a cloud without / with exact duplicate points: table path == per-row FPS path == oracle."""
+    B, G, P, L, T, sub = 3, 4, 2, 42, 15, 11
+    sd = util.dyn3d_sd(44)
+    dyn = engine.Dynamics(3, sd, L)
+    clean = synth.synth_object_3d(31)
+    dup = synth.synth_object_3d(32).clone()
+    dup[9] = dup[400]
+    dup[10] = dup[400]
+    objs = torch.stack([clean, dup])
+    gd = engine.Guidance(dyn, B, G, P, (-1.0, 1.0), 2, T, 512, sub, max_objects=2)
+    gd.set_objects(objs.to(dev))
+    gd.debug_fps_path(False)
+    x = torch.stack([synth.synth_noise(60, B, L), synth.synth_noise(61, B, L)]).clamp(-1, 1)
+    torch.manual_seed(3)
+    st = sampler.StartStream(512, sub)
+    starts = np.concatenate([st.call(gd.rows), st.call(gd.rows)])
+    objectives = [engine.make_objective('rotate', 0), engine.make_objective('counterclockwise_left', 1)]
+    fast = gd.grad(x.reshape(2, B, L).to(dev), 3, objectives, None, starts).cpu()
+    gd.debug_fps_path(True)
+    slow = gd.grad(x.reshape(2, B, L).to(dev), 3, objectives, None, starts).cpu()
+    gd.debug_fps_path(False)
+    assert torch.equal(fast, slow)
+    s = util.setup('point_3d', None, sd, T, 5, L, G, P, sub)
+    for c, (oi, o) in enumerate(((0, 'rotate'), (1, 'counterclockwise_left'))):
+        log = orc.StartLog(util.unpack_starts(starts[c * 2 * gd.rows:(c + 1) * 2 * gd.rows],
+                                              [n for r0 in range(0, gd.rows, sub) for n in (min(sub, gd.rows - r0),) * 2]))
+        ref = orc.cond_fn(s, x[c], torch.full((B,), 3, dtype=torch.int64), o, objs[oi], (-1.0, 1.0), None, log)
+        assert util.rel_l2(fast[c].reshape(B, L, 1), ref) < REL, (c, o)
