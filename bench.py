@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 from dgdm_amd import _lib, engine, sampler, synth          # noqa: E402
 from dgdm_amd.scheduler import DDIMScheduler               # noqa: E402
+from dgdm_amd.dist import gather_pairs                     # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
@@ -112,8 +113,7 @@ def timed_loop(wl, steps, warmup, dist):
         objs, pre = prepared.pop(k)
         out = wl.run(k, objs, pre)
         if dist is not None and dist.get_world_size() > 1:
-            gathered = [torch.empty_like(out) for _ in range(dist.get_world_size())]
-            dist.all_gather(gathered, out)                # the path's only collective: final samples
+            out = gather_pairs(out, wl.pairs * dist.get_world_size())   # the path's only collective: final samples
         if th is not None:
             th.join()
     torch.cuda.synchronize()

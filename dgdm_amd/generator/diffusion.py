@@ -1,0 +1,222 @@
+"""``Diffusion`` with the reference's constructor and sampling methods (generator/diffusion.py:35-709), running on
+libdgdm_hip.so.
+
+What is kept: constructor keywords, ``noise_pred_net`` / ``ema_nets`` naming (so Lightning checkpoints load),
+``cond_fn``, ``deltas_to_objective``, ``get_convergence_centers``, ``guided_sample``, ``guided_sample_multi_object``,
+``validation_step``, the ``SCALE_*`` constants and the exceptions.  What is different by design:
+
+* the objects of ``guided_sample`` are advanced as one batch of chains (dgdm_amd/sampler.py) instead of one after
+  the other; the FPS start draws are replayed in the reference's order so the numbers are the same;
+* the MuJoCo / Ray evaluation and wandb tables that follow each loop in the reference (:577-619, :678-709) are not
+  part of this package: the final samples are returned and, if ``save_dir`` is given, written as ``.npy`` where
+  the reference starts its simulation (out of scope);
+* Lightning is not required: the class is a plain ``nn.Module`` with the few hooks ``generator/train.py`` uses.
+"""
+from __future__ import annotations
+
+import os
+from typing import Any, Dict, List, Mapping, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import engine, sampler
+from ..dynamics import metrics
+from ..sampler import SCALE_2D, SCALE_2D_CONV, SCALE_3D, SCALE_3D_CONV, StartStream     # noqa: F401  (reference exports)
+
+OBJECTIVE_SWEEP = ['convergence', 'shift_up', 'shift_down', 'shift_left', 'shift_right', 'rotate_clockwise',
+                   'rotate_counterclockwise', 'rotate', 'clockwise_up', 'clockwise_left', 'counterclockwise_up',
+                   'counterclockwise_left']     # generator/diffusion.py:307
+
+
+class Diffusion(nn.Module):
+    def __init__(self, noise_pred_net, noise_scheduler, num_inference_steps: int, num_epochs: int = 10000, mode: str = "point",
+                 input_dim: int = 1, num_points: int = 10, H: int = 32, W: int = 32, learning_rate: float = 1e-4,
+                 lr_warmup_steps: int = 0, ema_power: float = 0.75, ema_update_after_step: int = 0, num_timesteps_per_batch: int = 1,
+                 action_groups: Optional[Dict[str, slice]] = None, float32_matmul_precision: str = "high", class_cond: bool = False,
+                 classifier_model=None, grid_size: int = 360, num_pos: int = 5, object_vertices: Optional[torch.Tensor] = None,
+                 object_ids: Optional[List[int]] = None, num_cpus: int = 32, sub_batch_size: int = 1024, pts_x_dim: int = 7,
+                 pts_z_dim: int = 3, render_video: bool = False, seed: int = 0):
+        super().__init__()
+        if mode not in ("point", "point_3d"):
+            raise ValueError('model type not supported')
+        self.ema_nets = nn.ModuleDict({"noise_pred_net": noise_pred_net})
+        self.mode, self.input_dim, self.num_points = mode, input_dim, num_points
+        self.pts_x_dim, self.pts_z_dim, self.H, self.W = pts_x_dim, pts_z_dim, H, W
+        self.learning_rate, self.lr_warmup_steps, self.num_epochs = learning_rate, lr_warmup_steps, num_epochs
+        self.noise_scheduler, self.num_inference_steps = noise_scheduler, num_inference_steps
+        self.num_timesteps_per_batch = num_timesteps_per_batch
+        self.action_groups = action_groups if action_groups is not None else {}
+        self.noise_scheduler.set_timesteps(num_inference_steps)
+        self.class_cond, self.seed = class_cond, seed
+        self.save_dir: Optional[str] = None
+        self.last_samples: Dict[str, np.ndarray] = {}
+        if class_cond:
+            self.classifier_model = classifier_model
+            self.grid_size, self.num_pos = grid_size, num_pos
+            self.object_vertices, self.object_ids = object_vertices, object_ids
+            self.num_cpus, self.sub_batch_size, self.render_video = num_cpus, sub_batch_size, render_video
+            self.use_sub_batch = mode == 'point_3d'
+            thr, std = ([0.02, 0.001, 0.001], [0.0312, 0.0016, 0.0026]) if mode == 'point_3d' else \
+                       ([0.03, 0.002, 0.003], [0.0565, 0.0026, 0.0047])
+            self.threshold, self.std = torch.tensor(thr), torch.tensor(std)
+            self.threshold_std = self.threshold / self.std
+        self._guidance: Dict[Any, engine.Guidance] = {}
+
+    # ------------------------------------------------------------------ plumbing
+    @property
+    def noise_pred_net(self):
+        return self.ema_nets["noise_pred_net"]
+
+    @property
+    def device(self) -> torch.device:
+        return next(self.noise_pred_net.parameters()).device
+
+    def _dyn(self):
+        m = self.classifier_model
+        return m.module if hasattr(m, "module") else m            # nn.DataParallel wrapper of generator/train.py:86,88
+
+    def clean_grad(self):
+        for p in self.classifier_model.parameters():
+            if p.grad is not None:
+                p.grad.zero_()
+
+    def load_state_dict(self, state_dict: Mapping[str, Any], strict: bool = True):
+        """Accepts a Lightning checkpoint ``state_dict`` (keys ``ema_nets.noise_pred_net.*``, optional nested
+        ``ema_model`` and ``_orig_mod.`` prefixes from torch.compile; reference :730-748)."""
+        flat = {k.replace("_orig_mod.", ""): v for k, v in state_dict.items() if k != "ema_model"}
+        return super().load_state_dict(flat, strict=False)
+
+    def _guidance_for(self, batch: int, ori_range: Sequence[float], objects: torch.Tensor, max_chains: int) -> engine.Guidance:
+        """Guidance handle for (B, ori_range) with `objects` as its bank."""
+        dyn = self._dyn().handle()
+        npts = objects.shape[1]
+        key = (batch, float(ori_range[0]), float(ori_range[1]), npts)
+        g = self._guidance.get(key)
+        if g is None or g.cfg.max_chains < max_chains or g.cfg.max_objects < objects.shape[0]:
+            g = engine.Guidance(dyn, batch, self.grid_size, self.num_pos, ori_range, max(max_chains, 1),
+                                self.noise_scheduler.config.num_train_timesteps, npts,
+                                self.sub_batch_size if self.mode == 'point_3d' else 0, max_objects=max(objects.shape[0], 1))
+            self._guidance[key] = g
+            g._bank = None
+        if g._bank is None or g._bank.shape != objects.shape or not torch.equal(g._bank, objects.detach().cpu()):
+            g.set_objects(objects.to(self.device))
+            g._bank = objects.detach().cpu().clone()
+        return g
+
+    # ------------------------------------------------------------------ a5
+    def deltas_to_objective(self, deltas, opt_obj, centers=None):
+        """generator/diffusion.py:430-471 on an arbitrary deltas tensor (the sampling path itself uses the form fused
+        into the trunk kernel; this is for callers that want the objective values)."""
+        sign = {'rotate_clockwise': (-1, 0, 0), 'rotate_counterclockwise': (1, 0, 0), 'shift_up': (0, -1, 0), 'shift_down': (0, 1, 0),
+                'shift_left': (0, 0, -1), 'shift_right': (0, 0, 1), 'clockwise_up': (-1, -1, 0), 'clockwise_down': (-1, 1, 0),
+                'clockwise_left': (-1, 0, -1), 'clockwise_right': (-1, 0, 1), 'counterclockwise_up': (1, -1, 0),
+                'counterclockwise_down': (1, 1, 0), 'counterclockwise_left': (1, 0, -1), 'counterclockwise_right': (1, 0, 1)}
+        if opt_obj == 'rotate':
+            return deltas[..., 0] ** 2
+        if opt_obj in sign:
+            terms = [deltas[..., j] if c > 0 else -deltas[..., j] for j, c in enumerate(sign[opt_obj]) if c]
+            return terms[0] if len(terms) == 1 else terms[0] + terms[1]
+        if opt_obj == 'convergence':
+            cells, pp = self.grid_size * self.num_pos ** 2, self.num_pos ** 2
+            half = (self.grid_size // 2) * pp
+            out = []
+            for i, c in enumerate(centers):
+                c = int(c)
+                d = deltas[i * cells:(i + 1) * cells, 0]
+                out += [metrics.slicer(d, c * pp - half, c * pp), metrics.slicer(-d, c * pp, c * pp + half)]
+            return torch.cat(out, dim=0)
+        raise ValueError('opt obj not supported')
+
+    # ------------------------------------------------------------------ a4
+    def cond_fn(self, x, t, opt_obj='rotate', object_vertices=None, ori_range=[-1.0, 1.0], convergence_centers=None):
+        """d sum(objective(dynamics(x, grid))) / dx, shape of x (generator/diffusion.py:473-504).  In 3-D the FPS starts
+        come from the torch CPU generator exactly as the reference's classifier calls would draw them."""
+        if self.mode not in ('point', 'point_3d'):
+            raise ValueError('model type not supported')
+        B = x.shape[0]
+        g = self._guidance_for(B, ori_range, object_vertices.reshape(1, *object_vertices.shape[-2:]), 1)
+        obj = engine.make_objective(opt_obj, 0)
+        tt = int(torch.as_tensor(t).reshape(-1)[0])
+        rc = None
+        if opt_obj == 'convergence':
+            rc = torch.from_numpy(g.rowcoef(torch.as_tensor(convergence_centers))).to(self.device).reshape(1, -1)
+        starts = StartStream(g.cfg.num_object_points, g.cfg.sub_batch_size).call(g.rows) if self.mode == 'point_3d' else None
+        grad = g.grad(x.reshape(1, B, -1).to(self.device), tt, [obj], rc, starts)
+        return grad.reshape(x.shape)
+
+    # ------------------------------------------------------------------ a6
+    def get_convergence_centers(self, unguided_sample, object_vertices, batch_size, ori_range=[-1.0, 1.0]):
+        g = self._guidance_for(batch_size, ori_range, object_vertices.reshape(1, *object_vertices.shape[-2:]), 1)
+        starts = StartStream(g.cfg.num_object_points, g.cfg.sub_batch_size).call(g.sweep_rows) if self.mode == 'point_3d' else None
+        return sampler.convergence_centers(g, self.mode, unguided_sample.to(self.device), [0], starts)[0].to(self.device)
+
+    # ------------------------------------------------------------------ a1
+    def guided_sample(self, batch_idx, batch_size, noise, save_dir, opt_obj='rotate', ori_range=[-1.0, 1.0], unguided_sample=None):
+        """All objects' chains of generator/diffusion.py:561-576 as one batch.  Returns (n_objects, B, L, 1)."""
+        objs = torch.as_tensor(self.object_vertices)
+        n = objs.shape[0]
+        g = self._guidance_for(batch_size, ori_range, objs, n)
+        out = sampler.guided_chains(self.noise_pred_net.handle(), g, self.noise_scheduler, self.mode, noise.to(self.device),
+                                    [(i, opt_obj) for i in range(n)],
+                                    unguided=None if unguided_sample is None else unguided_sample.to(self.device))
+        self._emit(save_dir, 'vis_guided', f"{opt_obj}_orirange={ori_range[0]:.3f}_{ori_range[1]:.3f}", out,
+                   [str(self.object_ids[i]) if self.object_ids is not None else str(i) for i in range(n)])
+        return out
+
+    # ------------------------------------------------------------------ a2
+    def guided_sample_multi_object(self, batch_idx, batch_size, noise, save_dir, opt_obj='rotate', ori_range=[-1.0, 1.0]):
+        objs = torch.as_tensor(self.object_vertices)
+        g = self._guidance_for(batch_size, ori_range, objs, objs.shape[0])
+        out = sampler.guided_multi_object(self.noise_pred_net.handle(), g, self.noise_scheduler, self.mode, noise.to(self.device),
+                                          list(range(objs.shape[0])), opt_obj)
+        self._emit(save_dir, 'vis_guided', f"{opt_obj}_orirange={ori_range[0]:.3f}_{ori_range[1]:.3f}", out[None], ["allobj"])
+        return out
+
+    def _emit(self, save_dir, sub, tag, samples, names):
+        """Where the reference hands `sample.cpu().numpy()` to its simulator (:578-580, :675-683), the samples are kept and saved."""
+        arr = samples.detach().cpu().numpy()
+        self.last_samples[tag] = arr
+        if save_dir:
+            d = os.path.join(save_dir, sub, tag)
+            os.makedirs(d, exist_ok=True)
+            for i, nm in enumerate(names):
+                np.save(os.path.join(d, f"{nm}.npy"), arr[i])
+
+    # ------------------------------------------------------------------ a3 + harness
+    def validation_step(self, tensor_data, batch_idx):
+        """Loops of generator/diffusion.py:179-339 without plotting / simulation: denoise from the partially noised data,
+        unguided chain from noise, then the 12-objective sweep (multi-object chain + per-object chains)."""
+        dev = self.device
+        data = tensor_data.to(dev)
+        B = data.shape[0]
+        rs = np.random.RandomState(self.seed)
+        noise = torch.from_numpy(rs.randn(B, self.num_points, self.input_dim)).float().to(dev)
+        ts = self.num_inference_steps * torch.ones((B,), dtype=torch.int64)
+        sample = self.noise_scheduler.add_noise(data, noise, ts)
+        net = self.noise_pred_net.handle()
+        noise_pred_loss = 0.0
+        for t in self.noise_scheduler.timesteps:
+            eps = net.forward(sample, torch.full((B,), int(t), device=dev))
+            noise_pred_loss += float(torch.mean((eps - noise) ** 2))
+            sample = self.noise_scheduler.step(eps, t, sample).prev_sample
+        stats = {"val/noise pred loss": noise_pred_loss / self.num_inference_steps,
+                 "val/denoise loss": float(torch.mean((sample - data) ** 2)),
+                 "val/accuracy": float(torch.mean((torch.abs(sample - data) < 0.01).float()))}
+        out: Dict[str, Any] = {"stats": stats}
+        if batch_idx != 0:
+            return out
+        unguided = sampler.unguided_sample(net, self.noise_scheduler, noise)
+        self._emit(self.save_dir, 'val_vis_noise', 'unguided', unguided[None], ["unguided"])
+        out["unguided"] = unguided
+        if self.class_cond:
+            if self.object_vertices is None:
+                raise ValueError('object vertices not provided')
+            for opt_obj in OBJECTIVE_SWEEP:
+                rng = [-1.0, 1.0]
+                if opt_obj != 'convergence':
+                    out[f"multi/{opt_obj}"] = self.guided_sample_multi_object(batch_idx, B, noise, self.save_dir, opt_obj=opt_obj, ori_range=rng)
+                out[f"guided/{opt_obj}"] = self.guided_sample(batch_idx, B, noise, self.save_dir, opt_obj=opt_obj, ori_range=rng,
+                                                              unguided_sample=unguided)
+        return out

@@ -1,0 +1,130 @@
+"""Entry point behind ``python generator/train.py --mode=test ...`` (reference: generator/train.py:38-166).
+
+Keeps the reference's flags (dynamics/parser.py) and construction order: synthetic finger set from ``RandomState(idx)``
+(:43-58), U-Net + DDIM scheduler (:80-83), frozen dynamics model loaded from ``--checkpoint_path`` (:84-92), normalised
+object point sets (:93-124), ``Diffusion`` (:129), then - in test mode - one pass of ``validation_step`` per batch of
+fingers, which is what Lightning's ``trainer.validate`` does (:152-156).  Training (``--mode=train``) is outside the
+MI355X sampling path.
+
+Assets the image does not have are substituted, loudly:
+* no checkpoint files  -> deterministic random-init weights (dgdm_amd.synth);
+* no Icons-50 / scanned meshes (and no open3d, cv2) -> synthetic contours / surface-sampled clouds with the same
+  normalisation; an ``--object_dir`` holding ``objects.npy`` ([n, vertices, 2|3], metres) is used when present.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+from .. import synth
+from ..dynamics.parser import parse
+from ..dynamics.profile_forward_2d import ProfileForward2DModel
+from ..dynamics.profile_forward_3d import ProfileForward3DModel
+from ..scheduler import DDIMScheduler
+from .dataloader import GripperDataset
+from .diffusion import Diffusion
+from .diffusion_utils import ConditionalUnet1D
+
+OBJECT_IDS = [10000, 2009, 2114, 2082, 1041, 2048, 1045, 1019]     # Icons-50 test ids, generator/train.py:36
+OBJECT_NAMES_3D = ["3D_Dollhouse_Swing", "BABY_CAR", "Ecoforms_Plant_Container_B4_Har", "Threshold_Bamboo_Ceramic_Soap_Dish",
+                   "Squirt_Strain_Fruit_Basket",
+                   "Office_Depot_Canon_CLI_8CMY_Remanufactured_Ink_Cartridges_Color_Cyan_Magenta_Yellow_3_count"]   # assets/object_names_test.txt
+
+
+def finger_control_points(num_fingers: int, fingers_3d: bool) -> np.ndarray:
+    """generator/train.py:43-58 and assets/finger_3d.py:82-88: per finger idx, RandomState(idx) draws the y of the left then
+    the right control points; x (and z) are fixed grids.  Shape (n, 14, 2) or (n, 42, 3)."""
+    out = []
+    for idx in range(num_fingers):
+        rs = np.random.RandomState(idx)
+        if fingers_3d:
+            yl, yr = rs.uniform(-0.1, 0, size=21), rs.uniform(-0.1, 0, size=21)
+            xg, zg = np.meshgrid(np.linspace(-0.12, 0.12, 7), np.linspace(0, 0.12, 3))
+            side = lambda y: np.stack([xg.T.reshape(-1), y, zg.T.reshape(-1)], axis=-1)      # noqa: E731
+            out.append(np.concatenate((side(yl), side(yr)), axis=0))
+        else:
+            x = np.linspace(-0.12, 0.12, 7)
+            yl, yr = rs.uniform(-0.045, 0.015, size=7), rs.uniform(-0.045, 0.015, size=7)
+            out.append(np.concatenate((np.stack([x, yl], axis=-1), np.stack([x, yr], axis=-1)), axis=0))
+    return np.stack(out, axis=0)
+
+
+def _load_or_synth(path, spec, seed, what):
+    if path and os.path.exists(path):
+        sd = torch.load(path, map_location="cpu")
+        sd = sd.get("state_dict", sd)
+        return {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}
+    print(f"[dgdm_amd] {what}: '{path}' not found - using deterministic random-init weights (seed {seed})", file=sys.stderr)
+    return synth.synth_state_dict(spec, seed)
+
+
+def _objects(args, fingers_3d: bool):
+    f = os.path.join(args.object_dir or "", "objects.npy")
+    nv = args.object_max_num_vertices
+    if os.path.isfile(f):
+        raw = torch.from_numpy(np.load(f)).float()
+        lo, hi = (torch.tensor([-0.1, -0.1, 0.0]), torch.tensor([0.1, 0.1, 0.12])) if fingers_3d else (torch.tensor([-0.05] * 2), torch.tensor([0.05] * 2))
+        return (raw - lo) / (hi - lo) * 2.0 - 1.0, list(range(raw.shape[0]))            # generator/train.py:94-124
+    print("[dgdm_amd] no objects.npy under --object_dir - using synthetic objects", file=sys.stderr)
+    if fingers_3d:
+        return torch.stack([synth.synth_object_3d(i, nv) for i in range(len(OBJECT_NAMES_3D))]), list(OBJECT_NAMES_3D)
+    return torch.stack([synth.synth_object_2d(i, nv) for i in range(len(OBJECT_IDS))]), list(OBJECT_IDS)
+
+
+def train(args):
+    if args.mode != 'test':
+        raise NotImplementedError("only --mode=test (guided sampling) runs on the MI355X path; training is out of scope")
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    pts = finger_control_points(args.num_fingers, args.fingers_3d)
+    max_y, min_y = (0.0, -0.1) if args.fingers_3d else (0.015, -0.045)
+    dataset = GripperDataset(pts, 0.12, -0.12, max_y, min_y)
+    L = args.ctrlpts_dim
+    unet = ConditionalUnet1D(input_dim=1, global_cond_dim=0, down_dims=[128, 256], diffusion_step_embed_dim=32)
+    mode = 'point_3d' if args.fingers_3d else 'point'
+    scheduler = DDIMScheduler(num_train_timesteps=args.num_train_timesteps, beta_schedule='squaredcos_cap_v2', clip_sample=True,
+                              prediction_type='epsilon')
+    classifier, objects, object_ids = None, None, None
+    if args.classifier_guidance:
+        if args.fingers_3d:
+            classifier = ProfileForward3DModel(output_ch=3, params_ch=L)
+            spec = synth.dyn3d_spec(L)
+        else:
+            classifier = ProfileForward2DModel(output_ch=3, params_ch=L, object_ch=2 * args.object_max_num_vertices)
+            spec = synth.dyn2d_spec(L, 2 * args.object_max_num_vertices)
+        classifier.load_state_dict(_load_or_synth(args.checkpoint_path, spec, 22 + int(args.fingers_3d), "dynamics checkpoint"))
+        classifier.eval().requires_grad_(False).to(dev)
+        objects, object_ids = _objects(args, args.fingers_3d)
+    model = Diffusion(noise_pred_net=unet, noise_scheduler=scheduler, num_inference_steps=args.num_inference_steps, mode=mode, input_dim=1,
+                      num_points=L, learning_rate=args.learning_rate, lr_warmup_steps=args.lr_warmup_steps, ema_power=args.ema_power,
+                      class_cond=args.classifier_guidance, classifier_model=classifier, grid_size=args.grid_size, num_pos=args.num_pos,
+                      object_vertices=objects, object_ids=object_ids, num_cpus=args.num_cpus, pts_x_dim=args.ctrlpts_x_dim,
+                      pts_z_dim=args.ctrlpts_z_dim, sub_batch_size=args.sub_bs, render_video=args.render_video, seed=args.seed)
+    ck = _load_or_synth(args.diffusion_checkpoint_path, [("ema_nets.noise_pred_net." + k, s) for k, s in synth.unet_spec()], 11,
+                        "diffusion checkpoint")
+    model.load_state_dict(ck)
+    model.eval().to(dev)
+    model.save_dir = args.save_dir or None
+    if model.save_dir:
+        os.makedirs(model.save_dir, exist_ok=True)
+    results = []
+    n_batches = len(dataset) // args.batch_size                       # DataLoader(drop_last=True), :69
+    with torch.no_grad():
+        for bi in range(n_batches):
+            batch = torch.from_numpy(np.stack([dataset[i] for i in range(bi * args.batch_size, (bi + 1) * args.batch_size)]))
+            res = model.validation_step(batch, bi)
+            print(f"[dgdm_amd] batch {bi}: " + ", ".join(f"{k}={v:.5f}" for k, v in res["stats"].items()))
+            results.append(res)
+    return model, results
+
+
+def main(argv=None):
+    from .. import _lib
+    _lib.device_init(int(os.environ.get("LOCAL_RANK", "0")))
+    train(parse(argv))
+
+
+if __name__ == "__main__":
+    main()

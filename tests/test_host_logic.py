@@ -1,0 +1,164 @@
+"""CPU tests of the host-side logic of the product path (no GPU, no HIP compute calls)."""
+import ctypes as C
+import os
+import re
+import shlex
+
+import numpy as np
+import pytest
+import torch
+
+from dgdm_amd import _lib, sampler, synth
+from oracle import dgdm_oracle as orc
+from tests import util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from dgdm_amd import build
+    build.build()
+    return _lib.lib()
+
+
+def test_abi_exports_every_declared_symbol(lib):
+    """include/dgdm_hip.h <-> libdgdm_hip.so <-> the ctypes prototype table agree on the symbol set."""
+    hdr = open(os.path.join(ROOT, "include", "dgdm_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(dgdm_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in dgdm_hip.h but not exported"
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    assert lib.dgdm_version() == 100
+    assert C.sizeof(_lib.Objective) == 32 and C.sizeof(_lib.Tensor) == 32 and C.sizeof(_lib.GuidanceConfig) == 40
+
+
+def test_objective_table_matches_oracle(lib):
+    d = torch.tensor([[0.3, -0.7, 1.1]], requires_grad=True)
+    names = list(orc._LINEAR_OBJ) + ['rotate']
+    for n in names:
+        o = _lib.Objective()
+        _lib.check(lib.dgdm_objective_from_name(n.encode(), C.byref(o)))
+        g = torch.autograd.grad(orc.deltas_to_objective(d, n).sum(), d)[0][0]
+        mine = torch.tensor([o.lin[j] + 2 * o.quad[j] * float(d[0, j]) for j in range(3)])
+        assert torch.allclose(g, mine), n
+    o = _lib.Objective()
+    with pytest.raises(ValueError, match='opt obj not supported'):
+        _lib.check(lib.dgdm_objective_from_name(b"spin", C.byref(o)))
+
+
+@pytest.mark.parametrize("rows,sub", [(24 * 4 * 3, 0), (150, 64), (150, 7), (1125 * 2, 512)])
+def test_convergence_rowcoef_matches_autograd(lib, rows, sub):
+    """dgdm_convergence_rowcoef == d objective / d delta_0 of the oracle's 'convergence' objective, per cond_fn call."""
+    G, P = 6, 2
+    cells = G * P * P
+    rs = np.random.RandomState(rows + sub)
+    centers = rs.randint(0, G, size=rs.randint(1, 9)).astype(np.int64)
+    out = np.empty(rows, np.float32)
+    _lib.check(lib.dgdm_convergence_rowcoef(centers.ctypes.data, len(centers), G, P, rows, sub, out.ctypes.data))
+    ref = np.zeros(rows, np.float32)
+    step = sub if sub > 0 else rows
+    for s0 in range(0, rows, step):
+        n = min(step, rows - s0)
+        d = torch.zeros(n, 3, requires_grad=True)
+        obj = orc.deltas_to_objective(d, 'convergence', centers=torch.from_numpy(centers), grid_size=G, num_pos=P)
+        if obj.numel():
+            ref[s0:s0 + n] = torch.autograd.grad(obj.sum(), d)[0][:, 0].numpy()
+    assert np.array_equal(out, ref)
+    assert cells > 0
+
+
+def test_start_stream_matches_reference_draws():
+    """StartStream replays torch.randint exactly as the oracle's (= the reference's) classifier calls consume it."""
+    g = util.load("g5_dyn3d.npz")
+    for sub, rows in ((7, 24), (512, 24)):
+        torch.manual_seed(99)
+        got = sampler.StartStream(512, sub).call(rows)
+        assert np.array_equal(got, g[f"starts_rotate_sub{sub}"])
+    torch.manual_seed(5)
+    a = sampler.StartStream(300, 64).call(150)          # N != 512: per-call draws with the two ranges
+    torch.manual_seed(5)
+    log = orc.StartLog()
+    for r0 in range(0, 150, 64):
+        n = min(64, 150 - r0)
+        log.draw(300, n)
+        log.draw(512, n)
+    assert np.array_equal(a, torch.cat(log.log).numpy())
+
+
+def test_scheduler_tables_match_oracle():
+    from dgdm_amd.scheduler import DDIMScheduler
+    for T, S in ((15, 5), (1000, 100), (1000, 1000)):
+        s, o = DDIMScheduler(num_train_timesteps=T), orc.DDIM(T)
+        s.set_timesteps(S)
+        o.set_timesteps(S)
+        assert torch.equal(s.betas, o.betas) and torch.equal(s.alphas_cumprod, o.alphas_cumprod) and torch.equal(s.timesteps, o.timesteps)
+        assert s.config.num_train_timesteps == T
+        for t in (int(s.timesteps[0]), int(s.timesteps[-1])):
+            prev = t - T // S
+            a_t, a_p = o.alphas_cumprod[t], (o.alphas_cumprod[prev] if prev >= 0 else o.final_alpha_cumprod)
+            want = (float(a_t ** 0.5), float((1 - a_t) ** 0.5), float(a_p ** 0.5), float((1 - a_p) ** 0.5))
+            assert s.coefficients(t) == want
+
+
+def test_metrics_match_golden():
+    from dgdm_amd.dynamics import metrics
+    g = util.load("g7_convergence.npz")
+    for k in ("all0", "all2", "all1", "wrap", "mixed", "single", "ones_between"):
+        l, c = metrics.convergence_mode_three_class(torch.from_numpy(g[f"{k}_profile"]))
+        assert np.array_equal(l.numpy(), g[f"{k}_lengths"]) and np.array_equal(c.numpy(), g[f"{k}_centers"]), k
+    a = torch.arange(10.0)
+    for i in range(6):
+        lo, hi = g[f"slicer_{i}_args"]
+        assert np.array_equal(metrics.slicer(a, int(lo), int(hi)).numpy(), g[f"slicer_{i}"])
+
+
+SHIPPED_3D = ("--mode='test' --checkpoint_path='ckpts/dynamics_3d.pt' --diffusion_checkpoint_path='ckpts/diffusion_3d.ckpt' --object_dir='' "
+              "--save_dir='' --classifier_guidance --num_fingers=16 --grid_size=45 --num_pos=5 --fingers_3d --object_max_num_vertices=512 "
+              "--ctrlpts_dim=42 --ctrlpts_x_dim=7 --ctrlpts_z_dim=3 --num_workers=0 --num_train_timesteps=15 --num_inference_steps=5 "
+              "--ema_power=0.85 --batch_size=16 --sub_bs=512 --num_cpus=32 --seed=0")
+SHIPPED_2D = ("--mode='test' --checkpoint_path='ckpts/dynamics_2d.pt' --classifier_guidance --diffusion_checkpoint_path='ckpts/diffusion_2d.pt' "
+              "--object_dir='x/Icons-50.npy' --save_dir='' --ctrlpts_dim=14 --num_fingers=16 --grid_size=360 --num_pos=5 "
+              "--object_max_num_vertices=100 --num_workers=0 --num_train_timesteps=15 --num_inference_steps=5 --ema_power=0.85 "
+              "--batch_size=16  --num_cpus=32 --seed=0")
+
+
+def test_parser_accepts_the_shipped_command_lines():
+    """The flag set of generator/guided_sample_{2d,3d}.sh parses; defaults equal the reference's (dynamics/parser.py)."""
+    from dynamics.parser import parse       # the reference's import path, served by the repo-root shim
+    a = parse(shlex.split(SHIPPED_3D))
+    assert (a.fingers_3d, a.grid_size, a.num_pos, a.sub_bs, a.ctrlpts_dim, a.batch_size) == (True, 45, 5, 512, 42, 16)
+    b = parse(shlex.split(SHIPPED_2D))
+    assert (b.fingers_3d, b.grid_size, b.object_max_num_vertices, b.num_train_timesteps) == (False, 360, 100, 15)
+    d = parse([])
+    assert (d.batch_size, d.sub_bs, d.num_pos, d.num_inference_steps, d.ema_power, d.seed, d.save_dir) == (1024, 1024, 9, 100, 0.75, 0, None)
+
+
+def test_module_trees_carry_reference_state_dict_keys():
+    from generator.diffusion_utils import ConditionalUnet1D
+    from dynamics.profile_forward_2d import ProfileForward2DModel
+    from dynamics.profile_forward_3d import ProfileForward3DModel
+    for m, spec in ((ConditionalUnet1D(1, 0, [128, 256], 32), synth.unet_spec()),
+                    (ProfileForward2DModel(params_ch=14, object_ch=200), synth.dyn2d_spec(14, 200)),
+                    (ProfileForward3DModel(params_ch=42), synth.dyn3d_spec(42))):
+        sd = m.state_dict()
+        assert sorted(sd) == sorted(k for k, _ in spec)
+        assert all(tuple(sd[k].shape) == tuple(s) for k, s in spec)
+    # and there is no CPU path: asking for a forward without a GPU fails loudly
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU path"):
+            ConditionalUnet1D(1, 0, [128, 256], 32)(torch.zeros(1, 14, 1), torch.zeros(1, dtype=torch.int64))
+
+
+def test_finger_dataset_is_the_reference_recipe():
+    from dgdm_amd.generator.train import finger_control_points
+    from generator.dataloader import GripperDataset
+    pts = finger_control_points(4, True)
+    rs = np.random.RandomState(2)
+    yl, yr = rs.uniform(-0.1, 0, size=21), rs.uniform(-0.1, 0, size=21)
+    assert np.array_equal(pts[2, :21, 1], yl) and np.array_equal(pts[2, 21:, 1], yr) and pts.shape == (4, 42, 3)
+    item = GripperDataset(pts, 0.12, -0.12, 0.0, -0.1)[2]
+    assert item.shape == (42, 1) and item.dtype == np.float32 and np.abs(item).max() <= 1.0
+    assert np.allclose(item[:21, 0], (yl.astype(np.float32) + 0.1) / 0.1 * 2 - 1)
