@@ -11,22 +11,26 @@ using namespace dgdm;
 // ================================================================================================ U-Net
 namespace {
 
-// torch Conv1d weight [Cout][Cin][KW] -> [(ci*KW + k)*Cout + co]
-std::vector<float> conv_ckn(const float *w, int cout, int cin, int kw) {
-    std::vector<float> o((size_t)cout * cin * kw);
-    for (int co = 0; co < cout; ++co)
-        for (int ci = 0; ci < cin; ++ci)
-            for (int k = 0; k < kw; ++k) o[((size_t)ci * kw + k) * cout + co] = w[((size_t)co * cin + ci) * kw + k];
+// MFMA image of a convolution (csrc/unet.hip conv_mfma): [Cout/16][ntaps][Cin/16][64 lanes][4];
+// lane (i = l & 15, q = l >> 4), component c  ->  W(co = 16 mt + i, ci = 16 g + 4 c + q, tap taps[t]).
+// `at(co, ci, k)` reads the torch tensor: Conv1d is [Cout][Cin][KW], ConvTranspose1d is [Cin][Cout][KW].
+template <class At>
+std::vector<float> conv_image(int cout, int cin, const std::vector<int> &taps, At at) {
+    const int mt = cout / 16, g = cin / 16, nt = (int)taps.size();
+    std::vector<float> o((size_t)cout * cin * nt);
+    for (int m = 0; m < mt; ++m)
+        for (int t = 0; t < nt; ++t)
+            for (int gg = 0; gg < g; ++gg)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int c = 0; c < 4; ++c)
+                        o[((((size_t)m * nt + t) * g + gg) * 64 + lane) * 4 + c] = at(16 * m + (lane & 15), 16 * gg + 4 * c + (lane >> 4), taps[t]);
     return o;
 }
 
-// torch ConvTranspose1d weight [Cin][Cout][KW] -> [(ci*KW + k)*Cout + co]
-std::vector<float> convT_ckn(const float *w, int cin, int cout, int kw) {
-    std::vector<float> o((size_t)cout * cin * kw);
-    for (int ci = 0; ci < cin; ++ci)
-        for (int co = 0; co < cout; ++co)
-            for (int k = 0; k < kw; ++k) o[((size_t)ci * kw + k) * cout + co] = w[((size_t)ci * cout + co) * kw + k];
-    return o;
+std::vector<float> conv1d_image(const float *w, int cout, int cin, int kw) {
+    std::vector<int> taps(kw);
+    for (int k = 0; k < kw; ++k) taps[k] = k;
+    return conv_image(cout, cin, taps, [=](int co, int ci, int k) { return w[((size_t)co * cin + ci) * kw + k]; });
 }
 
 struct ResOff { size_t c0w, c0b, g0w, g0b, c1w, c1b, g1w, g1b, cw, cb, rw, rb; bool has_res; int cin, cout; };
@@ -41,9 +45,16 @@ int pack_res(const StateDict &sd, Blob &bl, const std::string &p, int cin, int c
     o->cin = cin; o->cout = cout;
     const float *w;
     if (!(w = sd.f32(p + ".blocks.0.block.0.weight", (int64_t)cout * cin * kw))) return DGDM_EKEY;
-    o->c0w = bl.add(conv_ckn(w, cout, cin, kw));
+    if (cin == 1) {                                   // [tap][cout] for the VALU input convolution
+        std::vector<float> tw((size_t)kw * cout);
+        for (int co = 0; co < cout; ++co)
+            for (int k = 0; k < kw; ++k) tw[(size_t)k * cout + co] = w[(size_t)co * kw + k];
+        o->c0w = bl.add(tw);
+    } else {
+        o->c0w = bl.add(conv1d_image(w, cout, cin, kw));
+    }
     if (!(w = sd.f32(p + ".blocks.1.block.0.weight", (int64_t)cout * cout * kw))) return DGDM_EKEY;
-    o->c1w = bl.add(conv_ckn(w, cout, cout, kw));
+    o->c1w = bl.add(conv1d_image(w, cout, cout, kw));
     int rc;
     if ((rc = vec(p + ".blocks.0.block.0.bias", cout, &o->c0b))) return rc;
     if ((rc = vec(p + ".blocks.0.block.1.weight", cout, &o->g0w))) return rc;
@@ -57,7 +68,7 @@ int pack_res(const StateDict &sd, Blob &bl, const std::string &p, int cin, int c
     o->has_res = cin != cout;
     if (o->has_res) {
         if (!(w = sd.f32(p + ".residual_conv.weight", (int64_t)cout * cin))) return DGDM_EKEY;
-        o->rw = bl.add(conv_ckn(w, cout, cin, 1));
+        o->rw = cin == 1 ? bl.add(w, (size_t)cout) : bl.add(conv1d_image(w, cout, cin, 1));
         if ((rc = vec(p + ".residual_conv.bias", cout, &o->rb))) return rc;
     }
     return DGDM_OK;
@@ -72,6 +83,7 @@ extern "C" int dgdm_unet1d_create(DgdmUnet1d **out, const DgdmTensor *tensors, i
     DGDM_REQUIRE(kernel_size == 5, DGDM_EINVAL, "kernel_size %d unsupported (reference uses 5)", kernel_size);
     const int d0 = down_dims[0], d1 = down_dims[1];
     DGDM_REQUIRE(d0 % n_groups == 0 && d1 % n_groups == 0 && dsed % 2 == 0 && dsed >= 4, DGDM_EINVAL, "bad U-Net dims");
+    DGDM_REQUIRE(d0 % 32 == 0 && d1 % 32 == 0, DGDM_EINVAL, "U-Net widths must be multiples of 32 for the MFMA tiling (got %d, %d)", d0, d1);
     StateDict sd(tensors, n_tensors);
     std::unique_ptr<DgdmUnet1d> m(new DgdmUnet1d());
     Blob &bl = m->blob;
@@ -96,11 +108,15 @@ extern "C" int dgdm_unet1d_create(DgdmUnet1d **out, const DgdmTensor *tensors, i
     if (!(w = sd.f32("diffusion_step_encoder.3.weight", (int64_t)4 * dsed * dsed)) || !(b = sd.f32("diffusion_step_encoder.3.bias", dsed))) return DGDM_EKEY;
     const size_t o_s3w = bl.add(transpose(w, dsed, 4 * dsed)), o_s3b = bl.add(b, dsed);
     if (!(w = sd.f32("down_modules.0.2.conv.weight", (int64_t)d0 * d0 * 3)) || !(b = sd.f32("down_modules.0.2.conv.bias", d0))) return DGDM_EKEY;
-    const size_t o_dw = bl.add(conv_ckn(w, d0, d0, 3)), o_db = bl.add(b, d0);
+    const size_t o_dw = bl.add(conv1d_image(w, d0, d0, 3)), o_db = bl.add(b, d0);
     if (!(w = sd.f32("up_modules.0.2.conv.weight", (int64_t)d0 * d0 * 4)) || !(b = sd.f32("up_modules.0.2.conv.bias", d0))) return DGDM_EKEY;
-    const size_t o_uw = bl.add(convT_ckn(w, d0, d0, 4)), o_ub = bl.add(b, d0);
+    // ConvTranspose1d weight is [Cin][Cout][4]; even outputs use taps (1, 3), odd outputs taps (2, 0)
+    const float *wt = w;
+    auto atT = [=](int co, int ci, int k) { return wt[((size_t)ci * d0 + co) * 4 + k]; };
+    const size_t o_uwe = bl.add(conv_image(d0, d0, std::vector<int>{1, 3}, atT)), o_uwo = bl.add(conv_image(d0, d0, std::vector<int>{2, 0}, atT)),
+                 o_ub = bl.add(b, d0);
     if (!(w = sd.f32("final_conv.0.block.0.weight", (int64_t)d0 * d0 * kernel_size)) || !(b = sd.f32("final_conv.0.block.0.bias", d0))) return DGDM_EKEY;
-    const size_t o_fw = bl.add(conv_ckn(w, d0, d0, kernel_size)), o_fb = bl.add(b, d0);
+    const size_t o_fw = bl.add(conv1d_image(w, d0, d0, kernel_size)), o_fb = bl.add(b, d0);
     const float *gw, *gb;
     if (!(gw = sd.f32("final_conv.0.block.1.weight", d0)) || !(gb = sd.f32("final_conv.0.block.1.bias", d0))) return DGDM_EKEY;
     const size_t o_fgw = bl.add(gw, d0), o_fgb = bl.add(gb, d0);
@@ -122,7 +138,7 @@ extern "C" int dgdm_unet1d_create(DgdmUnet1d **out, const DgdmTensor *tensors, i
         r.res_w = ro[i].has_res ? bl.at(ro[i].rw) : nullptr;
         r.res_b = ro[i].has_res ? bl.at(ro[i].rb) : nullptr;
     }
-    p.down_w = bl.at(o_dw); p.down_b = bl.at(o_db); p.up_w = bl.at(o_uw); p.up_b = bl.at(o_ub);
+    p.down_w = bl.at(o_dw); p.down_b = bl.at(o_db); p.up_w_even = bl.at(o_uwe); p.up_w_odd = bl.at(o_uwo); p.up_b = bl.at(o_ub);
     p.fin_w = bl.at(o_fw); p.fin_b = bl.at(o_fb); p.fin_gw = bl.at(o_fgw); p.fin_gb = bl.at(o_fgb);
     p.out_w = bl.at(o_ow); p.out_b = bl.at(o_ob);
     *out = m.release();

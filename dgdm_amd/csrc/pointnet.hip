@@ -24,6 +24,11 @@
 #include "mfma_chain.h"
 #include "pointnet.h"
 
+// No implicit a*b+c -> fma contraction in this file: the scheduler update, FPS and ball-query distances must round
+// like the reference's separate float32 ops (HIP's __fmul_rn/__fadd_rn are plain * and + and would be contracted).
+// Explicit fmaf() calls are unaffected.
+#pragma clang fp contract(off)
+
 namespace dgdm {
 
 __device__ __forceinline__ float sq3(float x, float y, float z) {

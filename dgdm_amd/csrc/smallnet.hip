@@ -4,6 +4,11 @@
 #include "common.h"
 #include "smallnet.h"
 
+// No implicit a*b+c -> fma contraction in this file: the scheduler update, FPS and ball-query distances must round
+// like the reference's separate float32 ops (HIP's __fmul_rn/__fadd_rn are plain * and + and would be contracted).
+// Explicit fmaf() calls are unaffected.
+#pragma clang fp contract(off)
+
 namespace dgdm {
 
 // ------------------------------------------------------------------------------------------------

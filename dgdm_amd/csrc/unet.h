@@ -4,13 +4,13 @@
 namespace dgdm {
 
 // One ConditionalResidualBlock1D (generator/diffusion_utils.py:75-120), device pointers.
-// Conv weights are stored [(ci*KW + k)*Cout + co]; Linear weights [in][out].
+// Conv weights are MFMA images (csrc/unet.hip conv_mfma) except the single-channel ones; Linear weights [in][out].
 struct UnetRes {
     int cin, cout;
-    const float *c0_w, *c0_b, *g0_w, *g0_b;      // blocks.0: Conv1d k5, GroupNorm
+    const float *c0_w, *c0_b, *g0_w, *g0_b;      // blocks.0: Conv1d k5 (image; [tap][cout] when cin == 1), GroupNorm
     const float *c1_w, *c1_b, *g1_w, *g1_b;      // blocks.1
     const float *cond_wt, *cond_b;               // cond_encoder.1: Linear(cond_dim, 2*cout)
-    const float *res_w, *res_b;                  // residual_conv (1x1) or null
+    const float *res_w, *res_b;                  // residual_conv 1x1 (image; [cout] when cin == 1) or null
 };
 
 struct UnetParams {
@@ -19,8 +19,8 @@ struct UnetParams {
     const float *freqs;                          // SinusoidalPosEmb frequencies [dsed/2]
     const float *se1_wt, *se1_b, *se3_wt, *se3_b;
     UnetRes res[8];                              // down0.0 down0.1 down1.0 down1.1 mid0 mid1 up0.0 up0.1
-    const float *down_w, *down_b;                // Downsample1d conv k3 s2
-    const float *up_w, *up_b;                    // Upsample1d ConvTranspose1d k4 s2, stored [(ci*4+k)*C + co]
+    const float *down_w, *down_b;                // Downsample1d conv k3 s2 (image)
+    const float *up_w_even, *up_w_odd, *up_b;    // Upsample1d ConvTranspose1d k4 s2: images of taps (1,3) and (2,0)
     const float *fin_w, *fin_b, *fin_gw, *fin_gb;// final_conv.0
     const float *out_w, *out_b;                  // final_conv.1 (d0 -> 1)
 };

@@ -1,17 +1,25 @@
-// ConditionalUnet1D forward (generator/diffusion_utils.py:123-285), one workgroup per sample.
+// ConditionalUnet1D forward (generator/diffusion_utils.py:123-285), one workgroup per sample, one launch per forward.
 //
-// The whole network runs inside one launch: activations live in LDS ([channel][L+4] with a
-// zero halo of 2, <= 128 KiB for the shipped shapes), weights stream from L2, GroupNorm
-// statistics are wave-shuffle reductions, Mish/FiLM/residual adds are fused into the passes
-// that already touch the data.  One launch per denoise step instead of ~90 eager ops.
+// The whole network runs inside the launch: activations live in LDS as [position + 2][channels + 4]
+// (channel-contiguous rows, two zero halo rows on each side, <= 130 KiB for the shipped shapes), weights stream from
+// L2, GroupNorm statistics are wave-shuffle reductions, Mish / FiLM / residual adds are fused into the passes that
+// already touch the data.  One launch per denoise step instead of ~90 eager ops.
 //
-// Round-1 arithmetic: the k=5 convolutions run on the f32 VALU (same peak rate as f32 MFMA on
-// gfx950, but lower achieved efficiency); the net is < 2 % of a guided step.
+// Convolutions are implicit GEMMs on v_mfma_f32_16x16x4_f32 (exact f32): D[co][pos] += W[co][ci,tap] * in[ci][pos+tap-pad],
+// weights as the A operand from a pre-arranged global image (one coalesced float4 per lane feeds 4 K-steps),
+// activations as the B operand straight from LDS (row stride C+4 floats = 4 mod 32 banks: conflict-free).  Each wave
+// owns pairs of 16-channel output tiles and all position tiles, so a weight fragment is loaded once and reused for
+// every position tile.  The two convolutions that touch a single channel (1 -> d0 input conv, d0 -> 1 output conv) run
+// on the VALU.
 #include "common.h"
 #include "unet.h"
 #include <algorithm>
 
 namespace dgdm {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 __device__ __forceinline__ float mish(float x) {
     // torch.nn.functional.mish = x * tanh(softplus(x)), softplus threshold 20
@@ -25,98 +33,117 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// out[co][l] = bias[co] + sum_{ci,k} W[(ci*KW+k)*Cout+co] * in[ci][l*STRIDE + k - PAD],  l < Lout
-// in/out: LDS, row strides LPi/LPo, data starts at column 2.  Each thread item = 2 channels x 7 positions.
-template <int KW, int STRIDE, int PAD>
-__device__ void conv1d(const float *__restrict__ W, const float *__restrict__ bias, const float *in, int LPi, float *out, int LPo,
-                       int Cin, int Cout, int Lout) {
-    constexpr int NP = 7;
-    constexpr int WIN = (NP - 1) * STRIDE + KW;
-    const int nchunk = (Lout + NP - 1) / NP;
-    const int half = (Cout + 1) / 2;
-    for (int item = threadIdx.x; item < half * nchunk; item += blockDim.x) {
-        const int chunk = item / half, co0 = item - chunk * half, co1 = co0 + half;
-        const bool two = co1 < Cout;
-        const int l0 = chunk * NP;
-        float a0[NP], a1[NP];
+// Generic strided multi-tap convolution as implicit GEMM.
+//   out[(l*ostride + ooff) + 2][co] (+)= bias[co] + sum_{t < ntaps} sum_ci W_t[co][ci] * in[l*istride + ioff[t] + 2][ci],  l < Lout
+// img: [Cout/16][ntaps][Cin/16][64 lanes] float4; lane (i = l&15, q = l>>4), component c -> W_t[16 mt + i][16 g + 4 c + q].
+// MODE 0: store, 1: add to what is in `out` (residual).
+struct ConvArgs {
+    const float4 *img;
+    const float  *bias;
+    int cin, cout, ntaps, istride, ostride, ooff;
+    int ioff[5];
+};
+
+template <int NT, int MODE>
+__device__ void conv_mfma(const ConvArgs a, const float *in, int CPi, float *out, int CPo, int Lout) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int groups = a.cin >> 4, mtiles = a.cout >> 4;
+    int base[NT];
 #pragma unroll
-        for (int i = 0; i < NP; ++i) { a0[i] = 0.f; a1[i] = 0.f; }
-        const float *ip = in + 2 + l0 * STRIDE - PAD;
-        for (int ci = 0; ci < Cin; ++ci) {
-            float x[WIN];
+    for (int nt = 0; nt < NT; ++nt) base[nt] = (min(nt * 16 + j, Lout - 1) * a.istride + 2) * CPi + q;
+    for (int mp = wave; mp * 2 < mtiles; mp += nwave) {
+        const int mt0 = mp * 2, mt1 = min(mp * 2 + 1, mtiles - 1);
+        const bool two = mp * 2 + 1 < mtiles;
+        f32x4 acc0[NT], acc1[NT];
 #pragma unroll
-            for (int j = 0; j < WIN; ++j) x[j] = ip[ci * LPi + j];
-            const float *w = W + (size_t)ci * KW * Cout;
+        for (int nt = 0; nt < NT; ++nt) { acc0[nt] = (f32x4)(0.f); acc1[nt] = (f32x4)(0.f); }
+        const float4 *w0 = a.img + (size_t)mt0 * a.ntaps * groups * 64 + lane;
+        const float4 *w1 = a.img + (size_t)mt1 * a.ntaps * groups * 64 + lane;
+        const int iters = a.ntaps * groups;
+        float4 a0 = w0[0], a1 = w1[0];
+        int t = 0, g = 0;
+        for (int it = 0; it < iters; ++it) {
+            const float4 c0 = a0, c1 = a1;
+            if (it + 1 < iters) { a0 = w0[(size_t)(it + 1) * 64]; a1 = w1[(size_t)(it + 1) * 64]; }
+            const int off = a.ioff[t] * CPi + g * 16;
+            const float av0[4] = {c0.x, c0.y, c0.z, c0.w}, av1[4] = {c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
-            for (int k = 0; k < KW; ++k) {
-                const float w0 = w[k * Cout + co0];
-                const float w1 = two ? w[k * Cout + co1] : 0.f;
+            for (int c = 0; c < 4; ++c) {
 #pragma unroll
-                for (int i = 0; i < NP; ++i) {
-                    a0[i] = fmaf(w0, x[i * STRIDE + k], a0[i]);
-                    a1[i] = fmaf(w1, x[i * STRIDE + k], a1[i]);
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float b = in[base[nt] + off + 4 * c];
+                    acc0[nt] = mfma16(av0[c], b, acc0[nt]);
+                    acc1[nt] = mfma16(av1[c], b, acc1[nt]);
+                }
+            }
+            if (++g == groups) { g = 0; ++t; }
+        }
+        // D layout: column (position) = lane & 15, rows (channels) = 4*(lane >> 4) + r
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int l = nt * 16 + j;
+            if (l < Lout) {
+                float *o0 = out + ((l * a.ostride + a.ooff) + 2) * CPo + 4 * q;
+                const float4 b0 = *reinterpret_cast<const float4 *>(a.bias + mt0 * 16 + 4 * q);
+                float4 v = make_float4(acc0[nt][0] + b0.x, acc0[nt][1] + b0.y, acc0[nt][2] + b0.z, acc0[nt][3] + b0.w);
+                float4 *p0 = reinterpret_cast<float4 *>(o0 + mt0 * 16);
+                if (MODE == 1) { const float4 u = *p0; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+                *p0 = v;
+                if (two) {
+                    const float4 b1 = *reinterpret_cast<const float4 *>(a.bias + mt1 * 16 + 4 * q);
+                    float4 v1 = make_float4(acc1[nt][0] + b1.x, acc1[nt][1] + b1.y, acc1[nt][2] + b1.z, acc1[nt][3] + b1.w);
+                    float4 *p1 = reinterpret_cast<float4 *>(o0 + mt1 * 16);
+                    if (MODE == 1) { const float4 u = *p1; v1.x += u.x; v1.y += u.y; v1.z += u.z; v1.w += u.w; }
+                    *p1 = v1;
                 }
             }
         }
-        const float b0 = bias[co0], b1 = two ? bias[co1] : 0.f;
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            if (l0 + i < Lout) {
-                out[co0 * LPo + 2 + l0 + i] = a0[i] + b0;
-                if (two) out[co1 * LPo + 2 + l0 + i] = a1[i] + b1;
-            }
-        }
     }
 }
 
-// ConvTranspose1d(C, C, 4, stride 2, pad 1) (diffusion_utils.py:51): out[co][lo] = b + sum_{ci,k} in[ci][li] W[ci][k][co],
-// lo = 2 li - 1 + k.  W stored [(ci*4+k)*Cout+co].
-__device__ void conv_transpose4(const float *__restrict__ W, const float *__restrict__ bias, const float *in, int LPi, float *out, int LPo,
-                                int Cin, int Cout, int Lin) {
-    const int Lout = 2 * Lin;
-    for (int item = threadIdx.x; item < Cout * Lin; item += blockDim.x) {
-        const int li = item / Cout, co = item - li * Cout;
-        // outputs lo = 2 li (k=1 from li, k=3 from li-1) and lo = 2 li + 1 (k=2 from li, k=0 from li+1)
-        float e = 0.f, o = 0.f;
-        for (int ci = 0; ci < Cin; ++ci) {
-            const float *w = W + (size_t)ci * 4 * Cout + co;
-            const float xm = in[ci * LPi + 2 + li - 1], x0 = in[ci * LPi + 2 + li], xp = in[ci * LPi + 2 + li + 1];
-            e = fmaf(x0, w[1 * Cout], e);
-            e = fmaf(xm, w[3 * Cout], e);
-            o = fmaf(x0, w[2 * Cout], o);
-            o = fmaf(xp, w[0 * Cout], o);
-        }
-        out[co * LPo + 2 + 2 * li] = e + bias[co];
-        out[co * LPo + 2 + 2 * li + 1] = o + bias[co];
-    }
-    (void)Lout;
+template <int MODE>
+__device__ void conv(const ConvArgs &a, const float *in, int CPi, float *out, int CPo, int Lout) {
+    if (Lout <= 16) conv_mfma<1, MODE>(a, in, CPi, out, CPo, Lout);
+    else if (Lout <= 32) conv_mfma<2, MODE>(a, in, CPi, out, CPo, Lout);
+    else if (Lout <= 48) conv_mfma<3, MODE>(a, in, CPi, out, CPo, Lout);
+    else conv_mfma<4, MODE>(a, in, CPi, out, CPo, Lout);
 }
 
-__device__ void zero_halo(float *buf, int LP, int C, int L) {
-    for (int i = threadIdx.x; i < C * 4; i += blockDim.x) {
-        const int c = i >> 2, j = i & 3;
-        buf[c * LP + (j < 2 ? j : L + j)] = 0.f;
+__device__ ConvArgs conv_args(const float *img, const float *bias, int cin, int cout, int ntaps, int pad, int istride) {
+    ConvArgs a;
+    a.img = reinterpret_cast<const float4 *>(img); a.bias = bias; a.cin = cin; a.cout = cout; a.ntaps = ntaps;
+    a.istride = istride; a.ostride = 1; a.ooff = 0;
+    for (int t = 0; t < 5; ++t) a.ioff[t] = t - pad;
+    return a;
+}
+
+__device__ void zero_halo(float *buf, int CP, int C, int L) {
+    for (int i = threadIdx.x; i < 4 * C; i += blockDim.x) {
+        const int r = i / C, c = i - r * C;
+        buf[(r < 2 ? r : L + r) * CP + c] = 0.f;
     }
 }
 
-// GroupNorm(groups, C) -> Mish -> optional FiLM (scale*y + shift), in place.  (diffusion_utils.py:65-69,113-116)
-__device__ void gn_mish_film(float *buf, int LP, int C, int L, int groups, const float *__restrict__ gamma, const float *__restrict__ beta,
+// GroupNorm(groups, C) -> Mish -> optional FiLM (scale*y + shift), in place on a [pos+2][CP] buffer.  (diffusion_utils.py:65-69,113-116)
+__device__ void gn_mish_film(float *buf, int CP, int C, int L, int groups, const float *__restrict__ gamma, const float *__restrict__ beta,
                              const float *film /*LDS [2C] or null*/) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = blockDim.x >> 6;
     const int cg = C / groups, cnt = cg * L;
     for (int g = wave; g < groups; g += nwave) {
+        float *gb = buf + 2 * CP + g * cg;
         float s = 0.f;
-        for (int i = lane; i < cnt; i += 64) { const int c = g * cg + i / L, l = i % L; s += buf[c * LP + 2 + l]; }
+        for (int i = lane; i < cnt; i += 64) { const int l = i / cg, c = i - l * cg; s += gb[l * CP + c]; }
         const float mean = wave_sum(s) / (float)cnt;
         float q = 0.f;
-        for (int i = lane; i < cnt; i += 64) { const int c = g * cg + i / L, l = i % L; const float d = buf[c * LP + 2 + l] - mean; q = fmaf(d, d, q); }
+        for (int i = lane; i < cnt; i += 64) { const int l = i / cg, c = i - l * cg; const float d = gb[l * CP + c] - mean; q = fmaf(d, d, q); }
         const float rstd = 1.f / sqrtf(wave_sum(q) / (float)cnt + 1e-5f);
         for (int i = lane; i < cnt; i += 64) {
-            const int c = g * cg + i / L, l = i % L;
-            float y = (buf[c * LP + 2 + l] - mean) * rstd * gamma[c] + beta[c];
+            const int l = i / cg, c = i - l * cg, ch = g * cg + c;
+            float y = (gb[l * CP + c] - mean) * rstd * gamma[ch] + beta[ch];
             y = mish(y);
-            if (film) y = film[c] * y + film[C + c];
-            buf[c * LP + 2 + l] = y;
+            if (film) y = film[ch] * y + film[C + ch];
+            gb[l * CP + c] = y;
         }
     }
 }
@@ -130,27 +157,45 @@ __device__ void matvec(const float *__restrict__ WT, const float *__restrict__ b
     }
 }
 
-struct Bufs { float *A, *B, *C, *D, *film, *cond, *tmp; };
+struct Bufs { float *A, *B, *C, *D, *film, *cond, *tmp, *xin; };
 
-// ConditionalResidualBlock1D.forward (diffusion_utils.py:101-120): x(in) -> out; t1 scratch.
-__device__ void res_block(const UnetRes &w, const float *in, float *t1, float *out, int LP, int L, int cond_dim, int groups, const Bufs &s) {
+// ConditionalResidualBlock1D.forward (diffusion_utils.py:101-120): x(in, cin channels) -> out; t1 scratch.
+// `out` may be a wider buffer (row stride CPout >= cout + 4): the concat buffer of the up path.
+__device__ void res_block(const UnetRes &w, const float *in, float *t1, float *out, int CPout, int L, int cond_dim, int groups, const Bufs &s) {
+    const int CPi = w.cin + 4, CPo = w.cout + 4;
     matvec(w.cond_wt, w.cond_b, s.cond, s.film, cond_dim, 2 * w.cout);     // cond_encoder: Mish already applied to s.cond
-    conv1d<5, 1, 2>(w.c0_w, w.c0_b, in, LP, t1, LP, w.cin, w.cout, L);
-    zero_halo(t1, LP, w.cout, L);
-    __syncthreads();
-    gn_mish_film(t1, LP, w.cout, L, groups, w.g0_w, w.g0_b, s.film);
-    __syncthreads();
-    conv1d<5, 1, 2>(w.c1_w, w.c1_b, t1, LP, out, LP, w.cout, w.cout, L);
-    zero_halo(out, LP, w.cout, L);
-    __syncthreads();
-    gn_mish_film(out, LP, w.cout, L, groups, w.g1_w, w.g1_b, nullptr);
-    __syncthreads();
-    if (w.res_w) {   // residual 1x1 conv into t1, then add
-        conv1d<1, 1, 0>(w.res_w, w.res_b, in, LP, t1, LP, w.cin, w.cout, L);
-        __syncthreads();
-        for (int i = threadIdx.x; i < w.cout * L; i += blockDim.x) { const int c = i / L, l = i % L; out[c * LP + 2 + l] += t1[c * LP + 2 + l]; }
+    if (w.cin == 1) {   // first block: single input channel held in s.xin[pos + 2]; conv k5 and the 1x1 residual on the VALU
+        for (int i = threadIdx.x; i < L * w.cout; i += blockDim.x) {
+            const int l = i / w.cout, co = i - l * w.cout;
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) acc = fmaf(w.c0_w[t * w.cout + co], s.xin[l + t], acc);
+            t1[(l + 2) * CPo + co] = acc + w.c0_b[co];
+        }
     } else {
-        for (int i = threadIdx.x; i < w.cout * L; i += blockDim.x) { const int c = i / L, l = i % L; out[c * LP + 2 + l] += in[c * LP + 2 + l]; }
+        conv<0>(conv_args(w.c0_w, w.c0_b, w.cin, w.cout, 5, 2, 1), in, CPi, t1, CPo, L);
+    }
+    zero_halo(t1, CPo, w.cout, L);
+    __syncthreads();
+    gn_mish_film(t1, CPo, w.cout, L, groups, w.g0_w, w.g0_b, s.film);
+    __syncthreads();
+    conv<0>(conv_args(w.c1_w, w.c1_b, w.cout, w.cout, 5, 2, 1), t1, CPo, out, CPout, L);
+    zero_halo(out, CPout, w.cout, L);
+    __syncthreads();
+    gn_mish_film(out, CPout, w.cout, L, groups, w.g1_w, w.g1_b, nullptr);
+    __syncthreads();
+    if (w.cin == 1) {
+        for (int i = threadIdx.x; i < L * w.cout; i += blockDim.x) {
+            const int l = i / w.cout, co = i - l * w.cout;
+            out[(l + 2) * CPout + co] += fmaf(w.res_w[co], s.xin[l + 2], w.res_b[co]);
+        }
+    } else if (w.res_w) {
+        conv<1>(conv_args(w.res_w, w.res_b, w.cin, w.cout, 1, 0, 1), in, CPi, out, CPout, L);   // residual 1x1 conv, added in place
+    } else {
+        for (int i = threadIdx.x; i < L * w.cout; i += blockDim.x) {
+            const int l = i / w.cout, c = i - l * w.cout;
+            out[(l + 2) * CPout + c] += in[(l + 2) * CPi + c];
+        }
     }
     __syncthreads();
 }
@@ -160,7 +205,6 @@ __global__ __launch_bounds__(256) void unet_kernel(const UnetParams p, const flo
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.x, t = threadIdx.x;
     const int L2 = (L - 1) / 2 + 1;                 // Conv1d(k3, s2, p1)
-    const int LP = L + 4, LP2 = L2 + 4;
     Bufs s;
     s.A = lds;
     s.B = s.A + p.bufA;
@@ -169,6 +213,7 @@ __global__ __launch_bounds__(256) void unet_kernel(const UnetParams p, const flo
     s.film = s.D + p.bufS;
     s.cond = s.film + 2 * p.cmax;
     s.tmp = s.cond + p.dsed;
+    s.xin = s.tmp + 4 * p.dsed;
     const int G = p.groups;
 
     // ---- diffusion_step_encoder: SinusoidalPosEmb -> Linear -> Mish -> Linear   (diffusion_utils.py:25-37,149-154)
@@ -189,33 +234,43 @@ __global__ __launch_bounds__(256) void unet_kernel(const UnetParams p, const flo
         __syncthreads();
         for (int i = t; i < p.dsed; i += blockDim.x) s.cond[i] = mish(s.cond[i]);   // every cond_encoder starts with Mish (:90-92)
     }
-    // ---- input (B,L,1) -> [1][LP]
-    for (int i = t; i < LP; i += blockDim.x) s.A[i] = (i >= 2 && i < 2 + L) ? sample[(size_t)b * L + i - 2] : 0.f;
+    for (int i = t; i < L + 4; i += blockDim.x) s.xin[i] = (i >= 2 && i < 2 + L) ? sample[(size_t)b * L + i - 2] : 0.f;
     __syncthreads();
 
-    res_block(p.res[0], s.A, s.B, s.C, LP, L, p.dsed, G, s);        // down0.0   1 -> d0
-    res_block(p.res[1], s.C, s.B, s.D, LP, L, p.dsed, G, s);        // down0.1   d0 -> d0   (its skip is never consumed, :264-278)
-    conv1d<3, 2, 1>(p.down_w, p.down_b, s.D, LP, s.B, LP2, p.d0, p.d0, L2);   // Downsample1d (:42)
-    zero_halo(s.B, LP2, p.d0, L2);
+    const int CP0 = p.d0 + 4, CP1 = p.d1 + 4, CPcat = 2 * p.d1 + 4;
+    res_block(p.res[0], nullptr, s.B, s.C, CP0, L, p.dsed, G, s);     // down0.0   1 -> d0
+    res_block(p.res[1], s.C, s.B, s.D, CP0, L, p.dsed, G, s);         // down0.1   d0 -> d0   (its skip is never consumed, :264-278)
+    conv<0>(conv_args(p.down_w, p.down_b, p.d0, p.d0, 3, 1, 2), s.D, CP0, s.B, CP0, L2);       // Downsample1d (:42)
+    zero_halo(s.B, CP0, p.d0, L2);
     __syncthreads();
-    res_block(p.res[2], s.B, s.C, s.D, LP2, L2, p.dsed, G, s);      // down1.0   d0 -> d1
-    res_block(p.res[3], s.D, s.B, s.C, LP2, L2, p.dsed, G, s);      // down1.1   -> skip (kept in C)
-    res_block(p.res[4], s.C, s.B, s.D, LP2, L2, p.dsed, G, s);      // mid0
-    res_block(p.res[5], s.D, s.B, s.A, LP2, L2, p.dsed, G, s);      // mid1 -> A[0:d1]
-    for (int i = t; i < p.d1 * LP2; i += blockDim.x) s.A[p.d1 * LP2 + i] = s.C[i];   // torch.cat((x, h.pop()), dim=1) (:275)
+    res_block(p.res[2], s.B, s.C, s.D, CP1, L2, p.dsed, G, s);        // down1.0   d0 -> d1
+    res_block(p.res[3], s.D, s.B, s.C, CP1, L2, p.dsed, G, s);        // down1.1   -> skip, stays in C until the concat
+    res_block(p.res[4], s.C, s.B, s.D, CP1, L2, p.dsed, G, s);        // mid0
+    res_block(p.res[5], s.D, s.B, s.A, CPcat, L2, p.dsed, G, s);      // mid1 -> channels [0, d1) of the concat buffer
+    for (int i = t; i < (L2 + 4) * p.d1; i += blockDim.x) {           // torch.cat((x, h.pop()), dim=1) (:275): skip -> channels [d1, 2 d1)
+        const int r = i / p.d1, c = i - r * p.d1;
+        s.A[r * CPcat + p.d1 + c] = s.C[r * CP1 + c];
+    }
     __syncthreads();
-    res_block(p.res[6], s.A, s.B, s.D, LP2, L2, p.dsed, G, s);      // up0.0   2*d1 -> d0
-    res_block(p.res[7], s.D, s.B, s.C, LP2, L2, p.dsed, G, s);      // up0.1
-    conv_transpose4(p.up_w, p.up_b, s.C, LP2, s.A, LP, p.d0, p.d0, L2);      // Upsample1d (:51); 2*L2 == L for even L
-    zero_halo(s.A, LP, p.d0, L);
+    res_block(p.res[6], s.A, s.B, s.D, CP0, L2, p.dsed, G, s);        // up0.0   2*d1 -> d0
+    res_block(p.res[7], s.D, s.B, s.C, CP0, L2, p.dsed, G, s);        // up0.1
+    {   // Upsample1d: ConvTranspose1d(d0, d0, 4, 2, 1) (:51): out[2 li] = W1 in[li] + W3 in[li-1];  out[2 li + 1] = W2 in[li] + W0 in[li+1]
+        ConvArgs e = conv_args(p.up_w_even, p.up_b, p.d0, p.d0, 2, 0, 1);
+        e.ioff[0] = 0; e.ioff[1] = -1; e.ostride = 2; e.ooff = 0;
+        ConvArgs o = conv_args(p.up_w_odd, p.up_b, p.d0, p.d0, 2, 0, 1);
+        o.ioff[0] = 0; o.ioff[1] = 1; o.ostride = 2; o.ooff = 1;
+        conv<0>(e, s.C, CP0, s.A, CP0, L2);
+        conv<0>(o, s.C, CP0, s.A, CP0, L2);
+        zero_halo(s.A, CP0, p.d0, L);                                 // 2*L2 == L (checked by the launcher)
+        __syncthreads();
+    }
+    conv<0>(conv_args(p.fin_w, p.fin_b, p.d0, p.d0, 5, 2, 1), s.A, CP0, s.B, CP0, L);          // final_conv.0
     __syncthreads();
-    conv1d<5, 1, 2>(p.fin_w, p.fin_b, s.A, LP, s.B, LP, p.d0, p.d0, L);      // final_conv.0
+    gn_mish_film(s.B, CP0, p.d0, L, G, p.fin_gw, p.fin_gb, nullptr);
     __syncthreads();
-    gn_mish_film(s.B, LP, p.d0, L, G, p.fin_gw, p.fin_gb, nullptr);
-    __syncthreads();
-    for (int l = t; l < L; l += blockDim.x) {                        // final_conv.1: Conv1d(d0, 1, 1)
+    for (int l = t; l < L; l += blockDim.x) {                         // final_conv.1: Conv1d(d0, 1, 1)
         float acc = 0.f;
-        for (int c = 0; c < p.d0; ++c) acc = fmaf(p.out_w[c], s.B[c * LP + 2 + l], acc);
+        for (int c = 0; c < p.d0; ++c) acc = fmaf(p.out_w[c], s.B[(l + 2) * CP0 + c], acc);
         eps[(size_t)b * L + l] = acc + p.out_b[0];
     }
 }
@@ -224,12 +279,12 @@ int unet_launch(const UnetParams &p_in, const float *sample, const int *timestep
     if (B <= 0) return DGDM_OK;
     UnetParams p = p_in;
     const int L2 = (L - 1) / 2 + 1;
-    const int slack = 32;                                    // conv windows of a ragged last chunk read past the row end
-    p.bufS = std::max(p.d0 * (L + 4), p.d1 * (L2 + 4)) + slack;
-    p.bufA = std::max(p.d0 * (L + 4), 2 * p.d1 * (L2 + 4)) + slack;
     DGDM_REQUIRE(2 * L2 == L, DGDM_EINVAL, "U-Net needs an even number of control points (got %d): the skip concat of the reference "
                  "requires ConvTranspose1d(4,2,1) to restore L", L);
-    const size_t lds_floats = (size_t)p.bufA + 3 * (size_t)p.bufS + 2 * p.cmax + p.dsed + 4 * p.dsed;
+    DGDM_REQUIRE(L <= 64, DGDM_EINVAL, "U-Net kernel supports up to 64 control points (got %d)", L);
+    p.bufS = std::max((L + 4) * (p.d0 + 4), (L2 + 4) * (p.d1 + 4));
+    p.bufA = std::max((L + 4) * (p.d0 + 4), (L2 + 4) * (2 * p.d1 + 4));
+    const size_t lds_floats = (size_t)p.bufA + 3 * (size_t)p.bufS + 2 * p.cmax + p.dsed + 4 * p.dsed + (L + 4) + 16;
     DGDM_REQUIRE(lds_floats * 4 <= 160 * 1024, DGDM_EINVAL, "U-Net activations (%zu B) exceed the 160 KiB LDS", lds_floats * 4);
     static bool attr_set = false;
     if (!attr_set) {

@@ -38,6 +38,12 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 
 from dgdm_amd import synth                      # noqa: E402
 from oracle import dgdm_oracle as orc           # noqa: E402  (only its DDIM restatement is used here)
+from tests.golden.make_golden_names import OBJ16     # noqa: E402
+
+# From here on `generator` / `dynamics` must resolve to the REFERENCE (namespace packages under /root/reference), not to
+# this repository's import-path shims of the same names (regular packages win over namespace packages on sys.path).
+sys.path.remove(REPO)
+assert "generator" not in sys.modules and "dynamics" not in sys.modules
 
 RECORDED = []
 
@@ -111,6 +117,8 @@ from dynamics.models import pointnet2_utils as ref_pn              # noqa: E402
 from dynamics.models.pointnet2 import PointNet2                    # noqa: E402
 from dynamics import metrics as ref_metrics                        # noqa: E402
 from generator.diffusion import Diffusion                          # noqa: E402
+import generator.diffusion as _ref_diffusion                       # noqa: E402
+assert _ref_diffusion.__file__.startswith(REF), _ref_diffusion.__file__
 
 UNET_SEED, DYN2D_SEED, DYN3D_SEED = 11, 22, 33
 
@@ -191,6 +199,34 @@ def run_chain(fn):
     return [r.copy() for r in RECORDED]
 
 
+class StepTrace:
+    """Records, for every denoise step of the reference's own loop, the sample fed to the eps-net, its output and the
+    gradient cond_fn returned (per object for the multi-object loop) - the data for teacher-forced comparisons."""
+
+    def __init__(self, d):
+        self.d, self.x, self.eps, self.grad = d, [], [], []
+        def hook(module, inp, out):
+            self.x.append(inp[0].detach().clone())
+            self.eps.append(out.detach().clone())          # returns None: the output is left as it is
+        self._hook = d.noise_pred_net.register_forward_hook(hook)
+        cls_cond = type(d).cond_fn
+
+        def cond(*a, **k):
+            g = cls_cond(d, *a, **k)
+            self.grad.append(g.detach().clone())
+            return g
+        d.cond_fn = cond
+
+    def close(self):
+        self._hook.remove()
+        del self.d.cond_fn
+
+    def pack(self, prefix, out):
+        out[prefix + "_x"] = torch.stack(self.x).numpy()
+        out[prefix + "_eps"] = torch.stack(self.eps).numpy()
+        out[prefix + "_grad"] = torch.stack(self.grad).numpy()
+
+
 def g2_unet():
     unet = make_unet()
     out = {}
@@ -203,7 +239,6 @@ def g2_unet():
     np.savez_compressed(os.path.join(OUT, "g2_unet.npz"), seed=UNET_SEED, **out)
 
 
-from tests.golden.make_golden_names import OBJ16     # noqa: E402
 
 
 def g3_dyn2d():
@@ -330,12 +365,18 @@ def g6_chains():
     for o in ('rotate', 'shift_left', 'counterclockwise_up', 'convergence'):
         for oi in range(2):
             d.object_vertices, d.object_ids = objs2[oi:oi + 1], [oi]
+            tr = StepTrace(d)
             res = run_chain(lambda: d.guided_sample(0, B, noise, "/tmp/dgdm_golden", opt_obj=o, ori_range=[-1.0, 1.0],
                                                     unguided_sample=xs))
+            tr.close()
+            tr.pack(f"trace2d_{o}_obj{oi}", out)
             out[f"guided2d_{o}_obj{oi}"] = res[0]
     d.object_vertices, d.object_ids = objs2, [0, 1]
+    tr = StepTrace(d)
     res = run_chain(lambda: d.guided_sample_multi_object(0, B, noise, "/tmp/dgdm_golden", opt_obj='rotate_clockwise',
                                                          ori_range=[-1.0, 1.0]))
+    tr.close()
+    tr.pack("tracemulti2d", out)
     out["multi2d_rotate_clockwise"] = np.concatenate(res, axis=0)
     # ---- 3-D
     dyn3 = make_dyn3d()
@@ -354,16 +395,22 @@ def g6_chains():
     for o in ('rotate', 'convergence'):
         d.object_vertices, d.object_ids = objs3[:1], [0]
         torch.manual_seed(0)
+        tr = StepTrace(d)
         with RandintSpy() as spy:
             res = run_chain(lambda: d.guided_sample(0, B, noise, "/tmp/dgdm_golden", opt_obj=o, ori_range=[-1.0, 1.0],
                                                     unguided_sample=xs))
+        tr.close()
+        tr.pack(f"trace3d_{o}", out)
         out[f"guided3d_{o}"] = res[0]
         out[f"guided3d_{o}_starts"], out[f"guided3d_{o}_start_lens"] = spy.packed()
     d.object_vertices, d.object_ids = objs3, [0, 1]
     torch.manual_seed(0)
+    tr = StepTrace(d)
     with RandintSpy() as spy:
         res = run_chain(lambda: d.guided_sample_multi_object(0, B, noise, "/tmp/dgdm_golden", opt_obj='shift_up',
                                                              ori_range=[-1.0, 1.0]))
+    tr.close()
+    tr.pack("tracemulti3d", out)
     out["multi3d_shift_up"] = np.concatenate(res, axis=0)
     out["multi3d_shift_up_starts"], out["multi3d_shift_up_start_lens"] = spy.packed()
     np.savez_compressed(os.path.join(OUT, "g6_chains.npz"), unet_seed=UNET_SEED, dyn2d_seed=DYN2D_SEED,

@@ -135,6 +135,23 @@ def test_full_chains():
     assert util.rel_l2(out, g["multi3d_shift_up"]) < 1e-4
 
 
+def test_oracle_replays_reference_trajectory():
+    """Step-by-step: the oracle's eps-net / cond_fn / scheduler step on the reference's recorded per-step inputs."""
+    g = util.load("g6_chains.npz")
+    unet = util.unet_sd(g["unet_seed"])
+    B, G, P, L, T, S, nv = g["dims2d"]
+    s = util.setup('point', unet, util.dyn2d_sd(g["dyn2d_seed"], nv), T, S, L, G, P)
+    objs = torch.from_numpy(g["objs2d"])
+    xs, es, gs = (torch.from_numpy(g["trace2d_rotate_obj1" + k]) for k in ("_x", "_eps", "_grad"))
+    for si, t in enumerate(s.sched.timesteps):
+        ts = t * torch.ones(int(B), dtype=torch.int64)
+        assert util.rel_l2(orc.unet1d_forward(unet, xs[si], ts), es[si]) < TOL
+        assert util.rel_l2(orc.cond_fn(s, xs[si], ts, 'rotate', objs[1]), gs[si]) < 1e-5
+        nxt = s.sched.step(es[si] - (1 - s.sched.alphas_cumprod[t]).sqrt() * gs[si] * orc.SCALE_2D, t, xs[si])
+        want = xs[si + 1] if si + 1 < len(xs) else torch.from_numpy(g["guided2d_rotate_obj1"])
+        assert util.rel_l2(nxt, want) < 1e-6
+
+
 def test_convergence_helpers():
     g = util.load("g7_convergence.npz")
     for k in ("all0", "all2", "all1", "wrap", "mixed", "single", "ones_between"):
