@@ -39,7 +39,10 @@ struct DgdmGuidance {
     DevBuf ptab, ptab_sweep;                     // [C][W1], [G][W1]
     DevBuf objpart;                              // 2-D: [max_objects][W1]
     std::vector<std::unique_ptr<ObjectTables>> tables;   // 3-D
-    DevBuf tmpF1, tmpU, tmpY, tmpL2, vlist;      // 3-D table-build temporaries
+    static constexpr int NBUILD = 3;             // objects whose tables are built concurrently (own stream + temporaries each)
+    DevBuf tmpF1[NBUILD], tmpU[NBUILD], tmpY[NBUILD], tmpL2[NBUILD], vlist;      // 3-D table-build temporaries
+    hipStream_t bstream[NBUILD] = {nullptr, nullptr, nullptr};
+    hipEvent_t bev[NBUILD] = {nullptr, nullptr, nullptr}, bstart = nullptr;
     DevBuf V, genc, atab, chainbias, timepart, ttmp, partial, objdev, objidx, xobj, starts, order, xchains;
     int n_objects = 0;
     bool force_slow_xobj = false;   // test hook: always run the per-row FPS kernel
@@ -47,11 +50,16 @@ struct DgdmGuidance {
     ~DgdmGuidance() {
         if (pinned) (void)hipHostFree(pinned);
         if (pinned_ev) (void)hipEventDestroy(pinned_ev);
+        for (int i = 0; i < NBUILD; ++i) {
+            if (bstream[i]) (void)hipStreamDestroy(bstream[i]);
+            if (bev[i]) (void)hipEventDestroy(bev[i]);
+        }
+        if (bstart) (void)hipEventDestroy(bstart);
     }
     int build_pose_table(const std::vector<float> &ori, const std::vector<float> &pos, DevBuf *dst, hipStream_t s);
     int common_pre(const float *x_dev, float t_scaled, const int *objidx_host, int n_chains, hipStream_t s);
     int upload_starts(const int64_t *starts_host, int n_chains, int64_t rows, hipStream_t s);
-    int build_object(int oi, const float *xyz_dev, hipStream_t s);
+    int build_object(int oi, int slot, const float *xyz_dev, hipStream_t s);
     int run_xobj(const int *objidx_host, int n_chains, int64_t rows, hipStream_t s);
 };
 
@@ -134,7 +142,7 @@ extern "C" int64_t dgdm_guidance_rows(const DgdmGuidance *g) { return g ? g->R :
 extern "C" int64_t dgdm_guidance_starts_per_call(const DgdmGuidance *g) { return (g && g->m->kind == 3) ? 2 * g->R : 0; }
 
 // ------------------------------------------------------------------------------------------------ objects
-int DgdmGuidance::build_object(int oi, const float *xyz_dev, hipStream_t s) {
+int DgdmGuidance::build_object(int oi, int slot, const float *xyz_dev, hipStream_t s) {
     const int N = cfg.num_object_points;
     ObjectTables &t = *tables[oi];
     const PnWeights w = m->pn();
@@ -142,23 +150,19 @@ int DgdmGuidance::build_object(int oi, const float *xyz_dev, hipStream_t s) {
     if ((rc = t.xyz.alloc((size_t)N * 3 * 4)) || (rc = t.fps1.alloc((size_t)N * 512 * sizeof(int))) || (rc = t.Z.alloc((size_t)N * N * 256 * 4)) ||
         (rc = t.fps2.alloc((size_t)N * 128 * sizeof(int))) || (rc = t.flags.alloc((size_t)N * sizeof(int))))
         return rc;
-    if ((rc = tmpF1.alloc((size_t)N * 128 * 4)) || (rc = tmpU.alloc((size_t)N * 128 * 4)) || (rc = tmpY.alloc((size_t)N * N * 256 * 4)) ||
-        (rc = tmpL2.alloc((size_t)N * N * 256 * 4)))
+    DevBuf &tF1 = tmpF1[slot], &tU = tmpU[slot], &tY = tmpY[slot], &tL2 = tmpL2[slot];
+    if ((rc = tF1.alloc((size_t)N * 128 * 4)) || (rc = tU.alloc((size_t)N * 128 * 4)) || (rc = tY.alloc((size_t)N * N * 256 * 4)) ||
+        (rc = tL2.alloc((size_t)N * N * 256 * 4)))
         return rc;
-    if (vlist.bytes < (size_t)N * sizeof(int)) {
-        std::vector<int> v(N);
-        for (int i = 0; i < N; ++i) v[i] = i;
-        if ((rc = vlist.upload(v.data(), sizeof(int) * N))) return rc;
-    }
     DGDM_HIP_CHECK(hipMemcpyAsync(t.xyz.p, xyz_dev, (size_t)N * 3 * 4, hipMemcpyDeviceToDevice, s));
     const float *xyz = t.xyz.as<float>();
     if ((rc = pn_fps_table(xyz, N, N, 512, t.fps1.as<int>(), nullptr, s))) return rc;                          // T1
     if ((rc = pn_fps_table(xyz, N, N, 128, t.fps2.as<int>(), t.flags.as<int>(), s))) return rc;
-    if ((rc = pn_sa1(xyz, N, w, tmpF1.as<float>(), s))) return rc;                                             // T2
-    if ((rc = linear(tmpF1.as<float>(), 128, w.sa2_wf_t, w.sa2_b0, nullptr, 1, tmpU.as<float>(), 128, N, 128, 128, ACT_NONE, false, s))) return rc;  // T3
-    if ((rc = pn_pairs(xyz, N, tmpU.as<float>(), w, tmpY.as<float>(), s))) return rc;                          // T4
-    if ((rc = pn_l2(xyz, N, w, t.fps1.as<int>(), vlist.as<int>(), N, tmpY.as<float>(), tmpL2.as<float>(), s))) return rc;   // T5
-    return pn_z(xyz, N, N, w, tmpL2.as<float>(), t.Z.as<float>(), s);                                          // T6
+    if ((rc = pn_sa1(xyz, N, w, tF1.as<float>(), s))) return rc;                                               // T2
+    if ((rc = linear(tF1.as<float>(), 128, w.sa2_wf_t, w.sa2_b0, nullptr, 1, tU.as<float>(), 128, N, 128, 128, ACT_NONE, false, s))) return rc;  // T3
+    if ((rc = pn_pairs(xyz, N, tU.as<float>(), w, tY.as<float>(), s))) return rc;                              // T4
+    if ((rc = pn_l2(xyz, N, w, t.fps1.as<int>(), vlist.as<int>(), N, tY.as<float>(), tL2.as<float>(), s))) return rc;       // T5
+    return pn_z(xyz, N, N, w, tL2.as<float>(), t.Z.as<float>(), s);                                            // T6
 }
 
 extern "C" int dgdm_guidance_set_objects(DgdmGuidance *g, const float *objects_dev, int n_objects, void *stream) {
@@ -174,8 +178,27 @@ extern "C" int dgdm_guidance_set_objects(DgdmGuidance *g, const float *objects_d
     } else {
         while ((int)g->tables.size() < n_objects) g->tables.emplace_back(new ObjectTables());
         const int N = g->cfg.num_object_points;
+        if (g->vlist.bytes < (size_t)N * sizeof(int)) {
+            std::vector<int> v(N);
+            for (int i = 0; i < N; ++i) v[i] = i;
+            if ((rc = g->vlist.upload(v.data(), sizeof(int) * N))) return rc;
+        }
+        // objects are independent: build them round-robin on a few side streams so the latency-bound stages (FPS: 512
+        // dependent iterations on 128 workgroups) of one object overlap the bandwidth/MFMA-bound stages of the others
+        const int nb = std::min<int>(DgdmGuidance::NBUILD, n_objects);
+        if (!g->bstart) DGDM_HIP_CHECK(hipEventCreateWithFlags(&g->bstart, hipEventDisableTiming));
+        for (int i = 0; i < nb; ++i) {
+            if (!g->bstream[i]) DGDM_HIP_CHECK(hipStreamCreateWithFlags(&g->bstream[i], hipStreamNonBlocking));
+            if (!g->bev[i]) DGDM_HIP_CHECK(hipEventCreateWithFlags(&g->bev[i], hipEventDisableTiming));
+        }
+        DGDM_HIP_CHECK(hipEventRecord(g->bstart, s));
+        for (int i = 0; i < nb; ++i) DGDM_HIP_CHECK(hipStreamWaitEvent(g->bstream[i], g->bstart, 0));
         for (int i = 0; i < n_objects; ++i)
-            if ((rc = g->build_object(i, objects_dev + (size_t)i * N * 3, s))) return rc;
+            if ((rc = g->build_object(i, i % nb, objects_dev + (size_t)i * N * 3, g->bstream[i % nb]))) return rc;
+        for (int i = 0; i < nb; ++i) {
+            DGDM_HIP_CHECK(hipEventRecord(g->bev[i], g->bstream[i]));
+            DGDM_HIP_CHECK(hipStreamWaitEvent(s, g->bev[i], 0));
+        }
         // which objects may use the table of FPS(128) sequences (no order-dependent selection anywhere)
         std::vector<int> fl((size_t)n_objects * N);
         for (int i = 0; i < n_objects; ++i)

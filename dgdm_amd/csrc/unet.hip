@@ -44,7 +44,7 @@ struct ConvArgs {
     int ioff[5];
 };
 
-template <int NT, int MODE>
+template <int NT, int MT, int MODE>
 __device__ void conv_mfma(const ConvArgs a, const float *in, int CPi, float *out, int CPo, int Lout) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     const int j = lane & 15, q = lane >> 4;
@@ -52,62 +52,74 @@ __device__ void conv_mfma(const ConvArgs a, const float *in, int CPi, float *out
     int base[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) base[nt] = (min(nt * 16 + j, Lout - 1) * a.istride + 2) * CPi + q;
-    for (int mp = wave; mp * 2 < mtiles; mp += nwave) {
-        const int mt0 = mp * 2, mt1 = min(mp * 2 + 1, mtiles - 1);
-        const bool two = mp * 2 + 1 < mtiles;
-        f32x4 acc0[NT], acc1[NT];
+    const int iters = a.ntaps * groups;
+    for (int mp = wave; mp * MT < mtiles; mp += nwave) {
+        int mt[MT];
+        const float4 *w[MT];
+        float4 nxt[MT];
+        f32x4 acc[MT][NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) { acc0[nt] = (f32x4)(0.f); acc1[nt] = (f32x4)(0.f); }
-        const float4 *w0 = a.img + (size_t)mt0 * a.ntaps * groups * 64 + lane;
-        const float4 *w1 = a.img + (size_t)mt1 * a.ntaps * groups * 64 + lane;
-        const int iters = a.ntaps * groups;
-        float4 a0 = w0[0], a1 = w1[0];
+        for (int m = 0; m < MT; ++m) {
+            mt[m] = min(mp * MT + m, mtiles - 1);
+            w[m] = a.img + (size_t)mt[m] * iters * 64 + lane;
+            nxt[m] = w[m][0];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[m][nt] = (f32x4)(0.f);
+        }
         int t = 0, g = 0;
         for (int it = 0; it < iters; ++it) {
-            const float4 c0 = a0, c1 = a1;
-            if (it + 1 < iters) { a0 = w0[(size_t)(it + 1) * 64]; a1 = w1[(size_t)(it + 1) * 64]; }
-            const int off = a.ioff[t] * CPi + g * 16;
-            const float av0[4] = {c0.x, c0.y, c0.z, c0.w}, av1[4] = {c1.x, c1.y, c1.z, c1.w};
+            float av[MT][4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const float b = in[base[nt] + off + 4 * c];
-                    acc0[nt] = mfma16(av0[c], b, acc0[nt]);
-                    acc1[nt] = mfma16(av1[c], b, acc1[nt]);
-                }
+            for (int m = 0; m < MT; ++m) {
+                av[m][0] = nxt[m].x; av[m][1] = nxt[m].y; av[m][2] = nxt[m].z; av[m][3] = nxt[m].w;
+                if (it + 1 < iters) nxt[m] = w[m][(size_t)(it + 1) * 64];
             }
+            const int off = a.ioff[t] * CPi + g * 16;
+            float bv[4][NT];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv[c][nt] = in[base[nt] + off + 4 * c];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[m][nt] = mfma16(av[m][c], bv[c][nt], acc[m][nt]);
             if (++g == groups) { g = 0; ++t; }
         }
         // D layout: column (position) = lane & 15, rows (channels) = 4*(lane >> 4) + r
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int l = nt * 16 + j;
-            if (l < Lout) {
-                float *o0 = out + ((l * a.ostride + a.ooff) + 2) * CPo + 4 * q;
-                const float4 b0 = *reinterpret_cast<const float4 *>(a.bias + mt0 * 16 + 4 * q);
-                float4 v = make_float4(acc0[nt][0] + b0.x, acc0[nt][1] + b0.y, acc0[nt][2] + b0.z, acc0[nt][3] + b0.w);
-                float4 *p0 = reinterpret_cast<float4 *>(o0 + mt0 * 16);
-                if (MODE == 1) { const float4 u = *p0; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
-                *p0 = v;
-                if (two) {
-                    const float4 b1 = *reinterpret_cast<const float4 *>(a.bias + mt1 * 16 + 4 * q);
-                    float4 v1 = make_float4(acc1[nt][0] + b1.x, acc1[nt][1] + b1.y, acc1[nt][2] + b1.z, acc1[nt][3] + b1.w);
-                    float4 *p1 = reinterpret_cast<float4 *>(o0 + mt1 * 16);
-                    if (MODE == 1) { const float4 u = *p1; v1.x += u.x; v1.y += u.y; v1.z += u.z; v1.w += u.w; }
-                    *p1 = v1;
+        for (int m = 0; m < MT; ++m) {
+            if (mp * MT + m >= mtiles) break;
+            const float4 b4 = *reinterpret_cast<const float4 *>(a.bias + mt[m] * 16 + 4 * q);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int l = nt * 16 + j;
+                if (l < Lout) {
+                    float4 *p = reinterpret_cast<float4 *>(out + ((l * a.ostride + a.ooff) + 2) * CPo + 4 * q + mt[m] * 16);
+                    float4 v = make_float4(acc[m][nt][0] + b4.x, acc[m][nt][1] + b4.y, acc[m][nt][2] + b4.z, acc[m][nt][3] + b4.w);
+                    if (MODE == 1) { const float4 u = *p; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+                    *p = v;
                 }
             }
         }
     }
 }
 
+template <int NT, int MODE>
+__device__ void conv_nt(const ConvArgs &a, const float *in, int CPi, float *out, int CPo, int Lout) {
+    // two output tiles per wave share the activation fragments when there are enough tiles to keep every wave busy
+    if ((a.cout >> 4) >= 2 * (int)(blockDim.x >> 6)) conv_mfma<NT, 2, MODE>(a, in, CPi, out, CPo, Lout);
+    else conv_mfma<NT, 1, MODE>(a, in, CPi, out, CPo, Lout);
+}
+
 template <int MODE>
 __device__ void conv(const ConvArgs &a, const float *in, int CPi, float *out, int CPo, int Lout) {
-    if (Lout <= 16) conv_mfma<1, MODE>(a, in, CPi, out, CPo, Lout);
-    else if (Lout <= 32) conv_mfma<2, MODE>(a, in, CPi, out, CPo, Lout);
-    else if (Lout <= 48) conv_mfma<3, MODE>(a, in, CPi, out, CPo, Lout);
-    else conv_mfma<4, MODE>(a, in, CPi, out, CPo, Lout);
+    if (Lout <= 16) conv_nt<1, MODE>(a, in, CPi, out, CPo, Lout);
+    else if (Lout <= 32) conv_nt<2, MODE>(a, in, CPi, out, CPo, Lout);
+    else if (Lout <= 48) conv_nt<3, MODE>(a, in, CPi, out, CPo, Lout);
+    else conv_nt<4, MODE>(a, in, CPi, out, CPo, Lout);
 }
 
 __device__ ConvArgs conv_args(const float *img, const float *bias, int cin, int cout, int ntaps, int pad, int istride) {
@@ -200,7 +212,7 @@ __device__ void res_block(const UnetRes &w, const float *in, float *t1, float *o
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void unet_kernel(const UnetParams p, const float *__restrict__ sample, const int *__restrict__ timestep,
+__global__ __launch_bounds__(512) void unet_kernel(const UnetParams p, const float *__restrict__ sample, const int *__restrict__ timestep,
                                                    float *__restrict__ eps, int L) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int b = blockIdx.x, t = threadIdx.x;
@@ -291,7 +303,7 @@ int unet_launch(const UnetParams &p_in, const float *sample, const int *timestep
         DGDM_HIP_CHECK(hipFuncSetAttribute((const void *)unet_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(unet_kernel, dim3(B), dim3(256), lds_floats * 4, s, p, sample, timestep, eps, L);
+    hipLaunchKernelGGL(unet_kernel, dim3(B), dim3(512), lds_floats * 4, s, p, sample, timestep, eps, L);
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
 }
