@@ -170,6 +170,21 @@ def cpu_baseline(wl):
             "ms_per_denoise_step": chain / wl.S * 1e3}
 
 
+def pmc_traffic(workload):
+    """HBM bytes per trunk launch from the committed rocprofv3 PMC passes of this same command (profiles/r01_*_pmc_hbm.json:
+    separate --pmc FETCH_SIZE / WRITE_SIZE runs, counter unit KB).  FETCH_SIZE is the raw counter: on gfx950 it can under-count
+    wide coalesced reads by 2x (MI355X_MICROARCH.md §HBM), so the true read traffic lies between 1x and 2x of `fetch_bytes_raw`."""
+    f = os.path.join(ROOT, "profiles", f"r01_{workload}_pmc_hbm.json")
+    if not os.path.exists(f):
+        return None
+    d = json.load(open(f))
+    key = next((k for k in d["fetch"] if "trunk_kernel" in k), None)
+    if key is None:
+        return None
+    fe, wr = d["fetch"][key]["avg_KB"] * 1024.0, d["write"][key]["avg_KB"] * 1024.0
+    return {"bytes_per_launch": fe + wr, "fetch_bytes_raw": fe, "write_bytes": wr, "source": os.path.relpath(f, ROOT)}
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -208,7 +223,7 @@ def main():
         if n:
             ach = flops / (ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "trunk_kernel (fused dynamics trunk fwd+bwd)", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None, "launches": n, "avg_launch_ms": ms / n,
+                    "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(a.workload), "launches": n, "avg_launch_ms": ms / n,
                     "algorithmic_flops_per_launch": flops / n, "share_of_step": (ms * 1e-3) / (secs / a.steps)}
     if rank != 0:
         if dist is not None:

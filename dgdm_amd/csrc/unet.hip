@@ -34,14 +34,14 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // Generic strided multi-tap convolution as implicit GEMM.
-//   out[(l*ostride + ooff) + 2][co] (+)= bias[co] + sum_{t < ntaps} sum_ci W_t[co][ci] * in[l*istride + ioff[t] + 2][ci],  l < Lout
+//   out[(l*ostride + ooff) + 2][co] (+)= bias[co] + sum_{t < ntaps} sum_ci W_t[co][ci] * in[l*istride + ioff0 + t*iostep + 2][ci],  l < Lout
 // img: [Cout/16][ntaps][Cin/16][64 lanes] float4; lane (i = l&15, q = l>>4), component c -> W_t[16 mt + i][16 g + 4 c + q].
 // MODE 0: store, 1: add to what is in `out` (residual).
 struct ConvArgs {
     const float4 *img;
     const float  *bias;
     int cin, cout, ntaps, istride, ostride, ooff;
-    int ioff[5];
+    int ioff0, iostep;        // input row offset of tap t = ioff0 + t*iostep (an indexed array here ends up in scratch)
 };
 
 template <int NT, int MT, int MODE>
@@ -74,7 +74,7 @@ __device__ void conv_mfma(const ConvArgs a, const float *in, int CPi, float *out
                 av[m][0] = nxt[m].x; av[m][1] = nxt[m].y; av[m][2] = nxt[m].z; av[m][3] = nxt[m].w;
                 if (it + 1 < iters) nxt[m] = w[m][(size_t)(it + 1) * 64];
             }
-            const int off = a.ioff[t] * CPi + g * 16;
+            const int off = (a.ioff0 + t * a.iostep) * CPi + g * 16;
             float bv[4][NT];
 #pragma unroll
             for (int c = 0; c < 4; ++c)
@@ -126,7 +126,7 @@ __device__ ConvArgs conv_args(const float *img, const float *bias, int cin, int 
     ConvArgs a;
     a.img = reinterpret_cast<const float4 *>(img); a.bias = bias; a.cin = cin; a.cout = cout; a.ntaps = ntaps;
     a.istride = istride; a.ostride = 1; a.ooff = 0;
-    for (int t = 0; t < 5; ++t) a.ioff[t] = t - pad;
+    a.ioff0 = -pad; a.iostep = 1;
     return a;
 }
 
@@ -268,9 +268,9 @@ __global__ __launch_bounds__(512) void unet_kernel(const UnetParams p, const flo
     res_block(p.res[7], s.D, s.B, s.C, CP0, L2, p.dsed, G, s);        // up0.1
     {   // Upsample1d: ConvTranspose1d(d0, d0, 4, 2, 1) (:51): out[2 li] = W1 in[li] + W3 in[li-1];  out[2 li + 1] = W2 in[li] + W0 in[li+1]
         ConvArgs e = conv_args(p.up_w_even, p.up_b, p.d0, p.d0, 2, 0, 1);
-        e.ioff[0] = 0; e.ioff[1] = -1; e.ostride = 2; e.ooff = 0;
+        e.ioff0 = 0; e.iostep = -1; e.ostride = 2; e.ooff = 0;
         ConvArgs o = conv_args(p.up_w_odd, p.up_b, p.d0, p.d0, 2, 0, 1);
-        o.ioff[0] = 0; o.ioff[1] = 1; o.ostride = 2; o.ooff = 1;
+        o.ioff0 = 0; o.iostep = 1; o.ostride = 2; o.ooff = 1;
         conv<0>(e, s.C, CP0, s.A, CP0, L2);
         conv<0>(o, s.C, CP0, s.A, CP0, L2);
         zero_halo(s.A, CP0, p.d0, L);                                 // 2*L2 == L (checked by the launcher)
