@@ -27,6 +27,7 @@ struct ObjectTables {       // 3-D, per object
     DevBuf fps2;            // [N][128] int: FPS(128) sequence by start point
     DevBuf flags;           // [N] int: that sequence is order-dependent (exact distance tie / coordinates exhausted)
     bool   fast_ok = false; // no flag set: rows can take their centres from fps2 instead of running FPS
+    DevBuf crowded, clist;  // [N] int each + clist[N] = count: centres whose ball query truncates (pointnet.hip crowd_kernel)
 };
 
 }  // namespace
@@ -148,7 +149,8 @@ int DgdmGuidance::build_object(int oi, int slot, const float *xyz_dev, hipStream
     const PnWeights w = m->pn();
     int rc;
     if ((rc = t.xyz.alloc((size_t)N * 3 * 4)) || (rc = t.fps1.alloc((size_t)N * 512 * sizeof(int))) || (rc = t.Z.alloc((size_t)N * N * 256 * 4)) ||
-        (rc = t.fps2.alloc((size_t)N * 128 * sizeof(int))) || (rc = t.flags.alloc((size_t)N * sizeof(int))))
+        (rc = t.fps2.alloc((size_t)N * 128 * sizeof(int))) || (rc = t.flags.alloc((size_t)N * sizeof(int))) ||
+        (rc = t.crowded.alloc((size_t)N * sizeof(int))) || (rc = t.clist.alloc((size_t)(N + 1) * sizeof(int))))
         return rc;
     DevBuf &tF1 = tmpF1[slot], &tU = tmpU[slot], &tY = tmpY[slot], &tL2 = tmpL2[slot];
     if ((rc = tF1.alloc((size_t)N * 128 * 4)) || (rc = tU.alloc((size_t)N * 128 * 4)) || (rc = tY.alloc((size_t)N * N * 256 * 4)) ||
@@ -161,8 +163,9 @@ int DgdmGuidance::build_object(int oi, int slot, const float *xyz_dev, hipStream
     if ((rc = pn_sa1(xyz, N, w, tF1.as<float>(), s))) return rc;                                               // T2
     if ((rc = linear(tF1.as<float>(), 128, w.sa2_wf_t, w.sa2_b0, nullptr, 1, tU.as<float>(), 128, N, 128, 128, ACT_NONE, false, s))) return rc;  // T3
     if ((rc = pn_pairs(xyz, N, tU.as<float>(), w, tY.as<float>(), s))) return rc;                              // T4
-    if ((rc = pn_l2(xyz, N, w, t.fps1.as<int>(), vlist.as<int>(), N, tY.as<float>(), tL2.as<float>(), s))) return rc;       // T5
-    return pn_z(xyz, N, N, w, tL2.as<float>(), t.Z.as<float>(), s);                                            // T6
+    if ((rc = pn_crowd(xyz, N, w, t.crowded.as<int>(), t.clist.as<int>(), t.clist.as<int>() + N, s))) return rc;
+    if ((rc = pn_l2(xyz, N, w, t.fps1.as<int>(), vlist.as<int>(), N, tY.as<float>(), tL2.as<float>(), t.clist.as<int>(), t.clist.as<int>() + N, s))) return rc;   // T5
+    return pn_z(xyz, N, N, w, tL2.as<float>(), t.Z.as<float>(), t.clist.as<int>(), t.clist.as<int>() + N, s);                                      // T6
 }
 
 extern "C" int dgdm_guidance_set_objects(DgdmGuidance *g, const float *objects_dev, int n_objects, void *stream) {
@@ -274,7 +277,7 @@ int DgdmGuidance::run_xobj(const int *objidx_host, int n_chains, int64_t rows, h
         DGDM_REQUIRE(objidx_host[i] >= 0 && objidx_host[i] < n_objects, DGDM_EINVAL, "chain %d refers to object %d of %d", i, objidx_host[i], n_objects);
         const ObjectTables &t = *tables[objidx_host[i]];
         ch[i].xyz = t.xyz.as<float>(); ch[i].fps1 = t.fps1.as<int>(); ch[i].slot_of_start = nullptr; ch[i].Z = t.Z.as<float>();
-        ch[i].fps2 = t.fps2.as<int>(); ch[i].flags = t.flags.as<int>(); ch[i].N = cfg.num_object_points;
+        ch[i].fps2 = t.fps2.as<int>(); ch[i].flags = t.flags.as<int>(); ch[i].crowded = t.crowded.as<int>(); ch[i].N = cfg.num_object_points;
     }
     DGDM_HIP_CHECK(hipMemcpyAsync(xchains.p, ch.data(), sizeof(XobjChain) * n_chains, hipMemcpyHostToDevice, s));
     XobjParams xp{};
@@ -380,10 +383,11 @@ int pointnet_rows(DgdmDynamics *m, const float *xyz_dev /*[rows][3][N]*/, const 
         groups[gid].rows.push_back(r);
     }
     const PnWeights w = m->pn();
-    DevBuf xyz, fps1, F1, U, Y, L2, Z, vlist, slotmap, starts, chains, out;
+    DevBuf xyz, fps1, F1, U, Y, L2, Z, vlist, slotmap, starts, chains, out, crowded, clist;
     int rc;
     if ((rc = xyz.alloc((size_t)N * 12)) || (rc = fps1.alloc((size_t)N * 512 * 4)) || (rc = F1.alloc((size_t)N * 512)) || (rc = U.alloc((size_t)N * 512)) ||
-        (rc = Y.alloc((size_t)N * N * 1024)) || (rc = chains.alloc(sizeof(XobjChain))))
+        (rc = Y.alloc((size_t)N * N * 1024)) || (rc = chains.alloc(sizeof(XobjChain))) || (rc = crowded.alloc((size_t)N * 4)) ||
+        (rc = clist.alloc((size_t)(N + 1) * 4)))
         return rc;
     for (size_t gi = 0; gi < groups.size(); ++gi) {
         const std::vector<int> &rws = groups[gi].rows;
@@ -407,10 +411,11 @@ int pointnet_rows(DgdmDynamics *m, const float *xyz_dev /*[rows][3][N]*/, const 
         if ((rc = pn_sa1(x, N, w, F1.as<float>(), s))) return rc;
         if ((rc = linear(F1.as<float>(), 128, w.sa2_wf_t, w.sa2_b0, nullptr, 1, U.as<float>(), 128, N, 128, 128, ACT_NONE, false, s))) return rc;
         if ((rc = pn_pairs(x, N, U.as<float>(), w, Y.as<float>(), s))) return rc;
-        if ((rc = pn_l2(x, N, w, fps1.as<int>(), vlist.as<int>(), nv, Y.as<float>(), L2.as<float>(), s))) return rc;
-        if ((rc = pn_z(x, N, nv, w, L2.as<float>(), Z.as<float>(), s))) return rc;
+        if ((rc = pn_crowd(x, N, w, crowded.as<int>(), clist.as<int>(), clist.as<int>() + N, s))) return rc;
+        if ((rc = pn_l2(x, N, w, fps1.as<int>(), vlist.as<int>(), nv, Y.as<float>(), L2.as<float>(), clist.as<int>(), clist.as<int>() + N, s))) return rc;
+        if ((rc = pn_z(x, N, nv, w, L2.as<float>(), Z.as<float>(), clist.as<int>(), clist.as<int>() + N, s))) return rc;
         XobjChain ch{};
-        ch.xyz = x; ch.fps1 = fps1.as<int>(); ch.slot_of_start = slotmap.as<int>(); ch.Z = Z.as<float>(); ch.fps2 = nullptr; ch.flags = nullptr; ch.N = N;
+        ch.xyz = x; ch.fps1 = fps1.as<int>(); ch.slot_of_start = slotmap.as<int>(); ch.Z = Z.as<float>(); ch.fps2 = nullptr; ch.flags = nullptr; ch.crowded = crowded.as<int>(); ch.N = N;
         DGDM_HIP_CHECK(hipMemcpyAsync(chains.p, &ch, sizeof ch, hipMemcpyHostToDevice, s));
         XobjParams xp{};
         xp.chains = chains.as<XobjChain>(); xp.starts = starts.as<int>(); xp.xobj = out.as<float>(); xp.R = (int64_t)rws.size(); xp.total_rows = xp.R;

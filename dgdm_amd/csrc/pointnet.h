@@ -27,6 +27,7 @@ struct XobjChain {
     const float *Z;               // [nv][N][256]
     const int   *fps2;            // [N][128] FPS(128) sequences by start POINT, or null
     const int   *flags;           // [N] 1 = the sequence from this start point is order-dependent: run FPS for the row
+    const int   *crowded;         // [N] 1 = more than 64 points in the centre's r=0.4 ball: Z depends on the variant
     int          N;
 };
 
@@ -42,8 +43,10 @@ struct XobjParams {
 int pn_fps_table(const float *xyz, int N, int nv, int npoint, int *out, int *flags, hipStream_t s);
 int pn_sa1(const float *xyz, int N, const PnWeights &w, float *F1, hipStream_t s);
 int pn_pairs(const float *xyz, int N, const float *U, const PnWeights &w, float *Y, hipStream_t s);
-int pn_l2(const float *xyz, int N, const PnWeights &w, const int *fps1, const int *vlist, int nv, const float *Y, float *L2, hipStream_t s);
-int pn_z(const float *xyz, int N, int nv, const PnWeights &w, const float *L2, float *Z, hipStream_t s);
+int pn_crowd(const float *xyz, int N, const PnWeights &w, int *crowded, int *clist, int *ncr, hipStream_t s);
+int pn_l2(const float *xyz, int N, const PnWeights &w, const int *fps1, const int *vlist, int nv, const float *Y, float *L2,
+          const int *clist, const int *ncr, hipStream_t s);
+int pn_z(const float *xyz, int N, int nv, const PnWeights &w, const float *L2, float *Z, const int *clist, const int *ncr, hipStream_t s);
 int pn_xobj(const XobjParams &p, hipStream_t s);
 
 }  // namespace dgdm

@@ -217,16 +217,59 @@ __global__ __launch_bounds__(256, 1) void pair_kernel(const float *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------ T5
+// A centre whose r=0.4 ball holds at most 64 points keeps ALL of them whatever the ordering, so its sa2 feature (and
+// with it the sa3 feature Z) is the same for every variant and is computed once, in slot 0.  Only "crowded" centres
+// (more than 64 in-radius points: the ball query truncates, and which 64 survive depends on the variant's order) need
+// one value per variant.  crowded[c] in {0,1}; clist = the crowded centres, *ncr their number.
+__global__ __launch_bounds__(1024) void crowd_kernel(const float *__restrict__ xyz, int N, float r2, int *__restrict__ crowded,
+                                                     int *__restrict__ clist, int *__restrict__ ncr) {
+    __shared__ int wcount[16];
+    const int c = threadIdx.x, lane = c & 63, wave = c >> 6;
+    bool cr = false;
+    if (c < N) {
+        const float cx = xyz[3 * c], cy = xyz[3 * c + 1], cz = xyz[3 * c + 2];
+        const float cn = sq3(cx, cy, cz);
+        int cnt = 0;
+        for (int k = 0; k < N; ++k) {
+            const float x = xyz[3 * k], y = xyz[3 * k + 1], z = xyz[3 * k + 2];
+            cnt += !(sqdist_expanded(cx, cy, cz, cn, x, y, z, sq3(x, y, z)) > r2);
+        }
+        cr = cnt > 64;
+        crowded[c] = cr ? 1 : 0;
+    }
+    const unsigned long long m = __ballot(cr);
+    if (lane == 0) wcount[wave] = __popcll(m);
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wcount[w];
+    if (cr) clist[base + __popcll(m & ((1ull << lane) - 1ull))] = c;
+    if (c == 0) {
+        int tot = 0;
+        for (int w = 0; w < 16; ++w) tot += wcount[w];
+        *ncr = tot;
+    }
+}
+
 // L2[slot][c][256] = max over the first 64 in-radius (r=0.4) positions of variant vlist[slot] of Y[c][point].
-// grid (c, slot-group): consecutive waves share the centre so its Y slab stays cache resident.
+// mode 0: slot 0, every centre (blockIdx.y*4 + wave).  mode 1: slots >= 1, crowded centres only (clist[blockIdx.y]); the
+// waves of a workgroup then share the centre so its Y slab stays cache resident.
 __global__ __launch_bounds__(256) void l2_kernel(const float *__restrict__ xyz, int N, float r2, const int *__restrict__ fps1 /*[N][512]*/,
                                                  const int *__restrict__ vlist, int nv, const float *__restrict__ Y,
-                                                 float *__restrict__ L2 /*[nv][N][256]*/) {
+                                                 float *__restrict__ L2 /*[nv][N][256]*/, int mode, const int *__restrict__ clist,
+                                                 const int *__restrict__ ncr) {
     __shared__ int sel[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.y;
-    const int slot = blockIdx.x * 4 + wave;
-    if (slot >= nv) return;
+    int c, slot;
+    if (mode == 0) {
+        c = blockIdx.y * 4 + wave;
+        slot = 0;
+        if (c >= N) return;
+    } else {
+        if ((int)blockIdx.y >= *ncr) return;
+        c = clist[blockIdx.y];
+        slot = 1 + blockIdx.x * 4 + wave;
+        if (slot >= nv) return;
+    }
     const int *perm = fps1 + (size_t)vlist[slot] * 512;
     const float cx = xyz[3 * c], cy = xyz[3 * c + 1], cz = xyz[3 * c + 2];
     const float cn = sq3(cx, cy, cz);
@@ -265,15 +308,21 @@ __global__ __launch_bounds__(256) void l2_kernel(const float *__restrict__ xyz, 
 
 // ------------------------------------------------------------------------------------------------ T6
 // Z[row][256] = ReLU(W3'[:,3:] L2[row] + W3'[:,0:3] xyz_c + b3'),  row = slot*N + c   (sa3, pointnet2.py:19)
-__global__ __launch_bounds__(256, 1) void z_kernel(const float *__restrict__ xyz, int N, int64_t rows, const float *__restrict__ L2,
+// mode 0: slot 0, all N centres.  mode 1: slots 1..nv-1, crowded centres only (work item k -> slot 1 + k / ncr, centre clist[k % ncr]).
+__global__ __launch_bounds__(256, 1) void z_kernel(const float *__restrict__ xyz, int N, int nv, const float *__restrict__ L2,
                                                    const float4 *__restrict__ Wimg, const float *__restrict__ w3x /*[3][256]*/,
-                                                   const float *__restrict__ bias, float *__restrict__ Z) {
+                                                   const float *__restrict__ bias, float *__restrict__ Z, int mode,
+                                                   const int *__restrict__ clist, const int *__restrict__ ncr) {
     const int lane = threadIdx.x & 63, n = lane & 31, h4 = (lane >> 5) * 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-    if (tile * 32 >= rows) return;
-    const int64_t row = min(tile * 32 + n, rows - 1);
-    const int c = (int)(row % N);
+    const int ncrv = mode ? *ncr : N;
+    const int64_t items = mode ? (int64_t)(nv - 1) * ncrv : N;
+    if (tile * 32 >= items) return;
+    const int64_t item = min(tile * 32 + n, items - 1);
+    const int c = mode ? clist[item % ncrv] : (int)item;
+    const int64_t row = mode ? (1 + item / ncrv) * N + c : c;
+    const int64_t rows = items;
     const float x = xyz[3 * c], y = xyz[3 * c + 1], z = xyz[3 * c + 2];
     f32x16 in[8], out[8];
     const float *lrow = L2 + (size_t)row * 256;
@@ -293,7 +342,7 @@ __global__ __launch_bounds__(256, 1) void z_kernel(const float *__restrict__ xyz
     }
     chain_layer<8, 8, CHAIN_KEEP>(Wimg, nullptr, in, out, lane);
     if (tile * 32 + n < rows) {
-        float *dst = Z + (size_t)row * 256;
+        float *dst = Z + (size_t)row * 256;   // rows of one tile are distinct (item -> row is injective)
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
 #pragma unroll
@@ -352,11 +401,13 @@ __global__ __launch_bounds__(256) void xobj_kernel(const XobjParams p) {
         idA = perm[centres[wave][lane]];
         idB = perm[centres[wave][64 + lane]];
     }
-    const float *zt = ch.Z + (size_t)slot * ch.N * 256 + lane * 4;
+    // row of Z for a centre: its own variant's slot when the centre is crowded, slot 0 otherwise (see crowd_kernel)
+    const int rowA = (ch.crowded[idA] ? slot * ch.N : 0) + idA, rowB = (ch.crowded[idB] ? slot * ch.N : 0) + idB;
+    const float *zt = ch.Z + lane * 4;
     float4 best = make_float4(0.f, 0.f, 0.f, 0.f);      // Z >= 0 (ReLU)
 #pragma unroll 4
     for (int i = 0; i < 64; i += 2) {
-        const int c0 = __shfl(idA, i), c1 = __shfl(idA, i + 1), c2 = __shfl(idB, i), c3 = __shfl(idB, i + 1);
+        const int c0 = __shfl(rowA, i), c1 = __shfl(rowA, i + 1), c2 = __shfl(rowB, i), c3 = __shfl(rowB, i + 1);
         const float4 a = *reinterpret_cast<const float4 *>(zt + (size_t)c0 * 256);
         const float4 b = *reinterpret_cast<const float4 *>(zt + (size_t)c1 * 256);
         const float4 d = *reinterpret_cast<const float4 *>(zt + (size_t)c2 * 256);
@@ -389,16 +440,27 @@ int pn_pairs(const float *xyz, int N, const float *U, const PnWeights &w, float 
     return DGDM_OK;
 }
 
-int pn_l2(const float *xyz, int N, const PnWeights &w, const int *fps1, const int *vlist, int nv, const float *Y, float *L2, hipStream_t s) {
-    hipLaunchKernelGGL(l2_kernel, dim3((nv + 3) / 4, N), dim3(256), 0, s, xyz, N, w.r2sq, fps1, vlist, nv, Y, L2);
+int pn_crowd(const float *xyz, int N, const PnWeights &w, int *crowded, int *clist, int *ncr, hipStream_t s) {
+    hipLaunchKernelGGL(crowd_kernel, dim3(1), dim3(1024), 0, s, xyz, N, w.r2sq, crowded, clist, ncr);
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
 }
 
-int pn_z(const float *xyz, int N, int nv, const PnWeights &w, const float *L2, float *Z, hipStream_t s) {
-    const int64_t rows = (int64_t)nv * N;
-    const int64_t tiles = (rows + 31) / 32;
-    hipLaunchKernelGGL(z_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, xyz, N, rows, L2, w.sa3_w_img, w.sa3_wx, w.sa3_b, Z);
+int pn_l2(const float *xyz, int N, const PnWeights &w, const int *fps1, const int *vlist, int nv, const float *Y, float *L2,
+          const int *clist, const int *ncr, hipStream_t s) {
+    hipLaunchKernelGGL(l2_kernel, dim3(1, (N + 3) / 4), dim3(256), 0, s, xyz, N, w.r2sq, fps1, vlist, nv, Y, L2, 0, clist, ncr);
+    if (nv > 1) hipLaunchKernelGGL(l2_kernel, dim3((nv - 1 + 3) / 4, N), dim3(256), 0, s, xyz, N, w.r2sq, fps1, vlist, nv, Y, L2, 1, clist, ncr);
+    DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
+}
+
+int pn_z(const float *xyz, int N, int nv, const PnWeights &w, const float *L2, float *Z, const int *clist, const int *ncr, hipStream_t s) {
+    const int64_t t0 = (N + 31) / 32;
+    hipLaunchKernelGGL(z_kernel, dim3((unsigned)((t0 + 3) / 4)), dim3(256), 0, s, xyz, N, nv, L2, w.sa3_w_img, w.sa3_wx, w.sa3_b, Z, 0, clist, ncr);
+    if (nv > 1) {      // sized for the worst case (every centre crowded); surplus workgroups leave at once
+        const int64_t t1 = ((int64_t)(nv - 1) * N + 31) / 32;
+        hipLaunchKernelGGL(z_kernel, dim3((unsigned)((t1 + 3) / 4)), dim3(256), 0, s, xyz, N, nv, L2, w.sa3_w_img, w.sa3_wx, w.sa3_b, Z, 1, clist, ncr);
+    }
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
 }
