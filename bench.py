@@ -146,7 +146,7 @@ def cpu_baseline(wl):
         obj = synth.synth_object_3d(0, wl.N)
         xr = x.clone().requires_grad_(True)
         ori, pos = orc._pose_grid(s, B, (-1.0, 1.0))
-        n = 128                                          # a quarter of one 512-row sub-batch; cost is linear in rows
+        n = wl.sub                                       # one full sub-batch of 512 rows (10-20 s on 32 threads)
         t0 = time.perf_counter()
         with torch.enable_grad():
             pts = orc._pts3d(s, xr).repeat(cells, 1, 1)[:n]
@@ -155,8 +155,8 @@ def cpu_baseline(wl):
             torch.autograd.grad(orc.deltas_to_objective(logits, 'rotate').sum(), xr)
         t_rows = (time.perf_counter() - t0) / n
         chain = wl.S * (B * cells * t_rows + t_unet)
-        sample = (f"{n} of the {B * cells} replicated rows of one cond_fn call (PointNet++ + trunk forward, autograd backward) + 1 eps-net "
-                  f"forward, extrapolated to {B * cells} rows x {wl.S} steps")
+        sample = (f"1 of the {(B * cells + n - 1) // n} sub-batches ({n} of {B * cells} replicated rows) of one cond_fn call (PointNet++ + trunk "
+                  f"forward, autograd backward) + 1 eps-net forward, extrapolated to {B * cells} rows x {wl.S} steps")
     else:
         s = orc.Setup('point', wl.unet_sd, wl.dyn_sd, so, L, wl.G, wl.P)
         obj = synth.synth_object_2d(0, wl.N)
