@@ -40,7 +40,7 @@ __device__ __forceinline__ float4 feat4(const float *__restrict__ row, int o, in
 // Depth of the software prefetch ring on the weight stream: one float4 per lane feeds 4 MFMAs
 // (256 cycles), so DEPTH entries cover DEPTH*256 cycles of L2 latency with one wave per SIMD.
 #ifndef DGDM_CHAIN_DEPTH
-#define DGDM_CHAIN_DEPTH 8
+#define DGDM_CHAIN_DEPTH 12      // A/B on MI355X: 8 -> 12 is +6 % on the 3-D trunk, 0 on the 2-D one; 16 = 12
 #endif
 
 // Weight images are read through a buffer descriptor (wave-uniform base in SGPRs, per-lane byte
