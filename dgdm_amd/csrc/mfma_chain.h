@@ -169,6 +169,89 @@ __device__ __forceinline__ void chain_accumulate_block(const float4 *__restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Continuous weight stream: the images of consecutive layers (or block passes) are laid out back to back in ONE buffer in
+// the order the kernel consumes them, and a 16-entry ring (16 divides every pass length used: 32, 64, 256) is carried
+// in registers from pass to pass.  A pass always prefetches 16 entries past its own end - the head of the next pass -
+// so there is no ring drain/refill bubble between layers; reads past the end of the buffer are clipped to zero by the
+// buffer descriptor and never used.
+constexpr int CONT_DEPTH = 16;
+
+__device__ __forceinline__ void ring_fill(wrsrc_t rs, int voff, int base_off, float4 (&ring)[CONT_DEPTH]) {
+#pragma unroll
+    for (int i = 0; i < CONT_DEPTH; ++i) ring[i] = wload(rs, voff, base_off + i * 1024);
+}
+
+template <int TOTAL, class Body>
+__device__ __forceinline__ void stream_cont(wrsrc_t rs, int voff, int base_off, float4 (&ring)[CONT_DEPTH], Body &&body) {
+    static_assert(TOTAL % CONT_DEPTH == 0, "pass length must be a multiple of the ring depth");
+#pragma unroll
+    for (int i = 0; i < TOTAL; ++i) {
+        const float4 a = ring[i % CONT_DEPTH];
+        ring[i % CONT_DEPTH] = wload(rs, voff, base_off + (i + CONT_DEPTH) * 1024);
+        body(i, a);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// out[MB] (+)= W * in[KB] with the weights taken from the continuous stream at byte offset base_off (256 -> 256: 256 entries).
+template <int KB, int MB, int INIT>
+__device__ __forceinline__ void chain_layer_cont(wrsrc_t rs, int base_off, float4 (&ring)[CONT_DEPTH], const float *__restrict__ bias,
+                                                 const f32x16 (&in)[KB], f32x16 (&out)[MB], int lane) {
+    const int h4 = (lane >> 5) * 4;
+    if (INIT != CHAIN_KEEP) {
+#pragma unroll
+        for (int op = 0; op < MB; ++op) {
+            if (INIT == CHAIN_BIAS) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b4 = feat4(bias, op, q, h4);
+                    out[op][4 * q + 0] = b4.x; out[op][4 * q + 1] = b4.y; out[op][4 * q + 2] = b4.z; out[op][4 * q + 3] = b4.w;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) out[op][r] = 0.f;
+            }
+        }
+    }
+    stream_cont<MB * KB * 4>(rs, lane * 16, base_off, ring, [&](int i, const float4 a) {
+        const int op = i / (KB * 4), o = (i / 4) % KB, q = i % 4;
+        out[op] = mfma32(a.x, in[o][4 * q + 0], out[op]);
+        out[op] = mfma32(a.y, in[o][4 * q + 1], out[op]);
+        out[op] = mfma32(a.z, in[o][4 * q + 2], out[op]);
+        out[op] = mfma32(a.w, in[o][4 * q + 3], out[op]);
+    });
+}
+
+// one 32-feature output block: acc = W_block * in[KB]   (KB*4 entries)
+template <int KB>
+__device__ __forceinline__ f32x16 chain_block_cont(wrsrc_t rs, int base_off, float4 (&ring)[CONT_DEPTH], const f32x16 (&in)[KB], int lane) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    stream_cont<KB * 4>(rs, lane * 16, base_off, ring, [&](int i, const float4 a) {
+        const int o = i / 4, q = i % 4;
+        acc = mfma32(a.x, in[o][4 * q + 0], acc);
+        acc = mfma32(a.y, in[o][4 * q + 1], acc);
+        acc = mfma32(a.z, in[o][4 * q + 2], acc);
+        acc = mfma32(a.w, in[o][4 * q + 3], acc);
+    });
+    return acc;
+}
+
+// acc[MB] += W[:, one 32-feature input block] * x   (MB*4 entries, ordered (op, q))
+template <int MB>
+__device__ __forceinline__ void chain_accumulate_cont(wrsrc_t rs, int base_off, float4 (&ring)[CONT_DEPTH], const f32x16 &x,
+                                                      f32x16 (&acc)[MB], int lane) {
+    stream_cont<MB * 4>(rs, lane * 16, base_off, ring, [&](int i, const float4 a) {
+        const int op = i / 4, q = i % 4;
+        acc[op] = mfma32(a.x, x[4 * q + 0], acc[op]);
+        acc[op] = mfma32(a.y, x[4 * q + 1], acc[op]);
+        acc[op] = mfma32(a.z, x[4 * q + 2], acc[op]);
+        acc[op] = mfma32(a.w, x[4 * q + 3], acc[op]);
+    });
+}
+
 // ReLU in place; returns the sign bits (bit r set <=> x[r] > 0), torch's relu'(0) = 0.
 __device__ __forceinline__ uint32_t relu_bits(f32x16 &x) {
     uint32_t bits = 0;

@@ -15,9 +15,11 @@ struct DgdmUnet1d {
 namespace dgdm {
 struct DynOff {   // offsets (floats) into the blob
     size_t g0_wt, g0_b, g0_w, g2_wt, g2_b, g2_w;
-    size_t w1c_wt, w1c_w, w1p_wt, w1t_wt, b1, w1o_wt, w1o_img;
-    size_t w2f_img, b2, w2b_img;
-    size_t wf[8], bf[8], wb[8];
+    size_t w1c_wt, w1c_w, w1p_wt, w1t_wt, b1, w1o_wt;
+    size_t b2;
+    size_t bf[8];
+    size_t wfwd, wbwd;      // continuous forward / backward weight streams (trunk.h)
+    size_t fwd_floats, bwd_floats;
     size_t wout, bout;
     size_t te0_wt, te0_b, te2_wt, te2_b, oe0_wt, oe0_b, oe2_wt, oe2_b, tfreq;
     size_t sa1_w0t, sa1_b0, sa1_w1, sa1_b1, sa2_wf_t, sa2_b0, sa2_vx, sa2_w1_img, sa2_b1, sa3_w_img, sa3_wx, sa3_b;

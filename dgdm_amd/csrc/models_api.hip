@@ -190,6 +190,7 @@ extern "C" int dgdm_dynamics_create(DgdmDynamics **out, int kind, const DgdmTens
     if ((rc = fold_linear(sd, "linears.0", "linears.1", W1, IN1, &l1))) return rc;
     if ((rc = fold_linear(sd, "output", "", 3, W, &lout))) return rc;
     DynOff &o = m->off;
+    std::vector<float> fwd, bwd_tail;                             // continuous trunk weight streams (csrc/trunk.h)
     o.g0_wt = bl.add(transpose(g0.w.data(), W, params_ch)); o.g0_b = bl.add(g0.b); o.g0_w = bl.add(g0.w);
     o.g2_wt = bl.add(transpose(g2.w.data(), W, W)); o.g2_b = bl.add(g2.b); o.g2_w = bl.add(g2.w);
     // first trunk layer: concat order [x_object | x_ctrl | x_pose | time_emb]  (profile_forward_2d.py:154, _3d.py:84)
@@ -215,12 +216,19 @@ extern "C" int dgdm_dynamics_create(DgdmDynamics **out, int kind, const DgdmTens
         o.tfreq = bl.add(tfreqs(W / 4));
         m->thalf = W / 4;
     } else {
-        o.w1o_img = bl.add(pack_chain(w1o.data(), W1, W));
         Folded l2;
         if ((rc = fold_linear(sd, "linears.3", "linears.4", W, W1, &l2))) return rc;
-        o.w2f_img = bl.add(pack_chain(l2.w.data(), W, W1));
         o.b2 = bl.add(l2.b);
-        o.w2b_img = bl.add(pack_chain(transpose(l2.w.data(), W, W1).data(), W1, W));
+        // forward stream head: per 32-feature block of the 512-wide layer 1, its W1o' rows (32 entries) and then the matching
+        // column block of W2' (8 output blocks x 4 entries)
+        const std::vector<float> i1 = pack_chain(w1o.data(), W1, W), i2 = pack_chain(l2.w.data(), W, W1);
+        const size_t E = 64 * 4;                                  // floats per entry (64 lanes x float4)
+        for (int blk = 0; blk < 16; ++blk) {
+            fwd.insert(fwd.end(), i1.begin() + (size_t)blk * 32 * E, i1.begin() + (size_t)(blk + 1) * 32 * E);
+            for (int op = 0; op < 8; ++op)
+                fwd.insert(fwd.end(), i2.begin() + (size_t)((op * 16 + blk) * 4) * E, i2.begin() + (size_t)((op * 16 + blk) * 4 + 4) * E);
+        }
+        bwd_tail = pack_chain(transpose(l2.w.data(), W, W1).data(), W1, W);     // 16 blocks x 32 entries, consumed in order
         o.tfreq = bl.add(tfreqs(W / 2));
         m->thalf = W / 2;
         first_mid = 2;
@@ -240,14 +248,21 @@ extern "C" int dgdm_dynamics_create(DgdmDynamics **out, int kind, const DgdmTens
         o.sa3_wx = bl.add(transpose(cols(c0.w, 256, 259, 0, 3).data(), 256, 3)); o.sa3_b = bl.add(c0.b);
     }
     m->n_mid = 8 - first_mid;
+    std::vector<std::vector<float>> bwd_imgs;
     for (int i = 0; i < m->n_mid; ++i) {
         const int li = 3 * (first_mid + i);
         Folded f;
         if ((rc = fold_linear(sd, "linears." + std::to_string(li), "linears." + std::to_string(li + 1), W, W, &f))) return rc;
-        o.wf[i] = bl.add(pack_chain(f.w.data(), W, W));
+        const std::vector<float> fi = pack_chain(f.w.data(), W, W);
+        fwd.insert(fwd.end(), fi.begin(), fi.end());
         o.bf[i] = bl.add(f.b);
-        o.wb[i] = bl.add(pack_chain(transpose(f.w.data(), W, W).data(), W, W));
+        bwd_imgs.push_back(pack_chain(transpose(f.w.data(), W, W).data(), W, W));
     }
+    std::vector<float> bwd;
+    for (int i = m->n_mid - 1; i >= 0; --i) bwd.insert(bwd.end(), bwd_imgs[i].begin(), bwd_imgs[i].end());     // last layer first
+    bwd.insert(bwd.end(), bwd_tail.begin(), bwd_tail.end());
+    o.wfwd = bl.add(fwd); o.fwd_floats = fwd.size();
+    o.wbwd = bl.add(bwd); o.bwd_floats = bwd.size();
     if ((rc = bl.upload())) return rc;
     *out = m.release();
     return DGDM_OK;
@@ -257,12 +272,12 @@ extern "C" void dgdm_dynamics_destroy(DgdmDynamics *m) { delete m; }
 
 void DgdmDynamics::fill_trunk(TrunkParams *p) const {
     memset(p, 0, sizeof *p);
-    for (int i = 0; i < n_mid; ++i) { p->Wf[i] = blob.at4(off.wf[i]); p->bf[i] = blob.at(off.bf[i]); p->Wb[i] = blob.at4(off.wb[i]); }
+    for (int i = 0; i < n_mid; ++i) p->bf[i] = blob.at(off.bf[i]);
     p->n_mid = n_mid;
     p->Wout = blob.at(off.wout); p->bout = blob.at(off.bout);
-    if (kind == 3) {
-        p->W1o = blob.at4(off.w1o_img); p->W2f = blob.at4(off.w2f_img); p->b2 = blob.at(off.b2); p->W2b = blob.at4(off.w2b_img);
-    }
+    p->Wfwd = blob.at4(off.wfwd); p->fwd_bytes = (unsigned)(off.fwd_floats * 4);
+    p->Wbwd = blob.at4(off.wbwd); p->bwd_bytes = (unsigned)(off.bwd_floats * 4);
+    if (kind == 3) p->b2 = blob.at(off.b2);
 }
 
 PnWeights DgdmDynamics::pn() const {

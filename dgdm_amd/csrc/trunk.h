@@ -12,17 +12,17 @@ struct TrunkObjective {   // device copy of DgdmObjective (object index not need
 
 struct TrunkParams {
     // 256 -> 256 layers (trunk layers 2..8 for 2-D, 3..8 for 3-D), BatchNorm folded
-    const float4 *Wf[8];      // chain images of W'
     const float  *bf[8];      // folded biases
-    const float4 *Wb[8];      // chain images of W'^T
     int           n_mid;
+    // continuous weight streams (mfma_chain.h stream_cont), in consumption order:
+    //   forward : [3-D: 16 x (W1o block (32 entries) | W2' column block (32 entries))] then the n_mid images of W'
+    //   backward: the n_mid images of W'^T, LAST layer first, [3-D: then the 16 blocks of W2'^T]
+    const float4 *Wfwd, *Wbwd;
+    unsigned      fwd_bytes, bwd_bytes;
     const float  *Wout;       // [3][256] row-major
     const float  *bout;       // [3]
     // 3-D only
-    const float4 *W1o;        // image of W1'[:, object part]   [512 x 256]
-    const float4 *W2f;        // image of W2'                   [256 x 512]
     const float  *b2;         // folded bias of layer 2
-    const float4 *W2b;        // image of W2'^T                 [512 x 256]
     const float  *xobj;       // [nchain][R][256]  PointNet++ embedding per reference row
     // first-layer tables
     const float  *Atab;       // table mode: [nchain*B][W1]; rows mode: [rows][W1]

@@ -68,6 +68,10 @@ __global__ __launch_bounds__(256, 1) void trunk_kernel(const TrunkParams p) {
     f32x16 cur[8], nxt[8];
     uint32_t m[4];
     int slot = 0;
+    const wrsrc_t rsF = weight_rsrc(p.Wfwd, p.fwd_bytes);
+    float4 ring[CONT_DEPTH];
+    int woff = 0;                                             // byte offset of the next pass inside the forward stream
+    ring_fill(rsF, lane * 16, 0, ring);
 
     if (KIND == 2) {
         // ---- layer 1: table lookups
@@ -113,7 +117,8 @@ __global__ __launch_bounds__(256, 1) void trunk_kernel(const TrunkParams p) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int kb = blk + e;
-                f32x16 z = chain_block<8, false>(p.W1o + (size_t)kb * 8 * 4 * 64, nullptr, nxt, lane);
+                f32x16 z = chain_block_cont<8>(rsF, woff, ring, nxt, lane);
+                woff += 32 * 1024;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float4 v = *reinterpret_cast<const float4 *>(arow + 32 * kb + 8 * q + h4);
@@ -124,7 +129,8 @@ __global__ __launch_bounds__(256, 1) void trunk_kernel(const TrunkParams p) {
                     z[4 * q + 0] += v.x; z[4 * q + 1] += v.y; z[4 * q + 2] += v.z; z[4 * q + 3] += v.w;
                 }
                 bits2 |= relu_bits(z) << (16 * e);
-                chain_accumulate_block<8>(p.W2f, 16, kb, z, cur, lane);
+                chain_accumulate_cont<8>(rsF, woff, ring, z, cur, lane);
+                woff += 32 * 1024;
             }
             if (!FWD_ONLY) smask[blk / 2][tid] = bits2;
         }
@@ -139,7 +145,8 @@ __global__ __launch_bounds__(256, 1) void trunk_kernel(const TrunkParams p) {
 
     // ---- 256 -> 256 layers
     for (int l = 0; l < p.n_mid; ++l) {
-        chain_layer<8, 8, CHAIN_BIAS>(p.Wf[l], p.bf[l], cur, nxt, lane);
+        chain_layer_cont<8, 8, CHAIN_BIAS>(rsF, woff, ring, p.bf[l], cur, nxt, lane);
+        woff += 256 * 1024;
         relu_mask<8>(nxt, m);
         if (!FWD_ONLY) {
 #pragma unroll
@@ -177,6 +184,9 @@ __global__ __launch_bounds__(256, 1) void trunk_kernel(const TrunkParams p) {
         }
         return;
     } else {
+        const wrsrc_t rsB = weight_rsrc(p.Wbwd, p.bwd_bytes);
+        woff = 0;
+        ring_fill(rsB, lane * 16, 0, ring);                   // in flight while the output layer and the objective run on the VALU
         const TrunkObjective ob = p.obj[chain];
         float g0 = ob.lin[0] + 2.f * ob.quad[0] * d0;
         float g1 = ob.lin[1] + 2.f * ob.quad[1] * d1;
@@ -204,7 +214,8 @@ __global__ __launch_bounds__(256, 1) void trunk_kernel(const TrunkParams p) {
 
         // ---- backward through the 256 -> 256 layers
         for (int l = p.n_mid - 1; l >= 0; --l) {
-            chain_layer<8, 8, CHAIN_ZERO>(p.Wb[l], nullptr, cur, nxt, lane);
+            chain_layer_cont<8, 8, CHAIN_ZERO>(rsB, woff, ring, nullptr, cur, nxt, lane);
+            woff += 256 * 1024;
             slot -= 4;
 #pragma unroll
             for (int i = 0; i < 4; ++i) m[i] = smask[slot + i][tid];
@@ -233,7 +244,8 @@ __global__ __launch_bounds__(256, 1) void trunk_kernel(const TrunkParams p) {
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int kb = blk + e;
-                    f32x16 g = chain_block<8, false>(p.W2b + (size_t)kb * 8 * 4 * 64, nullptr, cur, lane);
+                    f32x16 g = chain_block_cont<8>(rsB, woff, ring, cur, lane);
+                    woff += 32 * 1024;
                     apply_bits(g, (bits2 >> (16 * e)) & 0xffffu);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
