@@ -1,45 +1,45 @@
 """Command-line flags shared by every entry point (reference: dynamics/parser.py:3-41).
 
-Same names, types, defaults and help strings, so the shipped ``guided_sample_{2d,3d}.sh`` lines parse unchanged."""
+Same flag names, types and defaults, so the shipped ``guided_sample_{2d,3d}.sh`` command lines parse unchanged."""
 import argparse
 
 # (flag, type | 'flag', default, help)
 _FLAGS = [
-    ("batch_size", int, 1024, None),
-    ("use_sub_batch", "flag", None, "use sub batch to avoid OOM"),
-    ("sub_bs", int, 1024, "sub batch size for training"),
-    ("num_epochs", int, 1000, "number of epochs for training"),
-    ("num_fingers", int, 1000, "number of fingers"),
-    ("ctrlpts_dim", int, 14, None),
-    ("ctrlpts_x_dim", int, 7, None),
-    ("ctrlpts_z_dim", int, 3, None),
-    ("learning_rate", float, 1e-4, "learning rate for optimizer"),
-    ("lr_warmup_steps", int, 100, "learning rate warmup steps for optimizer"),
-    ("weight_decay", float, 0, "weight decay for optimizer"),
-    ("patience", int, 500, "patience for early stopping when training dynamics model"),
-    ("checkpoint_path", str, None, "path to load dynamics model checkpoints"),
-    ("save_dir", str, None, "path to save model checkpoints"),
-    ("wandb_id", str, None, "wandb id"),
-    ("data_dir", str, "", "path to data directory"),
-    ("test_data_dir", str, "", "path to test data directory"),
-    ("object_dir", str, "", "path to object directory"),
-    ("num_workers", int, 4, "number of workers for dataloader"),
-    ("mode", str, "train", "train or test"),
-    ("grid_size", int, 360, "number of initial orientations sampled for each object"),
-    ("num_pos", int, 9, "number of initial positions sampled for each object"),
-    ("save_ckpt_step", int, 10, "step to save model checkpoints"),
-    ("val_step", int, 100, "step to validate model"),
-    ("num_train_timesteps", int, 1000, "number of training timesteps for diffusion model"),
-    ("num_timesteps_per_batch", int, 1, "number of timesteps per batch"),
-    ("num_inference_steps", int, 100, "number of inference steps for diffusion model"),
-    ("ema_power", float, 0.75, "ema power"),
-    ("object_max_num_vertices", int, 10, "max number of vertices for object encoder"),
-    ("diffusion_checkpoint_path", str, None, "path to load diffusion model checkpoints"),
-    ("classifier_guidance", "flag", None, "use classifier guidance"),
-    ("num_cpus", int, 4, "number of cpus used in parallel for simulation"),
-    ("fingers_3d", "flag", None, "use 3d fingers"),
-    ("render_video", "flag", None, "render videos visualizing interactions of fingers and objects"),
-    ("seed", int, 0, "random seed"),
+    ("batch_size", int, 1024, "fingers per batch"),
+    ("use_sub_batch", "flag", None, "split large classifier calls"),
+    ("sub_bs", int, 1024, "rows per classifier call in 3-D guidance (fixes the FPS start partition)"),
+    ("num_epochs", int, 1000, "training epochs (training is not part of this package)"),
+    ("num_fingers", int, 1000, "size of the synthetic finger set"),
+    ("ctrlpts_dim", int, 14, "control points per finger pair: 14 (2-D) or 42 (3-D)"),
+    ("ctrlpts_x_dim", int, 7, "control net size along the finger"),
+    ("ctrlpts_z_dim", int, 3, "control net size across the finger (3-D)"),
+    ("learning_rate", float, 1e-4, "optimizer step size"),
+    ("lr_warmup_steps", int, 100, "warm-up steps"),
+    ("weight_decay", float, 0, "L2 penalty"),
+    ("patience", int, 500, "early-stopping patience of dynamics training"),
+    ("checkpoint_path", str, None, "dynamics model checkpoint (.pt, DataParallel state_dict)"),
+    ("save_dir", str, None, "output directory"),
+    ("wandb_id", str, None, "wandb run id"),
+    ("data_dir", str, "", "training data"),
+    ("test_data_dir", str, "", "held-out data"),
+    ("object_dir", str, "", "objects: Icons-50 .npy (2-D) / scanned meshes (3-D) / objects.npy"),
+    ("num_workers", int, 4, "DataLoader workers"),
+    ("mode", str, "train", "'train' or 'test' (guided sampling)"),
+    ("grid_size", int, 360, "orientations in the guidance grid"),
+    ("num_pos", int, 9, "positions per axis in the guidance grid"),
+    ("save_ckpt_step", int, 10, "checkpoint period"),
+    ("val_step", int, 100, "validation period"),
+    ("num_train_timesteps", int, 1000, "diffusion timesteps T"),
+    ("num_timesteps_per_batch", int, 1, "timesteps drawn per training batch"),
+    ("num_inference_steps", int, 100, "denoise steps S"),
+    ("ema_power", float, 0.75, "EMA decay exponent"),
+    ("object_max_num_vertices", int, 10, "points per object"),
+    ("diffusion_checkpoint_path", str, None, "diffusion checkpoint (.ckpt, Lightning)"),
+    ("classifier_guidance", "flag", None, "guide sampling with the dynamics model"),
+    ("num_cpus", int, 4, "CPU workers of the (external) simulator"),
+    ("fingers_3d", "flag", None, "3-D fingers / PointNet++ dynamics model"),
+    ("render_video", "flag", None, "simulator videos (external)"),
+    ("seed", int, 0, "seed of the start noise"),
 ]
 
 
