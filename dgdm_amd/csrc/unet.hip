@@ -56,13 +56,14 @@ __device__ void conv_mfma(const ConvArgs a, const float *in, int CPi, float *out
     for (int mp = wave; mp * MT < mtiles; mp += nwave) {
         int mt[MT];
         const float4 *w[MT];
-        float4 nxt[MT];
+        float4 nxt[MT], nxt2[MT];                      // weight fragments of the next two iterations (two L2 latencies of cover)
         f32x4 acc[MT][NT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             mt[m] = min(mp * MT + m, mtiles - 1);
             w[m] = a.img + (size_t)mt[m] * iters * 64 + lane;
             nxt[m] = w[m][0];
+            nxt2[m] = w[m][(size_t)min(1, iters - 1) * 64];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[m][nt] = (f32x4)(0.f);
         }
@@ -72,7 +73,8 @@ __device__ void conv_mfma(const ConvArgs a, const float *in, int CPi, float *out
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 av[m][0] = nxt[m].x; av[m][1] = nxt[m].y; av[m][2] = nxt[m].z; av[m][3] = nxt[m].w;
-                if (it + 1 < iters) nxt[m] = w[m][(size_t)(it + 1) * 64];
+                nxt[m] = nxt2[m];
+                nxt2[m] = w[m][(size_t)min(it + 2, iters - 1) * 64];
             }
             const int off = (a.ioff0 + t * a.iostep) * CPi + g * 16;
             float bv[4][NT];
