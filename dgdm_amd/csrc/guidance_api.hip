@@ -28,6 +28,7 @@ struct ObjectTables {       // 3-D, per object
     DevBuf flags;           // [N] int: that sequence is order-dependent (exact distance tie / coordinates exhausted)
     bool   fast_ok = false; // no flag set: rows can take their centres from fps2 instead of running FPS
     DevBuf crowded, clist;  // [N] int each + clist[N] = count: centres whose ball query truncates (pointnet.hip crowd_kernel)
+    DevBuf M0, cl2, cnt2;   // [N][256] float, [N][128] int, [N] int: variant-independent part of the sa3 max (pointnet.hip m0_kernel)
 };
 
 }  // namespace
@@ -150,7 +151,8 @@ int DgdmGuidance::build_object(int oi, int slot, const float *xyz_dev, hipStream
     int rc;
     if ((rc = t.xyz.alloc((size_t)N * 3 * 4)) || (rc = t.fps1.alloc((size_t)N * 512 * sizeof(int))) || (rc = t.Z.alloc((size_t)N * N * 256 * 4)) ||
         (rc = t.fps2.alloc((size_t)N * 128 * sizeof(int))) || (rc = t.flags.alloc((size_t)N * sizeof(int))) ||
-        (rc = t.crowded.alloc((size_t)N * sizeof(int))) || (rc = t.clist.alloc((size_t)(N + 1) * sizeof(int))))
+        (rc = t.crowded.alloc((size_t)N * sizeof(int))) || (rc = t.clist.alloc((size_t)(N + 1) * sizeof(int))) ||
+        (rc = t.M0.alloc((size_t)N * 256 * 4)) || (rc = t.cl2.alloc((size_t)N * 128 * sizeof(int))) || (rc = t.cnt2.alloc((size_t)N * sizeof(int))))
         return rc;
     DevBuf &tF1 = tmpF1[slot], &tU = tmpU[slot], &tY = tmpY[slot], &tL2 = tmpL2[slot];
     if ((rc = tF1.alloc((size_t)N * 128 * 4)) || (rc = tU.alloc((size_t)N * 128 * 4)) || (rc = tY.alloc((size_t)N * N * 256 * 4)) ||
@@ -165,7 +167,8 @@ int DgdmGuidance::build_object(int oi, int slot, const float *xyz_dev, hipStream
     if ((rc = pn_pairs(xyz, N, tU.as<float>(), w, tY.as<float>(), s))) return rc;                              // T4
     if ((rc = pn_crowd(xyz, N, w, t.crowded.as<int>(), t.clist.as<int>(), t.clist.as<int>() + N, s))) return rc;
     if ((rc = pn_l2(xyz, N, w, t.fps1.as<int>(), vlist.as<int>(), N, tY.as<float>(), tL2.as<float>(), t.clist.as<int>(), t.clist.as<int>() + N, s))) return rc;   // T5
-    return pn_z(xyz, N, N, w, tL2.as<float>(), t.Z.as<float>(), t.clist.as<int>(), t.clist.as<int>() + N, s);                                      // T6
+    if ((rc = pn_z(xyz, N, N, w, tL2.as<float>(), t.Z.as<float>(), t.clist.as<int>(), t.clist.as<int>() + N, s))) return rc;                        // T6
+    return pn_m0(t.fps2.as<int>(), t.crowded.as<int>(), N, t.Z.as<float>(), t.M0.as<float>(), t.cl2.as<int>(), t.cnt2.as<int>(), s);              // T7
 }
 
 extern "C" int dgdm_guidance_set_objects(DgdmGuidance *g, const float *objects_dev, int n_objects, void *stream) {
@@ -278,6 +281,7 @@ int DgdmGuidance::run_xobj(const int *objidx_host, int n_chains, int64_t rows, h
         const ObjectTables &t = *tables[objidx_host[i]];
         ch[i].xyz = t.xyz.as<float>(); ch[i].fps1 = t.fps1.as<int>(); ch[i].slot_of_start = nullptr; ch[i].Z = t.Z.as<float>();
         ch[i].fps2 = t.fps2.as<int>(); ch[i].flags = t.flags.as<int>(); ch[i].crowded = t.crowded.as<int>(); ch[i].N = cfg.num_object_points;
+        ch[i].M0 = t.M0.as<float>(); ch[i].cl2 = t.cl2.as<int>(); ch[i].cnt2 = t.cnt2.as<int>();
     }
     DGDM_HIP_CHECK(hipMemcpyAsync(xchains.p, ch.data(), sizeof(XobjChain) * n_chains, hipMemcpyHostToDevice, s));
     XobjParams xp{};

@@ -28,6 +28,9 @@ struct XobjChain {
     const int   *fps2;            // [N][128] FPS(128) sequences by start POINT, or null
     const int   *flags;           // [N] 1 = the sequence from this start point is order-dependent: run FPS for the row
     const int   *crowded;         // [N] 1 = more than 64 points in the centre's r=0.4 ball: Z depends on the variant
+    const float *M0;              // [N][256] max of Z[0][c] over the non-crowded centres of fps2[q], or null (see m0_kernel)
+    const int   *cl2;             // [N][128] crowded centres of fps2[q], padded with the last one
+    const int   *cnt2;            // [N] their number
     int          N;
 };
 
@@ -47,6 +50,7 @@ int pn_crowd(const float *xyz, int N, const PnWeights &w, int *crowded, int *cli
 int pn_l2(const float *xyz, int N, const PnWeights &w, const int *fps1, const int *vlist, int nv, const float *Y, float *L2,
           const int *clist, const int *ncr, hipStream_t s);
 int pn_z(const float *xyz, int N, int nv, const PnWeights &w, const float *L2, float *Z, const int *clist, const int *ncr, hipStream_t s);
+int pn_m0(const int *fps2, const int *crowded, int N, const float *Z0, float *M0, int *cl2, int *cnt2, hipStream_t s);
 int pn_xobj(const XobjParams &p, hipStream_t s);
 
 }  // namespace dgdm

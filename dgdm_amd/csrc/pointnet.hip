@@ -356,6 +356,45 @@ __global__ __launch_bounds__(256, 1) void z_kernel(const float *__restrict__ xyz
     }
 }
 
+// ------------------------------------------------------------------------------------------------ T7
+// Non-crowded centres contribute the same Z row (slot 0) to every reference row whose sa2 FPS starts at point q, so their
+// part of the sa3 max is a per-object table:  M0[q][256] = max over the non-crowded centres c of fps2[q] of Z[0][c].
+// cl2[q][0..cnt2[q]) lists the crowded centres of fps2[q] (point ids), padded to 128 with its last entry so the per-row
+// loop can run in groups of four without a tail.  One wave per start point q.  max is exact, so the split is bit-neutral.
+__global__ __launch_bounds__(256) void m0_kernel(const int *__restrict__ fps2 /*[N][128]*/, const int *__restrict__ crowded, int N,
+                                                 const float *__restrict__ Z0 /*[N][256]*/, float *__restrict__ M0, int *__restrict__ cl2,
+                                                 int *__restrict__ cnt2) {
+    const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= N) return;
+    const int idA = fps2[(size_t)q * 128 + lane], idB = fps2[(size_t)q * 128 + 64 + lane];
+    const bool crA = crowded[idA] != 0, crB = crowded[idB] != 0;
+    const unsigned long long mA = __ballot(crA), mB = __ballot(crB);
+    const int nA = __popcll(mA), cnt = nA + __popcll(mB);
+    int *dst = cl2 + (size_t)q * 128;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (crA) dst[__popcll(mA & below)] = idA;
+    if (crB) dst[nA + __popcll(mB & below)] = idB;
+    // pad with the last crowded id (which lane holds it: the highest set bit of mB, else of mA)
+    int last = 0;
+    if (cnt > 0) last = mB ? __shfl(idB, 63 - __clzll(mB)) : __shfl(idA, 63 - __clzll(mA));
+    for (int j = cnt + lane; j < 128; j += 64) dst[j] = last;
+    if (lane == 0) cnt2[q] = cnt;
+    const float *zt = Z0 + lane * 4;
+    float4 best = make_float4(0.f, 0.f, 0.f, 0.f);      // Z >= 0 (ReLU)
+    for (int i = 0; i < 64; ++i) {
+        const int a = __shfl(idA, i), b = __shfl(idB, i);
+        if (!((mA >> i) & 1ull)) {
+            const float4 v = *reinterpret_cast<const float4 *>(zt + (size_t)a * 256);
+            best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y); best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w);
+        }
+        if (!((mB >> i) & 1ull)) {
+            const float4 v = *reinterpret_cast<const float4 *>(zt + (size_t)b * 256);
+            best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y); best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w);
+        }
+    }
+    *reinterpret_cast<float4 *>(M0 + (size_t)q * 256 + lane * 4) = best;
+}
+
 // ------------------------------------------------------------------------------------------------ per row
 // xobj[row][256] = max over the 128 centres FPS picks (start s2) on the cloud re-ordered by variant s1 of
 // Z[slot(s1)][point].  One wave per row.   (sa2's FPS + sa3's max, pointnet2_utils.py:132,208)
@@ -385,6 +424,27 @@ __global__ __launch_bounds__(256) void xobj_kernel(const XobjParams p) {
     const int q = __builtin_amdgcn_readfirstlane(perm[s2]);      // start point of sa2's FPS
     if (p.use_table && ch.fps2 && ch.flags[q] == 0) {
         // the FPS(128) sequence from start point q is the same for every ordering of the cloud (fps_wave TIES clear)
+        if (ch.M0) {
+            // non-crowded centres are already folded into M0[q]; only the crowded ones differ per variant
+            const int cnt = __builtin_amdgcn_readfirstlane(ch.cnt2[q]);
+            const int rowA = slot * ch.N + ch.cl2[(size_t)q * 128 + lane], rowB = slot * ch.N + ch.cl2[(size_t)q * 128 + 64 + lane];
+            const float *zt = ch.Z + lane * 4;
+            float4 best = *reinterpret_cast<const float4 *>(ch.M0 + (size_t)q * 256 + lane * 4);
+            for (int i = 0; i < cnt; i += 4) {           // groups of four never straddle lane 63|64; the list is padded
+                const int src = i < 64 ? rowA : rowB, j = i & 63;
+                const int c0 = __shfl(src, j), c1 = __shfl(src, j + 1), c2 = __shfl(src, j + 2), c3 = __shfl(src, j + 3);
+                const float4 a = *reinterpret_cast<const float4 *>(zt + (size_t)c0 * 256);
+                const float4 b = *reinterpret_cast<const float4 *>(zt + (size_t)c1 * 256);
+                const float4 d = *reinterpret_cast<const float4 *>(zt + (size_t)c2 * 256);
+                const float4 e = *reinterpret_cast<const float4 *>(zt + (size_t)c3 * 256);
+                best.x = fmaxf(fmaxf(best.x, fmaxf(a.x, b.x)), fmaxf(d.x, e.x));
+                best.y = fmaxf(fmaxf(best.y, fmaxf(a.y, b.y)), fmaxf(d.y, e.y));
+                best.z = fmaxf(fmaxf(best.z, fmaxf(a.z, b.z)), fmaxf(d.z, e.z));
+                best.w = fmaxf(fmaxf(best.w, fmaxf(a.w, b.w)), fmaxf(d.w, e.w));
+            }
+            *reinterpret_cast<float4 *>(p.xobj + (size_t)w * 256 + lane * 4) = best;
+            return;
+        }
         idA = ch.fps2[(size_t)q * 128 + lane];
         idB = ch.fps2[(size_t)q * 128 + 64 + lane];
     } else {
@@ -461,6 +521,12 @@ int pn_z(const float *xyz, int N, int nv, const PnWeights &w, const float *L2, f
         const int64_t t1 = ((int64_t)(nv - 1) * N + 31) / 32;
         hipLaunchKernelGGL(z_kernel, dim3((unsigned)((t1 + 3) / 4)), dim3(256), 0, s, xyz, N, nv, L2, w.sa3_w_img, w.sa3_wx, w.sa3_b, Z, 1, clist, ncr);
     }
+    DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
+}
+
+int pn_m0(const int *fps2, const int *crowded, int N, const float *Z0, float *M0, int *cl2, int *cnt2, hipStream_t s) {
+    hipLaunchKernelGGL(m0_kernel, dim3((N + 3) / 4), dim3(256), 0, s, fps2, crowded, N, Z0, M0, cl2, cnt2);
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
 }
