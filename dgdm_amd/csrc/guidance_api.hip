@@ -21,11 +21,12 @@ std::vector<float> linspace_f32(float start, float end, int steps) {
 }
 
 struct ObjectTables {       // 3-D, per object
-    DevBuf xyz;             // [N][3]
-    DevBuf fps1;            // [N][512] int
+    // slices of the guidance handle's pools (the FPS tables of all objects are built by one launch each)
+    const float *xyz = nullptr;   // [N][3]
+    const int   *fps1 = nullptr;  // [N][512]
+    const int   *fps2 = nullptr;  // [N][128] FPS(128) sequence by start point
+    const int   *flags = nullptr; // [N] that sequence is order-dependent (exact distance tie / coordinates exhausted)
     DevBuf Z;               // [N][N][256]
-    DevBuf fps2;            // [N][128] int: FPS(128) sequence by start point
-    DevBuf flags;           // [N] int: that sequence is order-dependent (exact distance tie / coordinates exhausted)
     bool   fast_ok = false; // no flag set: rows can take their centres from fps2 instead of running FPS
     DevBuf crowded, clist;  // [N] int each + clist[N] = count: centres whose ball query truncates (pointnet.hip crowd_kernel)
     DevBuf M0, cl2, cnt2;   // [N][256] float, [N][128] int, [N] int: variant-independent part of the sa3 max (pointnet.hip m0_kernel)
@@ -42,6 +43,7 @@ struct DgdmGuidance {
     DevBuf objpart;                              // 2-D: [max_objects][W1]
     std::vector<std::unique_ptr<ObjectTables>> tables;   // 3-D
     static constexpr int NBUILD = 3;             // objects whose tables are built concurrently (own stream + temporaries each)
+    DevBuf pool_xyz, pool_fps1, pool_fps2, pool_flags;   // [n_objects] x per-object FPS tables (ObjectTables point into these)
     DevBuf tmpF1[NBUILD], tmpU[NBUILD], tmpY[NBUILD], tmpL2[NBUILD], vlist;      // 3-D table-build temporaries
     hipStream_t bstream[NBUILD] = {nullptr, nullptr, nullptr};
     hipEvent_t bev[NBUILD] = {nullptr, nullptr, nullptr}, bstart = nullptr;
@@ -61,7 +63,7 @@ struct DgdmGuidance {
     int build_pose_table(const std::vector<float> &ori, const std::vector<float> &pos, DevBuf *dst, hipStream_t s);
     int common_pre(const float *x_dev, float t_scaled, const int *objidx_host, int n_chains, hipStream_t s);
     int upload_starts(const int64_t *starts_host, int n_chains, int64_t rows, hipStream_t s);
-    int build_object(int oi, int slot, const float *xyz_dev, hipStream_t s);
+    int build_object(int oi, int slot, hipStream_t s);
     int run_xobj(const int *objidx_host, int n_chains, int64_t rows, hipStream_t s);
 };
 
@@ -144,13 +146,12 @@ extern "C" int64_t dgdm_guidance_rows(const DgdmGuidance *g) { return g ? g->R :
 extern "C" int64_t dgdm_guidance_starts_per_call(const DgdmGuidance *g) { return (g && g->m->kind == 3) ? 2 * g->R : 0; }
 
 // ------------------------------------------------------------------------------------------------ objects
-int DgdmGuidance::build_object(int oi, int slot, const float *xyz_dev, hipStream_t s) {
+int DgdmGuidance::build_object(int oi, int slot, hipStream_t s) {
     const int N = cfg.num_object_points;
     ObjectTables &t = *tables[oi];
     const PnWeights w = m->pn();
     int rc;
-    if ((rc = t.xyz.alloc((size_t)N * 3 * 4)) || (rc = t.fps1.alloc((size_t)N * 512 * sizeof(int))) || (rc = t.Z.alloc((size_t)N * N * 256 * 4)) ||
-        (rc = t.fps2.alloc((size_t)N * 128 * sizeof(int))) || (rc = t.flags.alloc((size_t)N * sizeof(int))) ||
+    if ((rc = t.Z.alloc((size_t)N * N * 256 * 4)) ||
         (rc = t.crowded.alloc((size_t)N * sizeof(int))) || (rc = t.clist.alloc((size_t)(N + 1) * sizeof(int))) ||
         (rc = t.M0.alloc((size_t)N * 256 * 4)) || (rc = t.cl2.alloc((size_t)N * 128 * sizeof(int))) || (rc = t.cnt2.alloc((size_t)N * sizeof(int))))
         return rc;
@@ -158,17 +159,14 @@ int DgdmGuidance::build_object(int oi, int slot, const float *xyz_dev, hipStream
     if ((rc = tF1.alloc((size_t)N * 128 * 4)) || (rc = tU.alloc((size_t)N * 128 * 4)) || (rc = tY.alloc((size_t)N * N * 256 * 4)) ||
         (rc = tL2.alloc((size_t)N * N * 256 * 4)))
         return rc;
-    DGDM_HIP_CHECK(hipMemcpyAsync(t.xyz.p, xyz_dev, (size_t)N * 3 * 4, hipMemcpyDeviceToDevice, s));
-    const float *xyz = t.xyz.as<float>();
-    if ((rc = pn_fps_table(xyz, N, N, 512, t.fps1.as<int>(), nullptr, s))) return rc;                          // T1
-    if ((rc = pn_fps_table(xyz, N, N, 128, t.fps2.as<int>(), t.flags.as<int>(), s))) return rc;
+    const float *xyz = t.xyz;                                                                                  // T1: set_objects, batched
     if ((rc = pn_sa1(xyz, N, w, tF1.as<float>(), s))) return rc;                                               // T2
     if ((rc = linear(tF1.as<float>(), 128, w.sa2_wf_t, w.sa2_b0, nullptr, 1, tU.as<float>(), 128, N, 128, 128, ACT_NONE, false, s))) return rc;  // T3
     if ((rc = pn_pairs(xyz, N, tU.as<float>(), w, tY.as<float>(), s))) return rc;                              // T4
     if ((rc = pn_crowd(xyz, N, w, t.crowded.as<int>(), t.clist.as<int>(), t.clist.as<int>() + N, s))) return rc;
-    if ((rc = pn_l2(xyz, N, w, t.fps1.as<int>(), vlist.as<int>(), N, tY.as<float>(), tL2.as<float>(), t.clist.as<int>(), t.clist.as<int>() + N, s))) return rc;   // T5
+    if ((rc = pn_l2(xyz, N, w, t.fps1, vlist.as<int>(), N, tY.as<float>(), tL2.as<float>(), t.clist.as<int>(), t.clist.as<int>() + N, s))) return rc;   // T5
     if ((rc = pn_z(xyz, N, N, w, tL2.as<float>(), t.Z.as<float>(), t.clist.as<int>(), t.clist.as<int>() + N, s))) return rc;                        // T6
-    return pn_m0(t.fps2.as<int>(), t.crowded.as<int>(), N, t.Z.as<float>(), t.M0.as<float>(), t.cl2.as<int>(), t.cnt2.as<int>(), s);              // T7
+    return pn_m0(t.fps2, t.crowded.as<int>(), N, t.Z.as<float>(), t.M0.as<float>(), t.cl2.as<int>(), t.cnt2.as<int>(), s);              // T7
 }
 
 extern "C" int dgdm_guidance_set_objects(DgdmGuidance *g, const float *objects_dev, int n_objects, void *stream) {
@@ -197,18 +195,30 @@ extern "C" int dgdm_guidance_set_objects(DgdmGuidance *g, const float *objects_d
             if (!g->bstream[i]) DGDM_HIP_CHECK(hipStreamCreateWithFlags(&g->bstream[i], hipStreamNonBlocking));
             if (!g->bev[i]) DGDM_HIP_CHECK(hipEventCreateWithFlags(&g->bev[i], hipEventDisableTiming));
         }
+        // T1 for every object at once, on the caller's stream: fps1[obj][start][512], fps2[obj][start point][128] + tie flags
+        const size_t no = (size_t)n_objects;
+        if ((rc = g->pool_xyz.alloc(no * N * 3 * 4)) || (rc = g->pool_fps1.alloc(no * N * 512 * sizeof(int))) ||
+            (rc = g->pool_fps2.alloc(no * N * 128 * sizeof(int))) || (rc = g->pool_flags.alloc(no * N * sizeof(int))))
+            return rc;
+        DGDM_HIP_CHECK(hipMemcpyAsync(g->pool_xyz.p, objects_dev, no * N * 3 * 4, hipMemcpyDeviceToDevice, s));
+        if ((rc = pn_fps_table(g->pool_xyz.as<float>(), N, N, 512, g->pool_fps1.as<int>(), nullptr, s, n_objects))) return rc;
+        if ((rc = pn_fps_table(g->pool_xyz.as<float>(), N, N, 128, g->pool_fps2.as<int>(), g->pool_flags.as<int>(), s, n_objects))) return rc;
+        for (int i = 0; i < n_objects; ++i) {
+            ObjectTables &t = *g->tables[i];
+            t.xyz = g->pool_xyz.as<float>() + (size_t)i * N * 3; t.fps1 = g->pool_fps1.as<int>() + (size_t)i * N * 512;
+            t.fps2 = g->pool_fps2.as<int>() + (size_t)i * N * 128; t.flags = g->pool_flags.as<int>() + (size_t)i * N;
+        }
         DGDM_HIP_CHECK(hipEventRecord(g->bstart, s));
         for (int i = 0; i < nb; ++i) DGDM_HIP_CHECK(hipStreamWaitEvent(g->bstream[i], g->bstart, 0));
         for (int i = 0; i < n_objects; ++i)
-            if ((rc = g->build_object(i, i % nb, objects_dev + (size_t)i * N * 3, g->bstream[i % nb]))) return rc;
+            if ((rc = g->build_object(i, i % nb, g->bstream[i % nb]))) return rc;
         for (int i = 0; i < nb; ++i) {
             DGDM_HIP_CHECK(hipEventRecord(g->bev[i], g->bstream[i]));
             DGDM_HIP_CHECK(hipStreamWaitEvent(s, g->bev[i], 0));
         }
         // which objects may use the table of FPS(128) sequences (no order-dependent selection anywhere)
         std::vector<int> fl((size_t)n_objects * N);
-        for (int i = 0; i < n_objects; ++i)
-            DGDM_HIP_CHECK(hipMemcpyAsync(fl.data() + (size_t)i * N, g->tables[i]->flags.p, sizeof(int) * N, hipMemcpyDeviceToHost, s));
+        DGDM_HIP_CHECK(hipMemcpyAsync(fl.data(), g->pool_flags.p, sizeof(int) * no * N, hipMemcpyDeviceToHost, s));
         DGDM_HIP_CHECK(hipStreamSynchronize(s));
         for (int i = 0; i < n_objects; ++i) {
             bool ok = N >= 128;
@@ -279,8 +289,8 @@ int DgdmGuidance::run_xobj(const int *objidx_host, int n_chains, int64_t rows, h
     for (int i = 0; i < n_chains; ++i) {
         DGDM_REQUIRE(objidx_host[i] >= 0 && objidx_host[i] < n_objects, DGDM_EINVAL, "chain %d refers to object %d of %d", i, objidx_host[i], n_objects);
         const ObjectTables &t = *tables[objidx_host[i]];
-        ch[i].xyz = t.xyz.as<float>(); ch[i].fps1 = t.fps1.as<int>(); ch[i].slot_of_start = nullptr; ch[i].Z = t.Z.as<float>();
-        ch[i].fps2 = t.fps2.as<int>(); ch[i].flags = t.flags.as<int>(); ch[i].crowded = t.crowded.as<int>(); ch[i].N = cfg.num_object_points;
+        ch[i].xyz = t.xyz; ch[i].fps1 = t.fps1; ch[i].slot_of_start = nullptr; ch[i].Z = t.Z.as<float>();
+        ch[i].fps2 = t.fps2; ch[i].flags = t.flags; ch[i].crowded = t.crowded.as<int>(); ch[i].N = cfg.num_object_points;
         ch[i].M0 = t.M0.as<float>(); ch[i].cl2 = t.cl2.as<int>(); ch[i].cnt2 = t.cnt2.as<int>();
     }
     DGDM_HIP_CHECK(hipMemcpyAsync(xchains.p, ch.data(), sizeof(XobjChain) * n_chains, hipMemcpyHostToDevice, s));

@@ -43,7 +43,7 @@ struct XobjParams {
     int              use_table;   // 0: always run the per-row FPS (test hook)
 };
 
-int pn_fps_table(const float *xyz, int N, int nv, int npoint, int *out, int *flags, hipStream_t s);
+int pn_fps_table(const float *xyz, int N, int nv, int npoint, int *out, int *flags, hipStream_t s, int nobj = 1);
 int pn_sa1(const float *xyz, int N, const PnWeights &w, float *F1, hipStream_t s);
 int pn_pairs(const float *xyz, int N, const float *U, const PnWeights &w, float *Y, hipStream_t s);
 int pn_crowd(const float *xyz, int N, const PnWeights &w, int *crowded, int *clist, int *ncr, hipStream_t s);

@@ -95,11 +95,16 @@ __device__ bool fps_wave(const float *lx, const float *ly, const float *lz, int 
 }
 
 // ------------------------------------------------------------------------------------------------ T1
-// fps[v][0..npoint) for v = 0..nv-1 (start index v) on cloud xyz [N][3]; flags[v] (optional) = selection was order-dependent
+// fps[obj][v][0..npoint) for v = 0..nv-1 (start index v) on cloud xyz[obj] [N][3]; flags[obj][v] (optional) = selection was order-dependent.
+// All objects of a set_objects call go in one launch: the 512 dependent iterations are latency bound, so the more waves the better.
 __global__ __launch_bounds__(256) void fps_table_kernel(const float *__restrict__ xyz, int N, int nv, int npoint, int *__restrict__ out,
                                                         int *__restrict__ flags) {
     extern __shared__ float lds[];
     float *lx = lds, *ly = lds + N, *lz = lds + 2 * N;
+    // blockIdx.y = object: clouds, tables and flags of the objects lie back to back
+    xyz += (size_t)blockIdx.y * N * 3;
+    out += (size_t)blockIdx.y * nv * npoint;
+    if (flags) flags += (size_t)blockIdx.y * nv;
     for (int i = threadIdx.x; i < N; i += blockDim.x) { lx[i] = xyz[3 * i]; ly[i] = xyz[3 * i + 1]; lz[i] = xyz[3 * i + 2]; }
     __syncthreads();
     const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -481,8 +486,8 @@ __global__ __launch_bounds__(256) void xobj_kernel(const XobjParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-int pn_fps_table(const float *xyz, int N, int nv, int npoint, int *out, int *flags, hipStream_t s) {
-    hipLaunchKernelGGL(fps_table_kernel, dim3((nv + 3) / 4), dim3(256), (size_t)3 * N * sizeof(float), s, xyz, N, nv, npoint, out, flags);
+int pn_fps_table(const float *xyz, int N, int nv, int npoint, int *out, int *flags, hipStream_t s, int nobj) {
+    hipLaunchKernelGGL(fps_table_kernel, dim3((nv + 3) / 4, nobj), dim3(256), (size_t)3 * N * sizeof(float), s, xyz, N, nv, npoint, out, flags);
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
 }
