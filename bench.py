@@ -33,6 +33,7 @@ from dgdm_amd.scheduler import DDIMScheduler               # noqa: E402
 from dgdm_amd.dist import gather_pairs                     # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # same guide: v_mfma_f32_32x32x16_bf16, dense (not the 2:1-sparsity figure)
 
 
 def parse():
@@ -42,14 +43,16 @@ def parse():
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--workload", choices=["3d", "2d"], default="3d")
     p.add_argument("--pairs", type=int, default=0, help="(object x objective) pairs per GPU per step (default 32 for 3d, 4 for 2d)")
+    p.add_argument("--contraction", choices=["f32", "bf16"], default="f32",
+                   help="arithmetic of the dynamics-trunk contractions: f32 (the parity path, default) or bf16 operands with f32 accumulation")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true", help="skip the secondary workload summary")
     return p.parse_args()
 
 
 class Workload:
-    def __init__(self, kind, pairs, dev, rank):
-        self.kind, self.dev = kind, dev
+    def __init__(self, kind, pairs, dev, rank, contraction="f32"):
+        self.kind, self.dev, self.contraction = kind, dev, contraction
         if kind == "3d":
             self.mode, self.B, self.G, self.P, self.L, self.N, self.sub = 'point_3d', 32, 45, 5, 42, 512, 512
         else:
@@ -63,7 +66,7 @@ class Workload:
             self.dyn_sd = synth.synth_state_dict(synth.dyn2d_spec(self.L, 2 * self.N), 22)
             self.dyn = engine.Dynamics(2, self.dyn_sd, self.L, 2 * self.N)
         self.net = engine.Unet1d(self.unet_sd)
-        self.guid = engine.Guidance(self.dyn, self.B, self.G, self.P, (-1.0, 1.0), pairs, self.T, self.N, self.sub, max_objects=pairs)
+        self.guid = engine.Guidance(self.dyn, self.B, self.G, self.P, (-1.0, 1.0), pairs, self.T, self.N, self.sub, max_objects=pairs, contraction_dtype=contraction)
         self.sched = DDIMScheduler(num_train_timesteps=self.T)
         self.sched.set_timesteps(self.S)
         self.noise = synth.synth_noise(0, self.B, self.L).to(dev)
@@ -170,7 +173,7 @@ def cpu_baseline(wl):
             "ms_per_denoise_step": chain / wl.S * 1e3}
 
 
-def pmc_traffic(workload):
+def pmc_traffic(workload, kernel="trunk_kernel"):
     """HBM bytes per trunk launch from the committed rocprofv3 PMC passes of this same command (profiles/r01_*_pmc_hbm.json:
     separate --pmc FETCH_SIZE / WRITE_SIZE runs, counter unit KB).  FETCH_SIZE is the raw counter: on gfx950 it can under-count
     wide coalesced reads by 2x (MI355X_MICROARCH.md §HBM), so the true read traffic lies between 1x and 2x of `fetch_bytes_raw`."""
@@ -178,7 +181,7 @@ def pmc_traffic(workload):
     if not os.path.exists(f):
         return None
     d = json.load(open(f))
-    key = next((k for k in d["fetch"] if "trunk_kernel" in k), None)
+    key = next((k for k in d["fetch"] if kernel + "<" in k), None)
     if key is None:
         return None
     fe, wr = d["fetch"][key]["avg_KB"] * 1024.0, d["write"][key]["avg_KB"] * 1024.0
@@ -202,7 +205,7 @@ def main():
     dev = torch.device("cuda", local)
     torch.manual_seed(1234 + rank)
     pairs = a.pairs or (32 if a.workload == "3d" else 4)
-    wl = Workload(a.workload, pairs, dev, rank)
+    wl = Workload(a.workload, pairs, dev, rank, a.contraction)
 
     engine.prof_enable(False)
     secs, _ = timed_loop(wl, a.steps, a.warmup, dist)
@@ -222,8 +225,10 @@ def main():
         engine.prof_enable(False)
         if n:
             ach = flops / (ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "trunk_kernel (fused dynamics trunk fwd+bwd)", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(a.workload), "launches": n, "avg_launch_ms": ms / n,
+            peak = BF16_MFMA_PEAK_TFLOPS if a.contraction == "bf16" else F32_MFMA_PEAK_TFLOPS
+            kname = "trunk_bf16_kernel" if a.contraction == "bf16" else "trunk_kernel"
+            roof = {"bound": "mfma", "kernel": kname + " (fused dynamics trunk fwd+bwd)", "achieved": ach, "peak": peak,
+                    "unit": "TFLOP/s", "frac": ach / peak, "traffic": pmc_traffic(a.workload, kname), "launches": n, "avg_launch_ms": ms / n,
                     "algorithmic_flops_per_launch": flops / n, "share_of_step": (ms * 1e-3) / (secs / a.steps)}
     if rank != 0:
         if dist is not None:
@@ -233,7 +238,7 @@ def main():
     line = {
         "metric": "guided samples/sec (full DDIM chain)", "value": samples / secs, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": secs / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic (random-init checkpoints, synthetic objects, seeded noise; SURVEY.md §8(d))",
+        "dtype": a.contraction, "data": "synthetic (random-init checkpoints, synthetic objects, seeded noise; SURVEY.md §8(d))",
         "config": {"workload": ("3-D dynamics-guided sampling (BASELINE configs[2]; configs[3] at 8 GPUs): per GPU and step %d (object x objective) "
                                 "pairs x B=32 fingers, G=45, P=5 -> R=36000 rows per cond_fn, sub_bs=512, 512-point objects, T=15/S=5"
                                 if a.workload == "3d" else

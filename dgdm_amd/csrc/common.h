@@ -78,6 +78,8 @@ int fold_linear(const StateDict &sd, const std::string &lin, const std::string &
 // ---- MFMA-chain weight image (see mfma_chain.h).  src is [M][K] row-major, M,K multiples of 32.
 //   img[((op*KB + o)*4 + q)*64 + lane][0..3] = src[32 op + (lane&31)][32 o + 8 q + 4 (lane>>5) + 0..3]
 std::vector<float> pack_chain(const float *src, int M, int K);
+uint16_t f32_to_bf16(float x);                                              // round to nearest even
+std::vector<uint16_t> pack_chain_bf16(const float *src, int M, int K);     // A-operand image for trunk_bf16.hip
 std::vector<float> transpose(const float *src, int rows, int cols);   // -> [cols][rows]
 
 // profiling of the dominant kernel

@@ -42,6 +42,7 @@ struct DgdmGuidance {
     DevBuf ptab, ptab_sweep;                     // [C][W1], [G][W1]
     DevBuf objpart;                              // 2-D: [max_objects][W1]
     std::vector<std::unique_ptr<ObjectTables>> tables;   // 3-D
+    bool bf16 = false;                           // contractions of the trunk on bf16 MFMA (dgdm_guidance_set_contraction_dtype)
     static constexpr int NBUILD = 3;             // objects whose tables are built concurrently (own stream + temporaries each)
     DevBuf pool_xyz, pool_fps1, pool_fps2, pool_flags;   // [n_objects] x per-object FPS tables (ObjectTables point into these)
     DevBuf tmpF1[NBUILD], tmpU[NBUILD], tmpY[NBUILD], tmpL2[NBUILD], vlist;      // 3-D table-build temporaries
@@ -134,6 +135,13 @@ extern "C" int dgdm_guidance_create(DgdmGuidance **out, DgdmDynamics *model, con
 }
 
 extern "C" void dgdm_guidance_destroy(DgdmGuidance *g) { delete g; }
+
+extern "C" int dgdm_guidance_set_contraction_dtype(DgdmGuidance *g, int dtype) {
+    DGDM_REQUIRE(g, DGDM_EINVAL, "dgdm_guidance_set_contraction_dtype: null handle");
+    DGDM_REQUIRE(dtype == DGDM_DTYPE_F32 || dtype == DGDM_DTYPE_BF16, DGDM_EINVAL, "contraction dtype %d unsupported (0 = f32, 1 = bf16)", dtype);
+    g->bf16 = dtype == DGDM_DTYPE_BF16;
+    return DGDM_OK;
+}
 
 extern "C" int dgdm_guidance_debug_fps_path(DgdmGuidance *g, int force_per_row, int32_t *out_fast_ok) {
     DGDM_REQUIRE(g, DGDM_EINVAL, "dgdm_guidance_debug_fps_path: null handle");
@@ -329,7 +337,10 @@ static int guidance_grad(DgdmGuidance *g, int kind, const float *x_dev, int time
     p.Atab = g->atab.as<float>(); p.Ptab = g->ptab.as<float>(); p.obj = g->objdev.as<TrunkObjective>(); p.rowcoef = rowcoef_dev;
     p.partial = g->partial.as<float>();
     p.B = g->B; p.C = g->C; p.tiles_per_b = g->tiles_per_b; p.ntiles = n_chains * g->B * g->tiles_per_b; p.R = g->R;
-    if ((rc = trunk_launch(kind, false, false, p, s))) return rc;
+    if (g->bf16) {
+        g->m->fill_trunk_bf16(&p);       // only the two weight streams differ
+        if ((rc = trunk_bf16_launch(kind, p, s))) return rc;
+    } else if ((rc = trunk_launch(kind, false, false, p, s))) return rc;
     return dyn_post(g->m->W1, g->partial.as<float>(), g->tiles_per_b, g->m->blob.at(g->m->off.w1c_w), g->m->blob.at(g->m->off.g2_w),
                     g->m->blob.at(g->m->off.g0_w), g->V.as<float>(), grad_dev, n_chains * g->B, g->m->L, s);
 }

@@ -68,6 +68,33 @@ std::vector<float> pack_chain(const float *src, int M, int K) {
     return img;
 }
 
+uint16_t f32_to_bf16(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);      // NaN stays NaN
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+// Image of W [M x K] (row-major, M and K multiples of 32) for v_mfma_f32_32x32x16_bf16 with the weights as the A operand:
+// entry ((op * KB + ib) * 2 + s), lane (i = l & 31, h = l >> 5), slot j  =  bf16(W[32 op + i][32 ib + rho(8 s + j, h)]),
+// rho(r, h) = (r & 3) + 8 (r >> 2) + 4 h.  One entry = 64 lanes x 8 bf16 = 1 KiB.
+std::vector<uint16_t> pack_chain_bf16(const float *src, int M, int K) {
+    const int MB = M / 32, KB = K / 32;
+    std::vector<uint16_t> img((size_t)M * K);
+    for (int op = 0; op < MB; ++op)
+        for (int ib = 0; ib < KB; ++ib)
+            for (int s = 0; s < 2; ++s)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int i = lane & 31, h = lane >> 5;
+                    uint16_t *d = img.data() + ((((size_t)op * KB + ib) * 2 + s) * 64 + lane) * 8;
+                    for (int j = 0; j < 8; ++j) {
+                        const int r = 8 * s + j, f = (r & 3) + 8 * (r >> 2) + 4 * h;
+                        d[j] = f32_to_bf16(src[(size_t)(32 * op + i) * K + 32 * ib + f]);
+                    }
+                }
+    return img;
+}
+
 std::vector<float> transpose(const float *src, int rows, int cols) {
     std::vector<float> t((size_t)rows * cols);
     for (int r = 0; r < rows; ++r)

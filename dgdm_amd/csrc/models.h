@@ -32,8 +32,11 @@ struct DgdmDynamics {
     dgdm::DynOff off{};
     dgdm::DevBuf ws;        // grow-only workspace of the plain forward entry points
     dgdm::DevBuf ws2;
+    dgdm::DevBuf w16;       // bf16 weight streams of the trunk (trunk_bf16.hip): forward then backward
+    size_t fwd16_bytes = 0, bwd16_bytes = 0;
 
     void fill_trunk(dgdm::TrunkParams *p) const;
+    void fill_trunk_bf16(dgdm::TrunkParams *p) const;
     dgdm::PnWeights pn() const;
     int gripper_forward(const float *x, int ldx, float *V, float *genc, int rows, hipStream_t s) const;
     int time_part(const float *t_dev, float t_scalar, float *tmp, float *out, int rows, hipStream_t s) const;

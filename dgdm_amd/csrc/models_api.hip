@@ -191,6 +191,8 @@ extern "C" int dgdm_dynamics_create(DgdmDynamics **out, int kind, const DgdmTens
     if ((rc = fold_linear(sd, "output", "", 3, W, &lout))) return rc;
     DynOff &o = m->off;
     std::vector<float> fwd, bwd_tail;                             // continuous trunk weight streams (csrc/trunk.h)
+    std::vector<uint16_t> fwd16, bwd16_tail;                      // the same in bf16 (csrc/trunk_bf16.hip)
+    const size_t E16 = 64 * 8;                                    // bf16 values per entry
     o.g0_wt = bl.add(transpose(g0.w.data(), W, params_ch)); o.g0_b = bl.add(g0.b); o.g0_w = bl.add(g0.w);
     o.g2_wt = bl.add(transpose(g2.w.data(), W, W)); o.g2_b = bl.add(g2.b); o.g2_w = bl.add(g2.w);
     // first trunk layer: concat order [x_object | x_ctrl | x_pose | time_emb]  (profile_forward_2d.py:154, _3d.py:84)
@@ -229,6 +231,18 @@ extern "C" int dgdm_dynamics_create(DgdmDynamics **out, int kind, const DgdmTens
                 fwd.insert(fwd.end(), i2.begin() + (size_t)((op * 16 + blk) * 4) * E, i2.begin() + (size_t)((op * 16 + blk) * 4 + 4) * E);
         }
         bwd_tail = pack_chain(transpose(l2.w.data(), W, W1).data(), W1, W);     // 16 blocks x 32 entries, consumed in order
+        {   // bf16 head: z(0), z(1), l2(0), z(2), l2(1), ..., z(15), l2(14), l2(15), 16 entries each (trunk_bf16.hip front3d)
+            const std::vector<uint16_t> j1 = pack_chain_bf16(w1o.data(), W1, W), j2 = pack_chain_bf16(l2.w.data(), W, W1);
+            auto put_z = [&](int kb) { fwd16.insert(fwd16.end(), j1.begin() + (size_t)kb * 16 * E16, j1.begin() + (size_t)(kb + 1) * 16 * E16); };
+            auto put_l2 = [&](int kb) {
+                for (int op = 0; op < 8; ++op)
+                    fwd16.insert(fwd16.end(), j2.begin() + (size_t)((op * 16 + kb) * 2) * E16, j2.begin() + (size_t)((op * 16 + kb) * 2 + 2) * E16);
+            };
+            put_z(0);
+            for (int kb = 1; kb < 16; ++kb) { put_z(kb); put_l2(kb - 1); }
+            put_l2(15);
+            bwd16_tail = pack_chain_bf16(transpose(l2.w.data(), W, W1).data(), W1, W);   // 16 blocks x 16 entries
+        }
         o.tfreq = bl.add(tfreqs(W / 2));
         m->thalf = W / 2;
         first_mid = 2;
@@ -249,6 +263,7 @@ extern "C" int dgdm_dynamics_create(DgdmDynamics **out, int kind, const DgdmTens
     }
     m->n_mid = 8 - first_mid;
     std::vector<std::vector<float>> bwd_imgs;
+    std::vector<std::vector<uint16_t>> bwd16_imgs;
     for (int i = 0; i < m->n_mid; ++i) {
         const int li = 3 * (first_mid + i);
         Folded f;
@@ -257,6 +272,22 @@ extern "C" int dgdm_dynamics_create(DgdmDynamics **out, int kind, const DgdmTens
         fwd.insert(fwd.end(), fi.begin(), fi.end());
         o.bf[i] = bl.add(f.b);
         bwd_imgs.push_back(pack_chain(transpose(f.w.data(), W, W).data(), W, W));
+        const std::vector<uint16_t> f16 = pack_chain_bf16(f.w.data(), W, W);
+        fwd16.insert(fwd16.end(), f16.begin(), f16.end());
+        bwd16_imgs.push_back(pack_chain_bf16(transpose(f.w.data(), W, W).data(), W, W));
+    }
+    {   // output layer padded to one 32-row block (forward) / its transpose padded to K = 32 (backward, consumed first)
+        std::vector<float> wo((size_t)32 * W, 0.f), wot((size_t)W * 32, 0.f);
+        for (int j = 0; j < 3; ++j)
+            for (int k = 0; k < W; ++k) { wo[(size_t)j * W + k] = lout.w[(size_t)j * W + k]; wot[(size_t)k * 32 + j] = lout.w[(size_t)j * W + k]; }
+        const std::vector<uint16_t> o16 = pack_chain_bf16(wo.data(), 32, W), ot16 = pack_chain_bf16(wot.data(), W, 32);
+        fwd16.insert(fwd16.end(), o16.begin(), o16.end());
+        std::vector<uint16_t> bwd16(ot16);
+        for (int i = m->n_mid - 1; i >= 0; --i) bwd16.insert(bwd16.end(), bwd16_imgs[i].begin(), bwd16_imgs[i].end());
+        bwd16.insert(bwd16.end(), bwd16_tail.begin(), bwd16_tail.end());
+        m->fwd16_bytes = fwd16.size() * 2; m->bwd16_bytes = bwd16.size() * 2;
+        fwd16.insert(fwd16.end(), bwd16.begin(), bwd16.end());
+        if ((rc = m->w16.upload(fwd16.data(), fwd16.size() * 2))) return rc;
     }
     std::vector<float> bwd;
     for (int i = m->n_mid - 1; i >= 0; --i) bwd.insert(bwd.end(), bwd_imgs[i].begin(), bwd_imgs[i].end());     // last layer first
@@ -278,6 +309,11 @@ void DgdmDynamics::fill_trunk(TrunkParams *p) const {
     p->Wfwd = blob.at4(off.wfwd); p->fwd_bytes = (unsigned)(off.fwd_floats * 4);
     p->Wbwd = blob.at4(off.wbwd); p->bwd_bytes = (unsigned)(off.bwd_floats * 4);
     if (kind == 3) p->b2 = blob.at(off.b2);
+}
+
+void DgdmDynamics::fill_trunk_bf16(TrunkParams *p) const {     // after fill_trunk: swaps the two weight streams only
+    p->Wfwd = reinterpret_cast<const float4 *>(static_cast<const char *>(w16.p)); p->fwd_bytes = (unsigned)fwd16_bytes;
+    p->Wbwd = reinterpret_cast<const float4 *>(static_cast<const char *>(w16.p) + fwd16_bytes); p->bwd_bytes = (unsigned)bwd16_bytes;
 }
 
 PnWeights DgdmDynamics::pn() const {

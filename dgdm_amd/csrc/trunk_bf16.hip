@@ -1,0 +1,511 @@
+// bf16-contraction variant of the fused dynamics trunk (BASELINE configs[4]: "bf16 contractions, f32 accumulate/statistics").
+//
+// Same contract as trunk_kernel (trunk.hip): same first-layer tables, same TrunkParams, same per-tile partial d/dz1 output,
+// so everything around it (tables, dyn_post_kernel, DDIM step) is shared and stays float32.  What changes is the arithmetic
+// of the contractions: weights (BatchNorm folded in float64, then rounded once to bf16, round-to-nearest-even) and the
+// activations / gradients entering a contraction (rounded to bf16 by v_cvt_pk_bf16_f32) are multiplied on
+// v_mfma_f32_32x32x16_bf16 and accumulated in float32; biases, the first-layer tables, the objective and every sum over rows
+// are float32.  oracle/dgdm_oracle.py::trunk_grad_bf16 states the same rounding points on the CPU.
+//
+// Layout.  One wave owns TWO 32-row tiles (64 rows), so every weight operand read from L2 feeds two MFMAs.  An activation
+// block (32 features x 32 rows) is 8 VGPRs of packed bf16 pairs:
+//     dword d of block o, lane (n = l & 31, h = l >> 5)  =  { H[32 o + rho(2d, h)][n] , H[32 o + rho(2d+1, h)][n] },
+//     rho(r, h) = (r & 3) + 8 (r >> 2) + 4 h                      (the 32x32 MFMA C/D row of accumulator register r)
+// i.e. the accumulators of a layer, converted pairwise, ARE the next layer's B operand: K-step s of input block o is dwords
+// 4s..4s+3.  The matching A-operand image (host: pack_chain_bf16) holds, for lane (i, h) and slot j of K-step s,
+// W[32 o' + i][32 o + rho(8 s + j, h)].
+//
+// ReLU and its derivative work on the packed pairs: relu = v_pk_max_i16(x, 0) (a negative bf16 is a negative int16), the
+// sign bits of the pre-activations are collected into one dword per (layer, block) per lane (bits 15-k and 31-k for pair
+// k = d + 8 tile) and kept in LDS, and the backward pass turns them back into 16-bit masks (shift, v_pk_ashrrev_i16 15,
+// and-not).  A pre-activation that rounds to -0.0/+0.0 follows its sign bit; torch's relu'(0) = 0 differs only there.
+//
+// Pipeline.  A "stage" is one output block: NK weight entries (1 KiB each, prefetched 16 ahead through the buffer-load ring
+// of mfma_chain.h) x 2 tiles.  The convert/ReLU/mask epilogue of stage k runs in the first steps of stage k+1 (accumulators
+// are double buffered), also across layer boundaries, so the matrix pipe does not wait for the VALU between blocks.
+#include <type_traits>
+#include "common.h"
+#include "mfma_chain.h"
+#include "trunk.h"
+
+namespace dgdm {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x16 mfma_bf16(const float4 a, const u32x4_t b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {          // v_cvt_pk_bf16_f32 (RNE)
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+
+// Two 32-row tiles x 8 feature blocks of packed activations: v[tile][block][kstep] (4 dwords each)
+struct Act16 {
+    u32x4_t v[2][8][2];
+};
+
+// forward epilogue of one pair with shift SH = pair + 8 tile: convert, record the sign bits (mk starts at 0 per block), ReLU
+template <int SH>
+__device__ __forceinline__ uint32_t fwd_pair(float lo, float hi, uint32_t &mk) {
+    const uint32_t p = pack_bf16(lo, hi);
+    mk |= (p >> SH) & (0x80008000u >> SH);
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, p), s16x2_t{0, 0}));
+}
+
+// backward epilogue: convert, zero the entries whose forward pre-activation had its sign bit set
+template <int SH>
+__device__ __forceinline__ uint32_t bwd_pair(float lo, float hi, uint32_t mk) {
+    const uint32_t p = pack_bf16(lo, hi);
+    const s16x2_t neg = __builtin_bit_cast(s16x2_t, mk << SH) >> 15;        // 0xffff where the sign bit was set
+    return p & ~__builtin_bit_cast(uint32_t, neg);
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// Epilogue work item Q (0..15) of a finished stage: tile Q / 8, pair Q % 8 -> Y.v[tile][OB][pair / 4][pair % 4]
+template <bool FWD, int OB, int Q>
+__device__ __forceinline__ void epi_item(const f32x16 (&acc)[2], uint32_t &mk, Act16 &Y) {
+    constexpr int T = Q / 8, D = Q % 8;
+    if (FWD) Y.v[T][OB][D / 4][D % 4] = fwd_pair<Q>(acc[T][2 * D], acc[T][2 * D + 1], mk);
+    else Y.v[T][OB][D / 4][D % 4] = bwd_pair<Q>(acc[T][2 * D], acc[T][2 * D + 1], mk);
+}
+
+// The 16 items of a stage are spread over the first min(NK, 8) steps of the following stage.
+template <bool FWD, int OB, int NK, int I>
+__device__ __forceinline__ void epi_step(const f32x16 (&acc)[2], uint32_t &mk, Act16 &Y) {
+    constexpr int STEPS = NK < 8 ? NK : 8, PER = 16 / STEPS;
+    if constexpr (I < STEPS) {
+        static_for<0, PER>([&](auto jc) { epi_item<FWD, OB, I * PER + decltype(jc)::value>(acc, mk, Y); });
+    }
+}
+
+__device__ __forceinline__ void load_f32x16(const float *block, int h4, f32x16 &b) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4 *>(block + 8 * q + h4);
+        b[4 * q + 0] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
+    }
+}
+
+// State that crosses stage and layer boundaries.
+struct Pipe {
+    f32x16 acc[2][2];      // [parity][tile]; after a layer, acc[1] holds its block 7 with the epilogue still to do
+    f32x16 bias0;          // forward: bias block the next stage starts its accumulators from (prefetched one stage ahead)
+    uint32_t mk;           // backward: mask word of the pending block
+};
+
+// One layer Y = epi(W X (+ bias)) on both tiles: 8 output blocks, NK K-steps each (NK = 16: K = 256; NK = 2: K = 32).
+// When PEND is set, the epilogue of the PREVIOUS layer's block 7 (pipe.acc[1] -> X block 7) is finished during stage 0 -
+// X block 7 is first read in the last two steps of a stage.  This layer's own block 7 is left pending the same way.
+//   FWD : C starts from the bias block; epilogue = convert + sign bits (stored to smask[slot0 + block]) + ReLU;
+//         the pending block's sign bits go to smask[prev_slot].
+//   !FWD: C starts from zero; epilogue = convert + mask smask[slot0 + block] (pending block: pipe.mk).
+// `woff` is the byte offset of this layer's 8 NK entries in the weight stream.
+template <bool FWD, bool PEND, int NK>
+__device__ __forceinline__ void layer16(const wrsrc_t rs, const int voff, const int woff, float4 (&ring)[CONT_DEPTH], const float *bias,
+                                        const float *bias_next, Act16 &X, Act16 &Y, Pipe &pipe, uint32_t (*smask)[256], const int prev_slot,
+                                        const int slot0, const int tid, const int h4) {
+    constexpr int EA = (NK < 8 ? NK : 8) - 1;        // last step that carries epilogue items
+    constexpr int BS = NK > 9 ? 9 : NK - 1;          // step that prefetches the next stage's bias block
+    uint32_t mk = FWD ? 0u : pipe.mk;
+    static_for<0, 8>([&](auto opc) {
+        constexpr int OP = decltype(opc)::value;
+        constexpr int PAR = OP & 1;
+        static_for<0, NK>([&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            constexpr int E = OP * NK + I;
+            constexpr int IB = I / 2, S = I % 2;
+            const float4 a = ring[E % CONT_DEPTH];
+            ring[E % CONT_DEPTH] = wload(rs, voff, woff + (E + CONT_DEPTH) * 1024);
+            if constexpr (I == 0) {
+                if (FWD) mk = 0u;
+            }
+            if constexpr (OP == 0) {
+                if constexpr (PEND) epi_step<FWD, 7, NK, I>(pipe.acc[1], mk, X);
+            } else {
+                epi_step<FWD, OP - 1, NK, I>(pipe.acc[PAR ^ 1], mk, Y);
+            }
+            if constexpr (I == EA) {
+                if (FWD) {                            // the previous stage's sign-bit word is complete
+                    if constexpr (OP == 0) { if (PEND) smask[prev_slot][tid] = mk; }
+                    else smask[slot0 + OP - 1][tid] = mk;
+                } else {
+                    mk = smask[slot0 + OP][tid];      // for this stage's own epilogue, which runs in the next stage
+                }
+            }
+            if constexpr (I == 0) {
+                if (FWD) {
+                    pipe.acc[PAR][0] = mfma_bf16(a, X.v[0][IB][S], pipe.bias0);
+                    pipe.acc[PAR][1] = mfma_bf16(a, X.v[1][IB][S], pipe.bias0);
+                } else {
+                    f32x16 zero;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+                    pipe.acc[PAR][0] = mfma_bf16(a, X.v[0][IB][S], zero);
+                    pipe.acc[PAR][1] = mfma_bf16(a, X.v[1][IB][S], zero);
+                }
+            } else {
+                pipe.acc[PAR][0] = mfma_bf16(a, X.v[0][IB][S], pipe.acc[PAR][0]);
+                pipe.acc[PAR][1] = mfma_bf16(a, X.v[1][IB][S], pipe.acc[PAR][1]);
+            }
+            if constexpr (FWD && I == BS) load_f32x16(OP < 7 ? bias + 32 * (OP + 1) : bias_next, h4, pipe.bias0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    });
+    pipe.mk = mk;
+}
+
+// Finish a pending block 7 outside a layer (used before code that is not a layer16).
+template <bool FWD>
+__device__ __forceinline__ void finish_pending(Act16 &X, Pipe &pipe, uint32_t (*smask)[256], int prev_slot, int tid) {
+    uint32_t mk = FWD ? 0u : pipe.mk;
+    static_for<0, 16>([&](auto qc) { epi_item<FWD, 7, decltype(qc)::value>(pipe.acc[1], mk, X); });
+    if (FWD) smask[prev_slot][tid] = mk;
+}
+
+// Per-tile row bookkeeping (same mapping as trunk_kernel: a tile is one finger of one chain against 32 pose cells)
+struct TileRows {
+    int chain, b;
+    bool valid;
+    int64_t r;
+    const float *arow, *prow;
+};
+
+__device__ __forceinline__ TileRows tile_rows(const TrunkParams &p, int tile, int n, int W1) {
+    TileRows t;
+    const int per_chain = p.B * p.tiles_per_b;
+    t.chain = tile / per_chain;
+    const int rem = tile - t.chain * per_chain;
+    t.b = rem / p.tiles_per_b;
+    const int c = (rem - t.b * p.tiles_per_b) * 32 + n;
+    t.valid = c < p.C;
+    const int cc = t.valid ? c : p.C - 1;
+    t.r = (int64_t)cc * p.B + t.b;
+    t.arow = p.Atab + (size_t)(t.chain * p.B + t.b) * W1;
+    t.prow = p.Ptab + (size_t)cc * W1;
+    return t;
+}
+
+// z1 block `blk` of a tile from the first-layer tables (float32)
+__device__ __forceinline__ void table_block(const TileRows &t, int blk, int h4, f32x16 &z) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 a = *reinterpret_cast<const float4 *>(t.arow + 32 * blk + 8 * q + h4);
+        const float4 w = *reinterpret_cast<const float4 *>(t.prow + 32 * blk + 8 * q + h4);
+        z[4 * q + 0] = a.x + w.x; z[4 * q + 1] = a.y + w.y; z[4 * q + 2] = a.z + w.z; z[4 * q + 3] = a.w + w.w;
+    }
+}
+
+// 3-D layers 1 and 2 of ONE tile T (the 512-wide layer 1 does not fit in registers for two tiles at once):
+//   for each 32-feature block kb of layer 1:  z = W1o'[kb] bf(xobj) + (Atab + Ptab)[kb] ; a1 = relu ; acc2 += W2'[:, kb] bf(a1)
+// software-pipelined by one block: the stream order is z(0), z(1), l2(0), z(2), l2(1), ..., z(15), l2(14), l2(15) (16 entries each).
+// Leaves layer 2's blocks 0..6 packed in X.v[T] and block 7 pending in pipe.acc[1][T].
+template <int T>
+__device__ __forceinline__ void front3d(const wrsrc_t rs, const int voff, float4 (&ring)[CONT_DEPTH], const TrunkParams &p, const TileRows &tr,
+                                        Act16 &X, Pipe &pipe, uint32_t (*smask)[256], const int tid, const int h4) {
+    // xobj row -> packed B operand
+    u32x4_t xin[8][2];
+    const float *xrow = p.xobj + ((size_t)tr.chain * p.R + tr.r) * 256;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4 *>(xrow + 32 * o + 8 * q + h4);
+            xin[o][q / 2][(2 * q) % 4] = pack_bf16(v.x, v.y);
+            xin[o][q / 2][(2 * q + 1) % 4] = pack_bf16(v.z, v.w);
+        }
+    }
+    f32x16 acc2[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) load_f32x16(p.b2 + 32 * o, h4, acc2[o]);
+    f32x16 zacc[2];
+    u32x4_t zin[2];
+    uint32_t mk = 0;
+    static_for<0, 17>([&](auto kc) {
+        constexpr int KB = decltype(kc)::value;          // z(KB) for KB < 16, then l2(KB - 1) for KB >= 1
+        if constexpr (KB < 16) {
+            f32x16 init;
+            table_block(tr, KB, h4, init);
+            static_for<0, 16>([&](auto ic) {
+                constexpr int I = decltype(ic)::value;
+                constexpr int E = (KB == 0 ? 0 : 16 + 32 * (KB - 1)) + I;
+                const float4 a = ring[E % CONT_DEPTH];
+                ring[E % CONT_DEPTH] = wload(rs, voff, (E + CONT_DEPTH) * 1024);
+                if constexpr (KB > 0 && I == 0) mk = 0u;
+                if constexpr (KB > 0 && I < 8) {          // epilogue of z(KB-1): one pair per step
+                    zin[I / 4][I % 4] = fwd_pair<I + 8 * T>(zacc[(KB - 1) & 1][2 * I], zacc[(KB - 1) & 1][2 * I + 1], mk);
+                }
+                if constexpr (I == 0) zacc[KB & 1] = mfma_bf16(a, xin[0][0], init);
+                else zacc[KB & 1] = mfma_bf16(a, xin[I / 2][I % 2], zacc[KB & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        } else {
+            mk = 0u;
+            static_for<0, 8>([&](auto ic) {
+                constexpr int I = decltype(ic)::value;
+                zin[I / 4][I % 4] = fwd_pair<I + 8 * T>(zacc[1][2 * I], zacc[1][2 * I + 1], mk);
+            });
+        }
+        if constexpr (KB >= 1) {
+            constexpr int KP = KB - 1;                   // l2(KP): uses zin = a1 block KP
+            // sign bits of a1 block KP: this tile's 8 pairs; the two tile passes share the word
+            if (T == 0) smask[KP][tid] = mk;
+            else smask[KP][tid] |= mk;
+            static_for<0, 16>([&](auto ic) {
+                constexpr int I = decltype(ic)::value;
+                constexpr int E = (KP == 15 ? 16 + 32 * 15 : 32 * (KP + 1)) + I;
+                constexpr int OP = I / 2, S = I % 2;
+                const float4 a = ring[E % CONT_DEPTH];
+                ring[E % CONT_DEPTH] = wload(rs, voff, (E + CONT_DEPTH) * 1024);
+                acc2[OP] = mfma_bf16(a, zin[S], acc2[OP]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+    });
+    // layer 2 epilogue: blocks 0..6 here, block 7 left pending
+    static_for<0, 7>([&](auto oc) {
+        constexpr int O = decltype(oc)::value;
+        uint32_t m2 = 0;
+        static_for<0, 8>([&](auto dc) {
+            constexpr int D = decltype(dc)::value;
+            X.v[T][O][D / 4][D % 4] = fwd_pair<D + 8 * T>(acc2[O][2 * D], acc2[O][2 * D + 1], m2);
+        });
+        if (T == 0) smask[16 + O][tid] = m2;
+        else smask[16 + O][tid] |= m2;
+    });
+    pipe.acc[1][T] = acc2[7];
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256, 1) void trunk_bf16_kernel(const TrunkParams p) {
+    constexpr int W1B = (KIND == 3) ? 16 : 8;
+    constexpr int W1 = W1B * 32;
+    constexpr int S_MID = (KIND == 3) ? 24 : 8;           // mask slot of mid layer 0's output
+    constexpr int NSLOT = S_MID + 8 * ((KIND == 3) ? 6 : 7);
+    __shared__ uint32_t smask[NSLOT][256];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile0 = (blockIdx.x * 4 + wave) * 2;
+    if (tile0 >= p.ntiles) return;                        // wave-uniform; the kernel has no barrier
+    const bool has1 = tile0 + 1 < p.ntiles;               // an odd tile count leaves the last wave one real tile
+    const int n = lane & 31;
+    const int h4 = (lane >> 5) * 4;
+    const int voff = lane * 16;
+
+    const TileRows tr0 = tile_rows(p, tile0, n, W1);
+    const TileRows tr1 = tile_rows(p, has1 ? tile0 + 1 : tile0, n, W1);
+
+    Act16 X, Y;
+    Pipe pipe;
+    pipe.mk = 0;
+    load_f32x16(p.bf[0], h4, pipe.bias0);
+    const wrsrc_t rsF = weight_rsrc(p.Wfwd, p.fwd_bytes);
+    float4 ring[CONT_DEPTH];
+    ring_fill(rsF, voff, 0, ring);
+    int woff = 0;
+
+    if (KIND == 2) {
+        // ---- layer 1 from the tables; blocks 0..6 finished here, block 7 left pending like any other layer's
+        static_for<0, 8>([&](auto oc) {
+            constexpr int O = decltype(oc)::value;
+            f32x16 z0, z1;
+            table_block(tr0, O, h4, z0);
+            table_block(tr1, O, h4, z1);
+            if constexpr (O < 7) {
+                uint32_t mk = 0;
+                static_for<0, 8>([&](auto dc) {
+                    constexpr int D = decltype(dc)::value;
+                    X.v[0][O][D / 4][D % 4] = fwd_pair<D>(z0[2 * D], z0[2 * D + 1], mk);
+                });
+                static_for<0, 8>([&](auto dc) {
+                    constexpr int D = decltype(dc)::value;
+                    X.v[1][O][D / 4][D % 4] = fwd_pair<D + 8>(z1[2 * D], z1[2 * D + 1], mk);
+                });
+                smask[O][tid] = mk;
+            } else {
+                pipe.acc[1][0] = z0;
+                pipe.acc[1][1] = z1;
+            }
+        });
+    } else {
+        front3d<0>(rsF, voff, ring, p, tr0, X, pipe, smask, tid, h4);
+        // the second pass re-reads the same 512 entries; the ring currently holds the 16 entries AFTER them: refill
+        ring_fill(rsF, voff, 0, ring);
+        front3d<1>(rsF, voff, ring, p, tr1, X, pipe, smask, tid, h4);
+        woff = 512 * 1024;
+    }
+    int pend_slot = (KIND == 3) ? 16 + 7 : 7;
+
+    // ---- 256 -> 256 layers, two per iteration (X -> Y -> X)
+    int l = 0;
+    for (; l + 1 < p.n_mid; l += 2) {
+        layer16<true, true, 16>(rsF, voff, woff, ring, p.bf[l], p.bf[l + 1], X, Y, pipe, smask, pend_slot, S_MID + 8 * l, tid, h4);
+        woff += 128 * 1024;
+        layer16<true, true, 16>(rsF, voff, woff, ring, p.bf[l + 1], p.bf[l + 2 < p.n_mid ? l + 2 : l + 1], Y, X, pipe, smask, S_MID + 8 * l + 7, S_MID + 8 * (l + 1), tid, h4);
+        woff += 128 * 1024;
+        pend_slot = S_MID + 8 * (l + 1) + 7;
+    }
+    if (KIND == 2) {                                       // n_mid = 7: one more, result in Y
+        layer16<true, true, 16>(rsF, voff, woff, ring, p.bf[l], p.bf[l], X, Y, pipe, smask, pend_slot, S_MID + 8 * l, tid, h4);
+        woff += 128 * 1024;
+        pend_slot = S_MID + 8 * l + 7;
+    }
+    Act16 &H = (KIND == 2) ? Y : X;                        // a_8, block 7 pending
+
+    // ---- output layer 256 -> 3 (padded to one 32-row block): 16 entries; finishes the pending block on the way
+    f32x16 lo[2];
+    {
+        uint32_t mk = 0;
+        static_for<0, 16>([&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            const float4 a = ring[I];
+            ring[I] = wload(rsF, voff, woff + (I + CONT_DEPTH) * 1024);   // past the end of the stream: clipped to zero, unused
+            epi_step<true, 7, 16, I>(pipe.acc[1], mk, H);
+            if constexpr (I == 7) smask[pend_slot][tid] = mk;
+            if constexpr (I == 0) {
+                f32x16 zero;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+                lo[0] = mfma_bf16(a, H.v[0][0][0], zero);
+                lo[1] = mfma_bf16(a, H.v[1][0][0], zero);
+            } else {
+                lo[0] = mfma_bf16(a, H.v[0][I / 2][I % 2], lo[0]);
+                lo[1] = mfma_bf16(a, H.v[1][I / 2][I % 2], lo[1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+
+    // ---- objective gradient per row (float32), packed as the B operand of the transposed output layer
+    const wrsrc_t rsB = weight_rsrc(p.Wbwd, p.bwd_bytes);
+    ring_fill(rsB, voff, 0, ring);
+    woff = 0;
+    Act16 &GA = (KIND == 2) ? X : Y;                       // whichever of X/Y is not H
+    Act16 &GB = H;
+    {
+        const float b0 = p.bout[0], b1 = p.bout[1], b2 = p.bout[2];
+        const TileRows *trs[2] = {&tr0, &tr1};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const TileRows &tr = *trs[t];
+            const TrunkObjective ob = p.obj[tr.chain];
+            const float d0 = lo[t][0] + b0, d1 = lo[t][1] + b1, d2 = lo[t][2] + b2;     // rows 0..2 of the block live in lanes h = 0
+            float g0 = ob.lin[0] + 2.f * ob.quad[0] * d0;
+            float g1 = ob.lin[1] + 2.f * ob.quad[1] * d1;
+            float g2 = ob.lin[2] + 2.f * ob.quad[2] * d2;
+            if (ob.use_rowcoef) g0 = p.rowcoef[(size_t)tr.chain * p.R + tr.r];
+            const bool live = tr.valid && lane < 32 && (t == 0 || has1);
+            if (!live) { g0 = 0.f; g1 = 0.f; g2 = 0.f; }
+            GB.v[t][0][0][0] = pack_bf16(g0, g1);
+            GB.v[t][0][0][1] = pack_bf16(g2, 0.f);
+            GB.v[t][0][0][2] = 0u; GB.v[t][0][0][3] = 0u;
+            GB.v[t][0][1] = u32x4_t{0u, 0u, 0u, 0u};
+        }
+    }
+    // ---- transposed output layer: 8 blocks x 2 K-steps; masks of a_8
+    layer16<false, false, 2>(rsB, voff, woff, ring, nullptr, nullptr, GB, GA, pipe, smask, 0, S_MID + 8 * (p.n_mid - 1), tid, h4);
+    woff += 16 * 1024;
+
+    // ---- backward through the mid layers, two per iteration (GA -> GB -> GA); layer j masks with the output of layer j-1
+    for (int j = p.n_mid - 1; j >= ((KIND == 2) ? 2 : 1); j -= 2) {
+        layer16<false, true, 16>(rsB, voff, woff, ring, nullptr, nullptr, GA, GB, pipe, smask, 0, S_MID + 8 * (j - 1), tid, h4);
+        woff += 128 * 1024;
+        layer16<false, true, 16>(rsB, voff, woff, ring, nullptr, nullptr, GB, GA, pipe, smask, 0, S_MID + 8 * (j - 2), tid, h4);
+        woff += 128 * 1024;
+    }
+
+    // ---- last layer back (2-D: W2'^T, 8 blocks; 3-D: W2'^T onto the 512-wide layer 1, 16 blocks): float32 epilogue,
+    //      mask of a_1, fold of the tile's 32 cells, one partial vector per tile
+    const bool same_b = has1 && tr0.chain == tr1.chain && tr0.b == tr1.b;
+    float *dst0 = p.partial + (size_t)tile0 * W1;
+    float *dst1 = dst0 + W1;
+    static_for<0, W1B>([&](auto oc) {
+        constexpr int OB = decltype(oc)::value;
+        f32x16 g[2];
+        const uint32_t mk1 = smask[OB][tid];
+        static_for<0, 16>([&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            constexpr int E = OB * 16 + I;
+            const float4 a = ring[E % CONT_DEPTH];
+            ring[E % CONT_DEPTH] = wload(rsB, voff, woff + (E + CONT_DEPTH) * 1024);
+            if constexpr (OB == 0) epi_step<false, 7, 16, I>(pipe.acc[1], pipe.mk, GA);
+            if constexpr (I == 0) {
+                f32x16 zero;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+                g[0] = mfma_bf16(a, GA.v[0][0][0], zero);
+                g[1] = mfma_bf16(a, GA.v[1][0][0], zero);
+            } else {
+                g[0] = mfma_bf16(a, GA.v[0][I / 2][I % 2], g[0]);
+                g[1] = mfma_bf16(a, GA.v[1][I / 2][I % 2], g[1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // mask: pair d of tile t has its sign bits at 15 - (d + 8t) (low half, register 2d) and 31 - (d + 8t) (register 2d+1)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = r >> 1, hi = r & 1;
+            if ((mk1 >> (15 - d + 16 * hi)) & 1u) g[0][r] = 0.f;
+            if ((mk1 >> (15 - (d + 8) + 16 * hi)) & 1u) g[1][r] = 0.f;
+        }
+        if (!has1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g[1][r] = 0.f;
+        }
+        if (same_b) {
+            // both tiles belong to the same finger: dyn_post_kernel adds their partials anyway, so add first, fold once
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 v;
+                v.x = rows_sum(g[0][4 * q + 0] + g[1][4 * q + 0]); v.y = rows_sum(g[0][4 * q + 1] + g[1][4 * q + 1]);
+                v.z = rows_sum(g[0][4 * q + 2] + g[1][4 * q + 2]); v.w = rows_sum(g[0][4 * q + 3] + g[1][4 * q + 3]);
+                if (n == 0) {
+                    *reinterpret_cast<float4 *>(dst0 + 32 * OB + 8 * q + h4) = v;
+                    *reinterpret_cast<float4 *>(dst1 + 32 * OB + 8 * q + h4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 v, w;
+                v.x = rows_sum(g[0][4 * q + 0]); v.y = rows_sum(g[0][4 * q + 1]); v.z = rows_sum(g[0][4 * q + 2]); v.w = rows_sum(g[0][4 * q + 3]);
+                w.x = rows_sum(g[1][4 * q + 0]); w.y = rows_sum(g[1][4 * q + 1]); w.z = rows_sum(g[1][4 * q + 2]); w.w = rows_sum(g[1][4 * q + 3]);
+                if (n == 0) {
+                    *reinterpret_cast<float4 *>(dst0 + 32 * OB + 8 * q + h4) = v;
+                    if (has1) *reinterpret_cast<float4 *>(dst1 + 32 * OB + 8 * q + h4) = w;
+                }
+            }
+        }
+    });
+}
+
+int trunk_bf16_launch(int kind, const TrunkParams &p, hipStream_t s) {
+    if (p.n_mid != (kind == 3 ? 6 : 7)) return DGDM_EINVAL;
+    const int waves = (p.ntiles + 1) / 2, grid = (waves + 3) / 4;
+    if (grid == 0) return DGDM_OK;
+    const double rows = 32.0 * p.ntiles;
+    const double mid = 2.0 * 256 * 256 * p.n_mid;
+    const double per_row = (kind == 3) ? (2.0 * 256 * 512 * 2 + mid) + (2.0 * 256 * 512 + mid) : 2.0 * mid;
+    prof_begin(s);
+    if (kind == 2) hipLaunchKernelGGL((trunk_bf16_kernel<2>), dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((trunk_bf16_kernel<3>), dim3(grid), dim3(256), 0, s, p);
+    DGDM_HIP_CHECK(hipGetLastError());
+    prof_end(s, rows * per_row);
+    return DGDM_OK;
+}
+
+}  // namespace dgdm

@@ -32,7 +32,7 @@ class Unet1d:
         self._h = h
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:      # module globals are None during interpreter shutdown
             lib().dgdm_unet1d_destroy(self._h)
             self._h = None
 
@@ -57,7 +57,7 @@ class Dynamics:
         self._h, self.kind, self.params_ch, self.object_ch = h, kind, params_ch, object_ch
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:      # module globals are None during interpreter shutdown
             lib().dgdm_dynamics_destroy(self._h)
             self._h = None
 
@@ -101,7 +101,8 @@ class Guidance:
     """State of ``Diffusion.cond_fn`` for up to ``max_chains`` chains (generator/diffusion.py:473-504)."""
 
     def __init__(self, dyn: Dynamics, batch: int, grid_size: int, num_pos: int, ori_range: Sequence[float], max_chains: int,
-                 num_train_timesteps: int, num_object_points: int, sub_batch_size: int = 0, max_objects: int = 8):
+                 num_train_timesteps: int, num_object_points: int, sub_batch_size: int = 0, max_objects: int = 8,
+                 contraction_dtype: str = "f32"):
         cfg = _lib.GuidanceConfig(batch, grid_size, num_pos, float(ori_range[0]), float(ori_range[1]), max_chains,
                                   num_train_timesteps, sub_batch_size, num_object_points, max_objects)
         h = C.c_void_p()
@@ -111,9 +112,17 @@ class Guidance:
         self.starts_per_call = int(lib().dgdm_guidance_starts_per_call(h))
         self.sweep_rows = batch * grid_size
         self.n_objects = 0
+        self.set_contraction_dtype(contraction_dtype)
+
+    def set_contraction_dtype(self, dtype: str) -> None:
+        """'f32' (exact float32 MFMA, default) or 'bf16' (bf16 operands, float32 accumulate) for the trunk of cond_fn."""
+        if dtype not in ("f32", "bf16"):
+            raise ValueError(f"contraction dtype {dtype!r} not supported")
+        check(lib().dgdm_guidance_set_contraction_dtype(self._h, 1 if dtype == "bf16" else 0))
+        self.contraction_dtype = dtype
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:      # module globals are None during interpreter shutdown
             lib().dgdm_guidance_destroy(self._h)
             self._h = None
 

@@ -138,6 +138,13 @@ typedef struct DgdmGuidanceConfig {
 
 int  dgdm_guidance_create(DgdmGuidance **out, DgdmDynamics *model, const DgdmGuidanceConfig *cfg);
 void dgdm_guidance_destroy(DgdmGuidance *g);
+/* Arithmetic of the trunk contractions inside dgdm_dyn{2,3}d_guidance_grad (BASELINE configs[4]: "bf16 contractions,
+ * f32 accumulate").  DGDM_DTYPE_F32 (default): exact float32 MFMA, the parity path.  DGDM_DTYPE_BF16: weights and the
+ * activations/gradients entering a contraction rounded to bf16 (nearest even), float32 accumulation; first-layer tables,
+ * biases, objective and row sums stay float32.  The reference has no such switch (it calls
+ * torch.set_float32_matmul_precision('high'), generator/diffusion.py:102, which is a no-op on its CPU path).          */
+enum { DGDM_DTYPE_F32 = 0, DGDM_DTYPE_BF16 = 1 };
+int  dgdm_guidance_set_contraction_dtype(DgdmGuidance *g, int dtype);
 /* Objects the chains refer to.  2-D: objects_dev [n][num_vertices][2] (flattened to object_ch as
  * cond_fn does, diffusion.py:485).  3-D: objects_dev [n][N][3]; builds the per-object PointNet++
  * tables on `stream`.                                                            */

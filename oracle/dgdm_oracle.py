@@ -157,8 +157,75 @@ def _mlp2(sd: SD, p: str, x: torch.Tensor, act: Callable) -> torch.Tensor:
     return F.linear(x, sd[p + ".2.weight"], sd[p + ".2.bias"])
 
 
-def _trunk(sd: SD, x: torch.Tensor) -> torch.Tensor:
+# --- bf16-contraction mode (BASELINE configs[4]; no counterpart in the reference, which is float32 throughout) -------------
+# States on the CPU the rounding points of dgdm_amd/csrc/trunk_bf16.hip so that kernel has something to be checked against:
+# BatchNorm folded into the Linear in float64, the folded weight rounded once to bf16; every operand entering a trunk
+# contraction (activations forward, gradients backward) rounded to bf16 (nearest even); float32 accumulation, biases,
+# first-layer terms that do not depend on the row's object embedding, objective and sums.  Switched on with
+# ``with contraction('bf16'):`` around cond_fn / guided_sample*.
+_CONTRACTION = 'f32'
+
+
+class contraction:
+    def __init__(self, dtype: str):
+        assert dtype in ('f32', 'bf16')
+        self.dtype = dtype
+
+    def __enter__(self):
+        global _CONTRACTION
+        self.prev, _CONTRACTION = _CONTRACTION, self.dtype
+
+    def __exit__(self, *a):
+        global _CONTRACTION
+        _CONTRACTION = self.prev
+
+
+def _bf(x: torch.Tensor) -> torch.Tensor:
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+class _BfLinear(torch.autograd.Function):
+    """y = bf(x) bf(W)^T ;  dL/dx = bf(dL/dy) bf(W)   (float32 accumulation; W is frozen)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        wb = _bf(w)
+        ctx.save_for_backward(wb)
+        return _bf(x) @ wb.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        (wb,) = ctx.saved_tensors
+        return _bf(g) @ wb, None
+
+
+def _folded(sd: SD, i: int):
+    w, b = sd[f"linears.{3 * i}.weight"].double(), sd[f"linears.{3 * i}.bias"].double()
+    n = f"linears.{3 * i + 1}"
+    sc = sd[n + ".weight"].double() / torch.sqrt(sd[n + ".running_var"].double() + 1e-5)
+    return (sc[:, None] * w).float(), (sc * (b - sd[n + ".running_mean"].double()) + sd[n + ".bias"].double()).float()
+
+
+def _trunk_bf16(sd: SD, x: torch.Tensor, n_embed: int) -> torch.Tensor:
+    """The trunk with bf16 contractions.  ``n_embed`` leading input columns (3-D: the 256 PointNet++ features, which differ
+    per row) go through a bf16 contraction in layer 1; the rest of layer 1 is the float32 table part."""
+    w, b = _folded(sd, 0)
+    z = F.linear(x[:, n_embed:], w[:, n_embed:], b)
+    if n_embed:
+        z = z + _BfLinear.apply(x[:, :n_embed], w[:, :n_embed])
+    a = F.relu(z)
+    i = 1
+    while f"linears.{3 * i}.weight" in sd:
+        w, b = _folded(sd, i)
+        a = F.relu(_BfLinear.apply(a, w) + b)
+        i += 1
+    return _BfLinear.apply(a, sd["output.weight"]) + sd["output.bias"]
+
+
+def _trunk(sd: SD, x: torch.Tensor, n_embed: int = 0) -> torch.Tensor:
     # Linear -> BatchNorm1d(eval) -> ReLU x8, then Linear (profile_forward_2d.py:109-135,154-155)
+    if _CONTRACTION == 'bf16':
+        return _trunk_bf16(sd, x, n_embed)
     i = 0
     while f"linears.{3 * i}.weight" in sd:
         x = F.linear(x, sd[f"linears.{3 * i}.weight"], sd[f"linears.{3 * i}.bias"])
@@ -290,7 +357,7 @@ def dyn3d_forward(sd: SD, x_ctrl, x_ori, x_pos, timesteps, object_vertices, star
     o = pointnet2_forward(sd, object_vertices, starts, prefix="object_encoder.")
     W = sd["gripper_encoder.2.weight"].shape[0]
     te = timestep_embedding(timesteps, W)
-    return _trunk(sd, torch.cat([o, g, pose, te], dim=1))
+    return _trunk(sd, torch.cat([o, g, pose, te], dim=1), n_embed=o.shape[1])
 
 
 # =========================================================================== a5/a6  objectives
