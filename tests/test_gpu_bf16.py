@@ -1,0 +1,119 @@
+"""GPU tests of the bf16-contraction mode of cond_fn (BASELINE configs[4]: "bf16 contractions, f32 accumulate").
+
+The reference is float32 only, so this mode has no golden vectors; it is checked against
+  (a) the oracle's statement of the same rounding points (oracle/dgdm_oracle.py `contraction('bf16')`): what remains is
+      float32 summation order, which after a bf16 rounding shows up as occasional one-ulp-of-bf16 (2^-9) differences and
+      ReLU sign flips - tolerance 6e-3 (2-D, 1080 rows) / 2.5e-2 (3-D, 108 rows) relative L2 on the gradient;
+  (b) the float32 oracle: the price of bf16 itself, ~2e-2 (2-D) / ~3.5e-2 (3-D) relative L2 - tolerance 5e-2 / 8e-2;
+  (c) at BASELINE's full sizes: antisymmetry in the objective (to 1e-4: the bf16 MFMA accumulation is not sign-symmetric),
+      chain independence (exact) and the distance to the float32 HIP gradient.
+The float32 path must be untouched by the switch (bit-identical before and after)."""
+import numpy as np
+import pytest
+import torch
+
+from dgdm_amd import engine, sampler, synth
+from oracle import dgdm_oracle as orc
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from dgdm_amd import _lib
+    _lib.device_init(0)
+    return torch.device("cuda:0")
+
+
+def test_bf16_cond_fn_2d_vs_oracle(dev):
+    B, G, P, L, T, nv = 5, 24, 3, 14, 15, 100          # C = 216 cells -> 7 tiles per finger (odd): 105 tiles, last wave has one
+    sd = util.dyn2d_sd(22, nv)
+    dyn = engine.Dynamics(2, sd, L, 2 * nv)
+    objs = [synth.synth_object_2d(i, nv) for i in range(2)]
+    gd = engine.Guidance(dyn, B, G, P, (-1.0, 1.0), 4, T, nv, 0, max_objects=2)
+    gd.set_objects(torch.stack(objs).to(dev))
+    chains = [(0, 'rotate'), (1, 'shift_left'), (0, 'counterclockwise_up')]
+    x = torch.stack([synth.synth_noise(70 + i, B, L) for i in range(len(chains))]).clamp(-1, 1)
+    xd = x.reshape(len(chains), B, L).to(dev)
+    objectives = [engine.make_objective(o, oi) for oi, o in chains]
+    f32_before = gd.grad(xd, 6, objectives).cpu()
+    gd.set_contraction_dtype("bf16")
+    got = gd.grad(xd, 6, objectives).cpu()
+    gd.set_contraction_dtype("f32")
+    assert torch.equal(gd.grad(xd, 6, objectives).cpu(), f32_before)
+    s = util.setup('point', None, sd, T, 5, L, G, P)
+    ts = torch.full((B,), 6, dtype=torch.int64)
+    for c, (oi, o) in enumerate(chains):
+        ref32 = orc.cond_fn(s, x[c], ts, o, objs[oi])
+        with orc.contraction('bf16'):
+            ref16 = orc.cond_fn(s, x[c], ts, o, objs[oi])
+        assert util.rel_l2(f32_before[c].reshape(B, L, 1), ref32) < 2e-3      # float32 path: a single ReLU sign flip is 5e-4 at this R
+        assert util.rel_l2(got[c].reshape(B, L, 1), ref16) < 6e-3, (o, util.rel_l2(got[c].reshape(B, L, 1), ref16))
+        assert util.rel_l2(got[c].reshape(B, L, 1), ref32) < 5e-2, o
+    with pytest.raises(ValueError):
+        gd.set_contraction_dtype("fp8")
+
+
+def test_bf16_cond_fn_3d_vs_oracle(dev):
+    B, G, P, L, T, sub = 3, 4, 3, 42, 15, 11           # C = 36 -> 2 tiles per finger
+    sd = util.dyn3d_sd(44)
+    dyn = engine.Dynamics(3, sd, L)
+    objs = torch.stack([synth.synth_object_3d(31), synth.synth_object_3d(32)])
+    gd = engine.Guidance(dyn, B, G, P, (-1.0, 1.0), 2, T, 512, sub, max_objects=2, contraction_dtype="bf16")
+    gd.set_objects(objs.to(dev))
+    x = torch.stack([synth.synth_noise(60, B, L), synth.synth_noise(61, B, L)]).clamp(-1, 1)
+    torch.manual_seed(3)
+    st = sampler.StartStream(512, sub)
+    starts = np.concatenate([st.call(gd.rows), st.call(gd.rows)])
+    chains = ((0, 'rotate'), (1, 'counterclockwise_left'))
+    got = gd.grad(x.reshape(2, B, L).to(dev), 3, [engine.make_objective(o, oi) for oi, o in chains], None, starts).cpu()
+    s = util.setup('point_3d', None, sd, T, 5, L, G, P, sub)
+    ts = torch.full((B,), 3, dtype=torch.int64)
+    for c, (oi, o) in enumerate(chains):
+        def log():
+            return orc.StartLog(util.unpack_starts(starts[c * 2 * gd.rows:(c + 1) * 2 * gd.rows],
+                                                   [n for r0 in range(0, gd.rows, sub) for n in (min(sub, gd.rows - r0),) * 2]))
+        ref32 = orc.cond_fn(s, x[c], ts, o, objs[oi], (-1.0, 1.0), None, log())
+        with orc.contraction('bf16'):
+            ref16 = orc.cond_fn(s, x[c], ts, o, objs[oi], (-1.0, 1.0), None, log())
+        assert util.rel_l2(got[c].reshape(B, L, 1), ref16) < 2.5e-2, (o, util.rel_l2(got[c].reshape(B, L, 1), ref16))
+        assert util.rel_l2(got[c].reshape(B, L, 1), ref32) < 8e-2, o
+
+
+def test_bf16_full_size_properties(dev):
+    mk = engine.make_objective
+    # 2-D, BASELINE configs[1] size
+    B, G, P, L, nv, T = 64, 360, 5, 14, 100, 15
+    dyn = engine.Dynamics(2, util.dyn2d_sd(22, nv), L, 2 * nv)
+    gd = engine.Guidance(dyn, B, G, P, (-1.0, 1.0), 4, T, nv, 0, max_objects=2)
+    gd.set_objects(torch.stack([synth.synth_object_2d(i, nv) for i in range(2)]).to(dev))
+    x = synth.synth_noise(1, B, L).clamp(-1, 1).reshape(1, B, L).to(dev)
+    names = ['rotate_clockwise', 'rotate_counterclockwise', 'shift_up', 'rotate']
+    f32 = gd.grad(x.expand(4, -1, -1).contiguous(), 6, [mk(n, 0) for n in names])
+    gd.set_contraction_dtype("bf16")
+    b16 = gd.grad(x.expand(4, -1, -1).contiguous(), 6, [mk(n, 0) for n in names])
+    # negating the objective negates every backward operand, yet the result is not bit-identical up to sign (as it is on the
+    # f32 MFMA path): the bf16 matrix pipe's internal multi-term accumulation does not round sign-symmetrically.  Measured 1e-5.
+    assert util.rel_l2(b16[0].cpu(), (-b16[1]).cpu()) < 1e-4
+    alone = gd.grad(x, 6, [mk('shift_up', 0)])
+    assert torch.equal(alone[0], b16[2])
+    for k, n in enumerate(names):
+        e = util.rel_l2(b16[k].cpu(), f32[k].cpu())
+        assert e < 5e-2, (n, e)
+    # 3-D, BASELINE configs[2] size
+    B, G, P, L, T, sub = 32, 45, 5, 42, 15, 512
+    dyn3 = engine.Dynamics(3, util.dyn3d_sd(33), L)
+    g3 = engine.Guidance(dyn3, B, G, P, (-1.0, 1.0), 2, T, 512, sub, max_objects=1)
+    g3.set_objects(synth.synth_object_3d(70)[None].to(dev))
+    x3 = synth.synth_noise(2, B, L).clamp(-1, 1).reshape(1, B, L).to(dev)
+    torch.manual_seed(7)
+    st = sampler.StartStream(512, sub).call(g3.rows)
+    st2 = np.concatenate([st, st])
+    a = g3.grad(x3.expand(2, -1, -1).contiguous(), 3, [mk('shift_left', 0), mk('rotate', 0)], None, st2)
+    g3.set_contraction_dtype("bf16")
+    b = g3.grad(x3.expand(2, -1, -1).contiguous(), 3, [mk('shift_right', 0), mk('rotate', 0)], None, st2)
+    assert bool(torch.isfinite(b).all())
+    e0, e1 = util.rel_l2((-b[0]).cpu(), a[0].cpu()), util.rel_l2(b[1].cpu(), a[1].cpu())
+    assert e0 < 8e-2 and e1 < 8e-2, (e0, e1)
