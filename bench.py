@@ -41,8 +41,9 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=4)
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--workload", choices=["3d", "2d"], default="3d")
-    p.add_argument("--pairs", type=int, default=0, help="(object x objective) pairs per GPU per step (default 32 for 3d, 4 for 2d)")
+    p.add_argument("--workload", choices=["3d", "2d", "3d_ensemble"], default="3d")
+    p.add_argument("--pairs", type=int, default=0, help="(object x objective) pairs per GPU per step (default 32 for 3d, 4 for 2d; "
+                                                        "3d_ensemble: chains per GPU per step, default 8, each averaging 4 objects' gradients)")
     p.add_argument("--contraction", choices=["f32", "bf16"], default="f32",
                    help="arithmetic of the dynamics-trunk contractions: f32 (the parity path, default) or bf16 operands with f32 accumulation")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -53,6 +54,10 @@ def parse():
 class Workload:
     def __init__(self, kind, pairs, dev, rank, contraction="f32"):
         self.kind, self.dev, self.contraction = kind, dev, contraction
+        self.n_obj = 4 if kind == "3d_ensemble" else 1    # dynamics-gradient evaluations per chain and denoise step
+        self.ensemble = kind == "3d_ensemble"
+        if kind == "3d_ensemble":
+            kind = self.kind = "3d"
         if kind == "3d":
             self.mode, self.B, self.G, self.P, self.L, self.N, self.sub = 'point_3d', 32, 45, 5, 42, 512, 512
         else:
@@ -66,7 +71,8 @@ class Workload:
             self.dyn_sd = synth.synth_state_dict(synth.dyn2d_spec(self.L, 2 * self.N), 22)
             self.dyn = engine.Dynamics(2, self.dyn_sd, self.L, 2 * self.N)
         self.net = engine.Unet1d(self.unet_sd)
-        self.guid = engine.Guidance(self.dyn, self.B, self.G, self.P, (-1.0, 1.0), pairs, self.T, self.N, self.sub, max_objects=pairs, contraction_dtype=contraction)
+        nch = pairs * self.n_obj                           # gradient chains (= distinct objects) per launch
+        self.guid = engine.Guidance(self.dyn, self.B, self.G, self.P, (-1.0, 1.0), nch, self.T, self.N, self.sub, max_objects=nch, contraction_dtype=contraction)
         self.sched = DDIMScheduler(num_train_timesteps=self.T)
         self.sched.set_timesteps(self.S)
         self.noise = synth.synth_noise(0, self.B, self.L).to(dev)
@@ -77,17 +83,24 @@ class Workload:
 
     def objects(self, step):
         """Synthetic objects of this step's pairs (distinct for every pair, rank and step), already on the device."""
-        base = (self.rank * 100_000 + step) * self.pairs
+        n = self.pairs * self.n_obj
+        base = (self.rank * 100_000 + step) * n
         mk = synth.synth_object_3d if self.kind == "3d" else synth.synth_object_2d
-        return torch.stack([mk(base + i, self.N) for i in range(self.pairs)]).to(self.dev)
+        return torch.stack([mk(base + i, self.N) for i in range(n)]).to(self.dev)
 
     def draw(self, step):
         if self.kind != "3d":
             return None
+        if self.ensemble:
+            return sampler.draw_ensemble_starts(self.guid, self.pairs, self.n_obj, self.S)
         return sampler.draw_chain_starts(self.guid, self.chains(step), self.S)
 
     def run(self, step, objs, predrawn):
         self.guid.set_objects(objs)                      # 3-D: builds the PointNet++ tables of every pair (timed)
+        if self.ensemble:                                # chain k averages the gradients of objects 4k..4k+3 (diffusion.py:637-647)
+            groups = [list(range(self.n_obj * k, self.n_obj * (k + 1))) for k in range(self.pairs)]
+            return sampler.guided_multi_object_groups(self.net, self.guid, self.sched, self.mode, self.noise, groups,
+                                                      [o for _, o in self.chains(step)], predrawn=predrawn)
         return sampler.guided_chains(self.net, self.guid, self.sched, self.mode, self.noise, self.chains(step), predrawn=predrawn)
 
 
@@ -204,7 +217,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     torch.manual_seed(1234 + rank)
-    pairs = a.pairs or (32 if a.workload == "3d" else 4)
+    pairs = a.pairs or {"3d": 32, "2d": 4, "3d_ensemble": 8}[a.workload]
     wl = Workload(a.workload, pairs, dev, rank, a.contraction)
 
     engine.prof_enable(False)
@@ -228,7 +241,7 @@ def main():
             peak = BF16_MFMA_PEAK_TFLOPS if a.contraction == "bf16" else F32_MFMA_PEAK_TFLOPS
             kname = "trunk_bf16_kernel" if a.contraction == "bf16" else "trunk_kernel"
             roof = {"bound": "mfma", "kernel": kname + " (fused dynamics trunk fwd+bwd)", "achieved": ach, "peak": peak,
-                    "unit": "TFLOP/s", "frac": ach / peak, "traffic": pmc_traffic(a.workload, kname), "launches": n, "avg_launch_ms": ms / n,
+                    "unit": "TFLOP/s", "frac": ach / peak, "traffic": pmc_traffic(wl.kind, kname), "launches": n, "avg_launch_ms": ms / n,
                     "algorithmic_flops_per_launch": flops / n, "share_of_step": (ms * 1e-3) / (secs / a.steps)}
     if rank != 0:
         if dist is not None:
@@ -239,12 +252,17 @@ def main():
         "metric": "guided samples/sec (full DDIM chain)", "value": samples / secs, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": secs / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.contraction, "data": "synthetic (random-init checkpoints, synthetic objects, seeded noise; SURVEY.md §8(d))",
-        "config": {"workload": ("3-D dynamics-guided sampling (BASELINE configs[2]; configs[3] at 8 GPUs): per GPU and step %d (object x objective) "
+        "config": {"workload": ("3-D guided sampling with a 4x guidance ensemble (BASELINE configs[4], guided_sample_multi_object semantics): per GPU "
+                                "and step %d chains x B=32 fingers, each step averaging the dynamics gradients of 4 objects (4 cond_fn per chain-step), "
+                                "G=45, P=5 -> R=36000 rows per cond_fn, sub_bs=512, 512-point objects, T=15/S=5"
+                                if a.workload == "3d_ensemble" else
+                                "3-D dynamics-guided sampling (BASELINE configs[2]; configs[3] at 8 GPUs): per GPU and step %d (object x objective) "
                                 "pairs x B=32 fingers, G=45, P=5 -> R=36000 rows per cond_fn, sub_bs=512, 512-point objects, T=15/S=5"
                                 if a.workload == "3d" else
                                 "2-D dynamics-guided sampling (BASELINE configs[1]): per GPU and step %d (object x objective) pairs x B=64 fingers, "
                                 "G=360, P=5 -> R=576000 rows per cond_fn, 100-vertex objects, T=15/S=5") % pairs,
-                   "pairs_per_gpu_per_step": pairs, "fingers_per_pair": wl.B, "denoise_steps": wl.S, "rows_per_cond_fn": wl.rows},
+                   "pairs_per_gpu_per_step": pairs, "fingers_per_pair": wl.B, "denoise_steps": wl.S, "rows_per_cond_fn": wl.rows,
+                   "cond_fn_per_chain_step": wl.n_obj},
         "ms_per_denoise_step": secs / a.steps / wl.S * 1e3,
         "ms_per_denoise_step_per_pair": secs / a.steps / wl.S / pairs * 1e3,
     }
@@ -254,7 +272,7 @@ def main():
         line["cpu_baseline"] = cpu_baseline(wl)
         line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
     if world == 1 and not a.no_extra:
-        other = "2d" if a.workload == "3d" else "3d"
+        other = "2d" if wl.kind == "3d" else "3d"
         del wl
         torch.cuda.empty_cache()
         w2 = Workload(other, 4 if other == "2d" else 32, dev, rank)

@@ -176,3 +176,44 @@ def guided_multi_object(unet: Unet1d, guid: Guidance, sched: DDIMScheduler, mode
         g = guid.grad(x.reshape(1, B, L).expand(n_obj, -1, -1).contiguous(), t, objectives, None, st)
         x = engine.ddim_guided_step(x, eps, g, n_obj, sched.coefficients(t), scale)
     return x.reshape(B, L, 1)
+
+
+def draw_ensemble_starts(guid: Guidance, n_groups: int, n_obj: int, n_steps: int, streams: Optional[Sequence[StartStream]] = None):
+    """FPS starts of ``n_groups`` independent multi-object chains: every group has its own generator stream and consumes it as
+    ``guided_sample_multi_object`` does - step after step, inside a step object after object (generator/diffusion.py:641-643).
+    Returned as (n_steps, n_obj, n_groups, starts_per_call): the launch order of ``guided_multi_object_groups``."""
+    streams = streams or [StartStream(guid.cfg.num_object_points, guid.cfg.sub_batch_size) for _ in range(n_groups)]
+    out = np.zeros((n_steps, n_obj, n_groups, guid.starts_per_call), dtype=np.int64)
+    for k in range(n_groups):
+        for si in range(n_steps):
+            for j in range(n_obj):
+                out[si, j, k] = streams[k].call(guid.rows)
+    return out
+
+
+def guided_multi_object_groups(unet: Unet1d, guid: Guidance, sched: DDIMScheduler, mode: str, noise: torch.Tensor,
+                               groups: Sequence[Sequence[int]], opt_objs: Sequence[str], streams: Optional[Sequence[StartStream]] = None,
+                               predrawn: Optional[np.ndarray] = None) -> torch.Tensor:
+    """Several independent ``guided_sample_multi_object`` chains (:637-647) in the same launches: chain k averages the guidance
+    gradients of the objects ``groups[k]`` for objective ``opt_objs[k]`` (a guidance ensemble: n_obj dynamics-gradient
+    evaluations per denoise step).  All groups have the same size.  Launch order of the gradient chains is object-major,
+    (j, k) -> j * K + k, so the mean over j is one strided reduction for every group at once.  Returns (K, B, L, 1)."""
+    K, n_obj, (B, L, _) = len(groups), len(groups[0]), noise.shape
+    assert all(len(g) == n_obj for g in groups) and len(opt_objs) == K
+    if any(o == 'convergence' for o in opt_objs):
+        raise ValueError("the reference never runs the multi-object loop with 'convergence' (generator/diffusion.py:337)")
+    dev = noise.device
+    is3d = mode == 'point_3d'
+    S = len(sched.timesteps)
+    objectives = [make_objective(opt_objs[k], groups[k][j]) for j in range(n_obj) for k in range(K)]
+    if is3d and predrawn is None:
+        predrawn = draw_ensemble_starts(guid, K, n_obj, S, streams)
+    scale = classifier_scale(mode, opt_objs[0], multi=True)
+    x = noise.reshape(1, B, L).expand(K, -1, -1).contiguous().to(torch.float32)
+    for si, t in enumerate(sched.timesteps):
+        t = int(t)
+        ts = torch.full((K * B,), t, dtype=torch.int32, device=dev)
+        eps = unet.forward(x.reshape(K * B, L, 1), ts).reshape(K, B, L)
+        g = guid.grad(x.repeat(n_obj, 1, 1), t, objectives, None, predrawn[si].reshape(-1) if is3d else None)     # (n_obj*K, B, L)
+        x = engine.ddim_guided_step(x, eps, g, n_obj, sched.coefficients(t), scale)
+    return x.reshape(K, B, L, 1)

@@ -117,3 +117,48 @@ def test_bf16_full_size_properties(dev):
     assert bool(torch.isfinite(b).all())
     e0, e1 = util.rel_l2((-b[0]).cpu(), a[0].cpu()), util.rel_l2(b[1].cpu(), a[1].cpu())
     assert e0 < 8e-2 and e1 < 8e-2, (e0, e1)
+
+
+def test_ensemble_groups_equal_single_chains(dev):
+    """guided_multi_object_groups (configs[4]'s guidance ensemble, several chains per launch) is bit-identical to running
+    guided_multi_object chain by chain - float32 and bf16, 2-D and 3-D."""
+    from dgdm_amd.scheduler import DDIMScheduler
+    T, S = 15, 5
+    s = DDIMScheduler(num_train_timesteps=T)
+    s.set_timesteps(S)
+    net = engine.Unet1d(util.unet_sd(11))
+    # 2-D
+    B, G, P, L, nv = 3, 6, 2, 14, 100
+    dyn = engine.Dynamics(2, util.dyn2d_sd(22, nv), L, 2 * nv)
+    gd = engine.Guidance(dyn, B, G, P, (-1.0, 1.0), 6, T, nv, 0, max_objects=4)
+    gd.set_objects(torch.stack([synth.synth_object_2d(i, nv) for i in range(4)]).to(dev))
+    noise = synth.synth_noise(0, B, L).to(dev)
+    groups, objs = [[0, 1, 2], [3, 1, 0]], ['rotate_clockwise', 'shift_up']
+    for dt in ("f32", "bf16"):
+        gd.set_contraction_dtype(dt)
+        both = sampler.guided_multi_object_groups(net, gd, s, 'point', noise, groups, objs)
+        for k in range(2):
+            one = sampler.guided_multi_object(net, gd, s, 'point', noise, groups[k], objs[k])
+            assert torch.equal(both[k], one), (dt, k)
+    # 3-D
+    B, G, P, L, sub = 2, 3, 2, 42, 5
+    dyn3 = engine.Dynamics(3, util.dyn3d_sd(33), L)
+    g3 = engine.Guidance(dyn3, B, G, P, (-1.0, 1.0), 4, T, 512, sub, max_objects=3, contraction_dtype="bf16")
+    g3.set_objects(torch.stack([synth.synth_object_3d(80 + i) for i in range(3)]).to(dev))
+    noise = synth.synth_noise(0, B, L).to(dev)
+    groups, objs = [[0, 1], [2, 0]], ['shift_left', 'clockwise_up']
+    gens = [torch.Generator().manual_seed(100 + k) for k in range(2)]
+    draws = [[torch.randint(0, 512, (2 * g3.rows,), generator=gens[k]) for _ in range(S * 2)] for k in range(2)]
+
+    class Fixed(sampler.StartStream):
+        def __init__(self, seq):
+            super().__init__(512, sub)
+            self.seq = list(seq)
+
+        def call(self, rows):
+            return self.seq.pop(0).numpy()
+
+    both = sampler.guided_multi_object_groups(net, g3, s, 'point_3d', noise, groups, objs, streams=[Fixed(draws[0]), Fixed(draws[1])])
+    for k in range(2):
+        one = sampler.guided_multi_object(net, g3, s, 'point_3d', noise, groups[k], objs[k], starts=Fixed(draws[k]))
+        assert torch.equal(both[k], one), k
