@@ -10,6 +10,7 @@
 struct DgdmUnet1d {
     dgdm::Blob blob;
     dgdm::UnetParams p;
+    dgdm::DevBuf p_dev;     // copy of `p` in device memory (kernel argument)
 };
 
 namespace dgdm {

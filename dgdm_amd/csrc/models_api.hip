@@ -141,6 +141,7 @@ extern "C" int dgdm_unet1d_create(DgdmUnet1d **out, const DgdmTensor *tensors, i
     p.down_w = bl.at(o_dw); p.down_b = bl.at(o_db); p.up_w_even = bl.at(o_uwe); p.up_w_odd = bl.at(o_uwo); p.up_b = bl.at(o_ub);
     p.fin_w = bl.at(o_fw); p.fin_b = bl.at(o_fb); p.fin_gw = bl.at(o_fgw); p.fin_gb = bl.at(o_fgb);
     p.out_w = bl.at(o_ow); p.out_b = bl.at(o_ob);
+    if ((rc = m->p_dev.upload(&p, sizeof p))) return rc;
     *out = m.release();
     return DGDM_OK;
 }
@@ -150,7 +151,7 @@ extern "C" void dgdm_unet1d_destroy(DgdmUnet1d *m) { delete m; }
 extern "C" int dgdm_unet1d_forward(DgdmUnet1d *m, const float *sample_dev, const int32_t *timestep_dev, float *eps_dev, int B, int L,
                                    void *stream) {
     DGDM_REQUIRE(m && sample_dev && timestep_dev && eps_dev && B >= 0 && L > 0, DGDM_EINVAL, "dgdm_unet1d_forward: bad argument");
-    return unet_launch(m->p, sample_dev, timestep_dev, eps_dev, B, L, (hipStream_t)stream);
+    return unet_launch(m->p, m->p_dev.as<UnetParams>(), sample_dev, timestep_dev, eps_dev, B, L, (hipStream_t)stream);
 }
 
 // ================================================================================================ dynamics

@@ -15,7 +15,6 @@ struct UnetRes {
 
 struct UnetParams {
     int d0, d1, dsed, groups, cmax;
-    int bufA, bufS;                              // LDS buffer sizes in floats (set per launch from L)
     const float *freqs;                          // SinusoidalPosEmb frequencies [dsed/2]
     const float *se1_wt, *se1_b, *se3_wt, *se3_b;
     UnetRes res[8];                              // down0.0 down0.1 down1.0 down1.1 mid0 mid1 up0.0 up0.1
@@ -25,6 +24,7 @@ struct UnetParams {
     const float *out_w, *out_b;                  // final_conv.1 (d0 -> 1)
 };
 
-int unet_launch(const UnetParams &p, const float *sample, const int *timestep, float *eps, int B, int L, hipStream_t s);
+// p: host copy (sizes); p_dev: the same struct in device memory (what the kernel reads)
+int unet_launch(const UnetParams &p, const UnetParams *p_dev, const float *sample, const int *timestep, float *eps, int B, int L, hipStream_t s);
 
 }  // namespace dgdm

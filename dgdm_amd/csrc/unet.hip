@@ -18,13 +18,26 @@
 namespace dgdm {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// Activations live in LDS.  The device functions below are real calls (not inlined into the kernel), so a plain `float *`
+// parameter would be a generic pointer: every access a flat_load/flat_store with 64-bit address arithmetic on the VALU
+// (measured: 5.9 VALU instructions per MFMA in this kernel).  Address-space-3 pointers give ds_read/ds_write with
+// immediate offsets.
+typedef __attribute__((address_space(3))) float lds_f;
+typedef __attribute__((address_space(3))) f32x4 lds_f4;
+// ... and the weight images are global: a generic pointer loaded from the parameter struct would make them flat_load, which
+// also counts on lgkmcnt, so every wait for an LDS operand would wait for the weight prefetch as well.
+typedef const __attribute__((address_space(1))) f32x4 glb_f4;
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 __device__ __forceinline__ float mish(float x) {
-    // torch.nn.functional.mish = x * tanh(softplus(x)), softplus threshold 20
-    const float sp = x > 20.f ? x : log1pf(expf(x));
-    return x * tanhf(sp);
+    // torch.nn.functional.mish = x * tanh(softplus(x)).  With e = exp(x): tanh(log(1 + e)) = n / (n + 2), n = e (e + 2), which
+    // needs one exp and one division instead of log1p + tanh.  torch's softplus returns x above its threshold 20, where
+    // tanh(x) rounds to 1 in float32 - as does n / (n + 2) (n > 2e17) - so clamping the exponent at 20 reproduces that branch
+    // and keeps e*e finite.  Relative error ~2e-7 (one exp, one rounding per operation).
+    const float e = __expf(fminf(x, 20.f));
+    const float n = e * (e + 2.f);
+    return x * (n / (n + 2.f));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -45,7 +58,7 @@ struct ConvArgs {
 };
 
 template <int NT, int MT, int MODE>
-__device__ void conv_mfma(const ConvArgs a, const float *in, int CPi, float *out, int CPo, int Lout) {
+__device__ void conv_mfma(const ConvArgs a, const lds_f *in, int CPi, lds_f *out, int CPo, int Lout) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     const int j = lane & 15, q = lane >> 4;
     const int groups = a.cin >> 4, mtiles = a.cout >> 4;
@@ -55,13 +68,13 @@ __device__ void conv_mfma(const ConvArgs a, const float *in, int CPi, float *out
     const int iters = a.ntaps * groups;
     for (int mp = wave; mp * MT < mtiles; mp += nwave) {
         int mt[MT];
-        const float4 *w[MT];
-        float4 nxt[MT], nxt2[MT];                      // weight fragments of the next two iterations (two L2 latencies of cover)
+        glb_f4 *w[MT];
+        f32x4 nxt[MT], nxt2[MT];                       // weight fragments of the next two iterations (two L2 latencies of cover)
         f32x4 acc[MT][NT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             mt[m] = min(mp * MT + m, mtiles - 1);
-            w[m] = a.img + (size_t)mt[m] * iters * 64 + lane;
+            w[m] = (glb_f4 *)a.img + (size_t)mt[m] * iters * 64 + lane;
             nxt[m] = w[m][0];
             nxt2[m] = w[m][(size_t)min(1, iters - 1) * 64];
 #pragma unroll
@@ -72,10 +85,14 @@ __device__ void conv_mfma(const ConvArgs a, const float *in, int CPi, float *out
             float av[MT][4];
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                av[m][0] = nxt[m].x; av[m][1] = nxt[m].y; av[m][2] = nxt[m].z; av[m][3] = nxt[m].w;
+                av[m][0] = nxt[m][0]; av[m][1] = nxt[m][1]; av[m][2] = nxt[m][2]; av[m][3] = nxt[m][3];
                 nxt[m] = nxt2[m];
-                nxt2[m] = w[m][(size_t)min(it + 2, iters - 1) * 64];
             }
+            // hipcc otherwise proves nxt == w[it] and turns the two-deep prefetch back into load-then-use; an opaque index keeps it
+            int pre = min(it + 2, iters - 1);
+            asm volatile("" : "+v"(pre));
+#pragma unroll
+            for (int m = 0; m < MT; ++m) nxt2[m] = w[m][(size_t)pre * 64];
             const int off = (a.ioff0 + t * a.iostep) * CPi + g * 16;
             float bv[4][NT];
 #pragma unroll
@@ -99,9 +116,9 @@ __device__ void conv_mfma(const ConvArgs a, const float *in, int CPi, float *out
             for (int nt = 0; nt < NT; ++nt) {
                 const int l = nt * 16 + j;
                 if (l < Lout) {
-                    float4 *p = reinterpret_cast<float4 *>(out + ((l * a.ostride + a.ooff) + 2) * CPo + 4 * q + mt[m] * 16);
-                    float4 v = make_float4(acc[m][nt][0] + b4.x, acc[m][nt][1] + b4.y, acc[m][nt][2] + b4.z, acc[m][nt][3] + b4.w);
-                    if (MODE == 1) { const float4 u = *p; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+                    lds_f4 *p = (lds_f4 *)(out + ((l * a.ostride + a.ooff) + 2) * CPo + 4 * q + mt[m] * 16);
+                    f32x4 v = {acc[m][nt][0] + b4.x, acc[m][nt][1] + b4.y, acc[m][nt][2] + b4.z, acc[m][nt][3] + b4.w};
+                    if (MODE == 1) v += *p;
                     *p = v;
                 }
             }
@@ -110,14 +127,14 @@ __device__ void conv_mfma(const ConvArgs a, const float *in, int CPi, float *out
 }
 
 template <int NT, int MODE>
-__device__ void conv_nt(const ConvArgs &a, const float *in, int CPi, float *out, int CPo, int Lout) {
+__device__ void conv_nt(const ConvArgs &a, const lds_f *in, int CPi, lds_f *out, int CPo, int Lout) {
     // two output tiles per wave share the activation fragments when there are enough tiles to keep every wave busy
     if ((a.cout >> 4) >= 2 * (int)(blockDim.x >> 6)) conv_mfma<NT, 2, MODE>(a, in, CPi, out, CPo, Lout);
     else conv_mfma<NT, 1, MODE>(a, in, CPi, out, CPo, Lout);
 }
 
 template <int MODE>
-__device__ void conv(const ConvArgs &a, const float *in, int CPi, float *out, int CPo, int Lout) {
+__device__ void conv(const ConvArgs &a, const lds_f *in, int CPi, lds_f *out, int CPo, int Lout) {
     if (Lout <= 16) conv_nt<1, MODE>(a, in, CPi, out, CPo, Lout);
     else if (Lout <= 32) conv_nt<2, MODE>(a, in, CPi, out, CPo, Lout);
     else if (Lout <= 48) conv_nt<3, MODE>(a, in, CPi, out, CPo, Lout);
@@ -132,7 +149,7 @@ __device__ ConvArgs conv_args(const float *img, const float *bias, int cin, int 
     return a;
 }
 
-__device__ void zero_halo(float *buf, int CP, int C, int L) {
+__device__ void zero_halo(lds_f *buf, int CP, int C, int L) {
     for (int i = threadIdx.x; i < 4 * C; i += blockDim.x) {
         const int r = i / C, c = i - r * C;
         buf[(r < 2 ? r : L + r) * CP + c] = 0.f;
@@ -140,30 +157,49 @@ __device__ void zero_halo(float *buf, int CP, int C, int L) {
 }
 
 // GroupNorm(groups, C) -> Mish -> optional FiLM (scale*y + shift), in place on a [pos+2][CP] buffer.  (diffusion_utils.py:65-69,113-116)
-__device__ void gn_mish_film(float *buf, int CP, int C, int L, int groups, const float *__restrict__ gamma, const float *__restrict__ beta,
-                             const float *film /*LDS [2C] or null*/) {
+__device__ void gn_mish_film(lds_f *buf, int CP, int C, int L, int groups, const float *__restrict__ gamma, const float *__restrict__ beta,
+                             const lds_f *film /*LDS [2C] or null*/) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = blockDim.x >> 6;
     const int cg = C / groups, cnt = cg * L;
+    // lane -> (row offset, channel) without a division per element when the group width divides the wave (16 or 32 here)
+    const bool pow2 = cg <= 64 && (64 % cg) == 0;
+    const int rstep = pow2 ? 64 / cg : 0, c0 = pow2 ? lane % cg : 0, l0 = pow2 ? lane / cg : 0;
     for (int g = wave; g < groups; g += nwave) {
-        float *gb = buf + 2 * CP + g * cg;
-        float s = 0.f;
-        for (int i = lane; i < cnt; i += 64) { const int l = i / cg, c = i - l * cg; s += gb[l * CP + c]; }
-        const float mean = wave_sum(s) / (float)cnt;
-        float q = 0.f;
-        for (int i = lane; i < cnt; i += 64) { const int l = i / cg, c = i - l * cg; const float d = gb[l * CP + c] - mean; q = fmaf(d, d, q); }
-        const float rstd = 1.f / sqrtf(wave_sum(q) / (float)cnt + 1e-5f);
-        for (int i = lane; i < cnt; i += 64) {
-            const int l = i / cg, c = i - l * cg, ch = g * cg + c;
-            float y = (gb[l * CP + c] - mean) * rstd * gamma[ch] + beta[ch];
-            y = mish(y);
-            if (film) y = film[ch] * y + film[C + ch];
-            gb[l * CP + c] = y;
+        lds_f *gb = buf + 2 * CP + g * cg;
+        if (pow2) {
+            float s = 0.f;
+            for (int l = l0; l < L; l += rstep) s += gb[l * CP + c0];
+            const float mean = wave_sum(s) / (float)cnt;
+            float q = 0.f;
+            for (int l = l0; l < L; l += rstep) { const float d = gb[l * CP + c0] - mean; q = fmaf(d, d, q); }
+            const float rstd = 1.f / sqrtf(wave_sum(q) / (float)cnt + 1e-5f);
+            const int ch = g * cg + c0;
+            const float ga = gamma[ch] * rstd, be = beta[ch];
+            const float fs = film ? film[ch] : 1.f, fb = film ? film[C + ch] : 0.f;
+            for (int l = l0; l < L; l += rstep) {
+                float y = mish((gb[l * CP + c0] - mean) * ga + be);
+                if (film) y = fs * y + fb;
+                gb[l * CP + c0] = y;
+            }
+        } else {
+            float s = 0.f;
+            for (int i = lane; i < cnt; i += 64) { const int l = i / cg, c = i - l * cg; s += gb[l * CP + c]; }
+            const float mean = wave_sum(s) / (float)cnt;
+            float q = 0.f;
+            for (int i = lane; i < cnt; i += 64) { const int l = i / cg, c = i - l * cg; const float d = gb[l * CP + c] - mean; q = fmaf(d, d, q); }
+            const float rstd = 1.f / sqrtf(wave_sum(q) / (float)cnt + 1e-5f);
+            for (int i = lane; i < cnt; i += 64) {
+                const int l = i / cg, c = i - l * cg, ch = g * cg + c;
+                float y = mish((gb[l * CP + c] - mean) * (gamma[ch] * rstd) + beta[ch]);
+                if (film) y = film[ch] * y + film[C + ch];
+                gb[l * CP + c] = y;
+            }
         }
     }
 }
 
 // y[n] = b[n] + sum_k WT[k][n] x[k],  x in LDS
-__device__ void matvec(const float *__restrict__ WT, const float *__restrict__ b, const float *x, float *y, int K, int N) {
+__device__ void matvec(const float *__restrict__ WT, const float *__restrict__ b, const lds_f *x, lds_f *y, int K, int N) {
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
         float acc = 0.f;
         for (int k = 0; k < K; ++k) acc = fmaf(WT[(size_t)k * N + n], x[k], acc);
@@ -171,11 +207,11 @@ __device__ void matvec(const float *__restrict__ WT, const float *__restrict__ b
     }
 }
 
-struct Bufs { float *A, *B, *C, *D, *film, *cond, *tmp, *xin; };
+struct Bufs { lds_f *A, *B, *C, *D, *film, *cond, *tmp, *xin; };
 
 // ConditionalResidualBlock1D.forward (diffusion_utils.py:101-120): x(in, cin channels) -> out; t1 scratch.
 // `out` may be a wider buffer (row stride CPout >= cout + 4): the concat buffer of the up path.
-__device__ void res_block(const UnetRes &w, const float *in, float *t1, float *out, int CPout, int L, int cond_dim, int groups, const Bufs &s) {
+__device__ void res_block(const UnetRes &w, const lds_f *in, lds_f *t1, lds_f *out, int CPout, int L, int cond_dim, int groups, const Bufs s) {
     const int CPi = w.cin + 4, CPo = w.cout + 4;
     matvec(w.cond_wt, w.cond_b, s.cond, s.film, cond_dim, 2 * w.cout);     // cond_encoder: Mish already applied to s.cond
     if (w.cin == 1) {   // first block: single input channel held in s.xin[pos + 2]; conv k5 and the 1x1 residual on the VALU
@@ -214,17 +250,21 @@ __device__ void res_block(const UnetRes &w, const float *in, float *t1, float *o
     __syncthreads();
 }
 
-__global__ __launch_bounds__(512) void unet_kernel(const UnetParams p, const float *__restrict__ sample, const int *__restrict__ timestep,
-                                                   float *__restrict__ eps, int L) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+// `pp` points at the UnetParams in device memory: passing the struct by value and handing references to its members to the
+// (non-inlined) block functions made the compiler copy all 1.1 KB of it to scratch in every thread.
+__global__ __launch_bounds__(512) void unet_kernel(const UnetParams *__restrict__ pp, int bufA, int bufS, const float *__restrict__ sample,
+                                                   const int *__restrict__ timestep, float *__restrict__ eps, int L) {
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    lds_f *lds = (lds_f *)lds_raw;
+    const UnetParams &p = *pp;
     const int b = blockIdx.x, t = threadIdx.x;
     const int L2 = (L - 1) / 2 + 1;                 // Conv1d(k3, s2, p1)
     Bufs s;
     s.A = lds;
-    s.B = s.A + p.bufA;
-    s.C = s.B + p.bufS;
-    s.D = s.C + p.bufS;
-    s.film = s.D + p.bufS;
+    s.B = s.A + bufA;
+    s.C = s.B + bufS;
+    s.D = s.C + bufS;
+    s.film = s.D + bufS;
     s.cond = s.film + 2 * p.cmax;
     s.tmp = s.cond + p.dsed;
     s.xin = s.tmp + 4 * p.dsed;
@@ -289,23 +329,22 @@ __global__ __launch_bounds__(512) void unet_kernel(const UnetParams p, const flo
     }
 }
 
-int unet_launch(const UnetParams &p_in, const float *sample, const int *timestep, float *eps, int B, int L, hipStream_t s) {
+int unet_launch(const UnetParams &p, const UnetParams *p_dev, const float *sample, const int *timestep, float *eps, int B, int L, hipStream_t s) {
     if (B <= 0) return DGDM_OK;
-    UnetParams p = p_in;
     const int L2 = (L - 1) / 2 + 1;
     DGDM_REQUIRE(2 * L2 == L, DGDM_EINVAL, "U-Net needs an even number of control points (got %d): the skip concat of the reference "
                  "requires ConvTranspose1d(4,2,1) to restore L", L);
     DGDM_REQUIRE(L <= 64, DGDM_EINVAL, "U-Net kernel supports up to 64 control points (got %d)", L);
-    p.bufS = std::max((L + 4) * (p.d0 + 4), (L2 + 4) * (p.d1 + 4));
-    p.bufA = std::max((L + 4) * (p.d0 + 4), (L2 + 4) * (2 * p.d1 + 4));
-    const size_t lds_floats = (size_t)p.bufA + 3 * (size_t)p.bufS + 2 * p.cmax + p.dsed + 4 * p.dsed + (L + 4) + 16;
+    const int bufS = std::max((L + 4) * (p.d0 + 4), (L2 + 4) * (p.d1 + 4));
+    const int bufA = std::max((L + 4) * (p.d0 + 4), (L2 + 4) * (2 * p.d1 + 4));
+    const size_t lds_floats = (size_t)bufA + 3 * (size_t)bufS + 2 * p.cmax + p.dsed + 4 * p.dsed + (L + 4) + 16;
     DGDM_REQUIRE(lds_floats * 4 <= 160 * 1024, DGDM_EINVAL, "U-Net activations (%zu B) exceed the 160 KiB LDS", lds_floats * 4);
     static bool attr_set = false;
     if (!attr_set) {
         DGDM_HIP_CHECK(hipFuncSetAttribute((const void *)unet_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(unet_kernel, dim3(B), dim3(512), lds_floats * 4, s, p, sample, timestep, eps, L);
+    hipLaunchKernelGGL(unet_kernel, dim3(B), dim3(512), lds_floats * 4, s, p_dev, bufA, bufS, sample, timestep, eps, L);
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
 }
