@@ -45,7 +45,7 @@ struct DgdmGuidance {
     bool bf16 = false;                           // contractions of the trunk on bf16 MFMA (dgdm_guidance_set_contraction_dtype)
     static constexpr int NBUILD = 3;             // objects whose tables are built concurrently (own stream + temporaries each)
     DevBuf pool_xyz, pool_fps1, pool_fps2, pool_flags;   // [n_objects] x per-object FPS tables (ObjectTables point into these)
-    DevBuf tmpF1[NBUILD], tmpU[NBUILD], tmpY[NBUILD], tmpL2[NBUILD], vlist;      // 3-D table-build temporaries
+    DevBuf tmpF1[NBUILD], tmpU[NBUILD], tmpY[NBUILD], tmpL2[NBUILD], tmpOff[NBUILD], tmpPairs[NBUILD], tmpRank[NBUILD], vlist;      // 3-D table-build temporaries
     hipStream_t bstream[NBUILD] = {nullptr, nullptr, nullptr};
     hipEvent_t bev[NBUILD] = {nullptr, nullptr, nullptr}, bstart = nullptr;
     DevBuf V, genc, atab, chainbias, timepart, ttmp, partial, objdev, objidx, xobj, starts, order, xchains;
@@ -170,9 +170,13 @@ int DgdmGuidance::build_object(int oi, int slot, hipStream_t s) {
     const float *xyz = t.xyz;                                                                                  // T1: set_objects, batched
     if ((rc = pn_sa1(xyz, N, w, tF1.as<float>(), s))) return rc;                                               // T2
     if ((rc = linear(tF1.as<float>(), 128, w.sa2_wf_t, w.sa2_b0, nullptr, 1, tU.as<float>(), 128, N, 128, 128, ACT_NONE, false, s))) return rc;  // T3
-    if ((rc = pn_pairs(xyz, N, tU.as<float>(), w, tY.as<float>(), s))) return rc;                              // T4
-    if ((rc = pn_crowd(xyz, N, w, t.crowded.as<int>(), t.clist.as<int>(), t.clist.as<int>() + N, s))) return rc;
-    if ((rc = pn_l2(xyz, N, w, t.fps1, vlist.as<int>(), N, tY.as<float>(), tL2.as<float>(), t.clist.as<int>(), t.clist.as<int>() + N, s))) return rc;   // T5
+    DevBuf &tOff = tmpOff[slot], &tPairs = tmpPairs[slot], &tRank = tmpRank[slot];
+    if ((rc = tOff.alloc((size_t)(N + 1) * sizeof(int))) || (rc = tPairs.alloc((size_t)N * N * sizeof(int))) || (rc = tRank.alloc((size_t)N * N * sizeof(short))))
+        return rc;
+    if ((rc = pn_crowd(xyz, N, w, t.crowded.as<int>(), t.clist.as<int>(), t.clist.as<int>() + N, tOff.as<int>(), tPairs.as<int>(), tRank.as<short>(), s))) return rc;
+    if ((rc = pn_pairs(xyz, N, tU.as<float>(), w, tPairs.as<int>(), tOff.as<int>(), tY.as<float>(), s))) return rc;       // T4
+    if ((rc = pn_l2(xyz, N, w, t.fps1, vlist.as<int>(), N, tY.as<float>(), tL2.as<float>(), t.clist.as<int>(), t.clist.as<int>() + N,
+                    tOff.as<int>(), tRank.as<short>(), s))) return rc;                                                     // T5
     if ((rc = pn_z(xyz, N, N, w, tL2.as<float>(), t.Z.as<float>(), t.clist.as<int>(), t.clist.as<int>() + N, s))) return rc;                        // T6
     return pn_m0(t.fps2, t.crowded.as<int>(), N, t.Z.as<float>(), t.M0.as<float>(), t.cl2.as<int>(), t.cnt2.as<int>(), s);              // T7
 }
@@ -408,11 +412,12 @@ int pointnet_rows(DgdmDynamics *m, const float *xyz_dev /*[rows][3][N]*/, const 
         groups[gid].rows.push_back(r);
     }
     const PnWeights w = m->pn();
-    DevBuf xyz, fps1, F1, U, Y, L2, Z, vlist, slotmap, starts, chains, out, crowded, clist;
+    DevBuf xyz, fps1, F1, U, Y, L2, Z, vlist, slotmap, starts, chains, out, crowded, clist, poff, pairs, prank;
     int rc;
     if ((rc = xyz.alloc((size_t)N * 12)) || (rc = fps1.alloc((size_t)N * 512 * 4)) || (rc = F1.alloc((size_t)N * 512)) || (rc = U.alloc((size_t)N * 512)) ||
         (rc = Y.alloc((size_t)N * N * 1024)) || (rc = chains.alloc(sizeof(XobjChain))) || (rc = crowded.alloc((size_t)N * 4)) ||
-        (rc = clist.alloc((size_t)(N + 1) * 4)))
+        (rc = clist.alloc((size_t)(N + 1) * 4)) || (rc = poff.alloc((size_t)(N + 1) * 4)) || (rc = pairs.alloc((size_t)N * N * 4)) ||
+        (rc = prank.alloc((size_t)N * N * 2)))
         return rc;
     for (size_t gi = 0; gi < groups.size(); ++gi) {
         const std::vector<int> &rws = groups[gi].rows;
@@ -435,9 +440,10 @@ int pointnet_rows(DgdmDynamics *m, const float *xyz_dev /*[rows][3][N]*/, const 
         if ((rc = pn_fps_table(x, N, N, 512, fps1.as<int>(), nullptr, s))) return rc;
         if ((rc = pn_sa1(x, N, w, F1.as<float>(), s))) return rc;
         if ((rc = linear(F1.as<float>(), 128, w.sa2_wf_t, w.sa2_b0, nullptr, 1, U.as<float>(), 128, N, 128, 128, ACT_NONE, false, s))) return rc;
-        if ((rc = pn_pairs(x, N, U.as<float>(), w, Y.as<float>(), s))) return rc;
-        if ((rc = pn_crowd(x, N, w, crowded.as<int>(), clist.as<int>(), clist.as<int>() + N, s))) return rc;
-        if ((rc = pn_l2(x, N, w, fps1.as<int>(), vlist.as<int>(), nv, Y.as<float>(), L2.as<float>(), clist.as<int>(), clist.as<int>() + N, s))) return rc;
+        if ((rc = pn_crowd(x, N, w, crowded.as<int>(), clist.as<int>(), clist.as<int>() + N, poff.as<int>(), pairs.as<int>(), prank.as<short>(), s))) return rc;
+        if ((rc = pn_pairs(x, N, U.as<float>(), w, pairs.as<int>(), poff.as<int>(), Y.as<float>(), s))) return rc;
+        if ((rc = pn_l2(x, N, w, fps1.as<int>(), vlist.as<int>(), nv, Y.as<float>(), L2.as<float>(), clist.as<int>(), clist.as<int>() + N,
+                        poff.as<int>(), prank.as<short>(), s))) return rc;
         if ((rc = pn_z(x, N, nv, w, L2.as<float>(), Z.as<float>(), clist.as<int>(), clist.as<int>() + N, s))) return rc;
         XobjChain ch{};
         ch.xyz = x; ch.fps1 = fps1.as<int>(); ch.slot_of_start = slotmap.as<int>(); ch.Z = Z.as<float>(); ch.fps2 = nullptr; ch.flags = nullptr; ch.crowded = crowded.as<int>(); ch.N = N;

@@ -45,10 +45,11 @@ struct XobjParams {
 
 int pn_fps_table(const float *xyz, int N, int nv, int npoint, int *out, int *flags, hipStream_t s, int nobj = 1);
 int pn_sa1(const float *xyz, int N, const PnWeights &w, float *F1, hipStream_t s);
-int pn_pairs(const float *xyz, int N, const float *U, const PnWeights &w, float *Y, hipStream_t s);
-int pn_crowd(const float *xyz, int N, const PnWeights &w, int *crowded, int *clist, int *ncr, hipStream_t s);
+// crowded/clist/ncr: centres whose ball holds > 64 points; off [N+1], pairs [<= N*N], rank [N][N]: the in-radius pair list (T4/T5)
+int pn_crowd(const float *xyz, int N, const PnWeights &w, int *crowded, int *clist, int *ncr, int *off, int *pairs, short *rank, hipStream_t s);
+int pn_pairs(const float *xyz, int N, const float *U, const PnWeights &w, const int *pairs, const int *off, float *Y, hipStream_t s);
 int pn_l2(const float *xyz, int N, const PnWeights &w, const int *fps1, const int *vlist, int nv, const float *Y, float *L2,
-          const int *clist, const int *ncr, hipStream_t s);
+          const int *clist, const int *ncr, const int *off, const short *rank, hipStream_t s);
 int pn_z(const float *xyz, int N, int nv, const PnWeights &w, const float *L2, float *Z, const int *clist, const int *ncr, hipStream_t s);
 int pn_m0(const int *fps2, const int *crowded, int N, const float *Z0, float *M0, int *cl2, int *cnt2, hipStream_t s);
 int pn_xobj(const XobjParams &p, hipStream_t s);

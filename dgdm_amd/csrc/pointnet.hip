@@ -178,18 +178,21 @@ __global__ __launch_bounds__(128) void sa1_kernel(const float *__restrict__ xyz,
 }
 
 // ------------------------------------------------------------------------------------------------ T4
-// Y[c][k][256] = ReLU(W2b' ReLU(U[k] + Vx (xyz_k - xyz_c)) + b2b') for all ordered pairs of points.
-// One wave = centre c x 32 consecutive k.  Layer 128 -> 256 on the MFMA chain.
+// Y[pair][256] = ReLU(W2b' ReLU(U[k] + Vx (xyz_k - xyz_c)) + b2b') for every ordered pair (centre c, point k) with k inside
+// c's r = 0.4 ball - the only pairs sa2's ball query can ever select, whatever the ordering (crowd_kernel / nbr_fill_kernel
+// build the list: pairs[off[c] + j] = (c << 16 | k), j-th in-radius point of c in index order).
+// One wave = 32 consecutive pairs.  Layer 128 -> 256 on the MFMA chain.
 __global__ __launch_bounds__(256, 1) void pair_kernel(const float *__restrict__ xyz, int N, const float *__restrict__ U /*[N][128]*/,
                                                       const float *__restrict__ vx /*[3][128]*/, const float4 *__restrict__ Wimg,
-                                                      const float *__restrict__ bias, float *__restrict__ Y) {
+                                                      const float *__restrict__ bias, const int *__restrict__ pairs,
+                                                      const int *__restrict__ off /*[N+1]*/, float *__restrict__ Y) {
     const int lane = threadIdx.x & 63, n = lane & 31, h4 = (lane >> 5) * 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int kt = (N + 31) / 32;
+    const int total = off[N];
     const int tile = blockIdx.x * 4 + wave;
-    if (tile >= N * kt) return;
-    const int c = tile / kt, k0 = (tile - c * kt) * 32;
-    const int k = min(k0 + n, N - 1);
+    if (tile * 32 >= total) return;
+    const int p = min(tile * 32 + n, total - 1);
+    const int ck = pairs[p], c = ck >> 16, k = ck & 0xffff;
     const float dx = xyz[3 * k] - xyz[3 * c], dy = xyz[3 * k + 1] - xyz[3 * c + 1], dz = xyz[3 * k + 2] - xyz[3 * c + 2];
     f32x16 in[4], out[8];
     const float *urow = U + (size_t)k * 128;
@@ -206,8 +209,8 @@ __global__ __launch_bounds__(256, 1) void pair_kernel(const float *__restrict__ 
         }
     }
     chain_layer<4, 8, CHAIN_BIAS>(Wimg, bias, in, out, lane);
-    if (k0 + n < N) {
-        float *dst = Y + ((size_t)c * N + k) * 256;
+    if (tile * 32 + n < total) {
+        float *dst = Y + (size_t)p * 256;
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
 #pragma unroll
@@ -227,14 +230,14 @@ __global__ __launch_bounds__(256, 1) void pair_kernel(const float *__restrict__ 
 // (more than 64 in-radius points: the ball query truncates, and which 64 survive depends on the variant's order) need
 // one value per variant.  crowded[c] in {0,1}; clist = the crowded centres, *ncr their number.
 __global__ __launch_bounds__(1024) void crowd_kernel(const float *__restrict__ xyz, int N, float r2, int *__restrict__ crowded,
-                                                     int *__restrict__ clist, int *__restrict__ ncr) {
-    __shared__ int wcount[16];
+                                                     int *__restrict__ clist, int *__restrict__ ncr, int *__restrict__ off /*[N+1]*/) {
+    __shared__ int wcount[16], wsum[16];
     const int c = threadIdx.x, lane = c & 63, wave = c >> 6;
     bool cr = false;
+    int cnt = 0;
     if (c < N) {
         const float cx = xyz[3 * c], cy = xyz[3 * c + 1], cz = xyz[3 * c + 2];
         const float cn = sq3(cx, cy, cz);
-        int cnt = 0;
         for (int k = 0; k < N; ++k) {
             const float x = xyz[3 * k], y = xyz[3 * k + 1], z = xyz[3 * k + 2];
             cnt += !(sqdist_expanded(cx, cy, cz, cn, x, y, z, sq3(x, y, z)) > r2);
@@ -243,25 +246,60 @@ __global__ __launch_bounds__(1024) void crowd_kernel(const float *__restrict__ x
         crowded[c] = cr ? 1 : 0;
     }
     const unsigned long long m = __ballot(cr);
+    // exclusive prefix sum of the in-radius counts: off[c] = first row of centre c in the pair list, off[N] = number of pairs
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
     if (lane == 0) wcount[wave] = __popcll(m);
     __syncthreads();
-    int base = 0;
-    for (int w = 0; w < wave; ++w) base += wcount[w];
+    int base = 0, sbase = 0;
+    for (int w = 0; w < wave; ++w) { base += wcount[w]; sbase += wsum[w]; }
     if (cr) clist[base + __popcll(m & ((1ull << lane) - 1ull))] = c;
+    if (c < N) off[c] = sbase + incl - cnt;
     if (c == 0) {
-        int tot = 0;
-        for (int w = 0; w < 16; ++w) tot += wcount[w];
+        int tot = 0, stot = 0;
+        for (int w = 0; w < 16; ++w) { tot += wcount[w]; stot += wsum[w]; }
         *ncr = tot;
+        off[N] = stot;
     }
 }
 
-// L2[slot][c][256] = max over the first 64 in-radius (r=0.4) positions of variant vlist[slot] of Y[c][point].
+// Pair list and lookup for T4/T5.  One wave per centre c: rank[c][k] = position of point k among c's in-radius points in
+// index order (or -1), pairs[off[c] + rank] = (c << 16 | k).
+__global__ __launch_bounds__(256) void nbr_fill_kernel(const float *__restrict__ xyz, int N, float r2, const int *__restrict__ off,
+                                                       int *__restrict__ pairs, short *__restrict__ rank /*[N][N]*/) {
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= N) return;
+    const float cx = xyz[3 * c], cy = xyz[3 * c + 1], cz = xyz[3 * c + 2];
+    const float cn = sq3(cx, cy, cz);
+    const int o = off[c];
+    int seen = 0;
+    for (int k0 = 0; k0 < N; k0 += 64) {
+        const int k = k0 + lane;
+        bool in = false;
+        if (k < N) {
+            const float x = xyz[3 * k], y = xyz[3 * k + 1], z = xyz[3 * k + 2];
+            in = !(sqdist_expanded(cx, cy, cz, cn, x, y, z, sq3(x, y, z)) > r2);
+        }
+        const unsigned long long m = __ballot(in);
+        const int r = seen + __popcll(m & ((1ull << lane) - 1ull));
+        if (k < N) rank[(size_t)c * N + k] = in ? (short)r : (short)-1;
+        if (in) pairs[o + r] = (c << 16) | k;
+        seen += __popcll(m);
+    }
+}
+
+// L2[slot][c][256] = max over the first 64 in-radius (r=0.4) positions of variant vlist[slot] of Y[(c, point)].
 // mode 0: slot 0, every centre (blockIdx.y*4 + wave).  mode 1: slots >= 1, crowded centres only (clist[blockIdx.y]); the
 // waves of a workgroup then share the centre so its Y slab stays cache resident.
 __global__ __launch_bounds__(256) void l2_kernel(const float *__restrict__ xyz, int N, float r2, const int *__restrict__ fps1 /*[N][512]*/,
                                                  const int *__restrict__ vlist, int nv, const float *__restrict__ Y,
                                                  float *__restrict__ L2 /*[nv][N][256]*/, int mode, const int *__restrict__ clist,
-                                                 const int *__restrict__ ncr) {
+                                                 const int *__restrict__ ncr, const int *__restrict__ off, const short *__restrict__ rank) {
     __shared__ int sel[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int c, slot;
@@ -276,6 +314,7 @@ __global__ __launch_bounds__(256) void l2_kernel(const float *__restrict__ xyz, 
         if (slot >= nv) return;
     }
     const int *perm = fps1 + (size_t)vlist[slot] * 512;
+    const short *rk = rank + (size_t)c * N;
     const float cx = xyz[3 * c], cy = xyz[3 * c + 1], cz = xyz[3 * c + 2];
     const float cn = sq3(cx, cy, cz);
     int cnt = 0;
@@ -284,13 +323,13 @@ __global__ __launch_bounds__(256) void l2_kernel(const float *__restrict__ xyz, 
         const float x = xyz[3 * pk], y = xyz[3 * pk + 1], z = xyz[3 * pk + 2];
         const bool in = !(sqdist_expanded(cx, cy, cz, cn, x, y, z, sq3(x, y, z)) > r2);
         const unsigned long long m = __ballot(in);
-        const int rank = cnt + __popcll(m & ((1ull << lane) - 1ull));
-        if (in && rank < 64) sel[wave][rank] = pk;
+        const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+        if (in && pos < 64) sel[wave][pos] = rk[pk];      // row of (c, pk) inside c's block of the pair list
         cnt += __popcll(m);
     }
     cnt = min(cnt, 64);
     __builtin_amdgcn_wave_barrier();
-    const float *slab = Y + (size_t)c * N * 256 + lane * 4;
+    const float *slab = Y + (size_t)off[c] * 256 + lane * 4;
     float4 best = make_float4(0.f, 0.f, 0.f, 0.f);       // Y >= 0 (ReLU); an empty ball cannot happen for a centre of the set,
                                                          // and a centre outside the variant's set is never read
     int i = 0;
@@ -498,23 +537,24 @@ int pn_sa1(const float *xyz, int N, const PnWeights &w, float *F1, hipStream_t s
     return DGDM_OK;
 }
 
-int pn_pairs(const float *xyz, int N, const float *U, const PnWeights &w, float *Y, hipStream_t s) {
-    const int tiles = N * ((N + 31) / 32);
-    hipLaunchKernelGGL(pair_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, xyz, N, U, w.sa2_vx, w.sa2_w1_img, w.sa2_b1, Y);
+int pn_pairs(const float *xyz, int N, const float *U, const PnWeights &w, const int *pairs, const int *off, float *Y, hipStream_t s) {
+    const int tiles = N * ((N + 31) / 32);     // worst case (every point inside every ball); surplus workgroups leave at once
+    hipLaunchKernelGGL(pair_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, xyz, N, U, w.sa2_vx, w.sa2_w1_img, w.sa2_b1, pairs, off, Y);
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
 }
 
-int pn_crowd(const float *xyz, int N, const PnWeights &w, int *crowded, int *clist, int *ncr, hipStream_t s) {
-    hipLaunchKernelGGL(crowd_kernel, dim3(1), dim3(1024), 0, s, xyz, N, w.r2sq, crowded, clist, ncr);
+int pn_crowd(const float *xyz, int N, const PnWeights &w, int *crowded, int *clist, int *ncr, int *off, int *pairs, short *rank, hipStream_t s) {
+    hipLaunchKernelGGL(crowd_kernel, dim3(1), dim3(1024), 0, s, xyz, N, w.r2sq, crowded, clist, ncr, off);
+    hipLaunchKernelGGL(nbr_fill_kernel, dim3((N + 3) / 4), dim3(256), 0, s, xyz, N, w.r2sq, off, pairs, rank);
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
 }
 
 int pn_l2(const float *xyz, int N, const PnWeights &w, const int *fps1, const int *vlist, int nv, const float *Y, float *L2,
-          const int *clist, const int *ncr, hipStream_t s) {
-    hipLaunchKernelGGL(l2_kernel, dim3(1, (N + 3) / 4), dim3(256), 0, s, xyz, N, w.r2sq, fps1, vlist, nv, Y, L2, 0, clist, ncr);
-    if (nv > 1) hipLaunchKernelGGL(l2_kernel, dim3((nv - 1 + 3) / 4, N), dim3(256), 0, s, xyz, N, w.r2sq, fps1, vlist, nv, Y, L2, 1, clist, ncr);
+          const int *clist, const int *ncr, const int *off, const short *rank, hipStream_t s) {
+    hipLaunchKernelGGL(l2_kernel, dim3(1, (N + 3) / 4), dim3(256), 0, s, xyz, N, w.r2sq, fps1, vlist, nv, Y, L2, 0, clist, ncr, off, rank);
+    if (nv > 1) hipLaunchKernelGGL(l2_kernel, dim3((nv - 1 + 3) / 4, N), dim3(256), 0, s, xyz, N, w.r2sq, fps1, vlist, nv, Y, L2, 1, clist, ncr, off, rank);
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
 }
