@@ -40,6 +40,7 @@ struct DgdmGuidance {
     int C = 0, G = 0, B = 0, tiles_per_b = 0, sweep_tiles_per_b = 0;
     int64_t R = 0, Rs = 0;                       // rows per chain: cond_fn grid, orientation sweep
     DevBuf ptab, ptab_sweep;                     // [C][W1], [G][W1]
+    DevBuf ptab_t, ptab_sweep_t;                 // the same tables tiled for the trunk kernels (smallnet.h tile_table)
     DevBuf objpart;                              // 2-D: [max_objects][W1]
     std::vector<std::unique_ptr<ObjectTables>> tables;   // 3-D
     bool bf16 = false;                           // contractions of the trunk on bf16 MFMA (dgdm_guidance_set_contraction_dtype)
@@ -61,14 +62,14 @@ struct DgdmGuidance {
         }
         if (bstart) (void)hipEventDestroy(bstart);
     }
-    int build_pose_table(const std::vector<float> &ori, const std::vector<float> &pos, DevBuf *dst, hipStream_t s);
+    int build_pose_table(const std::vector<float> &ori, const std::vector<float> &pos, DevBuf *dst, DevBuf *dst_tiled, hipStream_t s);
     int common_pre(const float *x_dev, float t_scaled, const int *objidx_host, int n_chains, hipStream_t s);
     int upload_starts(const int64_t *starts_host, int n_chains, int64_t rows, hipStream_t s);
     int build_object(int oi, int slot, hipStream_t s);
     int run_xobj(const int *objidx_host, int n_chains, int64_t rows, hipStream_t s);
 };
 
-int DgdmGuidance::build_pose_table(const std::vector<float> &ori, const std::vector<float> &pos, DevBuf *dst, hipStream_t s) {
+int DgdmGuidance::build_pose_table(const std::vector<float> &ori, const std::vector<float> &pos, DevBuf *dst, DevBuf *dst_tiled, hipStream_t s) {
     const int n = (int)ori.size(), W1 = m->W1;
     DevBuf d_ori, d_pos, d_emb;
     int rc;
@@ -78,6 +79,8 @@ int DgdmGuidance::build_pose_table(const std::vector<float> &ori, const std::vec
     if ((rc = dst->alloc(sizeof(float) * (size_t)W1 * n))) return rc;
     if ((rc = pose_embed(d_ori.as<float>(), d_pos.as<float>(), d_emb.as<float>(), n, s))) return rc;
     if ((rc = linear(d_emb.as<float>(), 27, m->blob.at(m->off.w1p_wt), nullptr, nullptr, 1, dst->as<float>(), W1, n, 27, W1, ACT_NONE, false, s))) return rc;
+    if ((rc = dst_tiled->alloc(sizeof(float) * (size_t)W1 * ((n + 31) / 32) * 32))) return rc;
+    if ((rc = tile_table(dst->as<float>(), n, W1, dst_tiled->as<float>(), s))) return rc;
     DGDM_HIP_CHECK(hipStreamSynchronize(s));     // temporaries die here
     return DGDM_OK;
 }
@@ -110,9 +113,9 @@ extern "C" int dgdm_guidance_create(DgdmGuidance **out, DgdmDynamics *model, con
                 ori[c] = lo[gi]; pos[2 * c] = lp[a]; pos[2 * c + 1] = lp[b];
             }
     int rc;
-    if ((rc = g->build_pose_table(ori, pos, &g->ptab, nullptr))) return rc;
+    if ((rc = g->build_pose_table(ori, pos, &g->ptab, &g->ptab_t, nullptr))) return rc;
     std::vector<float> pos0(2 * (size_t)g->G, 0.f);                       // get_convergence_centers: pos = 0 (:511)
-    if ((rc = g->build_pose_table(lo, pos0, &g->ptab_sweep, nullptr))) return rc;
+    if ((rc = g->build_pose_table(lo, pos0, &g->ptab_sweep, &g->ptab_sweep_t, nullptr))) return rc;
     const int W1 = model->W1, nc = cfg->max_chains;
     const size_t rows = (size_t)nc * g->B;
     if ((rc = g->V.alloc(rows * 256 * 4)) || (rc = g->genc.alloc(rows * 256 * 4)) || (rc = g->atab.alloc(rows * W1 * 4)) ||
@@ -338,7 +341,7 @@ static int guidance_grad(DgdmGuidance *g, int kind, const float *x_dev, int time
         if ((rc = g->run_xobj(oidx.data(), n_chains, g->R, s))) return rc;
         p.xobj = g->xobj.as<float>();
     }
-    p.Atab = g->atab.as<float>(); p.Ptab = g->ptab.as<float>(); p.obj = g->objdev.as<TrunkObjective>(); p.rowcoef = rowcoef_dev;
+    p.Atab = g->atab.as<float>(); p.Ptab = g->ptab.as<float>(); p.PtabT = g->ptab_t.as<float>(); p.obj = g->objdev.as<TrunkObjective>(); p.rowcoef = rowcoef_dev;
     p.partial = g->partial.as<float>();
     p.B = g->B; p.C = g->C; p.tiles_per_b = g->tiles_per_b; p.ntiles = n_chains * g->B * g->tiles_per_b; p.R = g->R;
     if (g->bf16) {
@@ -376,7 +379,7 @@ extern "C" int dgdm_guidance_orientation_sweep(DgdmGuidance *g, const float *x_d
         if ((rc = g->run_xobj(object_of_chain, n_chains, g->Rs, s))) return rc;
         p.xobj = g->xobj.as<float>();
     }
-    p.Atab = g->atab.as<float>(); p.Ptab = g->ptab_sweep.as<float>(); p.logits = logits_dev;
+    p.Atab = g->atab.as<float>(); p.Ptab = g->ptab_sweep.as<float>(); p.PtabT = g->ptab_sweep_t.as<float>(); p.logits = logits_dev;
     p.B = g->B; p.C = g->G; p.tiles_per_b = g->sweep_tiles_per_b; p.ntiles = n_chains * g->B * g->sweep_tiles_per_b; p.R = g->Rs;
     return trunk_launch(kind, false, true, p, s);
 }

@@ -92,6 +92,26 @@ __global__ void pose_embed_kernel(const float *__restrict__ ori, const float *__
     }
 }
 
+__global__ void tile_table_kernel(const float *__restrict__ T, int rows, int W, float4 *__restrict__ out, int64_t total) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one float4 of the output
+    if (e >= total) return;
+    const int lane = (int)(e & 63), n = lane & 31, h = lane >> 5;
+    const int64_t t = e >> 6;
+    const int q = (int)(t & 3);
+    const int wb = W / 32;
+    const int o = (int)((t >> 2) % wb);
+    const int64_t g = (t >> 2) / wb;
+    const int64_t r = min((int64_t)32 * g + n, (int64_t)rows - 1);
+    out[e] = *reinterpret_cast<const float4 *>(T + r * W + 32 * o + 8 * q + 4 * h);
+}
+
+int tile_table(const float *T, int rows, int W, float *out, hipStream_t s) {
+    const int64_t total = (int64_t)((rows + 31) / 32) * (W / 32) * 4 * 64;
+    hipLaunchKernelGGL(tile_table_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, T, rows, W, reinterpret_cast<float4 *>(out), total);
+    DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
+}
+
 int pose_embed(const float *ori, const float *pos, float *out, int rows, hipStream_t s) {
     if (rows <= 0) return DGDM_OK;
     hipLaunchKernelGGL(pose_embed_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, ori, pos, out, rows);

@@ -27,6 +27,7 @@ struct TrunkParams {
     // first-layer tables
     const float  *Atab;       // table mode: [nchain*B][W1]; rows mode: [rows][W1]
     const float  *Ptab;       // [C][W1]  (table mode)
+    const float  *PtabT;      // the same, tiled per 32 cells in operand layout (smallnet.h tile_table)
     const TrunkObjective *obj;// [nchain]
     const float  *rowcoef;    // [nchain][R] or null
     float        *partial;    // [ntiles][W1]

@@ -44,14 +44,14 @@ __global__ __launch_bounds__(256, 1) void trunk_kernel(const TrunkParams p) {
     int chain, b, c;
     bool valid;
     int64_t r;                                                // reference row index inside the chain
-    const float *arow, *prow;
+    const float *arow;
+    const float4 *ptile = nullptr;                            // table mode: this tile's cells in the tiled pose table, + lane
     if (ROWS) {
         chain = 0; b = 0;
         c = tile * 32 + n;
         valid = c < p.C;
         r = valid ? c : p.C - 1;
         arow = p.Atab + (size_t)r * W1;
-        prow = nullptr;
     } else {
         const int per_chain = p.B * p.tiles_per_b;
         chain = tile / per_chain;
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256, 1) void trunk_kernel(const TrunkParams p) {
         const int cc = valid ? c : p.C - 1;
         r = (int64_t)cc * p.B + b;
         arow = p.Atab + (size_t)(chain * p.B + b) * W1;
-        prow = p.Ptab + (size_t)cc * W1;
+        ptile = reinterpret_cast<const float4 *>(p.PtabT) + (size_t)(rem - b * p.tiles_per_b) * W1B * 4 * 64 + lane;
     }
 
     f32x16 cur[8], nxt[8];
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256, 1) void trunk_kernel(const TrunkParams p) {
             for (int q = 0; q < 4; ++q) {
                 float4 v = feat4(arow, o, q, h4);
                 if (!ROWS) {
-                    const float4 w = feat4(prow, o, q, h4);
+                    const float4 w = ptile[(o * 4 + q) * 64];
                     v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
                 }
                 cur[o][4 * q + 0] = v.x; cur[o][4 * q + 1] = v.y; cur[o][4 * q + 2] = v.z; cur[o][4 * q + 3] = v.w;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256, 1) void trunk_kernel(const TrunkParams p) {
                 for (int q = 0; q < 4; ++q) {
                     float4 v = *reinterpret_cast<const float4 *>(arow + 32 * kb + 8 * q + h4);
                     if (!ROWS) {
-                        const float4 w = *reinterpret_cast<const float4 *>(prow + 32 * kb + 8 * q + h4);
+                        const float4 w = ptile[(kb * 4 + q) * 64];
                         v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
                     }
                     z[4 * q + 0] += v.x; z[4 * q + 1] += v.y; z[4 * q + 2] += v.z; z[4 * q + 3] += v.w;

@@ -74,18 +74,23 @@ __device__ __forceinline__ void static_for(F &&f) {
     }
 }
 
-// Epilogue work item Q (0..15) of a finished stage: tile Q / 8, pair Q % 8 -> Y.v[tile][OB][pair / 4][pair % 4]
+// Epilogue work item Q (0..15) of a finished stage -> Y.v[tile][OB][pair / 4][pair % 4]
 template <bool FWD, int OB, int Q>
 __device__ __forceinline__ void epi_item(const f32x16 (&acc)[2], uint32_t &mk, Act16 &Y) {
-    constexpr int T = Q / 8, D = Q % 8;
-    if (FWD) Y.v[T][OB][D / 4][D % 4] = fwd_pair<Q>(acc[T][2 * D], acc[T][2 * D + 1], mk);
-    else Y.v[T][OB][D / 4][D % 4] = bwd_pair<Q>(acc[T][2 * D], acc[T][2 * D + 1], mk);
+    constexpr int T = (Q / 4) & 1, D = (Q & 3) + 4 * (Q / 8);      // order: K-step 0 dwords of both tiles first, then K-step 1
+    constexpr int SH = D + 8 * T;                                    // bit position of the pair in the mask word
+    if (FWD) Y.v[T][OB][D / 4][D % 4] = fwd_pair<SH>(acc[T][2 * D], acc[T][2 * D + 1], mk);
+    else Y.v[T][OB][D / 4][D % 4] = bwd_pair<SH>(acc[T][2 * D], acc[T][2 * D + 1], mk);
 }
 
-// The 16 items of a stage are spread over the first min(NK, 8) steps of the following stage.
+// The 16 items of a stage are spread over the first min(NK, 16) steps of the following stage: with NK = 16 one item per step,
+// i.e. ~7 VALU instructions (the accumulators sit in AGPRs, so each item starts with two v_accvgpr_read) beside the step's two
+// MFMAs - measured on MI355X, a v_mfma_f32_32x32x16_bf16 hides at most 5 other instructions, and two items per step (11 VALU
+// per MFMA) left the matrix pipe idle half of every stage.  Items (tile 0, pairs 0..3), (1, 0..3), (0, 4..7), (1, 4..7): the
+// dwords of K-step 0 of a pending block are complete after step 7, those of K-step 1 at step 15, where they are first read.
 template <bool FWD, int OB, int NK, int I>
 __device__ __forceinline__ void epi_step(const f32x16 (&acc)[2], uint32_t &mk, Act16 &Y) {
-    constexpr int STEPS = NK < 8 ? NK : 8, PER = 16 / STEPS;
+    constexpr int STEPS = NK < 16 ? NK : 16, PER = 16 / STEPS;
     if constexpr (I < STEPS) {
         static_for<0, PER>([&](auto jc) { epi_item<FWD, OB, I * PER + decltype(jc)::value>(acc, mk, Y); });
     }
@@ -117,9 +122,10 @@ template <bool FWD, bool PEND, int NK>
 __device__ __forceinline__ void layer16(const wrsrc_t rs, const int voff, const int woff, float4 (&ring)[CONT_DEPTH], const float *bias,
                                         const float *bias_next, Act16 &X, Act16 &Y, Pipe &pipe, uint32_t (*smask)[256], const int prev_slot,
                                         const int slot0, const int tid, const int h4) {
-    constexpr int EA = (NK < 8 ? NK : 8) - 1;        // last step that carries epilogue items
+    constexpr int EA = (NK < 16 ? NK : 16) - 1;      // last step that carries epilogue items
     constexpr int BS = NK > 9 ? 9 : NK - 1;          // step that prefetches the next stage's bias block
-    uint32_t mk = FWD ? 0u : pipe.mk;
+    constexpr int MS = NK > 8 ? 8 : NK - 1;          // backward: step that fetches the mask word of this stage's own epilogue
+    uint32_t mk = FWD ? 0u : pipe.mk, mkn = 0u;
     static_for<0, 8>([&](auto opc) {
         constexpr int OP = decltype(opc)::value;
         constexpr int PAR = OP & 1;
@@ -141,10 +147,10 @@ __device__ __forceinline__ void layer16(const wrsrc_t rs, const int voff, const 
                 if (FWD) {                            // the previous stage's sign-bit word is complete
                     if constexpr (OP == 0) { if (PEND) smask[prev_slot][tid] = mk; }
                     else smask[slot0 + OP - 1][tid] = mk;
-                } else {
-                    mk = smask[slot0 + OP][tid];      // for this stage's own epilogue, which runs in the next stage
                 }
             }
+            if constexpr (!FWD && I == MS) mkn = smask[slot0 + OP][tid];     // for this stage's own epilogue, which runs in the next stage
+            if constexpr (!FWD && I == NK - 1) mk = mkn;
             if constexpr (I == 0) {
                 if (FWD) {
                     pipe.acc[PAR][0] = mfma_bf16(a, X.v[0][IB][S], pipe.bias0);
@@ -180,10 +186,11 @@ struct TileRows {
     int chain, b;
     bool valid;
     int64_t r;
-    const float *arow, *prow;
+    const float *arow;
+    const float4 *ptile;      // this tile's 32 cells in the tiled pose table, + lane
 };
 
-__device__ __forceinline__ TileRows tile_rows(const TrunkParams &p, int tile, int n, int W1) {
+__device__ __forceinline__ TileRows tile_rows(const TrunkParams &p, int tile, int n, int lane, int W1) {
     TileRows t;
     const int per_chain = p.B * p.tiles_per_b;
     t.chain = tile / per_chain;
@@ -194,7 +201,7 @@ __device__ __forceinline__ TileRows tile_rows(const TrunkParams &p, int tile, in
     const int cc = t.valid ? c : p.C - 1;
     t.r = (int64_t)cc * p.B + t.b;
     t.arow = p.Atab + (size_t)(t.chain * p.B + t.b) * W1;
-    t.prow = p.Ptab + (size_t)cc * W1;
+    t.ptile = reinterpret_cast<const float4 *>(p.PtabT) + (size_t)(rem - t.b * p.tiles_per_b) * (W1 / 32) * 4 * 64 + lane;
     return t;
 }
 
@@ -203,7 +210,7 @@ __device__ __forceinline__ void table_block(const TileRows &t, int blk, int h4, 
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float4 a = *reinterpret_cast<const float4 *>(t.arow + 32 * blk + 8 * q + h4);
-        const float4 w = *reinterpret_cast<const float4 *>(t.prow + 32 * blk + 8 * q + h4);
+        const float4 w = t.ptile[(blk * 4 + q) * 64];                          // coalesced: 1 KiB per (block, quarter)
         z[4 * q + 0] = a.x + w.x; z[4 * q + 1] = a.y + w.y; z[4 * q + 2] = a.z + w.z; z[4 * q + 3] = a.w + w.w;
     }
 }
@@ -295,6 +302,7 @@ __global__ __launch_bounds__(256, 1) void trunk_bf16_kernel(const TrunkParams p)
     constexpr int S_MID = (KIND == 3) ? 24 : 8;           // mask slot of mid layer 0's output
     constexpr int NSLOT = S_MID + 8 * ((KIND == 3) ? 6 : 7);
     __shared__ uint32_t smask[NSLOT][256];
+    __shared__ __attribute__((aligned(16))) float red[4][32][36];       // per wave: one 32-feature block x 32 rows (+pad) for the final fold
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -306,8 +314,8 @@ __global__ __launch_bounds__(256, 1) void trunk_bf16_kernel(const TrunkParams p)
     const int h4 = (lane >> 5) * 4;
     const int voff = lane * 16;
 
-    const TileRows tr0 = tile_rows(p, tile0, n, W1);
-    const TileRows tr1 = tile_rows(p, has1 ? tile0 + 1 : tile0, n, W1);
+    const TileRows tr0 = tile_rows(p, tile0, n, lane, W1);
+    const TileRows tr1 = tile_rows(p, has1 ? tile0 + 1 : tile0, n, lane, W1);
 
     Act16 X, Y;
     Pipe pipe;
@@ -375,7 +383,7 @@ __global__ __launch_bounds__(256, 1) void trunk_bf16_kernel(const TrunkParams p)
             const float4 a = ring[I];
             ring[I] = wload(rsF, voff, woff + (I + CONT_DEPTH) * 1024);   // past the end of the stream: clipped to zero, unused
             epi_step<true, 7, 16, I>(pipe.acc[1], mk, H);
-            if constexpr (I == 7) smask[pend_slot][tid] = mk;
+            if constexpr (I == 15) smask[pend_slot][tid] = mk;
             if constexpr (I == 0) {
                 f32x16 zero;
 #pragma unroll
@@ -462,33 +470,35 @@ __global__ __launch_bounds__(256, 1) void trunk_bf16_kernel(const TrunkParams p)
             if ((mk1 >> (15 - d + 16 * hi)) & 1u) g[0][r] = 0.f;
             if ((mk1 >> (15 - (d + 8) + 16 * hi)) & 1u) g[1][r] = 0.f;
         }
-        if (!has1) {
+        // fold of the 32 cells of a tile: through LDS, transposed - lane (feature f, half) adds 16 rows of its feature, one
+        // cross-half add finishes it (36 instructions per block instead of 5 shuffle+add rounds on each of 16-32 registers),
+        // and the result leaves as one coalesced 128-byte store per tile and block.
+        float (*rw)[36] = red[wave];
+        const int fl = lane & 31, hf = lane >> 5;
+        auto fold = [&](const f32x16 &v, float *dst) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) g[1][r] = 0.f;
-        }
+            for (int r = 0; r < 16; ++r) rw[(r & 3) + 8 * (r >> 2) + h4][n] = v[r];
+            __builtin_amdgcn_wave_barrier();
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 q4 = *reinterpret_cast<const float4 *>(&rw[fl][16 * hf + 4 * j]);
+                s += (q4.x + q4.y) + (q4.z + q4.w);
+            }
+            s += __shfl_xor(s, 32);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 32) dst[32 * OB + fl] = s;
+        };
         if (same_b) {
             // both tiles belong to the same finger: dyn_post_kernel adds their partials anyway, so add first, fold once
+            f32x16 both;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float4 v;
-                v.x = rows_sum(g[0][4 * q + 0] + g[1][4 * q + 0]); v.y = rows_sum(g[0][4 * q + 1] + g[1][4 * q + 1]);
-                v.z = rows_sum(g[0][4 * q + 2] + g[1][4 * q + 2]); v.w = rows_sum(g[0][4 * q + 3] + g[1][4 * q + 3]);
-                if (n == 0) {
-                    *reinterpret_cast<float4 *>(dst0 + 32 * OB + 8 * q + h4) = v;
-                    *reinterpret_cast<float4 *>(dst1 + 32 * OB + 8 * q + h4) = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
+            for (int r = 0; r < 16; ++r) both[r] = g[0][r] + g[1][r];
+            fold(both, dst0);
+            if (lane < 32) dst1[32 * OB + fl] = 0.f;
         } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float4 v, w;
-                v.x = rows_sum(g[0][4 * q + 0]); v.y = rows_sum(g[0][4 * q + 1]); v.z = rows_sum(g[0][4 * q + 2]); v.w = rows_sum(g[0][4 * q + 3]);
-                w.x = rows_sum(g[1][4 * q + 0]); w.y = rows_sum(g[1][4 * q + 1]); w.z = rows_sum(g[1][4 * q + 2]); w.w = rows_sum(g[1][4 * q + 3]);
-                if (n == 0) {
-                    *reinterpret_cast<float4 *>(dst0 + 32 * OB + 8 * q + h4) = v;
-                    if (has1) *reinterpret_cast<float4 *>(dst1 + 32 * OB + 8 * q + h4) = w;
-                }
-            }
+            fold(g[0], dst0);
+            if (has1) fold(g[1], dst1);
         }
     });
 }
