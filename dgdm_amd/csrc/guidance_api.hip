@@ -346,8 +346,26 @@ static int guidance_grad(DgdmGuidance *g, int kind, const float *x_dev, int time
     p.B = g->B; p.C = g->C; p.tiles_per_b = g->tiles_per_b; p.ntiles = n_chains * g->B * g->tiles_per_b; p.R = g->R;
     if (g->bf16) {
         g->m->fill_trunk_bf16(&p);       // only the two weight streams differ
+#ifdef DGDM_TRUNK_CLOCKS
+        static long long *dclk = nullptr;
+        if (!dclk) (void)hipMalloc(&dclk, (size_t)1 << 26);
+        p.clk = dclk;
+#endif
         if ((rc = trunk_bf16_launch(kind, p, s))) return rc;
     } else if ((rc = trunk_launch(kind, false, false, p, s))) return rc;
+#ifdef DGDM_TRUNK_CLOCKS
+    if (g->bf16) {      // mean cycles per phase over all waves (experiment build)
+        const size_t nw = (size_t)(p.ntiles + 1) / 2;
+        std::vector<long long> h(nw * 8);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h.data(), p.clk, nw * 64, hipMemcpyDeviceToHost);
+        double ph[6] = {0, 0, 0, 0, 0, 0};
+        for (size_t w = 0; w < nw; ++w)
+            for (int i = 0; i < 6; ++i) ph[i] += (double)(h[w * 8 + i + 1] - h[w * 8 + i]);
+        fprintf(stderr, "PHASES(mean cycles, %zu waves) first %.0f fwdmid %.0f wout+obj %.0f woutT %.0f bwdmid %.0f final %.0f\n", nw, ph[0] / nw, ph[1] / nw, ph[2] / nw,
+                ph[3] / nw, ph[4] / nw, ph[5] / nw);
+    }
+#endif
     return dyn_post(g->m->W1, g->partial.as<float>(), g->tiles_per_b, g->m->blob.at(g->m->off.w1c_w), g->m->blob.at(g->m->off.g2_w),
                     g->m->blob.at(g->m->off.g0_w), g->V.as<float>(), grad_dev, n_chains * g->B, g->m->L, s);
 }

@@ -33,6 +33,9 @@ struct TrunkParams {
     float        *partial;    // [ntiles][W1]
     float        *logits;     // fwd-only: [nchain][R][3]
     int           B, C, tiles_per_b, ntiles;
+#ifdef DGDM_TRUNK_CLOCKS
+    long long    *clk;        // experiment build only: [waves][8] phase time stamps (scripts/README: -DDGDM_TRUNK_CLOCKS)
+#endif
     int64_t       R;          // rows per chain (B*C in table mode, rows in rows mode)
 };
 

@@ -66,6 +66,15 @@ __device__ __forceinline__ uint32_t bwd_pair(float lo, float hi, uint32_t mk) {
     return p & ~__builtin_bit_cast(uint32_t, neg);
 }
 
+// End of a pipeline step.  sched_barrier(0) stops the machine schedulers, but it is a no-memory intrinsic: instruction selection
+// still moved the weight loads of a step below the MFMAs of the following steps (seen in front3d: eight MFMAs back to back, then
+// seventeen loads).  The empty asm with a memory clobber orders the loads as well.
+#define STEP_FENCE()                          \
+    do {                                      \
+        __builtin_amdgcn_sched_barrier(0);    \
+        asm volatile("" ::: "memory");        \
+    } while (0)
+
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F &&f) {
     if constexpr (I < N) {
@@ -167,7 +176,7 @@ __device__ __forceinline__ void layer16(const wrsrc_t rs, const int voff, const 
                 pipe.acc[PAR][1] = mfma_bf16(a, X.v[1][IB][S], pipe.acc[PAR][1]);
             }
             if constexpr (FWD && I == BS) load_f32x16(OP < 7 ? bias + 32 * (OP + 1) : bias_next, h4, pipe.bias0);
-            __builtin_amdgcn_sched_barrier(0);
+            STEP_FENCE();
         });
     });
     pipe.mk = mk;
@@ -205,13 +214,26 @@ __device__ __forceinline__ TileRows tile_rows(const TrunkParams &p, int tile, in
     return t;
 }
 
-// z1 block `blk` of a tile from the first-layer tables (float32)
-__device__ __forceinline__ void table_block(const TileRows &t, int blk, int h4, f32x16 &z) {
+// z1 block `blk` of a tile from the first-layer tables (float32), in two halves so that the loads of the next block can be put
+// in flight before the arithmetic of the current one (left to itself hipcc emits load, load, s_waitcnt vmcnt(0), 64 times over:
+// 36 k cycles of exposed L2 latency per wave)
+struct TabRaw {
+    float4 a[4], w[4];
+};
+
+__device__ __forceinline__ void table_load(const TileRows &t, int blk, int h4, TabRaw &raw) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const float4 a = *reinterpret_cast<const float4 *>(t.arow + 32 * blk + 8 * q + h4);
-        const float4 w = t.ptile[(blk * 4 + q) * 64];                          // coalesced: 1 KiB per (block, quarter)
-        z[4 * q + 0] = a.x + w.x; z[4 * q + 1] = a.y + w.y; z[4 * q + 2] = a.z + w.z; z[4 * q + 3] = a.w + w.w;
+        raw.a[q] = *reinterpret_cast<const float4 *>(t.arow + 32 * blk + 8 * q + h4);
+        raw.w[q] = t.ptile[(blk * 4 + q) * 64];                                // coalesced: 1 KiB per (block, quarter)
+    }
+}
+
+__device__ __forceinline__ void table_sum(const TabRaw &raw, f32x16 &z) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        z[4 * q + 0] = raw.a[q].x + raw.w[q].x; z[4 * q + 1] = raw.a[q].y + raw.w[q].y;
+        z[4 * q + 2] = raw.a[q].z + raw.w[q].z; z[4 * q + 3] = raw.a[q].w + raw.w[q].w;
     }
 }
 
@@ -222,21 +244,28 @@ __device__ __forceinline__ void table_block(const TileRows &t, int blk, int h4, 
 template <int T>
 __device__ __forceinline__ void front3d(const wrsrc_t rs, const int voff, float4 (&ring)[CONT_DEPTH], const TrunkParams &p, const TileRows &tr,
                                         Act16 &X, Pipe &pipe, uint32_t (*smask)[256], const int tid, const int h4) {
-    // xobj row -> packed B operand
+    // first z1 block of the tables and the xobj row (all 32 loads in flight together), then xobj -> packed B operand
+    TabRaw raw[2];
+    table_load(tr, 0, h4, raw[0]);
     u32x4_t xin[8][2];
     const float *xrow = p.xobj + ((size_t)tr.chain * p.R + tr.r) * 256;
+    float4 xv[8][4];
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xv[o][q] = *reinterpret_cast<const float4 *>(xrow + 32 * o + 8 * q + h4);
+    f32x16 acc2[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) load_f32x16(p.b2 + 32 * o, h4, acc2[o]);
+    STEP_FENCE();
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 v = *reinterpret_cast<const float4 *>(xrow + 32 * o + 8 * q + h4);
-            xin[o][q / 2][(2 * q) % 4] = pack_bf16(v.x, v.y);
-            xin[o][q / 2][(2 * q + 1) % 4] = pack_bf16(v.z, v.w);
+            xin[o][q / 2][(2 * q) % 4] = pack_bf16(xv[o][q].x, xv[o][q].y);
+            xin[o][q / 2][(2 * q + 1) % 4] = pack_bf16(xv[o][q].z, xv[o][q].w);
         }
     }
-    f32x16 acc2[8];
-#pragma unroll
-    for (int o = 0; o < 8; ++o) load_f32x16(p.b2 + 32 * o, h4, acc2[o]);
     f32x16 zacc[2];
     u32x4_t zin[2];
     uint32_t mk = 0;
@@ -244,7 +273,7 @@ __device__ __forceinline__ void front3d(const wrsrc_t rs, const int voff, float4
         constexpr int KB = decltype(kc)::value;          // z(KB) for KB < 16, then l2(KB - 1) for KB >= 1
         if constexpr (KB < 16) {
             f32x16 init;
-            table_block(tr, KB, h4, init);
+            table_sum(raw[KB & 1], init);
             static_for<0, 16>([&](auto ic) {
                 constexpr int I = decltype(ic)::value;
                 constexpr int E = (KB == 0 ? 0 : 16 + 32 * (KB - 1)) + I;
@@ -256,7 +285,8 @@ __device__ __forceinline__ void front3d(const wrsrc_t rs, const int voff, float4
                 }
                 if constexpr (I == 0) zacc[KB & 1] = mfma_bf16(a, xin[0][0], init);
                 else zacc[KB & 1] = mfma_bf16(a, xin[I / 2][I % 2], zacc[KB & 1]);
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (I == 8 && KB < 15) table_load(tr, KB + 1, h4, raw[(KB + 1) & 1]);     // next block's table part
+                STEP_FENCE();
             });
         } else {
             mk = 0u;
@@ -269,7 +299,7 @@ __device__ __forceinline__ void front3d(const wrsrc_t rs, const int voff, float4
             constexpr int KP = KB - 1;                   // l2(KP): uses zin = a1 block KP
             // sign bits of a1 block KP: this tile's 8 pairs; the two tile passes share the word
             if (T == 0) smask[KP][tid] = mk;
-            else smask[KP][tid] |= mk;
+            else (void)__hip_atomic_fetch_or(&smask[KP][tid], mk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // ds_or_b32, no read-back
             static_for<0, 16>([&](auto ic) {
                 constexpr int I = decltype(ic)::value;
                 constexpr int E = (KP == 15 ? 16 + 32 * 15 : 32 * (KP + 1)) + I;
@@ -277,7 +307,7 @@ __device__ __forceinline__ void front3d(const wrsrc_t rs, const int voff, float4
                 const float4 a = ring[E % CONT_DEPTH];
                 ring[E % CONT_DEPTH] = wload(rs, voff, (E + CONT_DEPTH) * 1024);
                 acc2[OP] = mfma_bf16(a, zin[S], acc2[OP]);
-                __builtin_amdgcn_sched_barrier(0);
+                STEP_FENCE();
             });
         }
     });
@@ -290,7 +320,7 @@ __device__ __forceinline__ void front3d(const wrsrc_t rs, const int voff, float4
             X.v[T][O][D / 4][D % 4] = fwd_pair<D + 8 * T>(acc2[O][2 * D], acc2[O][2 * D + 1], m2);
         });
         if (T == 0) smask[16 + O][tid] = m2;
-        else smask[16 + O][tid] |= m2;
+        else (void)__hip_atomic_fetch_or(&smask[16 + O][tid], m2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     });
     pipe.acc[1][T] = acc2[7];
 }
@@ -317,6 +347,14 @@ __global__ __launch_bounds__(256, 1) void trunk_bf16_kernel(const TrunkParams p)
     const TileRows tr0 = tile_rows(p, tile0, n, lane, W1);
     const TileRows tr1 = tile_rows(p, has1 ? tile0 + 1 : tile0, n, lane, W1);
 
+#ifdef DGDM_TRUNK_CLOCKS
+    long long tstamp[8];
+    int nts = 0;
+#define STAMP() tstamp[nts++] = __builtin_readcyclecounter()
+#else
+#define STAMP()
+#endif
+    STAMP();
     Act16 X, Y;
     Pipe pipe;
     pipe.mk = 0;
@@ -328,11 +366,19 @@ __global__ __launch_bounds__(256, 1) void trunk_bf16_kernel(const TrunkParams p)
 
     if (KIND == 2) {
         // ---- layer 1 from the tables; blocks 0..6 finished here, block 7 left pending like any other layer's
+        TabRaw raw[2][2];                                  // [parity][tile]: block O+1 is in flight while block O is converted
+        table_load(tr0, 0, h4, raw[0][0]);
+        table_load(tr1, 0, h4, raw[0][1]);
         static_for<0, 8>([&](auto oc) {
             constexpr int O = decltype(oc)::value;
+            if constexpr (O < 7) {
+                table_load(tr0, O + 1, h4, raw[(O + 1) & 1][0]);
+                table_load(tr1, O + 1, h4, raw[(O + 1) & 1][1]);
+            }
+            STEP_FENCE();
             f32x16 z0, z1;
-            table_block(tr0, O, h4, z0);
-            table_block(tr1, O, h4, z1);
+            table_sum(raw[O & 1][0], z0);
+            table_sum(raw[O & 1][1], z1);
             if constexpr (O < 7) {
                 uint32_t mk = 0;
                 static_for<0, 8>([&](auto dc) {
@@ -348,6 +394,7 @@ __global__ __launch_bounds__(256, 1) void trunk_bf16_kernel(const TrunkParams p)
                 pipe.acc[1][0] = z0;
                 pipe.acc[1][1] = z1;
             }
+            STEP_FENCE();
         });
     } else {
         front3d<0>(rsF, voff, ring, p, tr0, X, pipe, smask, tid, h4);
@@ -357,6 +404,7 @@ __global__ __launch_bounds__(256, 1) void trunk_bf16_kernel(const TrunkParams p)
         woff = 512 * 1024;
     }
     int pend_slot = (KIND == 3) ? 16 + 7 : 7;
+    STAMP();
 
     // ---- 256 -> 256 layers, two per iteration (X -> Y -> X)
     int l = 0;
@@ -373,6 +421,7 @@ __global__ __launch_bounds__(256, 1) void trunk_bf16_kernel(const TrunkParams p)
         pend_slot = S_MID + 8 * l + 7;
     }
     Act16 &H = (KIND == 2) ? Y : X;                        // a_8, block 7 pending
+    STAMP();
 
     // ---- output layer 256 -> 3 (padded to one 32-row block): 16 entries; finishes the pending block on the way
     f32x16 lo[2];
@@ -394,7 +443,7 @@ __global__ __launch_bounds__(256, 1) void trunk_bf16_kernel(const TrunkParams p)
                 lo[0] = mfma_bf16(a, H.v[0][I / 2][I % 2], lo[0]);
                 lo[1] = mfma_bf16(a, H.v[1][I / 2][I % 2], lo[1]);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            STEP_FENCE();
         });
     }
 
@@ -424,10 +473,12 @@ __global__ __launch_bounds__(256, 1) void trunk_bf16_kernel(const TrunkParams p)
             GB.v[t][0][1] = u32x4_t{0u, 0u, 0u, 0u};
         }
     }
+    STAMP();
     // ---- transposed output layer: 8 blocks x 2 K-steps; masks of a_8
     layer16<false, false, 2>(rsB, voff, woff, ring, nullptr, nullptr, GB, GA, pipe, smask, 0, S_MID + 8 * (p.n_mid - 1), tid, h4);
     woff += 16 * 1024;
 
+    STAMP();
     // ---- backward through the mid layers, two per iteration (GA -> GB -> GA); layer j masks with the output of layer j-1
     for (int j = p.n_mid - 1; j >= ((KIND == 2) ? 2 : 1); j -= 2) {
         layer16<false, true, 16>(rsB, voff, woff, ring, nullptr, nullptr, GA, GB, pipe, smask, 0, S_MID + 8 * (j - 1), tid, h4);
@@ -436,6 +487,7 @@ __global__ __launch_bounds__(256, 1) void trunk_bf16_kernel(const TrunkParams p)
         woff += 128 * 1024;
     }
 
+    STAMP();
     // ---- last layer back (2-D: W2'^T, 8 blocks; 3-D: W2'^T onto the 512-wide layer 1, 16 blocks): float32 epilogue,
     //      mask of a_1, fold of the tile's 32 cells, one partial vector per tile
     const bool same_b = has1 && tr0.chain == tr1.chain && tr0.b == tr1.b;
@@ -461,7 +513,7 @@ __global__ __launch_bounds__(256, 1) void trunk_bf16_kernel(const TrunkParams p)
                 g[0] = mfma_bf16(a, GA.v[0][I / 2][I % 2], g[0]);
                 g[1] = mfma_bf16(a, GA.v[1][I / 2][I % 2], g[1]);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            STEP_FENCE();
         });
         // mask: pair d of tile t has its sign bits at 15 - (d + 8t) (low half, register 2d) and 31 - (d + 8t) (register 2d+1)
 #pragma unroll
@@ -501,6 +553,11 @@ __global__ __launch_bounds__(256, 1) void trunk_bf16_kernel(const TrunkParams p)
             if (has1) fold(g[1], dst1);
         }
     });
+    STAMP();
+#ifdef DGDM_TRUNK_CLOCKS
+    if (p.clk && lane == 0)
+        for (int i = 0; i < 7; ++i) p.clk[(size_t)(blockIdx.x * 4 + wave) * 8 + i] = tstamp[i];
+#endif
 }
 
 int trunk_bf16_launch(int kind, const TrunkParams &p, hipStream_t s) {
