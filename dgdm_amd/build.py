@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libdgdm_hip.so")
-SOURCES = ["host_util.hip", "smallnet.hip", "unet.hip", "trunk.hip", "trunk_bf16.hip", "pointnet.hip", "models_api.hip", "guidance_api.hip", "debug.hip"]
+SOURCES = ["host_util.hip", "smallnet.hip", "unet.hip", "trunk.hip", "trunk_bf16.hip", "pointnet.hip", "models_api.hip", "guidance_api.hip", "decode.hip", "debug.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("DGDM_EXTRA_FLAGS", "").split()
 
 

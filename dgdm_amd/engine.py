@@ -196,6 +196,24 @@ def ddim_add_noise(x0: torch.Tensor, noise: torch.Tensor, sqrt_abar: float, sqrt
     return out
 
 
+def finger_decode_2d(samples: torch.Tensor, num_points: int = 200, scale: float = 0.03, offset: float = -0.015) -> torch.Tensor:
+    """(B, L, 1) or (B, L) control values -> (B, 2 fingers, num_points, 2) spline points in metres; the defaults map sampler
+    units [-1, 1] as dynamics/sim_test_mj.py:257-262 does before assets/finger_sampler.py:39-51."""
+    s = _f32(samples).reshape(samples.shape[0], -1)
+    out = torch.empty((s.shape[0], 2, num_points, 2), dtype=torch.float32, device=s.device)
+    check(lib().dgdm_finger_decode_2d(dptr(s), s.shape[0], s.shape[1], int(num_points), float(scale), float(offset), dptr(out), stream_ptr()))
+    return out
+
+
+def finger_decode_3d(samples: torch.Tensor, sample_size: int = 25, scale: float = 0.05, offset: float = -0.05) -> torch.Tensor:
+    """(B, 42, 1) or (B, 42) control values -> (B, 2 fingers, sample_size^2, 3) surface points in metres; the defaults map
+    sampler units [-1, 1] as dynamics/sim_test_mj_3d.py:236-237 does before assets/finger_3d.py:60-81."""
+    s = _f32(samples).reshape(samples.shape[0], -1)
+    out = torch.empty((s.shape[0], 2, sample_size * sample_size, 3), dtype=torch.float32, device=s.device)
+    check(lib().dgdm_finger_decode_3d(dptr(s), s.shape[0], s.shape[1], int(sample_size), float(scale), float(offset), dptr(out), stream_ptr()))
+    return out
+
+
 def prof_enable(on: bool) -> None:
     check(lib().dgdm_prof_enable(int(on)))
 

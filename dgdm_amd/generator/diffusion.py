@@ -52,6 +52,7 @@ class Diffusion(nn.Module):
         self.class_cond, self.seed = class_cond, seed
         self.save_dir: Optional[str] = None
         self.last_samples: Dict[str, np.ndarray] = {}
+        self.last_geometry: Dict[str, Any] = {}            # decoded finger curves / surfaces of the same batches (engine.finger_decode_*)
         if class_cond:
             self.classifier_model = classifier_model
             self.grid_size, self.num_pos = grid_size, num_pos
@@ -178,11 +179,22 @@ class Diffusion(nn.Module):
         """Where the reference hands `sample.cpu().numpy()` to its simulator (:578-580, :675-683), the samples are kept and saved."""
         arr = samples.detach().cpu().numpy()
         self.last_samples[tag] = arr
+        # the geometry the simulator would build from these control values on the host (sim_test_mj.py:254-262 ->
+        # assets/finger_sampler.py; sim_test_mj_3d.py:233-237 -> assets/finger_3d.py), decoded on the device
+        flat = samples.detach().reshape(-1, samples.shape[-2], 1)
+        if samples.is_cuda and (self.mode == 'point_3d') == (flat.shape[1] == 42) and flat.shape[1] >= 8 and flat.shape[1] % 2 == 0:
+            geo = engine.finger_decode_3d(flat) if self.mode == 'point_3d' else engine.finger_decode_2d(flat)
+            geo = geo.reshape(*samples.shape[:-2], *geo.shape[1:]).cpu().numpy()
+        else:
+            geo = None
+        self.last_geometry[tag] = geo
         if save_dir:
             d = os.path.join(save_dir, sub, tag)
             os.makedirs(d, exist_ok=True)
             for i, nm in enumerate(names):
                 np.save(os.path.join(d, f"{nm}.npy"), arr[i])
+                if geo is not None:
+                    np.save(os.path.join(d, f"{nm}_geometry.npy"), geo[i])
 
     # ------------------------------------------------------------------ a3 + harness
     def validation_step(self, tensor_data, batch_idx):

@@ -181,6 +181,30 @@ int dgdm_guidance_orientation_sweep(DgdmGuidance *g, const float *x_dev, const i
 int dgdm_convergence_rowcoef(const int64_t *centers_host, int n_centers, int grid_size, int num_pos,
                              int64_t total_rows, int64_t sub_batch_size /* 0 = no sub-batching */, float *rowcoef_host);
 
+/* ------------------------------------------------------------------ (f) next: finger-geometry decode
+ * What the reference does on the host, gripper by gripper, between the sampler and the simulator.  Both maps are linear in
+ * the control values, so the library applies one constant matrix (built in double precision) to the whole batch on the device.
+ *
+ * 2-D  sim_test_batch (dynamics/sim_test_mj.py:257-262): y = 0.03 p - 0.015 over x = linspace(-0.12, 0.12, num_ctrl/2) for the
+ *      left finger (first half of the control values) and the right one; generate_gripper / generate_finger_shape
+ *      (assets/finger_sampler.py:7-12,39-51): scipy CubicSpline (not-a-knot) on linspace(x_0, x_last, num_points).
+ *      samples_dev [batch][num_ctrl] -> curve_dev [batch][2 fingers][num_points][2] = (x, y) in metres.
+ * 3-D  sim_test_batch_3d (dynamics/sim_test_mj_3d.py:236-237): y = 0.05 p - 0.05 on the 7 x 3 control net of
+ *      generate_3d_ctrlpts (assets/finger_3d.py:77-81: x = linspace(-0.12, 0.12, 7), z = linspace(0, 0.12, 3), control point
+ *      (i, j) = y[3 i + j]); generate_3d_finger_vertices (assets/finger_3d.py:60-68): geomdl BSpline.Surface of degree (3, 2),
+ *      generate_knot_vector (clamped, uniform), sample_size x sample_size evaluation points in u-major order.
+ *      samples_dev [batch][42] -> surface_dev [batch][2 fingers][sample_size^2][3] = (x, y, z) in metres.
+ * The affine map from sampler units to metres is an argument (y = scale * p + offset): DGDM_DECODE_2D_* / DGDM_DECODE_3D_* are
+ * the reference's constants; scale 1, offset 0 decodes control values that are already in metres.                              */
+#define DGDM_DECODE_2D_SCALE 0.03f
+#define DGDM_DECODE_2D_OFFSET (-0.015f)
+#define DGDM_DECODE_3D_SCALE 0.05f
+#define DGDM_DECODE_3D_OFFSET (-0.05f)
+int dgdm_finger_decode_2d(const float *samples_dev, int batch, int num_ctrl, int num_points, float scale, float offset,
+                          float *curve_dev, void *stream);
+int dgdm_finger_decode_3d(const float *samples_dev, int batch, int num_ctrl, int sample_size, float scale, float offset,
+                          float *surface_dev, void *stream);
+
 /* ------------------------------------------------------------------ measurement hooks
  * When enabled, every launch of the trunk kernel (the dominant kernel) is
  * bracketed by hipEvents on its own stream.  dgdm_prof_read synchronises those events and

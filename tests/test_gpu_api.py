@@ -161,6 +161,12 @@ def test_cli_entry_point(dev, tmp_path):
     assert len(results) == 2 and "guided/rotate" in results[0] and results[0]["guided/rotate"].shape == (6, 2, 42, 1)
     assert os.path.exists(os.path.join(tmp_path, "vis_guided", "rotate_orirange=-1.000_1.000", "BABY_CAR.npy"))
     assert float(results[0]["guided/rotate"].abs().max()) <= 1.0 + 1e-6
+    # the decoded finger surfaces are written next to the control values and agree with the CPU decode of those values
+    from oracle import finger_decode_oracle as dec
+    d = os.path.join(tmp_path, "vis_guided", "rotate_orirange=-1.000_1.000")
+    smp, geo = np.load(os.path.join(d, "BABY_CAR.npy")), np.load(os.path.join(d, "BABY_CAR_geometry.npy"))
+    assert smp.shape == (2, 42, 1) and geo.shape == (2, 2, 625, 3)
+    assert np.abs(geo - dec.decode_3d(smp.reshape(2, 42), 25)).max() < 2e-7
 
 
 def test_checkpoint_formats(dev, tmp_path):
