@@ -23,6 +23,7 @@ import torch.nn as nn
 
 from .. import engine, sampler
 from ..dynamics import metrics
+from ..dynamics.metrics import metric2objective, objective_directions     # noqa: F401  (metric2objective: reference import)
 from ..sampler import SCALE_2D, SCALE_2D_CONV, SCALE_3D, SCALE_3D_CONV, StartStream     # noqa: F401  (reference exports)
 
 OBJECTIVE_SWEEP = ['convergence', 'shift_up', 'shift_down', 'shift_left', 'shift_right', 'rotate_clockwise',
@@ -152,6 +153,28 @@ class Diffusion(nn.Module):
         g = self._guidance_for(batch_size, ori_range, object_vertices.reshape(1, *object_vertices.shape[-2:]), 1)
         starts = StartStream(g.cfg.num_object_points, g.cfg.sub_batch_size).call(g.sweep_rows) if self.mode == 'point_3d' else None
         return sampler.convergence_centers(g, self.mode, unguided_sample.to(self.device), [0], starts)[0].to(self.device)
+
+    # ------------------------------------------------------------------ harness selection
+    def get_best_ids_all_metrics(self, objectives, opt_obj='rotate'):
+        """Index of the best gripper for every score of ``opt_obj`` (generator/diffusion.py:391-428)."""
+        directions, _ = objective_directions(opt_obj)
+        best = {k: (np.argmax if sgn > 0 else np.argmin)([o[k] for o in objectives]) for k, sgn in directions.items()}
+        if opt_obj != 'convergence':
+            best['success_rate'] = np.argmax([o['success_rate'] for o in objectives])
+        return best
+
+    def get_best_ids(self, objectives_unguided, num_grippers, num_objects, opt_obj='rotate'):
+        """Per object (scores are laid out object-major, gripper-minor): best flat indices per score (:346-352)."""
+        out = []
+        for i in range(num_objects):
+            block = objectives_unguided[i * num_grippers:(i + 1) * num_grippers]
+            out.append({k: v + i * num_grippers for k, v in self.get_best_ids_all_metrics(block, opt_obj=opt_obj).items()})
+        return out
+
+    def get_average_best_ids(self, objectives, opt_obj='rotate'):
+        """Best gripper by the objective's primary count (:354-389)."""
+        directions, primary = objective_directions(opt_obj)
+        return (np.argmax if directions[primary] > 0 else np.argmin)([o[primary] for o in objectives])
 
     # ------------------------------------------------------------------ a1
     def guided_sample(self, batch_idx, batch_size, noise, save_dir, opt_obj='rotate', ori_range=[-1.0, 1.0], unguided_sample=None):

@@ -454,12 +454,72 @@ def g7_convergence():
     np.savez_compressed(os.path.join(OUT, "g7_convergence.npz"), dyn2d_seed=DYN2D_SEED, dyn3d_seed=DYN3D_SEED, **out)
 
 
+def synth_metrics(seed, n_ori=360):
+    """Synthetic stand-in for what the simulator returns per (object, gripper) pair (dynamics/sim_test_mj.py:210-232):
+    three-class profiles and the motion statistics metric2objective reads.  Inputs only; the outputs come from the reference."""
+    rs = np.random.RandomState(seed)
+    walk = np.cumsum(rs.normal(0, 2.0, n_ori))
+    return {
+        "profile": rs.randint(0, 3, n_ori).astype(np.int64),
+        "profile_x": rs.randint(0, 3, n_ori).astype(np.int64),
+        "profile_y": rs.randint(0, 3, n_ori).astype(np.int64),
+        "delta_theta": rs.normal(0, 0.3, n_ori),
+        "final_delta_theta": rs.normal(0, 0.5, n_ori),
+        "delta_pos": rs.normal(0, 0.01, (n_ori, 2)),
+        "final_pos": rs.normal(0, 0.02, (n_ori, 2)),
+        "final_theta": np.where(rs.rand(n_ori) < 0.1, rs.uniform(-180, 180, n_ori), walk),
+    }
+
+
+def g8_harness():
+    """Selection helpers of the validation harness (generator/diffusion.py:346-428, dynamics/metrics.py:40-234) on synthetic
+    simulator metrics: 3 objects x 5 grippers, the slicing of validation_step :304, every objective."""
+    import json
+    num_objects, num_grippers = 3, 5
+    metrics = [synth_metrics(100 + i) for i in range(num_objects * num_grippers)]
+    d = object.__new__(Diffusion)            # the helpers use no instance state
+    names = OBJ16 + ['rotate_in_place']
+    out = {"num_objects": num_objects, "num_grippers": num_grippers, "seeds": [100 + i for i in range(len(metrics))], "objectives": {}}
+    for ori_range in ([-1.0, 1.0], [-0.5, 0.25]):
+        lo, hi = int((ori_range[0] + 1) * 180), int((ori_range[1] + 1) * 180)
+        sliced = [{k: m[k][lo:hi] for k in m} for m in metrics]                  # validation_step :304
+        for name in names:
+            if name == 'rotate_in_place':      # metric2objective has no such branch; the selectors alias it to 'rotate'
+                objs = [ref_metrics.metric2objective(m, 'rotate') for m in sliced]
+            else:
+                objs = [ref_metrics.metric2objective(m, name) for m in sliced]
+            best = d.get_best_ids(objs, num_grippers, num_objects, opt_obj=name)
+            avg = [{k: float(np.mean([objs[i * num_grippers + g][k] for i in range(num_objects)])) for k in objs[0]} for g in range(num_grippers)]
+            out["objectives"][f"{name}|{ori_range[0]}|{ori_range[1]}"] = {
+                "values": [{k: float(v) for k, v in o.items()} for o in objs],
+                "keys": list(objs[0].keys()),
+                "best_ids": [{k: int(v) for k, v in b.items()} for b in best],
+                "average_best": int(d.get_average_best_ids(avg, opt_obj=name)),
+            }
+    finals = [synth_metrics(200 + i)["final_theta"] for i in range(4)] + [np.zeros(10), np.arange(10) * 10.0, np.array([0.0])]
+    out["convergence_ranges"] = [{"finals": [float(v) for v in f], "thr": thr,
+                                  "ranges": [[int(a), int(b)] for a, b in ref_metrics.convergence_range_from_finals(f, threshold=thr)]}
+                                 for f in finals for thr in (0.1, 3, 10)]
+    for bad in ('shift', 'rotate_in_place'):
+        try:
+            ref_metrics.metric2objective(metrics[0], bad)
+            out.setdefault("errors", {})[bad] = None
+        except NotImplementedError:
+            out.setdefault("errors", {})[bad] = "NotImplementedError"
+    try:
+        d.get_average_best_ids([{}], opt_obj='shift')
+    except ValueError as e:
+        out["errors"]["selector"] = str(e)
+    with open(os.path.join(OUT, "g8_harness.json"), "w") as f:
+        json.dump(out, f)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs("/tmp/dgdm_golden", exist_ok=True)
     only = sys.argv[1:]
     for name, fn in (("g2", g2_unet), ("g3", g3_dyn2d), ("g4", g4_pointnet), ("g5", g5_dyn3d), ("g6", g6_chains),
-                     ("g7", g7_convergence)):
+                     ("g7", g7_convergence), ("g8", g8_harness)):
         if only and name not in only:
             continue
         fn()
