@@ -213,6 +213,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29512")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world)
+    if world > 1:       # ranks share the host: keep torch's CPU pools (input synthesis, FPS start draws) from oversubscribing it
+        torch.set_num_threads(max(1, (os.cpu_count() or 8) // (2 * world)))
     _lib.device_init(local)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
