@@ -11,6 +11,9 @@ struct DgdmUnet1d {
     dgdm::Blob blob;
     dgdm::UnetParams p;
     dgdm::DevBuf p_dev;     // copy of `p` in device memory (kernel argument)
+    dgdm::DevBuf w16;       // bf16 images of the MFMA convolutions
+    dgdm::DevBuf p16_dev;   // `p` with those images (bf16 = 1)
+    bool bf16 = false;      // dgdm_unet1d_set_contraction_dtype
 };
 
 namespace dgdm {

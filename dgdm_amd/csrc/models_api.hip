@@ -27,15 +27,39 @@ std::vector<float> conv_image(int cout, int cin, const std::vector<int> &taps, A
     return o;
 }
 
+// bf16 image for conv_mfma_bf16: [Cout/16][ntaps][Cin/32][64 lanes][8]; lane (i = l & 15, kg = l >> 4), slot j ->
+// bf16(W(co = 16 mt + i, ci = 32 g + 8 kg + j, tap taps[t])).  Appended to `dst`; returns the element offset.
+template <class At>
+size_t conv_image16(std::vector<uint16_t> &dst, int cout, int cin, const std::vector<int> &taps, At at) {
+    const size_t off = dst.size();
+    const int mt = cout / 16, g = cin / 32, nt = (int)taps.size();
+    dst.resize(off + (size_t)cout * cin * nt);
+    for (int m = 0; m < mt; ++m)
+        for (int t = 0; t < nt; ++t)
+            for (int gg = 0; gg < g; ++gg)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j)
+                        dst[off + ((((size_t)m * nt + t) * g + gg) * 64 + lane) * 8 + j] =
+                            f32_to_bf16(at(16 * m + (lane & 15), 32 * gg + 8 * (lane >> 4) + j, taps[t]));
+    return off;
+}
+
+size_t conv1d_image16(std::vector<uint16_t> &dst, const float *w, int cout, int cin, int kw) {
+    std::vector<int> taps(kw);
+    for (int k = 0; k < kw; ++k) taps[k] = k;
+    return conv_image16(dst, cout, cin, taps, [=](int co, int ci, int k) { return w[((size_t)co * cin + ci) * kw + k]; });
+}
+
 std::vector<float> conv1d_image(const float *w, int cout, int cin, int kw) {
     std::vector<int> taps(kw);
     for (int k = 0; k < kw; ++k) taps[k] = k;
     return conv_image(cout, cin, taps, [=](int co, int ci, int k) { return w[((size_t)co * cin + ci) * kw + k]; });
 }
 
-struct ResOff { size_t c0w, c0b, g0w, g0b, c1w, c1b, g1w, g1b, cw, cb, rw, rb; bool has_res; int cin, cout; };
+struct ResOff { size_t c0w, c0b, g0w, g0b, c1w, c1b, g1w, g1b, cw, cb, rw, rb; bool has_res; int cin, cout;
+                size_t c0w16 = 0, c1w16 = 0, rw16 = 0; };      // element offsets of the bf16 images (MFMA convolutions only)
 
-int pack_res(const StateDict &sd, Blob &bl, const std::string &p, int cin, int cout, int cond, int kw, ResOff *o) {
+int pack_res(const StateDict &sd, Blob &bl, std::vector<uint16_t> &b16, const std::string &p, int cin, int cout, int cond, int kw, ResOff *o) {
     auto vec = [&](const std::string &k, int64_t n, size_t *off) -> int {
         const float *d = sd.f32(k, n);
         if (!d) return DGDM_EKEY;
@@ -52,9 +76,11 @@ int pack_res(const StateDict &sd, Blob &bl, const std::string &p, int cin, int c
         o->c0w = bl.add(tw);
     } else {
         o->c0w = bl.add(conv1d_image(w, cout, cin, kw));
+        o->c0w16 = conv1d_image16(b16, w, cout, cin, kw);
     }
     if (!(w = sd.f32(p + ".blocks.1.block.0.weight", (int64_t)cout * cout * kw))) return DGDM_EKEY;
     o->c1w = bl.add(conv1d_image(w, cout, cout, kw));
+    o->c1w16 = conv1d_image16(b16, w, cout, cout, kw);
     int rc;
     if ((rc = vec(p + ".blocks.0.block.0.bias", cout, &o->c0b))) return rc;
     if ((rc = vec(p + ".blocks.0.block.1.weight", cout, &o->g0w))) return rc;
@@ -69,6 +95,7 @@ int pack_res(const StateDict &sd, Blob &bl, const std::string &p, int cin, int c
     if (o->has_res) {
         if (!(w = sd.f32(p + ".residual_conv.weight", (int64_t)cout * cin))) return DGDM_EKEY;
         o->rw = cin == 1 ? bl.add(w, (size_t)cout) : bl.add(conv1d_image(w, cout, cin, 1));
+        if (cin != 1) o->rw16 = conv1d_image16(b16, w, cout, cin, 1);
         if ((rc = vec(p + ".residual_conv.bias", cout, &o->rb))) return rc;
     }
     return DGDM_OK;
@@ -88,12 +115,13 @@ extern "C" int dgdm_unet1d_create(DgdmUnet1d **out, const DgdmTensor *tensors, i
     std::unique_ptr<DgdmUnet1d> m(new DgdmUnet1d());
     Blob &bl = m->blob;
     ResOff ro[8];
+    std::vector<uint16_t> b16;                       // bf16 images of every MFMA convolution (unet.hip conv_mfma_bf16)
     const struct { const char *name; int cin, cout; } spec[8] = {
         {"down_modules.0.0", 1, d0}, {"down_modules.0.1", d0, d0}, {"down_modules.1.0", d0, d1}, {"down_modules.1.1", d1, d1},
         {"mid_modules.0", d1, d1}, {"mid_modules.1", d1, d1}, {"up_modules.0.0", 2 * d1, d0}, {"up_modules.0.1", d0, d0}};
     int rc;
     for (int i = 0; i < 8; ++i)
-        if ((rc = pack_res(sd, bl, spec[i].name, spec[i].cin, spec[i].cout, dsed, kernel_size, &ro[i]))) return rc;
+        if ((rc = pack_res(sd, bl, b16, spec[i].name, spec[i].cin, spec[i].cout, dsed, kernel_size, &ro[i]))) return rc;
     const float *w, *b;
     // diffusion_step_encoder
     std::vector<float> fr(dsed / 2);
@@ -109,14 +137,17 @@ extern "C" int dgdm_unet1d_create(DgdmUnet1d **out, const DgdmTensor *tensors, i
     const size_t o_s3w = bl.add(transpose(w, dsed, 4 * dsed)), o_s3b = bl.add(b, dsed);
     if (!(w = sd.f32("down_modules.0.2.conv.weight", (int64_t)d0 * d0 * 3)) || !(b = sd.f32("down_modules.0.2.conv.bias", d0))) return DGDM_EKEY;
     const size_t o_dw = bl.add(conv1d_image(w, d0, d0, 3)), o_db = bl.add(b, d0);
+    const size_t o_dw16 = conv1d_image16(b16, w, d0, d0, 3);
     if (!(w = sd.f32("up_modules.0.2.conv.weight", (int64_t)d0 * d0 * 4)) || !(b = sd.f32("up_modules.0.2.conv.bias", d0))) return DGDM_EKEY;
     // ConvTranspose1d weight is [Cin][Cout][4]; even outputs use taps (1, 3), odd outputs taps (2, 0)
     const float *wt = w;
     auto atT = [=](int co, int ci, int k) { return wt[((size_t)ci * d0 + co) * 4 + k]; };
     const size_t o_uwe = bl.add(conv_image(d0, d0, std::vector<int>{1, 3}, atT)), o_uwo = bl.add(conv_image(d0, d0, std::vector<int>{2, 0}, atT)),
                  o_ub = bl.add(b, d0);
+    const size_t o_uwe16 = conv_image16(b16, d0, d0, std::vector<int>{1, 3}, atT), o_uwo16 = conv_image16(b16, d0, d0, std::vector<int>{2, 0}, atT);
     if (!(w = sd.f32("final_conv.0.block.0.weight", (int64_t)d0 * d0 * kernel_size)) || !(b = sd.f32("final_conv.0.block.0.bias", d0))) return DGDM_EKEY;
     const size_t o_fw = bl.add(conv1d_image(w, d0, d0, kernel_size)), o_fb = bl.add(b, d0);
+    const size_t o_fw16 = conv1d_image16(b16, w, d0, d0, kernel_size);
     const float *gw, *gb;
     if (!(gw = sd.f32("final_conv.0.block.1.weight", d0)) || !(gb = sd.f32("final_conv.0.block.1.bias", d0))) return DGDM_EKEY;
     const size_t o_fgw = bl.add(gw, d0), o_fgb = bl.add(gb, d0);
@@ -142,6 +173,19 @@ extern "C" int dgdm_unet1d_create(DgdmUnet1d **out, const DgdmTensor *tensors, i
     p.fin_w = bl.at(o_fw); p.fin_b = bl.at(o_fb); p.fin_gw = bl.at(o_fgw); p.fin_gb = bl.at(o_fgb);
     p.out_w = bl.at(o_ow); p.out_b = bl.at(o_ob);
     if ((rc = m->p_dev.upload(&p, sizeof p))) return rc;
+    {   // the same parameter block with the MFMA convolutions pointing at their bf16 images
+        if ((rc = m->w16.upload(b16.data(), b16.size() * sizeof(uint16_t)))) return rc;
+        auto at16 = [&](size_t off) { return reinterpret_cast<const float *>(static_cast<const uint16_t *>(m->w16.p) + off); };
+        UnetParams q = p;
+        q.bf16 = 1;
+        for (int i = 0; i < 8; ++i) {
+            if (ro[i].cin != 1) q.res[i].c0_w = at16(ro[i].c0w16);
+            q.res[i].c1_w = at16(ro[i].c1w16);
+            if (ro[i].has_res && ro[i].cin != 1) q.res[i].res_w = at16(ro[i].rw16);
+        }
+        q.down_w = at16(o_dw16); q.up_w_even = at16(o_uwe16); q.up_w_odd = at16(o_uwo16); q.fin_w = at16(o_fw16);
+        if ((rc = m->p16_dev.upload(&q, sizeof q))) return rc;
+    }
     *out = m.release();
     return DGDM_OK;
 }
@@ -151,7 +195,14 @@ extern "C" void dgdm_unet1d_destroy(DgdmUnet1d *m) { delete m; }
 extern "C" int dgdm_unet1d_forward(DgdmUnet1d *m, const float *sample_dev, const int32_t *timestep_dev, float *eps_dev, int B, int L,
                                    void *stream) {
     DGDM_REQUIRE(m && sample_dev && timestep_dev && eps_dev && B >= 0 && L > 0, DGDM_EINVAL, "dgdm_unet1d_forward: bad argument");
-    return unet_launch(m->p, m->p_dev.as<UnetParams>(), sample_dev, timestep_dev, eps_dev, B, L, (hipStream_t)stream);
+    return unet_launch(m->p, (m->bf16 ? m->p16_dev : m->p_dev).as<UnetParams>(), sample_dev, timestep_dev, eps_dev, B, L, (hipStream_t)stream);
+}
+
+extern "C" int dgdm_unet1d_set_contraction_dtype(DgdmUnet1d *m, int dtype) {
+    DGDM_REQUIRE(m, DGDM_EINVAL, "dgdm_unet1d_set_contraction_dtype: null handle");
+    DGDM_REQUIRE(dtype == DGDM_DTYPE_F32 || dtype == DGDM_DTYPE_BF16, DGDM_EINVAL, "contraction dtype %d unsupported (0 = f32, 1 = bf16)", dtype);
+    m->bf16 = dtype == DGDM_DTYPE_BF16;
+    return DGDM_OK;
 }
 
 // ================================================================================================ dynamics

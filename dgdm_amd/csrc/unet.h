@@ -15,6 +15,7 @@ struct UnetRes {
 
 struct UnetParams {
     int d0, d1, dsed, groups, cmax;
+    int bf16;                                    // 1: the MFMA convolution images are bf16 (unet.hip conv_mfma_bf16)
     const float *freqs;                          // SinusoidalPosEmb frequencies [dsed/2]
     const float *se1_wt, *se1_b, *se3_wt, *se3_b;
     UnetRes res[8];                              // down0.0 down0.1 down1.0 down1.1 mid0 mid1 up0.0 up0.1

@@ -55,6 +55,7 @@ struct ConvArgs {
     const float  *bias;
     int cin, cout, ntaps, istride, ostride, ooff;
     int ioff0, iostep;        // input row offset of tap t = ioff0 + t*iostep (an indexed array here ends up in scratch)
+    int bf16;                 // img is a bf16 image: conv_mfma_bf16
 };
 
 template <int NT, int MT, int MODE>
@@ -126,9 +127,96 @@ __device__ void conv_mfma(const ConvArgs a, const lds_f *in, int CPi, lds_f *out
     }
 }
 
+// The same convolution with bf16 operands (BASELINE configs[4], "bf16 contractions"): v_mfma_f32_16x16x32_bf16, K-step = 32 input
+// channels of one tap.  img16: [Cout/16][ntaps][Cin/32][64 lanes][8 bf16]; lane (i = l & 15, kg = l >> 4), slot j ->
+// W_t[16 mt + i][32 g + 8 kg + j] (rounded to bf16 on the host).  The activations stay float32 in LDS; a lane reads its 8
+// consecutive channels with two ds_read_b128 and rounds them with four v_cvt_pk_bf16_f32.  Accumulation, bias and everything
+// around the convolution are float32.
+typedef __bf16 bf16x8_u __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_u __attribute__((ext_vector_type(2)));
+typedef float f32x2_u __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_u __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+    const f32x2_u v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_u));
+}
+
+template <int NT, int MT, int MODE>
+__device__ void conv_mfma_bf16(const ConvArgs a, const lds_f *in, int CPi, lds_f *out, int CPo, int Lout) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int groups = a.cin >> 5, mtiles = a.cout >> 4;
+    int base[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) base[nt] = (min(nt * 16 + j, Lout - 1) * a.istride + 2) * CPi + 8 * q;
+    const int iters = a.ntaps * groups;
+    for (int mp = wave; mp * MT < mtiles; mp += nwave) {
+        int mt[MT];
+        glb_f4 *w[MT];
+        f32x4 nxt[MT], nxt2[MT];
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            mt[m] = min(mp * MT + m, mtiles - 1);
+            w[m] = (glb_f4 *)a.img + (size_t)mt[m] * iters * 64 + lane;
+            nxt[m] = w[m][0];
+            nxt2[m] = w[m][(size_t)min(1, iters - 1) * 64];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[m][nt] = (f32x4)(0.f);
+        }
+        int t = 0, g = 0;
+        for (int it = 0; it < iters; ++it) {
+            bf16x8_u av[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                av[m] = __builtin_bit_cast(bf16x8_u, nxt[m]);
+                nxt[m] = nxt2[m];
+            }
+            int pre = min(it + 2, iters - 1);
+            asm volatile("" : "+v"(pre));
+#pragma unroll
+            for (int m = 0; m < MT; ++m) nxt2[m] = w[m][(size_t)pre * 64];
+            const int off = (a.ioff0 + t * a.iostep) * CPi + g * 32;
+            bf16x8_u bv[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const f32x4 lo = *(const lds_f4 *)(in + base[nt] + off), hi = *(const lds_f4 *)(in + base[nt] + off + 4);
+                const u32x4_u pk = {pack2_bf16(lo[0], lo[1]), pack2_bf16(lo[2], lo[3]), pack2_bf16(hi[0], hi[1]), pack2_bf16(hi[2], hi[3])};
+                bv[nt] = __builtin_bit_cast(bf16x8_u, pk);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[m], bv[nt], acc[m][nt], 0, 0, 0);
+            if (++g == groups) { g = 0; ++t; }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (mp * MT + m >= mtiles) break;
+            const float4 b4 = *reinterpret_cast<const float4 *>(a.bias + mt[m] * 16 + 4 * q);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int l = nt * 16 + j;
+                if (l < Lout) {
+                    lds_f4 *p = (lds_f4 *)(out + ((l * a.ostride + a.ooff) + 2) * CPo + 4 * q + mt[m] * 16);
+                    f32x4 v = {acc[m][nt][0] + b4.x, acc[m][nt][1] + b4.y, acc[m][nt][2] + b4.z, acc[m][nt][3] + b4.w};
+                    if (MODE == 1) v += *p;
+                    *p = v;
+                }
+            }
+        }
+    }
+}
+
 template <int NT, int MODE>
 __device__ void conv_nt(const ConvArgs &a, const lds_f *in, int CPi, lds_f *out, int CPo, int Lout) {
     // two output tiles per wave share the activation fragments when there are enough tiles to keep every wave busy
+    if (a.bf16) {
+        if ((a.cout >> 4) >= 2 * (int)(blockDim.x >> 6)) conv_mfma_bf16<NT, 2, MODE>(a, in, CPi, out, CPo, Lout);
+        else conv_mfma_bf16<NT, 1, MODE>(a, in, CPi, out, CPo, Lout);
+        return;
+    }
     if ((a.cout >> 4) >= 2 * (int)(blockDim.x >> 6)) conv_mfma<NT, 2, MODE>(a, in, CPi, out, CPo, Lout);
     else conv_mfma<NT, 1, MODE>(a, in, CPi, out, CPo, Lout);
 }
@@ -141,8 +229,9 @@ __device__ void conv(const ConvArgs &a, const lds_f *in, int CPi, lds_f *out, in
     else conv_nt<4, MODE>(a, in, CPi, out, CPo, Lout);
 }
 
-__device__ ConvArgs conv_args(const float *img, const float *bias, int cin, int cout, int ntaps, int pad, int istride) {
+__device__ ConvArgs conv_args(const float *img, const float *bias, int cin, int cout, int ntaps, int pad, int istride, int bf16) {
     ConvArgs a;
+    a.bf16 = bf16;
     a.img = reinterpret_cast<const float4 *>(img); a.bias = bias; a.cin = cin; a.cout = cout; a.ntaps = ntaps;
     a.istride = istride; a.ostride = 1; a.ooff = 0;
     a.ioff0 = -pad; a.iostep = 1;
@@ -207,7 +296,7 @@ __device__ void matvec(const float *__restrict__ WT, const float *__restrict__ b
     }
 }
 
-struct Bufs { lds_f *A, *B, *C, *D, *film, *cond, *tmp, *xin; };
+struct Bufs { lds_f *A, *B, *C, *D, *film, *cond, *tmp, *xin; int bf16; };
 
 // ConditionalResidualBlock1D.forward (diffusion_utils.py:101-120): x(in, cin channels) -> out; t1 scratch.
 // `out` may be a wider buffer (row stride CPout >= cout + 4): the concat buffer of the up path.
@@ -223,13 +312,13 @@ __device__ void res_block(const UnetRes &w, const lds_f *in, lds_f *t1, lds_f *o
             t1[(l + 2) * CPo + co] = acc + w.c0_b[co];
         }
     } else {
-        conv<0>(conv_args(w.c0_w, w.c0_b, w.cin, w.cout, 5, 2, 1), in, CPi, t1, CPo, L);
+        conv<0>(conv_args(w.c0_w, w.c0_b, w.cin, w.cout, 5, 2, 1, s.bf16), in, CPi, t1, CPo, L);
     }
     zero_halo(t1, CPo, w.cout, L);
     __syncthreads();
     gn_mish_film(t1, CPo, w.cout, L, groups, w.g0_w, w.g0_b, s.film);
     __syncthreads();
-    conv<0>(conv_args(w.c1_w, w.c1_b, w.cout, w.cout, 5, 2, 1), t1, CPo, out, CPout, L);
+    conv<0>(conv_args(w.c1_w, w.c1_b, w.cout, w.cout, 5, 2, 1, s.bf16), t1, CPo, out, CPout, L);
     zero_halo(out, CPout, w.cout, L);
     __syncthreads();
     gn_mish_film(out, CPout, w.cout, L, groups, w.g1_w, w.g1_b, nullptr);
@@ -240,7 +329,7 @@ __device__ void res_block(const UnetRes &w, const lds_f *in, lds_f *t1, lds_f *o
             out[(l + 2) * CPout + co] += fmaf(w.res_w[co], s.xin[l + 2], w.res_b[co]);
         }
     } else if (w.res_w) {
-        conv<1>(conv_args(w.res_w, w.res_b, w.cin, w.cout, 1, 0, 1), in, CPi, out, CPout, L);   // residual 1x1 conv, added in place
+        conv<1>(conv_args(w.res_w, w.res_b, w.cin, w.cout, 1, 0, 1, s.bf16), in, CPi, out, CPout, L);   // residual 1x1 conv, added in place
     } else {
         for (int i = threadIdx.x; i < L * w.cout; i += blockDim.x) {
             const int l = i / w.cout, c = i - l * w.cout;
@@ -268,6 +357,7 @@ __global__ __launch_bounds__(512) void unet_kernel(const UnetParams *__restrict_
     s.cond = s.film + 2 * p.cmax;
     s.tmp = s.cond + p.dsed;
     s.xin = s.tmp + 4 * p.dsed;
+    s.bf16 = p.bf16;
     const int G = p.groups;
 
     // ---- diffusion_step_encoder: SinusoidalPosEmb -> Linear -> Mish -> Linear   (diffusion_utils.py:25-37,149-154)
@@ -294,7 +384,7 @@ __global__ __launch_bounds__(512) void unet_kernel(const UnetParams *__restrict_
     const int CP0 = p.d0 + 4, CP1 = p.d1 + 4, CPcat = 2 * p.d1 + 4;
     res_block(p.res[0], nullptr, s.B, s.C, CP0, L, p.dsed, G, s);     // down0.0   1 -> d0
     res_block(p.res[1], s.C, s.B, s.D, CP0, L, p.dsed, G, s);         // down0.1   d0 -> d0   (its skip is never consumed, :264-278)
-    conv<0>(conv_args(p.down_w, p.down_b, p.d0, p.d0, 3, 1, 2), s.D, CP0, s.B, CP0, L2);       // Downsample1d (:42)
+    conv<0>(conv_args(p.down_w, p.down_b, p.d0, p.d0, 3, 1, 2, p.bf16), s.D, CP0, s.B, CP0, L2);       // Downsample1d (:42)
     zero_halo(s.B, CP0, p.d0, L2);
     __syncthreads();
     res_block(p.res[2], s.B, s.C, s.D, CP1, L2, p.dsed, G, s);        // down1.0   d0 -> d1
@@ -309,16 +399,16 @@ __global__ __launch_bounds__(512) void unet_kernel(const UnetParams *__restrict_
     res_block(p.res[6], s.A, s.B, s.D, CP0, L2, p.dsed, G, s);        // up0.0   2*d1 -> d0
     res_block(p.res[7], s.D, s.B, s.C, CP0, L2, p.dsed, G, s);        // up0.1
     {   // Upsample1d: ConvTranspose1d(d0, d0, 4, 2, 1) (:51): out[2 li] = W1 in[li] + W3 in[li-1];  out[2 li + 1] = W2 in[li] + W0 in[li+1]
-        ConvArgs e = conv_args(p.up_w_even, p.up_b, p.d0, p.d0, 2, 0, 1);
+        ConvArgs e = conv_args(p.up_w_even, p.up_b, p.d0, p.d0, 2, 0, 1, p.bf16);
         e.ioff0 = 0; e.iostep = -1; e.ostride = 2; e.ooff = 0;
-        ConvArgs o = conv_args(p.up_w_odd, p.up_b, p.d0, p.d0, 2, 0, 1);
+        ConvArgs o = conv_args(p.up_w_odd, p.up_b, p.d0, p.d0, 2, 0, 1, p.bf16);
         o.ioff0 = 0; o.iostep = 1; o.ostride = 2; o.ooff = 1;
         conv<0>(e, s.C, CP0, s.A, CP0, L2);
         conv<0>(o, s.C, CP0, s.A, CP0, L2);
         zero_halo(s.A, CP0, p.d0, L);                                 // 2*L2 == L (checked by the launcher)
         __syncthreads();
     }
-    conv<0>(conv_args(p.fin_w, p.fin_b, p.d0, p.d0, 5, 2, 1), s.A, CP0, s.B, CP0, L);          // final_conv.0
+    conv<0>(conv_args(p.fin_w, p.fin_b, p.d0, p.d0, 5, 2, 1, p.bf16), s.A, CP0, s.B, CP0, L);          // final_conv.0
     __syncthreads();
     gn_mish_film(s.B, CP0, p.d0, L, G, p.fin_gw, p.fin_gb, nullptr);
     __syncthreads();

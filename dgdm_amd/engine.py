@@ -24,12 +24,20 @@ class Unet1d:
     """``ConditionalUnet1D`` weights packed on the device (generator/diffusion_utils.py:123-285)."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], down_dims: Sequence[int] = (128, 256), step_embed_dim: int = 32,
-                 kernel_size: int = 5, n_groups: int = 8):
+                 kernel_size: int = 5, n_groups: int = 8, contraction_dtype: str = "f32"):
         packed = _lib.PackedStateDict(state_dict)
         dd = (C.c_int32 * len(down_dims))(*down_dims)
         h = C.c_void_p()
         check(lib().dgdm_unet1d_create(C.byref(h), packed.array, packed.n, dd, len(down_dims), step_embed_dim, kernel_size, n_groups))
         self._h = h
+        self.set_contraction_dtype(contraction_dtype)
+
+    def set_contraction_dtype(self, dtype: str) -> None:
+        """'f32' (default, the parity path) or 'bf16': bf16 operands / float32 accumulation in the multi-channel convolutions."""
+        if dtype not in ("f32", "bf16"):
+            raise ValueError(f"contraction dtype {dtype!r} not supported")
+        check(lib().dgdm_unet1d_set_contraction_dtype(self._h, 1 if dtype == "bf16" else 0))
+        self.contraction_dtype = dtype
 
     def __del__(self):
         if getattr(self, "_h", None) and lib is not None:      # module globals are None during interpreter shutdown

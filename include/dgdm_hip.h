@@ -35,6 +35,9 @@ extern "C" {
 #define DGDM_ENODEVICE    -6   /* no gfx950 device visible                                  */
 
 /* One host tensor of a reference-format state_dict (torch layout, contiguous). */
+/* contraction dtypes of dgdm_unet1d_set_contraction_dtype / dgdm_guidance_set_contraction_dtype */
+enum { DGDM_DTYPE_F32 = 0, DGDM_DTYPE_BF16 = 1 };
+
 typedef struct DgdmTensor {
     const char *name;     /* e.g. "linears.3.weight", "module."-prefix already stripped     */
     const void *data;     /* host memory                                                    */
@@ -76,6 +79,10 @@ void dgdm_unet1d_destroy(DgdmUnet1d *m);
  * timestep_dev [B] int32 (one per sample), eps_dev [B][L].                                      */
 int dgdm_unet1d_forward(DgdmUnet1d *m, const float *sample_dev, const int32_t *timestep_dev, float *eps_dev,
                         int B, int L, void *stream);
+/* Arithmetic of the convolutions with more than one input and output channel: DGDM_DTYPE_F32 (default, the parity path) or
+ * DGDM_DTYPE_BF16 (weights and activations entering those convolutions rounded to bf16, float32 accumulation; GroupNorm, Mish,
+ * FiLM, residual adds, the Linear layers and the single-channel first/last convolutions stay float32).  BASELINE configs[4].   */
+int dgdm_unet1d_set_contraction_dtype(DgdmUnet1d *m, int dtype);
 
 /* ------------------------------------------------------------------ a13/a14: scheduler step
  * noise_pred - sqrt(1-abar_t)*grad*scale  (generator/diffusion.py:575,645) followed by
@@ -143,7 +150,6 @@ void dgdm_guidance_destroy(DgdmGuidance *g);
  * activations/gradients entering a contraction rounded to bf16 (nearest even), float32 accumulation; first-layer tables,
  * biases, objective and row sums stay float32.  The reference has no such switch (it calls
  * torch.set_float32_matmul_precision('high'), generator/diffusion.py:102, which is a no-op on its CPU path).          */
-enum { DGDM_DTYPE_F32 = 0, DGDM_DTYPE_BF16 = 1 };
 int  dgdm_guidance_set_contraction_dtype(DgdmGuidance *g, int dtype);
 /* Objects the chains refer to.  2-D: objects_dev [n][num_vertices][2] (flattened to object_ch as
  * cond_fn does, diffusion.py:485).  3-D: objects_dev [n][N][3]; builds the per-object PointNet++

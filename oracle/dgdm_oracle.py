@@ -81,10 +81,20 @@ class DDIM:
 
 
 # =========================================================================== a7  U-Net
+def _rc(x: torch.Tensor, w: torch.Tensor):
+    """bf16-contraction mode (see `contraction` below): a convolution whose input AND output have more than one channel runs on
+    the matrix pipe with its input and weight rounded to bf16 (float32 accumulation, float32 bias); the single-channel
+    input/output convolutions, the Linear layers, GroupNorm, Mish, FiLM and the residual adds stay float32."""
+    if _CONTRACTION == 'bf16' and x.shape[1] > 1 and w.shape[0] > 1 and w.shape[1] > 1:
+        return _bf(x), _bf(w)
+    return x, w
+
+
 def _conv_gn_mish(sd: SD, p: str, x: torch.Tensor, groups: int = 8) -> torch.Tensor:
     # generator/diffusion_utils.py:57-72
     w = sd[p + ".block.0.weight"]
-    x = F.conv1d(x, w, sd[p + ".block.0.bias"], padding=w.shape[-1] // 2)
+    xc, wc = _rc(x, w)
+    x = F.conv1d(xc, wc, sd[p + ".block.0.bias"], padding=w.shape[-1] // 2)
     x = F.group_norm(x, groups, sd[p + ".block.1.weight"], sd[p + ".block.1.bias"])
     return F.mish(x)
 
@@ -97,7 +107,8 @@ def _film_res_block(sd: SD, p: str, x: torch.Tensor, cond: torch.Tensor) -> torc
     out = e[:, :c, None] * out + e[:, c:, None]
     out = _conv_gn_mish(sd, p + ".blocks.1", out)
     if p + ".residual_conv.weight" in sd:
-        x = F.conv1d(x, sd[p + ".residual_conv.weight"], sd[p + ".residual_conv.bias"])
+        xc, wc = _rc(x, sd[p + ".residual_conv.weight"])
+        x = F.conv1d(xc, wc, sd[p + ".residual_conv.bias"])
     return out + x
 
 
@@ -119,8 +130,8 @@ def unet1d_forward(sd: SD, sample: torch.Tensor, timestep: torch.Tensor) -> torc
         x = _film_res_block(sd, f"down_modules.{lvl}.1", x, g)
         skips.append(x)
         if f"down_modules.{lvl}.2.conv.weight" in sd:
-            x = F.conv1d(x, sd[f"down_modules.{lvl}.2.conv.weight"], sd[f"down_modules.{lvl}.2.conv.bias"],
-                         stride=2, padding=1)
+            xc, wc = _rc(x, sd[f"down_modules.{lvl}.2.conv.weight"])
+            x = F.conv1d(xc, wc, sd[f"down_modules.{lvl}.2.conv.bias"], stride=2, padding=1)
     for i in range(2):                                                        # :271-272
         x = _film_res_block(sd, f"mid_modules.{i}", x, g)
     for lvl in range(n_up):                                                   # :274-278
@@ -128,8 +139,8 @@ def unet1d_forward(sd: SD, sample: torch.Tensor, timestep: torch.Tensor) -> torc
         x = _film_res_block(sd, f"up_modules.{lvl}.0", x, g)
         x = _film_res_block(sd, f"up_modules.{lvl}.1", x, g)
         if f"up_modules.{lvl}.2.conv.weight" in sd:
-            x = F.conv_transpose1d(x, sd[f"up_modules.{lvl}.2.conv.weight"], sd[f"up_modules.{lvl}.2.conv.bias"],
-                                   stride=2, padding=1)
+            xc, wc = _rc(x, sd[f"up_modules.{lvl}.2.conv.weight"])
+            x = F.conv_transpose1d(xc, wc, sd[f"up_modules.{lvl}.2.conv.bias"], stride=2, padding=1)
     x = _conv_gn_mish(sd, "final_conv.0", x)                                  # :280
     x = F.conv1d(x, sd["final_conv.1.weight"], sd["final_conv.1.bias"])
     return x.transpose(1, 2)

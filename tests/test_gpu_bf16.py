@@ -162,3 +162,29 @@ def test_ensemble_groups_equal_single_chains(dev):
     for k in range(2):
         one = sampler.guided_multi_object(net, g3, s, 'point_3d', noise, groups[k], objs[k], starts=Fixed(draws[k]))
         assert torch.equal(both[k], one), k
+
+
+def test_bf16_unet_vs_oracle(dev):
+    """eps-net with bf16 multi-channel convolutions: against the oracle's statement of the same rounding points and against the
+    float32 oracle (the price of bf16 operands: 7e-3..1e-2).  Tolerance vs the bf16 statement is 1e-2, measured 4e-3..6.5e-3: with
+    17 convolutions between GroupNorms, an activation that sits on a bf16 rounding boundary flips under any change of float32
+    summation order - the oracle's own bf16 statement moves by 4.6e-3 when its accumulation is done in float64 instead of float32
+    with the rounding points untouched (measured on the CPU).  The float32 path is bit-identical before and after the switch."""
+    sd = util.unet_sd(11)
+    net = engine.Unet1d(sd)
+    for L, B in ((14, 5), (42, 3)):
+        x = synth.synth_noise(20 + L, B, L).to(dev)
+        for t in (0, 6, 12):
+            ts = torch.full((B,), t, device=dev)
+            f32 = net.forward(x, ts).cpu()
+            net.set_contraction_dtype("bf16")
+            b16 = net.forward(x, ts).cpu()
+            net.set_contraction_dtype("f32")
+            assert torch.equal(net.forward(x, ts).cpu(), f32)
+            ref32 = orc.unet1d_forward(sd, x.cpu(), ts.cpu())
+            with orc.contraction('bf16'):
+                ref16 = orc.unet1d_forward(sd, x.cpu(), ts.cpu())
+            e16, e32 = util.rel_l2(b16, ref16), util.rel_l2(b16, ref32)
+            assert util.rel_l2(f32, ref32) < 2e-5
+            assert e16 < 1e-2, (L, t, e16)
+            assert e32 < 4e-2, (L, t, e32)
