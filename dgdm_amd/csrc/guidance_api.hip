@@ -49,7 +49,7 @@ struct DgdmGuidance {
     DevBuf tmpF1[NBUILD], tmpU[NBUILD], tmpY[NBUILD], tmpL2[NBUILD], tmpOff[NBUILD], tmpPairs[NBUILD], tmpRank[NBUILD], vlist;      // 3-D table-build temporaries
     hipStream_t bstream[NBUILD] = {nullptr, nullptr, nullptr};
     hipEvent_t bev[NBUILD] = {nullptr, nullptr, nullptr}, bstart = nullptr;
-    DevBuf V, genc, atab, chainbias, timepart, ttmp, partial, objdev, objidx, xobj, starts, order, xchains;
+    DevBuf V, genc, atab, chainbias, timepart, ttmp, partial, objdev, objidx, xobj, starts, order, xchains, todo;
     int n_objects = 0;
     bool force_slow_xobj = false;   // test hook: always run the per-row FPS kernel
     void *pinned = nullptr; size_t pinned_bytes = 0; hipEvent_t pinned_ev = nullptr;
@@ -127,7 +127,8 @@ extern "C" int dgdm_guidance_create(DgdmGuidance **out, DgdmDynamics *model, con
         if ((rc = g->objpart.alloc((size_t)std::max(1, cfg->max_objects) * W1 * 4))) return rc;
     } else {
         if ((rc = g->xobj.alloc((size_t)nc * g->R * 256 * 4)) || (rc = g->starts.alloc((size_t)nc * g->R * 2 * sizeof(int))) ||
-            (rc = g->order.alloc((size_t)nc * g->R * sizeof(int))) || (rc = g->xchains.alloc(sizeof(XobjChain) * nc)))
+            (rc = g->order.alloc((size_t)nc * g->R * sizeof(int))) || (rc = g->xchains.alloc(sizeof(XobjChain) * nc)) ||
+            (rc = g->todo.alloc(((size_t)nc * g->R + 1) * sizeof(int))))
             return rc;
         g->pinned_bytes = (size_t)nc * g->R * 3 * sizeof(int);
         DGDM_HIP_CHECK(hipHostMalloc(&g->pinned, g->pinned_bytes, hipHostMallocDefault));
@@ -312,7 +313,10 @@ int DgdmGuidance::run_xobj(const int *objidx_host, int n_chains, int64_t rows, h
     XobjParams xp{};
     xp.chains = xchains.as<XobjChain>(); xp.starts = starts.as<int>(); xp.order = order.as<int>(); xp.xobj = xobj.as<float>();
     xp.R = rows; xp.total_rows = rows * n_chains; xp.use_table = force_slow_xobj ? 0 : 1;
-    return pn_xobj(xp, s);
+    xp.todo = todo.as<int>(); xp.todo_count = todo.as<int>() + (size_t)cfg.max_chains * R; xp.todo_capacity = (int64_t)cfg.max_chains * R;
+    bool all_fast = true;
+    for (int i = 0; i < n_chains; ++i) all_fast = all_fast && tables[objidx_host[i]]->fast_ok;
+    return pn_xobj(xp, all_fast, s);
 }
 
 static int guidance_grad(DgdmGuidance *g, int kind, const float *x_dev, int timestep, const DgdmObjective *objectives, const float *rowcoef_dev,
@@ -471,7 +475,7 @@ int pointnet_rows(DgdmDynamics *m, const float *xyz_dev /*[rows][3][N]*/, const 
         DGDM_HIP_CHECK(hipMemcpyAsync(chains.p, &ch, sizeof ch, hipMemcpyHostToDevice, s));
         XobjParams xp{};
         xp.chains = chains.as<XobjChain>(); xp.starts = starts.as<int>(); xp.xobj = out.as<float>(); xp.R = (int64_t)rws.size(); xp.total_rows = xp.R;
-        if ((rc = pn_xobj(xp, s))) return rc;
+        if ((rc = pn_xobj(xp, false, s))) return rc;
         // scatter the group's rows back
         bool contiguous = true;
         for (size_t k = 1; k < rws.size(); ++k) contiguous = contiguous && rws[k] == rws[k - 1] + 1;

@@ -41,6 +41,10 @@ struct XobjParams {
     float           *xobj;        // [nchain][R][256]
     int64_t          R, total_rows;
     int              use_table;   // 0: always run the per-row FPS (test hook)
+    int              skip_fast;   // set by pn_xobj: xobj_kernel handles only the rows listed in todo
+    int             *todo;        // [total_rows] rows xobj_fast_kernel left to xobj_kernel, or null (then xobj_kernel does everything)
+    int             *todo_count;  // device counter of that list
+    int64_t          todo_capacity;
 };
 
 int pn_fps_table(const float *xyz, int N, int nv, int npoint, int *out, int *flags, hipStream_t s, int nobj = 1);
@@ -52,6 +56,7 @@ int pn_l2(const float *xyz, int N, const PnWeights &w, const int *fps1, const in
           const int *clist, const int *ncr, const int *off, const short *rank, hipStream_t s);
 int pn_z(const float *xyz, int N, int nv, const PnWeights &w, const float *L2, float *Z, const int *clist, const int *ncr, hipStream_t s);
 int pn_m0(const int *fps2, const int *crowded, int N, const float *Z0, float *M0, int *cl2, int *cnt2, hipStream_t s);
-int pn_xobj(const XobjParams &p, hipStream_t s);
+// all_fast: every chain has its tables and no start point with an order-dependent FPS(128) sequence (then one kernel does it all)
+int pn_xobj(const XobjParams &p, bool all_fast, hipStream_t s);
 
 }  // namespace dgdm

@@ -450,13 +450,57 @@ __device__ __forceinline__ int64_t xcd_contiguous(int64_t block, int64_t nblocks
     return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + i;
 }
 
-__global__ __launch_bounds__(256) void xobj_kernel(const XobjParams p) {
-    __shared__ float coords[4][3][512];
-    __shared__ int centres[4][128];
+// The common case on its own: rows whose 128-centre sequence comes from the fps2 table, reduced to M0[q] plus the crowded
+// centres.  No LDS (the per-row FPS of xobj_kernel needs 26 KB per workgroup, which caps it at 24 waves per CU) and eight
+// 1 KiB gathers in flight per wave instead of four: the kernel is bound by L2 latency, so both show up one for one.
+__global__ __launch_bounds__(256) void xobj_fast_kernel(const XobjParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int64_t w = xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wave;
     if (w >= p.total_rows) return;
     if (p.order) w = (w / p.R) * p.R + p.order[w];
+    const int chain = (int)(w / p.R);
+    const int64_t r = w - (int64_t)chain * p.R;
+    const XobjChain ch = p.chains[chain];
+    auto leave = [&]() {                               // one lane records the row for xobj_kernel (rare: tie-flagged start points)
+        if (lane == 0) p.todo[atomicAdd(p.todo_count, 1)] = w;
+    };
+    if (!ch.M0 || !ch.fps2) { leave(); return; }
+    const int *st = p.starts + (size_t)chain * 2 * p.R;
+    const int s1 = __builtin_amdgcn_readfirstlane(st[2 * r]), s2 = __builtin_amdgcn_readfirstlane(st[2 * r + 1]);
+    const int slot = ch.slot_of_start ? ch.slot_of_start[s1] : s1;
+    const int q = __builtin_amdgcn_readfirstlane(ch.fps1[(size_t)s1 * 512 + s2]);      // start point of sa2's FPS
+    if (ch.flags[q] != 0) { leave(); return; }                                          // xobj_kernel's row
+    const int cnt = __builtin_amdgcn_readfirstlane(ch.cnt2[q]);
+    const int rowA = slot * ch.N + ch.cl2[(size_t)q * 128 + lane], rowB = slot * ch.N + ch.cl2[(size_t)q * 128 + 64 + lane];
+    const float *zt = ch.Z + lane * 4;
+    float4 best = *reinterpret_cast<const float4 *>(ch.M0 + (size_t)q * 256 + lane * 4);
+    for (int i = 0; i < cnt; i += 8) {               // groups of eight never straddle lane 63|64; the list is padded to 128
+        const int src = i < 64 ? rowA : rowB, j = i & 63;
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4 *>(zt + (size_t)__builtin_amdgcn_readlane(src, j + k) * 256);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            best.x = fmaxf(best.x, v[k].x); best.y = fmaxf(best.y, v[k].y); best.z = fmaxf(best.z, v[k].z); best.w = fmaxf(best.w, v[k].w);
+        }
+    }
+    *reinterpret_cast<float4 *>(p.xobj + (size_t)w * 256 + lane * 4) = best;
+}
+
+__global__ __launch_bounds__(256) void xobj_kernel(const XobjParams p) {
+    __shared__ float coords[4][3][512];
+    __shared__ int centres[4][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t w;
+    if (p.skip_fast) {                                  // only the rows xobj_fast_kernel left out
+        const int i = blockIdx.x * 4 + wave;
+        if (i >= *p.todo_count) return;
+        w = p.todo[i];
+    } else {
+        w = xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wave;
+        if (w >= p.total_rows) return;
+        if (p.order) w = (w / p.R) * p.R + p.order[w];
+    }
     const int chain = (int)(w / p.R);
     const int64_t r = w - (int64_t)chain * p.R;
     const XobjChain ch = p.chains[chain];
@@ -576,8 +620,23 @@ int pn_m0(const int *fps2, const int *crowded, int N, const float *Z0, float *M0
     return DGDM_OK;
 }
 
-int pn_xobj(const XobjParams &p, hipStream_t s) {
-    if (p.total_rows <= 0) return DGDM_OK;
+int pn_xobj(const XobjParams &p_in, bool all_fast, hipStream_t s) {
+    if (p_in.total_rows <= 0) return DGDM_OK;
+    XobjParams p = p_in;
+    p.skip_fast = 0;
+    if (p.use_table && p.todo) {
+        DGDM_HIP_CHECK(hipMemsetAsync(p.todo_count, 0, sizeof(int), s));
+        hipLaunchKernelGGL(xobj_fast_kernel, dim3((unsigned)((p.total_rows + 3) / 4)), dim3(256), 0, s, p);
+        DGDM_HIP_CHECK(hipGetLastError());
+        if (all_fast) return DGDM_OK;               // no chain without tables, no start point with an order-dependent sequence
+        // the rows it recorded (a fraction of a percent: tie-flagged start points); the grid covers the worst case the caller
+        // allows for, surplus workgroups leave on the count
+        p.skip_fast = 1;
+        const int64_t cap = std::min<int64_t>(p.total_rows, p.todo_capacity);
+        hipLaunchKernelGGL(xobj_kernel, dim3((unsigned)((cap + 3) / 4)), dim3(256), 0, s, p);
+        DGDM_HIP_CHECK(hipGetLastError());
+        return DGDM_OK;
+    }
     hipLaunchKernelGGL(xobj_kernel, dim3((unsigned)((p.total_rows + 3) / 4)), dim3(256), 0, s, p);
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
