@@ -118,57 +118,6 @@ __device__ __forceinline__ void chain_layer(const float4 *__restrict__ Wp, const
     });
 }
 
-// One output block only (used when a wide layer is streamed block by block).
-template <int KB, bool BIAS>
-__device__ __forceinline__ f32x16 chain_block(const float4 *__restrict__ Wp_block, const float *__restrict__ bias_block,
-                                              const f32x16 (&in)[KB], int lane) {
-    const int h4 = (lane >> 5) * 4;
-    f32x16 acc;
-    if (BIAS) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 b4 = feat4(bias_block, 0, q, h4);
-            acc[4 * q + 0] = b4.x; acc[4 * q + 1] = b4.y; acc[4 * q + 2] = b4.z; acc[4 * q + 3] = b4.w;
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    }
-    stream_weights<KB * 4>(weight_rsrc(Wp_block, KB * 4 * 1024), lane * 16, 0, [&](int i, const float4 a) {
-        const int o = i / 4, q = i % 4;
-        acc = mfma32(a.x, in[o][4 * q + 0], acc);
-        acc = mfma32(a.y, in[o][4 * q + 1], acc);
-        acc = mfma32(a.z, in[o][4 * q + 2], acc);
-        acc = mfma32(a.w, in[o][4 * q + 3], acc);
-    });
-    return acc;
-}
-
-// acc[MB] += W[:, block kb] * x   for one 32-feature input block x (16 K-steps).
-// Wp is the image of the full [32 MB x 32 KBtot] matrix; kb selects the input block.
-template <int MB>
-__device__ __forceinline__ void chain_accumulate_block(const float4 *__restrict__ Wp, int KBtot, int kb, const f32x16 &x,
-                                                       f32x16 (&acc)[MB], int lane) {
-    const wrsrc_t rs = weight_rsrc(Wp, (uint32_t)MB * KBtot * 4 * 1024);
-    const int voff = lane * 16;
-    float4 a[MB * 4];
-#pragma unroll
-    for (int op = 0; op < MB; ++op)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) a[op * 4 + q] = wload(rs, voff, ((op * KBtot + kb) * 4 + q) * 1024);
-#pragma unroll
-    for (int op = 0; op < MB; ++op) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 w = a[op * 4 + q];
-            acc[op] = mfma32(w.x, x[4 * q + 0], acc[op]);
-            acc[op] = mfma32(w.y, x[4 * q + 1], acc[op]);
-            acc[op] = mfma32(w.z, x[4 * q + 2], acc[op]);
-            acc[op] = mfma32(w.w, x[4 * q + 3], acc[op]);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Continuous weight stream: the images of consecutive layers (or block passes) are laid out back to back in ONE buffer in
 // the order the kernel consumes them, and a 16-entry ring (16 divides every pass length used: 32, 64, 256) is carried

@@ -221,6 +221,9 @@ int dgdm_prof_enable(int on);
  * bank, whether the table path is admissible (out_fast_ok[n_objects], may be NULL).                   */
 int dgdm_guidance_debug_fps_path(DgdmGuidance *g, int force_per_row, int32_t *out_fast_ok);
 int dgdm_prof_read(int64_t *launches, double *total_ms, double *total_flops);
+/* Unit-test hook for the register-resident MFMA chain (csrc/mfma_chain.h): one 32-row tile through one 256 -> 256 layer,
+ * Y = X W^T + bias.  W_host [256][256] row-major, bias_host [256] (host memory); X_dev, Y_dev [32][256] (device).  Synchronises. */
+int dgdm_debug_chain_layer(const float *W_host, const float *bias_host, const float *X_dev, float *Y_dev, void *stream);
 
 #ifdef __cplusplus
 }
