@@ -30,6 +30,8 @@ struct ObjectTables {       // 3-D, per object
     bool   fast_ok = false; // no flag set: rows can take their centres from fps2 instead of running FPS
     DevBuf crowded, clist;  // [N] int each + clist[N] = count: centres whose ball query truncates (pointnet.hip crowd_kernel)
     DevBuf M0, cl2, cnt2;   // [N][256] float, [N][128] int, [N] int: variant-independent part of the sa3 max (pointnet.hip m0_kernel)
+    DevBuf Z16, M0_16;      // bf16 operand-order copies, built when the handle is in bf16 mode at set_objects time
+    bool   has16 = false;
 };
 
 }  // namespace
@@ -49,7 +51,7 @@ struct DgdmGuidance {
     DevBuf tmpF1[NBUILD], tmpU[NBUILD], tmpY[NBUILD], tmpL2[NBUILD], tmpOff[NBUILD], tmpPairs[NBUILD], tmpRank[NBUILD], vlist;      // 3-D table-build temporaries
     hipStream_t bstream[NBUILD] = {nullptr, nullptr, nullptr};
     hipEvent_t bev[NBUILD] = {nullptr, nullptr, nullptr}, bstart = nullptr;
-    DevBuf V, genc, atab, chainbias, timepart, ttmp, partial, objdev, objidx, xobj, starts, order, xchains, todo;
+    DevBuf V, genc, atab, chainbias, timepart, ttmp, partial, objdev, objidx, xobj, xobj16, starts, order, xchains, todo;
     int n_objects = 0;
     bool force_slow_xobj = false;   // test hook: always run the per-row FPS kernel
     void *pinned = nullptr; size_t pinned_bytes = 0; hipEvent_t pinned_ev = nullptr;
@@ -66,7 +68,7 @@ struct DgdmGuidance {
     int common_pre(const float *x_dev, float t_scaled, const int *objidx_host, int n_chains, hipStream_t s);
     int upload_starts(const int64_t *starts_host, int n_chains, int64_t rows, hipStream_t s);
     int build_object(int oi, int slot, hipStream_t s);
-    int run_xobj(const int *objidx_host, int n_chains, int64_t rows, hipStream_t s);
+    int run_xobj(const int *objidx_host, int n_chains, int64_t rows, bool want16, bool *used16, hipStream_t s);
 };
 
 int DgdmGuidance::build_pose_table(const std::vector<float> &ori, const std::vector<float> &pos, DevBuf *dst, DevBuf *dst_tiled, hipStream_t s) {
@@ -167,6 +169,9 @@ int DgdmGuidance::build_object(int oi, int slot, hipStream_t s) {
         (rc = t.crowded.alloc((size_t)N * sizeof(int))) || (rc = t.clist.alloc((size_t)(N + 1) * sizeof(int))) ||
         (rc = t.M0.alloc((size_t)N * 256 * 4)) || (rc = t.cl2.alloc((size_t)N * 128 * sizeof(int))) || (rc = t.cnt2.alloc((size_t)N * sizeof(int))))
         return rc;
+    t.has16 = bf16;
+    if (bf16 && ((rc = t.Z16.alloc((size_t)N * N * 128 * 4)) || (rc = t.M0_16.alloc((size_t)N * 128 * 4)))) return rc;
+    uint32_t *z16 = bf16 ? t.Z16.as<uint32_t>() : nullptr;
     DevBuf &tF1 = tmpF1[slot], &tU = tmpU[slot], &tY = tmpY[slot], &tL2 = tmpL2[slot];
     if ((rc = tF1.alloc((size_t)N * 128 * 4)) || (rc = tU.alloc((size_t)N * 128 * 4)) || (rc = tY.alloc((size_t)N * N * 256 * 4)) ||
         (rc = tL2.alloc((size_t)N * N * 256 * 4)))
@@ -181,8 +186,9 @@ int DgdmGuidance::build_object(int oi, int slot, hipStream_t s) {
     if ((rc = pn_pairs(xyz, N, tU.as<float>(), w, tPairs.as<int>(), tOff.as<int>(), tY.as<float>(), s))) return rc;       // T4
     if ((rc = pn_l2(xyz, N, w, t.fps1, vlist.as<int>(), N, tY.as<float>(), tL2.as<float>(), t.clist.as<int>(), t.clist.as<int>() + N,
                     tOff.as<int>(), tRank.as<short>(), s))) return rc;                                                     // T5
-    if ((rc = pn_z(xyz, N, N, w, tL2.as<float>(), t.Z.as<float>(), t.clist.as<int>(), t.clist.as<int>() + N, s))) return rc;                        // T6
-    return pn_m0(t.fps2, t.crowded.as<int>(), N, t.Z.as<float>(), t.M0.as<float>(), t.cl2.as<int>(), t.cnt2.as<int>(), s);              // T7
+    if ((rc = pn_z(xyz, N, N, w, tL2.as<float>(), t.Z.as<float>(), z16, t.clist.as<int>(), t.clist.as<int>() + N, s))) return rc;                   // T6
+    return pn_m0(t.fps2, t.crowded.as<int>(), N, t.Z.as<float>(), t.M0.as<float>(), t.cl2.as<int>(), t.cnt2.as<int>(), z16,
+                 bf16 ? t.M0_16.as<uint32_t>() : nullptr, s);                                                                                       // T7
 }
 
 extern "C" int dgdm_guidance_set_objects(DgdmGuidance *g, const float *objects_dev, int n_objects, void *stream) {
@@ -300,7 +306,7 @@ int DgdmGuidance::upload_starts(const int64_t *starts_host, int n_chains, int64_
     return DGDM_OK;
 }
 
-int DgdmGuidance::run_xobj(const int *objidx_host, int n_chains, int64_t rows, hipStream_t s) {
+int DgdmGuidance::run_xobj(const int *objidx_host, int n_chains, int64_t rows, bool want16, bool *used16, hipStream_t s) {
     std::vector<XobjChain> ch(n_chains);
     for (int i = 0; i < n_chains; ++i) {
         DGDM_REQUIRE(objidx_host[i] >= 0 && objidx_host[i] < n_objects, DGDM_EINVAL, "chain %d refers to object %d of %d", i, objidx_host[i], n_objects);
@@ -308,10 +314,18 @@ int DgdmGuidance::run_xobj(const int *objidx_host, int n_chains, int64_t rows, h
         ch[i].xyz = t.xyz; ch[i].fps1 = t.fps1; ch[i].slot_of_start = nullptr; ch[i].Z = t.Z.as<float>();
         ch[i].fps2 = t.fps2; ch[i].flags = t.flags; ch[i].crowded = t.crowded.as<int>(); ch[i].N = cfg.num_object_points;
         ch[i].M0 = t.M0.as<float>(); ch[i].cl2 = t.cl2.as<int>(); ch[i].cnt2 = t.cnt2.as<int>();
+        ch[i].Z16 = t.has16 ? t.Z16.as<uint32_t>() : nullptr; ch[i].M0_16 = t.has16 ? t.M0_16.as<uint32_t>() : nullptr;
+        want16 = want16 && t.has16;          // bf16 rows only if every chain's object was built with its bf16 tables
     }
+    if (want16 && xobj16.bytes < (size_t)n_chains * rows * 512) {
+        int rc = xobj16.alloc((size_t)cfg.max_chains * R * 512);
+        if (rc) return rc;
+    }
+    if (used16) *used16 = want16;
     DGDM_HIP_CHECK(hipMemcpyAsync(xchains.p, ch.data(), sizeof(XobjChain) * n_chains, hipMemcpyHostToDevice, s));
     XobjParams xp{};
     xp.chains = xchains.as<XobjChain>(); xp.starts = starts.as<int>(); xp.order = order.as<int>(); xp.xobj = xobj.as<float>();
+    xp.xobj16 = want16 ? xobj16.as<uint32_t>() : nullptr;
     xp.R = rows; xp.total_rows = rows * n_chains; xp.use_table = force_slow_xobj ? 0 : 1;
     xp.todo = todo.as<int>(); xp.todo_count = todo.as<int>() + (size_t)cfg.max_chains * R; xp.todo_capacity = (int64_t)cfg.max_chains * R;
     bool all_fast = true;
@@ -342,8 +356,10 @@ static int guidance_grad(DgdmGuidance *g, int kind, const float *x_dev, int time
     if (kind == 3) {
         DGDM_REQUIRE(starts_host, DGDM_EINVAL, "3-D guidance needs the FPS start indices");
         if ((rc = g->upload_starts(starts_host, n_chains, g->R, s))) return rc;
-        if ((rc = g->run_xobj(oidx.data(), n_chains, g->R, s))) return rc;
+        bool used16 = false;
+        if ((rc = g->run_xobj(oidx.data(), n_chains, g->R, g->bf16, &used16, s))) return rc;
         p.xobj = g->xobj.as<float>();
+        p.xobj16 = used16 ? g->xobj16.as<uint32_t>() : nullptr;
     }
     p.Atab = g->atab.as<float>(); p.Ptab = g->ptab.as<float>(); p.PtabT = g->ptab_t.as<float>(); p.obj = g->objdev.as<TrunkObjective>(); p.rowcoef = rowcoef_dev;
     p.partial = g->partial.as<float>();
@@ -398,7 +414,7 @@ extern "C" int dgdm_guidance_orientation_sweep(DgdmGuidance *g, const float *x_d
     if (kind == 3) {
         DGDM_REQUIRE(starts_host, DGDM_EINVAL, "3-D sweep needs the FPS start indices");
         if ((rc = g->upload_starts(starts_host, n_chains, g->Rs, s))) return rc;
-        if ((rc = g->run_xobj(object_of_chain, n_chains, g->Rs, s))) return rc;
+        if ((rc = g->run_xobj(object_of_chain, n_chains, g->Rs, false, nullptr, s))) return rc;      // the sweep stays float32
         p.xobj = g->xobj.as<float>();
     }
     p.Atab = g->atab.as<float>(); p.Ptab = g->ptab_sweep.as<float>(); p.PtabT = g->ptab_sweep_t.as<float>(); p.logits = logits_dev;
@@ -469,7 +485,7 @@ int pointnet_rows(DgdmDynamics *m, const float *xyz_dev /*[rows][3][N]*/, const 
         if ((rc = pn_pairs(x, N, U.as<float>(), w, pairs.as<int>(), poff.as<int>(), Y.as<float>(), s))) return rc;
         if ((rc = pn_l2(x, N, w, fps1.as<int>(), vlist.as<int>(), nv, Y.as<float>(), L2.as<float>(), clist.as<int>(), clist.as<int>() + N,
                         poff.as<int>(), prank.as<short>(), s))) return rc;
-        if ((rc = pn_z(x, N, nv, w, L2.as<float>(), Z.as<float>(), clist.as<int>(), clist.as<int>() + N, s))) return rc;
+        if ((rc = pn_z(x, N, nv, w, L2.as<float>(), Z.as<float>(), nullptr, clist.as<int>(), clist.as<int>() + N, s))) return rc;
         XobjChain ch{};
         ch.xyz = x; ch.fps1 = fps1.as<int>(); ch.slot_of_start = slotmap.as<int>(); ch.Z = Z.as<float>(); ch.fps2 = nullptr; ch.flags = nullptr; ch.crowded = crowded.as<int>(); ch.N = N;
         DGDM_HIP_CHECK(hipMemcpyAsync(chains.p, &ch, sizeof ch, hipMemcpyHostToDevice, s));

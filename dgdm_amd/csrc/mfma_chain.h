@@ -32,6 +32,23 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// bf16 helpers shared by the bf16-contraction kernels.  pack_bf16 is v_cvt_pk_bf16_f32 (round to nearest even).  Rows of
+// NON-NEGATIVE bf16 values (post-ReLU features) compare like unsigned 16-bit integers, so their elementwise max is v_pk_max_u16;
+// and rounding is monotonic, so max(bf(a), bf(b)) == bf(max(a, b)): a feature table whose only consumer rounds to bf16 can be
+// stored in bf16 without changing a bit of the result.
+typedef __bf16 dgdm_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float dgdm_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short dgdm_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    const dgdm_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, dgdm_bf16x2));
+}
+__device__ __forceinline__ uint32_t pkmax_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(dgdm_u16x2, a), __builtin_bit_cast(dgdm_u16x2, b)));
+}
+// A 256-feature row in bf16 "operand order" (512 bytes): dword 16 o + 8 h + d = features 32 o + rho(2d, h), +1 - i.e. exactly the
+// eight dwords lane (n, h) of the bf16 trunk needs as the B operand of block o, contiguous (trunk_bf16.hip).
+
 // float4 holding features 32 o + 8 q + 4 h + {0..3} of a row-major feature vector
 __device__ __forceinline__ float4 feat4(const float *__restrict__ row, int o, int q, int h4) {
     return *reinterpret_cast<const float4 *>(row + 32 * o + 8 * q + h4);

@@ -25,6 +25,7 @@ struct XobjChain {
     const int   *fps1;            // [N][512]
     const int   *slot_of_start;   // [N] start index -> table slot, or null (slot = start)
     const float *Z;               // [nv][N][256]
+    const uint32_t *Z16, *M0_16;  // bf16 operand-order copies of Z and M0 ([.][128 dwords], mfma_chain.h) or null
     const int   *fps2;            // [N][128] FPS(128) sequences by start POINT, or null
     const int   *flags;           // [N] 1 = the sequence from this start point is order-dependent: run FPS for the row
     const int   *crowded;         // [N] 1 = more than 64 points in the centre's r=0.4 ball: Z depends on the variant
@@ -39,6 +40,7 @@ struct XobjParams {
     const int       *starts;      // [nchain][R][2]  (s1, s2) per reference row
     const int       *order;       // [nchain][R] row ids of each chain sorted by s1, or null (natural order)
     float           *xobj;        // [nchain][R][256]
+    uint32_t        *xobj16;      // when set: gather from Z16 / M0_16 and write bf16 operand-order rows [nchain][R][128] here instead
     int64_t          R, total_rows;
     int              use_table;   // 0: always run the per-row FPS (test hook)
     int              skip_fast;   // set by pn_xobj: xobj_kernel handles only the rows listed in todo
@@ -54,8 +56,11 @@ int pn_crowd(const float *xyz, int N, const PnWeights &w, int *crowded, int *cli
 int pn_pairs(const float *xyz, int N, const float *U, const PnWeights &w, const int *pairs, const int *off, float *Y, hipStream_t s);
 int pn_l2(const float *xyz, int N, const PnWeights &w, const int *fps1, const int *vlist, int nv, const float *Y, float *L2,
           const int *clist, const int *ncr, const int *off, const short *rank, hipStream_t s);
-int pn_z(const float *xyz, int N, int nv, const PnWeights &w, const float *L2, float *Z, const int *clist, const int *ncr, hipStream_t s);
-int pn_m0(const int *fps2, const int *crowded, int N, const float *Z0, float *M0, int *cl2, int *cnt2, hipStream_t s);
+// Z16 (optional): the same rows again in bf16 operand order
+int pn_z(const float *xyz, int N, int nv, const PnWeights &w, const float *L2, float *Z, uint32_t *Z16, const int *clist, const int *ncr,
+         hipStream_t s);
+int pn_m0(const int *fps2, const int *crowded, int N, const float *Z0, float *M0, int *cl2, int *cnt2, const uint32_t *Z0_16, uint32_t *M0_16,
+          hipStream_t s);
 // all_fast: every chain has its tables and no start point with an order-dependent FPS(128) sequence (then one kernel does it all)
 int pn_xobj(const XobjParams &p, bool all_fast, hipStream_t s);
 

@@ -355,8 +355,8 @@ __global__ __launch_bounds__(256) void l2_kernel(const float *__restrict__ xyz, 
 // mode 0: slot 0, all N centres.  mode 1: slots 1..nv-1, crowded centres only (work item k -> slot 1 + k / ncr, centre clist[k % ncr]).
 __global__ __launch_bounds__(256, 1) void z_kernel(const float *__restrict__ xyz, int N, int nv, const float *__restrict__ L2,
                                                    const float4 *__restrict__ Wimg, const float *__restrict__ w3x /*[3][256]*/,
-                                                   const float *__restrict__ bias, float *__restrict__ Z, int mode,
-                                                   const int *__restrict__ clist, const int *__restrict__ ncr) {
+                                                   const float *__restrict__ bias, float *__restrict__ Z, uint32_t *__restrict__ Z16,
+                                                   int mode, const int *__restrict__ clist, const int *__restrict__ ncr) {
     const int lane = threadIdx.x & 63, n = lane & 31, h4 = (lane >> 5) * 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
@@ -397,6 +397,18 @@ __global__ __launch_bounds__(256, 1) void z_kernel(const float *__restrict__ xyz
                 *reinterpret_cast<float4 *>(dst + 32 * o + 8 * q + h4) = v;
             }
         }
+        if (Z16) {
+            // the same row in bf16 operand order for the bf16 trunk (mfma_chain.h): the lane's 8 dwords of block o are contiguous
+            uint4 *d16 = reinterpret_cast<uint4 *>(Z16 + (size_t)row * 128) + (h4 >> 1);
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                uint32_t pk[8];
+#pragma unroll
+                for (int d = 0; d < 8; ++d) pk[d] = pack_bf16(fmaxf(out[o][2 * d], 0.f), fmaxf(out[o][2 * d + 1], 0.f));
+                d16[4 * o] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                d16[4 * o + 1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+            }
+        }
     }
 }
 
@@ -407,7 +419,7 @@ __global__ __launch_bounds__(256, 1) void z_kernel(const float *__restrict__ xyz
 // loop can run in groups of four without a tail.  One wave per start point q.  max is exact, so the split is bit-neutral.
 __global__ __launch_bounds__(256) void m0_kernel(const int *__restrict__ fps2 /*[N][128]*/, const int *__restrict__ crowded, int N,
                                                  const float *__restrict__ Z0 /*[N][256]*/, float *__restrict__ M0, int *__restrict__ cl2,
-                                                 int *__restrict__ cnt2) {
+                                                 int *__restrict__ cnt2, const uint32_t *__restrict__ Z0_16, uint32_t *__restrict__ M0_16) {
     const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= N) return;
     const int idA = fps2[(size_t)q * 128 + lane], idB = fps2[(size_t)q * 128 + 64 + lane];
@@ -437,6 +449,21 @@ __global__ __launch_bounds__(256) void m0_kernel(const int *__restrict__ fps2 /*
         }
     }
     *reinterpret_cast<float4 *>(M0 + (size_t)q * 256 + lane * 4) = best;
+    if (M0_16) {                                        // the same table over the bf16 rows (two dwords per lane)
+        uint2 b16 = make_uint2(0u, 0u);
+        for (int i = 0; i < 64; ++i) {
+            const int a = __shfl(idA, i), b = __shfl(idB, i);
+            if (!((mA >> i) & 1ull)) {
+                const uint2 v = reinterpret_cast<const uint2 *>(Z0_16 + (size_t)a * 128)[lane];
+                b16.x = pkmax_u16(b16.x, v.x); b16.y = pkmax_u16(b16.y, v.y);
+            }
+            if (!((mB >> i) & 1ull)) {
+                const uint2 v = reinterpret_cast<const uint2 *>(Z0_16 + (size_t)b * 128)[lane];
+                b16.x = pkmax_u16(b16.x, v.x); b16.y = pkmax_u16(b16.y, v.y);
+            }
+        }
+        reinterpret_cast<uint2 *>(M0_16 + (size_t)q * 128)[lane] = b16;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ per row
@@ -450,10 +477,34 @@ __device__ __forceinline__ int64_t xcd_contiguous(int64_t block, int64_t nblocks
     return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + i;
 }
 
+// One row of a feature table per wave-load: float32 rows are 1 KiB (a float4 per lane), bf16 operand-order rows 512 B (a uint2).
+template <bool BF16> struct RowOps;
+template <> struct RowOps<false> {
+    typedef float4 V;
+    static __device__ __forceinline__ V zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }       // features are >= 0 (ReLU)
+    static __device__ __forceinline__ V load(const XobjChain &ch, bool m0, size_t row, int lane) {
+        return reinterpret_cast<const float4 *>((m0 ? ch.M0 : ch.Z) + row * 256)[lane];
+    }
+    static __device__ __forceinline__ V vmax(V a, V b) { return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)); }
+    static __device__ __forceinline__ void store(const XobjParams &p, size_t row, int lane, V v) { reinterpret_cast<float4 *>(p.xobj + row * 256)[lane] = v; }
+};
+template <> struct RowOps<true> {
+    typedef uint2 V;
+    static __device__ __forceinline__ V zero() { return make_uint2(0u, 0u); }
+    static __device__ __forceinline__ V load(const XobjChain &ch, bool m0, size_t row, int lane) {
+        return reinterpret_cast<const uint2 *>((m0 ? ch.M0_16 : ch.Z16) + row * 128)[lane];
+    }
+    static __device__ __forceinline__ V vmax(V a, V b) { return make_uint2(pkmax_u16(a.x, b.x), pkmax_u16(a.y, b.y)); }
+    static __device__ __forceinline__ void store(const XobjParams &p, size_t row, int lane, V v) { reinterpret_cast<uint2 *>(p.xobj16 + row * 128)[lane] = v; }
+};
+
 // The common case on its own: rows whose 128-centre sequence comes from the fps2 table, reduced to M0[q] plus the crowded
 // centres.  No LDS (the per-row FPS of xobj_kernel needs 26 KB per workgroup, which caps it at 24 waves per CU) and eight
-// 1 KiB gathers in flight per wave instead of four: the kernel is bound by L2 latency, so both show up one for one.
+// gathers in flight per wave instead of four: the kernel is bound by L2 latency.  BF16: gathers from the bf16 copies of Z / M0
+// and writes bf16 operand-order rows for the bf16 trunk - half the bytes, bit-identical after the trunk's own rounding.
+template <bool BF16>
 __global__ __launch_bounds__(256) void xobj_fast_kernel(const XobjParams p) {
+    typedef RowOps<BF16> R;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int64_t w = xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wave;
     if (w >= p.total_rows) return;
@@ -472,22 +523,21 @@ __global__ __launch_bounds__(256) void xobj_fast_kernel(const XobjParams p) {
     if (ch.flags[q] != 0) { leave(); return; }                                          // xobj_kernel's row
     const int cnt = __builtin_amdgcn_readfirstlane(ch.cnt2[q]);
     const int rowA = slot * ch.N + ch.cl2[(size_t)q * 128 + lane], rowB = slot * ch.N + ch.cl2[(size_t)q * 128 + 64 + lane];
-    const float *zt = ch.Z + lane * 4;
-    float4 best = *reinterpret_cast<const float4 *>(ch.M0 + (size_t)q * 256 + lane * 4);
+    typename R::V best = R::load(ch, true, (size_t)q, lane);
     for (int i = 0; i < cnt; i += 8) {               // groups of eight never straddle lane 63|64; the list is padded to 128
         const int src = i < 64 ? rowA : rowB, j = i & 63;
-        float4 v[8];
+        typename R::V v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4 *>(zt + (size_t)__builtin_amdgcn_readlane(src, j + k) * 256);
+        for (int k = 0; k < 8; ++k) v[k] = R::load(ch, false, (size_t)__builtin_amdgcn_readlane(src, j + k), lane);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            best.x = fmaxf(best.x, v[k].x); best.y = fmaxf(best.y, v[k].y); best.z = fmaxf(best.z, v[k].z); best.w = fmaxf(best.w, v[k].w);
-        }
+        for (int k = 0; k < 8; ++k) best = R::vmax(best, v[k]);
     }
-    *reinterpret_cast<float4 *>(p.xobj + (size_t)w * 256 + lane * 4) = best;
+    R::store(p, (size_t)w, lane, best);
 }
 
+template <bool BF16>
 __global__ __launch_bounds__(256) void xobj_kernel(const XobjParams p) {
+    typedef RowOps<BF16> R;
     __shared__ float coords[4][3][512];
     __shared__ int centres[4][128];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -516,21 +566,15 @@ __global__ __launch_bounds__(256) void xobj_kernel(const XobjParams p) {
             // non-crowded centres are already folded into M0[q]; only the crowded ones differ per variant
             const int cnt = __builtin_amdgcn_readfirstlane(ch.cnt2[q]);
             const int rowA = slot * ch.N + ch.cl2[(size_t)q * 128 + lane], rowB = slot * ch.N + ch.cl2[(size_t)q * 128 + 64 + lane];
-            const float *zt = ch.Z + lane * 4;
-            float4 best = *reinterpret_cast<const float4 *>(ch.M0 + (size_t)q * 256 + lane * 4);
+            typename R::V best = R::load(ch, true, (size_t)q, lane);
             for (int i = 0; i < cnt; i += 4) {           // groups of four never straddle lane 63|64; the list is padded
                 const int src = i < 64 ? rowA : rowB, j = i & 63;
                 const int c0 = __shfl(src, j), c1 = __shfl(src, j + 1), c2 = __shfl(src, j + 2), c3 = __shfl(src, j + 3);
-                const float4 a = *reinterpret_cast<const float4 *>(zt + (size_t)c0 * 256);
-                const float4 b = *reinterpret_cast<const float4 *>(zt + (size_t)c1 * 256);
-                const float4 d = *reinterpret_cast<const float4 *>(zt + (size_t)c2 * 256);
-                const float4 e = *reinterpret_cast<const float4 *>(zt + (size_t)c3 * 256);
-                best.x = fmaxf(fmaxf(best.x, fmaxf(a.x, b.x)), fmaxf(d.x, e.x));
-                best.y = fmaxf(fmaxf(best.y, fmaxf(a.y, b.y)), fmaxf(d.y, e.y));
-                best.z = fmaxf(fmaxf(best.z, fmaxf(a.z, b.z)), fmaxf(d.z, e.z));
-                best.w = fmaxf(fmaxf(best.w, fmaxf(a.w, b.w)), fmaxf(d.w, e.w));
+                const typename R::V a = R::load(ch, false, (size_t)c0, lane), b = R::load(ch, false, (size_t)c1, lane);
+                const typename R::V d = R::load(ch, false, (size_t)c2, lane), e = R::load(ch, false, (size_t)c3, lane);
+                best = R::vmax(R::vmax(best, R::vmax(a, b)), R::vmax(d, e));
             }
-            *reinterpret_cast<float4 *>(p.xobj + (size_t)w * 256 + lane * 4) = best;
+            R::store(p, (size_t)w, lane, best);
             return;
         }
         idA = ch.fps2[(size_t)q * 128 + lane];
@@ -551,21 +595,15 @@ __global__ __launch_bounds__(256) void xobj_kernel(const XobjParams p) {
     }
     // row of Z for a centre: its own variant's slot when the centre is crowded, slot 0 otherwise (see crowd_kernel)
     const int rowA = (ch.crowded[idA] ? slot * ch.N : 0) + idA, rowB = (ch.crowded[idB] ? slot * ch.N : 0) + idB;
-    const float *zt = ch.Z + lane * 4;
-    float4 best = make_float4(0.f, 0.f, 0.f, 0.f);      // Z >= 0 (ReLU)
+    typename R::V best = R::zero();
 #pragma unroll 4
     for (int i = 0; i < 64; i += 2) {
         const int c0 = __shfl(rowA, i), c1 = __shfl(rowA, i + 1), c2 = __shfl(rowB, i), c3 = __shfl(rowB, i + 1);
-        const float4 a = *reinterpret_cast<const float4 *>(zt + (size_t)c0 * 256);
-        const float4 b = *reinterpret_cast<const float4 *>(zt + (size_t)c1 * 256);
-        const float4 d = *reinterpret_cast<const float4 *>(zt + (size_t)c2 * 256);
-        const float4 e = *reinterpret_cast<const float4 *>(zt + (size_t)c3 * 256);
-        best.x = fmaxf(fmaxf(best.x, fmaxf(a.x, b.x)), fmaxf(d.x, e.x));
-        best.y = fmaxf(fmaxf(best.y, fmaxf(a.y, b.y)), fmaxf(d.y, e.y));
-        best.z = fmaxf(fmaxf(best.z, fmaxf(a.z, b.z)), fmaxf(d.z, e.z));
-        best.w = fmaxf(fmaxf(best.w, fmaxf(a.w, b.w)), fmaxf(d.w, e.w));
+        const typename R::V a = R::load(ch, false, (size_t)c0, lane), b = R::load(ch, false, (size_t)c1, lane);
+        const typename R::V d = R::load(ch, false, (size_t)c2, lane), e = R::load(ch, false, (size_t)c3, lane);
+        best = R::vmax(R::vmax(best, R::vmax(a, b)), R::vmax(d, e));
     }
-    *reinterpret_cast<float4 *>(p.xobj + (size_t)w * 256 + lane * 4) = best;
+    R::store(p, (size_t)w, lane, best);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -603,43 +641,49 @@ int pn_l2(const float *xyz, int N, const PnWeights &w, const int *fps1, const in
     return DGDM_OK;
 }
 
-int pn_z(const float *xyz, int N, int nv, const PnWeights &w, const float *L2, float *Z, const int *clist, const int *ncr, hipStream_t s) {
+int pn_z(const float *xyz, int N, int nv, const PnWeights &w, const float *L2, float *Z, uint32_t *Z16, const int *clist, const int *ncr,
+         hipStream_t s) {
     const int64_t t0 = (N + 31) / 32;
-    hipLaunchKernelGGL(z_kernel, dim3((unsigned)((t0 + 3) / 4)), dim3(256), 0, s, xyz, N, nv, L2, w.sa3_w_img, w.sa3_wx, w.sa3_b, Z, 0, clist, ncr);
+    hipLaunchKernelGGL(z_kernel, dim3((unsigned)((t0 + 3) / 4)), dim3(256), 0, s, xyz, N, nv, L2, w.sa3_w_img, w.sa3_wx, w.sa3_b, Z, Z16, 0, clist, ncr);
     if (nv > 1) {      // sized for the worst case (every centre crowded); surplus workgroups leave at once
         const int64_t t1 = ((int64_t)(nv - 1) * N + 31) / 32;
-        hipLaunchKernelGGL(z_kernel, dim3((unsigned)((t1 + 3) / 4)), dim3(256), 0, s, xyz, N, nv, L2, w.sa3_w_img, w.sa3_wx, w.sa3_b, Z, 1, clist, ncr);
+        hipLaunchKernelGGL(z_kernel, dim3((unsigned)((t1 + 3) / 4)), dim3(256), 0, s, xyz, N, nv, L2, w.sa3_w_img, w.sa3_wx, w.sa3_b, Z, Z16, 1, clist, ncr);
     }
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
 }
 
-int pn_m0(const int *fps2, const int *crowded, int N, const float *Z0, float *M0, int *cl2, int *cnt2, hipStream_t s) {
-    hipLaunchKernelGGL(m0_kernel, dim3((N + 3) / 4), dim3(256), 0, s, fps2, crowded, N, Z0, M0, cl2, cnt2);
+int pn_m0(const int *fps2, const int *crowded, int N, const float *Z0, float *M0, int *cl2, int *cnt2, const uint32_t *Z0_16, uint32_t *M0_16,
+          hipStream_t s) {
+    hipLaunchKernelGGL(m0_kernel, dim3((N + 3) / 4), dim3(256), 0, s, fps2, crowded, N, Z0, M0, cl2, cnt2, Z0_16, M0_16);
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
 }
 
-int pn_xobj(const XobjParams &p_in, bool all_fast, hipStream_t s) {
-    if (p_in.total_rows <= 0) return DGDM_OK;
-    XobjParams p = p_in;
+template <bool BF16>
+static int xobj_launch(XobjParams p, bool all_fast, hipStream_t s) {
     p.skip_fast = 0;
     if (p.use_table && p.todo) {
         DGDM_HIP_CHECK(hipMemsetAsync(p.todo_count, 0, sizeof(int), s));
-        hipLaunchKernelGGL(xobj_fast_kernel, dim3((unsigned)((p.total_rows + 3) / 4)), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(xobj_fast_kernel<BF16>, dim3((unsigned)((p.total_rows + 3) / 4)), dim3(256), 0, s, p);
         DGDM_HIP_CHECK(hipGetLastError());
         if (all_fast) return DGDM_OK;               // no chain without tables, no start point with an order-dependent sequence
         // the rows it recorded (a fraction of a percent: tie-flagged start points); the grid covers the worst case the caller
         // allows for, surplus workgroups leave on the count
         p.skip_fast = 1;
         const int64_t cap = std::min<int64_t>(p.total_rows, p.todo_capacity);
-        hipLaunchKernelGGL(xobj_kernel, dim3((unsigned)((cap + 3) / 4)), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(xobj_kernel<BF16>, dim3((unsigned)((cap + 3) / 4)), dim3(256), 0, s, p);
         DGDM_HIP_CHECK(hipGetLastError());
         return DGDM_OK;
     }
-    hipLaunchKernelGGL(xobj_kernel, dim3((unsigned)((p.total_rows + 3) / 4)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(xobj_kernel<BF16>, dim3((unsigned)((p.total_rows + 3) / 4)), dim3(256), 0, s, p);
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
+}
+
+int pn_xobj(const XobjParams &p, bool all_fast, hipStream_t s) {
+    if (p.total_rows <= 0) return DGDM_OK;
+    return p.xobj16 ? xobj_launch<true>(p, all_fast, s) : xobj_launch<false>(p, all_fast, s);
 }
 
 }  // namespace dgdm

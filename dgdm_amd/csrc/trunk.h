@@ -24,6 +24,7 @@ struct TrunkParams {
     // 3-D only
     const float  *b2;         // folded bias of layer 2
     const float  *xobj;       // [nchain][R][256]  PointNet++ embedding per reference row
+    const uint32_t *xobj16;   // bf16 trunk only: the same rows in bf16 operand order [nchain][R][128 dwords] (mfma_chain.h), or null
     // first-layer tables
     const float  *Atab;       // table mode: [nchain*B][W1]; rows mode: [rows][W1]
     const float  *Ptab;       // [C][W1]  (table mode)

@@ -40,11 +40,6 @@ __device__ __forceinline__ f32x16 mfma_bf16(const float4 a, const u32x4_t b, con
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
-__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {          // v_cvt_pk_bf16_f32 (RNE)
-    const f32x2_t v = {lo, hi};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
-}
-
 // Two 32-row tiles x 8 feature blocks of packed activations: v[tile][block][kstep] (4 dwords each)
 struct Act16 {
     u32x4_t v[2][8][2];
@@ -249,21 +244,30 @@ __device__ __forceinline__ void front3d(const wrsrc_t rs, const int voff, float4
     table_load(tr, 0, h4, raw[0]);
     u32x4_t xin[8][2];
     const float *xrow = p.xobj + ((size_t)tr.chain * p.R + tr.r) * 256;
-    float4 xv[8][4];
-#pragma unroll
-    for (int o = 0; o < 8; ++o)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) xv[o][q] = *reinterpret_cast<const float4 *>(xrow + 32 * o + 8 * q + h4);
     f32x16 acc2[8];
+    if (p.xobj16) {
+        // the embedding was produced in bf16 operand order (pointnet.hip xobj kernels): the row IS the B operand
+        const u32x4_t *row16 = reinterpret_cast<const u32x4_t *>(p.xobj16 + ((size_t)tr.chain * p.R + tr.r) * 128) + (h4 >> 1);
 #pragma unroll
-    for (int o = 0; o < 8; ++o) load_f32x16(p.b2 + 32 * o, h4, acc2[o]);
-    STEP_FENCE();
+        for (int o = 0; o < 8; ++o) { xin[o][0] = row16[4 * o]; xin[o][1] = row16[4 * o + 1]; }
 #pragma unroll
-    for (int o = 0; o < 8; ++o) {
+        for (int o = 0; o < 8; ++o) load_f32x16(p.b2 + 32 * o, h4, acc2[o]);
+    } else {
+        float4 xv[8][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            xin[o][q / 2][(2 * q) % 4] = pack_bf16(xv[o][q].x, xv[o][q].y);
-            xin[o][q / 2][(2 * q + 1) % 4] = pack_bf16(xv[o][q].z, xv[o][q].w);
+        for (int o = 0; o < 8; ++o)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xv[o][q] = *reinterpret_cast<const float4 *>(xrow + 32 * o + 8 * q + h4);
+#pragma unroll
+        for (int o = 0; o < 8; ++o) load_f32x16(p.b2 + 32 * o, h4, acc2[o]);
+        STEP_FENCE();
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                xin[o][q / 2][(2 * q) % 4] = pack_bf16(xv[o][q].x, xv[o][q].y);
+                xin[o][q / 2][(2 * q + 1) % 4] = pack_bf16(xv[o][q].z, xv[o][q].w);
+            }
         }
     }
     f32x16 zacc[2];
