@@ -308,9 +308,15 @@ __global__ __launch_bounds__(256) void l2_kernel(const float *__restrict__ xyz, 
         slot = 0;
         if (c >= N) return;
     } else {
-        if ((int)blockIdx.y >= *ncr) return;
-        c = clist[blockIdx.y];
-        slot = 1 + blockIdx.x * 4 + wave;
+        // 1-D grid.  Workgroups go round-robin to the 8 XCDs, so workgroup L runs on XCD L % 8: give every XCD whole centres
+        // (crowded centre 8 k + xcd, all of its variant groups in a row), so that the centre's block of Y rows - which each of
+        // its ~511 variants gathers 64 rows from - is served by that XCD's L2 instead of the memory-side cache.
+        const int nvg = (nv - 1 + 3) / 4;
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int ci = (j / nvg) * 8 + xcd;
+        if (ci >= *ncr) return;
+        c = clist[ci];
+        slot = 1 + (j % nvg) * 4 + wave;
         if (slot >= nv) return;
     }
     const int *perm = fps1 + (size_t)vlist[slot] * 512;
@@ -636,7 +642,8 @@ int pn_crowd(const float *xyz, int N, const PnWeights &w, int *crowded, int *cli
 int pn_l2(const float *xyz, int N, const PnWeights &w, const int *fps1, const int *vlist, int nv, const float *Y, float *L2,
           const int *clist, const int *ncr, const int *off, const short *rank, hipStream_t s) {
     hipLaunchKernelGGL(l2_kernel, dim3(1, (N + 3) / 4), dim3(256), 0, s, xyz, N, w.r2sq, fps1, vlist, nv, Y, L2, 0, clist, ncr, off, rank);
-    if (nv > 1) hipLaunchKernelGGL(l2_kernel, dim3((nv - 1 + 3) / 4, N), dim3(256), 0, s, xyz, N, w.r2sq, fps1, vlist, nv, Y, L2, 1, clist, ncr, off, rank);
+    if (nv > 1)     // sized for the worst case (every centre crowded); surplus workgroups leave at once
+        hipLaunchKernelGGL(l2_kernel, dim3((unsigned)(((nv - 1 + 3) / 4) * ((N + 7) / 8) * 8)), dim3(256), 0, s, xyz, N, w.r2sq, fps1, vlist, nv, Y, L2, 1, clist, ncr, off, rank);
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
 }
