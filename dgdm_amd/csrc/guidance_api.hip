@@ -183,10 +183,14 @@ int DgdmGuidance::build_object(int oi, int slot, hipStream_t s) {
     if ((rc = tOff.alloc((size_t)(N + 1) * sizeof(int))) || (rc = tPairs.alloc((size_t)N * N * sizeof(int))) || (rc = tRank.alloc((size_t)N * N * sizeof(short))))
         return rc;
     if ((rc = pn_crowd(xyz, N, w, t.crowded.as<int>(), t.clist.as<int>(), t.clist.as<int>() + N, tOff.as<int>(), tPairs.as<int>(), tRank.as<short>(), s))) return rc;
-    if ((rc = pn_pairs(xyz, N, tU.as<float>(), w, tPairs.as<int>(), tOff.as<int>(), tY.as<float>(), s))) return rc;       // T4
+    // bf16 mode: the sa3 contraction (T6) runs on the bf16 matrix pipe and rounds its input, so T4 writes and T5 reduces bf16
+    // rows (the temporaries tY / tL2 are simply used at half size); float32 mode: everything float32
+    if ((rc = pn_pairs(xyz, N, tU.as<float>(), w, tPairs.as<int>(), tOff.as<int>(), tY.as<float>(), bf16 ? tY.as<uint32_t>() : nullptr, s))) return rc;   // T4
     if ((rc = pn_l2(xyz, N, w, t.fps1, vlist.as<int>(), N, tY.as<float>(), tL2.as<float>(), t.clist.as<int>(), t.clist.as<int>() + N,
-                    tOff.as<int>(), tRank.as<short>(), s))) return rc;                                                     // T5
-    if ((rc = pn_z(xyz, N, N, w, tL2.as<float>(), t.Z.as<float>(), z16, t.clist.as<int>(), t.clist.as<int>() + N, s))) return rc;                   // T6
+                    tOff.as<int>(), tRank.as<short>(), bf16, s))) return rc;                                               // T5
+    if (bf16) {
+        if ((rc = pn_z16(xyz, N, N, w, tL2.as<uint32_t>(), t.Z.as<float>(), z16, t.clist.as<int>(), t.clist.as<int>() + N, s))) return rc;          // T6
+    } else if ((rc = pn_z(xyz, N, N, w, tL2.as<float>(), t.Z.as<float>(), z16, t.clist.as<int>(), t.clist.as<int>() + N, s))) return rc;
     return pn_m0(t.fps2, t.crowded.as<int>(), N, t.Z.as<float>(), t.M0.as<float>(), t.cl2.as<int>(), t.cnt2.as<int>(), z16,
                  bf16 ? t.M0_16.as<uint32_t>() : nullptr, s);                                                                                       // T7
 }
@@ -482,9 +486,9 @@ int pointnet_rows(DgdmDynamics *m, const float *xyz_dev /*[rows][3][N]*/, const 
         if ((rc = pn_sa1(x, N, w, F1.as<float>(), s))) return rc;
         if ((rc = linear(F1.as<float>(), 128, w.sa2_wf_t, w.sa2_b0, nullptr, 1, U.as<float>(), 128, N, 128, 128, ACT_NONE, false, s))) return rc;
         if ((rc = pn_crowd(x, N, w, crowded.as<int>(), clist.as<int>(), clist.as<int>() + N, poff.as<int>(), pairs.as<int>(), prank.as<short>(), s))) return rc;
-        if ((rc = pn_pairs(x, N, U.as<float>(), w, pairs.as<int>(), poff.as<int>(), Y.as<float>(), s))) return rc;
+        if ((rc = pn_pairs(x, N, U.as<float>(), w, pairs.as<int>(), poff.as<int>(), Y.as<float>(), nullptr, s))) return rc;
         if ((rc = pn_l2(x, N, w, fps1.as<int>(), vlist.as<int>(), nv, Y.as<float>(), L2.as<float>(), clist.as<int>(), clist.as<int>() + N,
-                        poff.as<int>(), prank.as<short>(), s))) return rc;
+                        poff.as<int>(), prank.as<short>(), false, s))) return rc;
         if ((rc = pn_z(x, N, nv, w, L2.as<float>(), Z.as<float>(), nullptr, clist.as<int>(), clist.as<int>() + N, s))) return rc;
         XobjChain ch{};
         ch.xyz = x; ch.fps1 = fps1.as<int>(); ch.slot_of_start = slotmap.as<int>(); ch.Z = Z.as<float>(); ch.fps2 = nullptr; ch.flags = nullptr; ch.crowded = crowded.as<int>(); ch.N = N;

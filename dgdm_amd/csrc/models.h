@@ -37,7 +37,7 @@ struct DgdmDynamics {
     dgdm::DevBuf ws;        // grow-only workspace of the plain forward entry points
     dgdm::DevBuf ws2;
     dgdm::DevBuf w16;       // bf16 weight streams of the trunk (trunk_bf16.hip): forward then backward
-    size_t fwd16_bytes = 0, bwd16_bytes = 0;
+    size_t fwd16_bytes = 0, bwd16_bytes = 0, sa3_16_offset = 0;     // sa3 bf16 image (z16_kernel) follows the two trunk streams
 
     void fill_trunk(dgdm::TrunkParams *p) const;
     void fill_trunk_bf16(dgdm::TrunkParams *p) const;

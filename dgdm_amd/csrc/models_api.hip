@@ -243,7 +243,7 @@ extern "C" int dgdm_dynamics_create(DgdmDynamics **out, int kind, const DgdmTens
     if ((rc = fold_linear(sd, "output", "", 3, W, &lout))) return rc;
     DynOff &o = m->off;
     std::vector<float> fwd, bwd_tail;                             // continuous trunk weight streams (csrc/trunk.h)
-    std::vector<uint16_t> fwd16, bwd16_tail;                      // the same in bf16 (csrc/trunk_bf16.hip)
+    std::vector<uint16_t> fwd16, bwd16_tail, sa3_img16;           // the same in bf16 (csrc/trunk_bf16.hip); sa3 image for z16_kernel
     const size_t E16 = 64 * 8;                                    // bf16 values per entry
     o.g0_wt = bl.add(transpose(g0.w.data(), W, params_ch)); o.g0_b = bl.add(g0.b); o.g0_w = bl.add(g0.w);
     o.g2_wt = bl.add(transpose(g2.w.data(), W, W)); o.g2_b = bl.add(g2.b); o.g2_w = bl.add(g2.w);
@@ -311,6 +311,7 @@ extern "C" int dgdm_dynamics_create(DgdmDynamics **out, int kind, const DgdmTens
         o.sa2_vx = bl.add(transpose(cols(b0.w, 128, 131, 0, 3).data(), 128, 3));
         o.sa2_w1_img = bl.add(pack_chain(b1.w.data(), 256, 128)); o.sa2_b1 = bl.add(b1.b);
         o.sa3_w_img = bl.add(pack_chain(cols(c0.w, 256, 259, 3, 256).data(), 256, 256));
+        sa3_img16 = pack_chain_bf16(cols(c0.w, 256, 259, 3, 256).data(), 256, 256);
         o.sa3_wx = bl.add(transpose(cols(c0.w, 256, 259, 0, 3).data(), 256, 3)); o.sa3_b = bl.add(c0.b);
     }
     m->n_mid = 8 - first_mid;
@@ -339,6 +340,8 @@ extern "C" int dgdm_dynamics_create(DgdmDynamics **out, int kind, const DgdmTens
         bwd16.insert(bwd16.end(), bwd16_tail.begin(), bwd16_tail.end());
         m->fwd16_bytes = fwd16.size() * 2; m->bwd16_bytes = bwd16.size() * 2;
         fwd16.insert(fwd16.end(), bwd16.begin(), bwd16.end());
+        m->sa3_16_offset = fwd16.size() * 2;
+        fwd16.insert(fwd16.end(), sa3_img16.begin(), sa3_img16.end());
         if ((rc = m->w16.upload(fwd16.data(), fwd16.size() * 2))) return rc;
     }
     std::vector<float> bwd;
@@ -375,7 +378,9 @@ PnWeights DgdmDynamics::pn() const {
     w.sa1_w0t = blob.at(off.sa1_w0t); w.sa1_b0 = blob.at(off.sa1_b0); w.sa1_w1 = blob.at(off.sa1_w1); w.sa1_b1 = blob.at(off.sa1_b1);
     w.sa2_wf_t = blob.at(off.sa2_wf_t); w.sa2_b0 = blob.at(off.sa2_b0); w.sa2_vx = blob.at(off.sa2_vx);
     w.sa2_w1_img = blob.at4(off.sa2_w1_img); w.sa2_b1 = blob.at(off.sa2_b1);
-    w.sa3_w_img = blob.at4(off.sa3_w_img); w.sa3_wx = blob.at(off.sa3_wx); w.sa3_b = blob.at(off.sa3_b);
+    w.sa3_w_img = blob.at4(off.sa3_w_img);
+    w.sa3_w_img16 = reinterpret_cast<const float4 *>(static_cast<const char *>(w16.p) + sa3_16_offset);
+    w.sa3_wx = blob.at(off.sa3_wx); w.sa3_b = blob.at(off.sa3_b);
     return w;
 }
 

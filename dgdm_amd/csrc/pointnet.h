@@ -16,6 +16,7 @@ struct PnWeights {
     const float4 *sa2_w1_img;     // chain image of sa2.mlp_convs.1 [256 x 128]
     const float *sa2_b1;          // [256]
     const float4 *sa3_w_img;      // chain image of sa3.mlp_convs.0[:, 3:] [256 x 256]
+    const float4 *sa3_w_img16;    // the same as a pack_chain_bf16 image (bf16 mode, z16_kernel)
     const float *sa3_wx;          // [3][256]   sa3.mlp_convs.0[:, 0:3] (kn)
     const float *sa3_b;           // [256]
 };
@@ -53,9 +54,13 @@ int pn_fps_table(const float *xyz, int N, int nv, int npoint, int *out, int *fla
 int pn_sa1(const float *xyz, int N, const PnWeights &w, float *F1, hipStream_t s);
 // crowded/clist/ncr: centres whose ball holds > 64 points; off [N+1], pairs [<= N*N], rank [N][N]: the in-radius pair list (T4/T5)
 int pn_crowd(const float *xyz, int N, const PnWeights &w, int *crowded, int *clist, int *ncr, int *off, int *pairs, short *rank, hipStream_t s);
-int pn_pairs(const float *xyz, int N, const float *U, const PnWeights &w, const int *pairs, const int *off, float *Y, hipStream_t s);
+// Y16 (optional): write bf16 operand-order rows there INSTEAD of the float32 rows (bf16 mode)
+int pn_pairs(const float *xyz, int N, const float *U, const PnWeights &w, const int *pairs, const int *off, float *Y, uint32_t *Y16, hipStream_t s);
 int pn_l2(const float *xyz, int N, const PnWeights &w, const int *fps1, const int *vlist, int nv, const float *Y, float *L2,
-          const int *clist, const int *ncr, const int *off, const short *rank, hipStream_t s);
+          const int *clist, const int *ncr, const int *off, const short *rank, bool bf16 /* Y and L2 are bf16 operand-order rows */, hipStream_t s);
+// bf16 mode T6: bf16 contraction from L2_16 rows; writes the float32 rows and their bf16 copy
+int pn_z16(const float *xyz, int N, int nv, const PnWeights &w, const uint32_t *L2_16, float *Z, uint32_t *Z16, const int *clist, const int *ncr,
+           hipStream_t s);
 // Z16 (optional): the same rows again in bf16 operand order
 int pn_z(const float *xyz, int N, int nv, const PnWeights &w, const float *L2, float *Z, uint32_t *Z16, const int *clist, const int *ncr,
          hipStream_t s);

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(128) void sa1_kernel(const float *__restrict__ xyz,
 __global__ __launch_bounds__(256, 1) void pair_kernel(const float *__restrict__ xyz, int N, const float *__restrict__ U /*[N][128]*/,
                                                       const float *__restrict__ vx /*[3][128]*/, const float4 *__restrict__ Wimg,
                                                       const float *__restrict__ bias, const int *__restrict__ pairs,
-                                                      const int *__restrict__ off /*[N+1]*/, float *__restrict__ Y) {
+                                                      const int *__restrict__ off /*[N+1]*/, float *__restrict__ Y, uint32_t *__restrict__ Y16) {
     const int lane = threadIdx.x & 63, n = lane & 31, h4 = (lane >> 5) * 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int total = off[N];
@@ -209,6 +209,22 @@ __global__ __launch_bounds__(256, 1) void pair_kernel(const float *__restrict__ 
         }
     }
     chain_layer<4, 8, CHAIN_BIAS>(Wimg, bias, in, out, lane);
+    if (Y16) {
+        // bf16 mode (the only consumer, z16_kernel's contraction, rounds to bf16 and rounding commutes with l2's max): bf16
+        // operand-order rows, the lane's 8 dwords of a block contiguous, instead of the float32 rows
+        if (tile * 32 + n < total) {
+            uint4 *d16 = reinterpret_cast<uint4 *>(Y16 + (size_t)p * 128) + (h4 >> 1);
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                uint32_t pk[8];
+#pragma unroll
+                for (int d = 0; d < 8; ++d) pk[d] = pack_bf16(fmaxf(out[o][2 * d], 0.f), fmaxf(out[o][2 * d + 1], 0.f));
+                d16[4 * o] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                d16[4 * o + 1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+            }
+        }
+        return;
+    }
     if (tile * 32 + n < total) {
         float *dst = Y + (size_t)p * 256;
 #pragma unroll
@@ -296,6 +312,7 @@ __global__ __launch_bounds__(256) void nbr_fill_kernel(const float *__restrict__
 // L2[slot][c][256] = max over the first 64 in-radius (r=0.4) positions of variant vlist[slot] of Y[(c, point)].
 // mode 0: slot 0, every centre (blockIdx.y*4 + wave).  mode 1: slots >= 1, crowded centres only (clist[blockIdx.y]); the
 // waves of a workgroup then share the centre so its Y slab stays cache resident.
+template <bool BF16>
 __global__ __launch_bounds__(256) void l2_kernel(const float *__restrict__ xyz, int N, float r2, const int *__restrict__ fps1 /*[N][512]*/,
                                                  const int *__restrict__ vlist, int nv, const float *__restrict__ Y,
                                                  float *__restrict__ L2 /*[nv][N][256]*/, int mode, const int *__restrict__ clist,
@@ -335,6 +352,24 @@ __global__ __launch_bounds__(256) void l2_kernel(const float *__restrict__ xyz, 
     }
     cnt = min(cnt, 64);
     __builtin_amdgcn_wave_barrier();
+    if (BF16) {
+        // Y and L2 are bf16 operand-order rows (128 dwords): two dwords per lane, v_pk_max_u16 (values are >= 0)
+        const uint2 *slab = reinterpret_cast<const uint2 *>(reinterpret_cast<const uint32_t *>(Y) + (size_t)off[c] * 128) + lane;
+        uint2 best = make_uint2(0u, 0u);
+        int i = 0;
+        for (; i + 4 <= cnt; i += 4) {
+            const uint2 a = slab[(size_t)sel[wave][i] * 64], b = slab[(size_t)sel[wave][i + 1] * 64];
+            const uint2 d = slab[(size_t)sel[wave][i + 2] * 64], e = slab[(size_t)sel[wave][i + 3] * 64];
+            best.x = pkmax_u16(pkmax_u16(best.x, pkmax_u16(a.x, b.x)), pkmax_u16(d.x, e.x));
+            best.y = pkmax_u16(pkmax_u16(best.y, pkmax_u16(a.y, b.y)), pkmax_u16(d.y, e.y));
+        }
+        for (; i < cnt; ++i) {
+            const uint2 a = slab[(size_t)sel[wave][i] * 64];
+            best.x = pkmax_u16(best.x, a.x); best.y = pkmax_u16(best.y, a.y);
+        }
+        reinterpret_cast<uint2 *>(reinterpret_cast<uint32_t *>(L2) + ((size_t)slot * N + c) * 128)[lane] = best;
+        return;
+    }
     const float *slab = Y + (size_t)off[c] * 256 + lane * 4;
     float4 best = make_float4(0.f, 0.f, 0.f, 0.f);       // Y >= 0 (ReLU); an empty ball cannot happen for a centre of the set,
                                                          // and a centre outside the variant's set is never read
@@ -414,6 +449,87 @@ __global__ __launch_bounds__(256, 1) void z_kernel(const float *__restrict__ xyz
                 d16[4 * o] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
                 d16[4 * o + 1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
             }
+        }
+    }
+}
+
+// T6 in bf16 mode: the sa3 contraction on v_mfma_f32_32x32x16_bf16.  One wave = two 32-row tiles (each weight entry feeds two
+// MFMAs).  L2_16 rows are already the B operand (operand order); W3'[:, 3:] comes as a pack_chain_bf16 image through the
+// buffer-load ring; the coordinate part W3'[:, 0:3] xyz_c + b3' is the float32 accumulator start.  Writes the float32 rows
+// (orientation sweep, M0) and their bf16 operand-order copy (xobj gathers).  Items as in z_kernel.
+typedef __bf16 zbf16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256, 1) void z16_kernel(const float *__restrict__ xyz, int N, int nv, const uint32_t *__restrict__ L2_16,
+                                                     const float4 *__restrict__ Wimg16, const float *__restrict__ w3x /*[3][256]*/,
+                                                     const float *__restrict__ bias, float *__restrict__ Z, uint32_t *__restrict__ Z16,
+                                                     int mode, const int *__restrict__ clist, const int *__restrict__ ncr) {
+    const int lane = threadIdx.x & 63, n = lane & 31, h4 = (lane >> 5) * 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wave) * 2;
+    const int ncrv = mode ? *ncr : N;
+    const int64_t items = mode ? (int64_t)(nv - 1) * ncrv : N;
+    if (tile0 * 32 >= items) return;
+    int64_t row[2];
+    float cx[2], cy[2], cz[2];
+    bool live[2];
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    u4 in[2][8][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int64_t idx = (tile0 + t) * 32 + n;
+        live[t] = idx < items;
+        const int64_t item = min(idx, items - 1);
+        const int c = mode ? clist[item % ncrv] : (int)item;
+        row[t] = mode ? (1 + item / ncrv) * N + c : c;
+        cx[t] = xyz[3 * c]; cy[t] = xyz[3 * c + 1]; cz[t] = xyz[3 * c + 2];
+        const u4 *src = reinterpret_cast<const u4 *>(L2_16 + (size_t)row[t] * 128) + (h4 >> 1);
+#pragma unroll
+        for (int o = 0; o < 8; ++o) { in[t][o][0] = src[4 * o]; in[t][o][1] = src[4 * o + 1]; }
+    }
+    const wrsrc_t rs = weight_rsrc(Wimg16, 128 * 1024);
+    float4 ring[CONT_DEPTH];
+    ring_fill(rs, lane * 16, 0, ring);
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 b = feat4(bias, o, q, h4);
+            const float4 a0 = feat4(w3x, o, q, h4), a1 = feat4(w3x + 256, o, q, h4), a2 = feat4(w3x + 512, o, q, h4);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                acc[t][4 * q + 0] = fmaf(a2.x, cz[t], fmaf(a1.x, cy[t], fmaf(a0.x, cx[t], b.x)));
+                acc[t][4 * q + 1] = fmaf(a2.y, cz[t], fmaf(a1.y, cy[t], fmaf(a0.y, cx[t], b.y)));
+                acc[t][4 * q + 2] = fmaf(a2.z, cz[t], fmaf(a1.z, cy[t], fmaf(a0.z, cx[t], b.z)));
+                acc[t][4 * q + 3] = fmaf(a2.w, cz[t], fmaf(a1.w, cy[t], fmaf(a0.w, cx[t], b.w)));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int e = o * 16 + i;
+            const float4 a = ring[e % CONT_DEPTH];
+            ring[e % CONT_DEPTH] = wload(rs, lane * 16, (e + CONT_DEPTH) * 1024);       // past the image: clipped to zero, unused
+            const zbf16x8 av = __builtin_bit_cast(zbf16x8, a);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(zbf16x8, in[0][i / 2][i % 2]), acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(zbf16x8, in[1][i / 2][i % 2]), acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (!live[t]) continue;                    // rows of one tile are distinct (item -> row is injective)
+            float *dst = Z + (size_t)row[t] * 256;
+            uint32_t pk[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 v;
+                v.x = fmaxf(acc[t][4 * q + 0], 0.f); v.y = fmaxf(acc[t][4 * q + 1], 0.f);
+                v.z = fmaxf(acc[t][4 * q + 2], 0.f); v.w = fmaxf(acc[t][4 * q + 3], 0.f);
+                *reinterpret_cast<float4 *>(dst + 32 * o + 8 * q + h4) = v;
+                pk[2 * q] = pack_bf16(v.x, v.y); pk[2 * q + 1] = pack_bf16(v.z, v.w);
+            }
+            uint4 *d16 = reinterpret_cast<uint4 *>(Z16 + (size_t)row[t] * 128) + (h4 >> 1);
+            d16[4 * o] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            d16[4 * o + 1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
         }
     }
 }
@@ -625,9 +741,9 @@ int pn_sa1(const float *xyz, int N, const PnWeights &w, float *F1, hipStream_t s
     return DGDM_OK;
 }
 
-int pn_pairs(const float *xyz, int N, const float *U, const PnWeights &w, const int *pairs, const int *off, float *Y, hipStream_t s) {
+int pn_pairs(const float *xyz, int N, const float *U, const PnWeights &w, const int *pairs, const int *off, float *Y, uint32_t *Y16, hipStream_t s) {
     const int tiles = N * ((N + 31) / 32);     // worst case (every point inside every ball); surplus workgroups leave at once
-    hipLaunchKernelGGL(pair_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, xyz, N, U, w.sa2_vx, w.sa2_w1_img, w.sa2_b1, pairs, off, Y);
+    hipLaunchKernelGGL(pair_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, xyz, N, U, w.sa2_vx, w.sa2_w1_img, w.sa2_b1, pairs, off, Y, Y16);
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
 }
@@ -640,10 +756,15 @@ int pn_crowd(const float *xyz, int N, const PnWeights &w, int *crowded, int *cli
 }
 
 int pn_l2(const float *xyz, int N, const PnWeights &w, const int *fps1, const int *vlist, int nv, const float *Y, float *L2,
-          const int *clist, const int *ncr, const int *off, const short *rank, hipStream_t s) {
-    hipLaunchKernelGGL(l2_kernel, dim3(1, (N + 3) / 4), dim3(256), 0, s, xyz, N, w.r2sq, fps1, vlist, nv, Y, L2, 0, clist, ncr, off, rank);
-    if (nv > 1)     // sized for the worst case (every centre crowded); surplus workgroups leave at once
-        hipLaunchKernelGGL(l2_kernel, dim3((unsigned)(((nv - 1 + 3) / 4) * ((N + 7) / 8) * 8)), dim3(256), 0, s, xyz, N, w.r2sq, fps1, vlist, nv, Y, L2, 1, clist, ncr, off, rank);
+          const int *clist, const int *ncr, const int *off, const short *rank, bool bf16, hipStream_t s) {
+    const dim3 g0(1, (N + 3) / 4), g1((unsigned)(((nv - 1 + 3) / 4) * ((N + 7) / 8) * 8));   // g1: worst case (every centre crowded)
+    if (bf16) {
+        hipLaunchKernelGGL(l2_kernel<true>, g0, dim3(256), 0, s, xyz, N, w.r2sq, fps1, vlist, nv, Y, L2, 0, clist, ncr, off, rank);
+        if (nv > 1) hipLaunchKernelGGL(l2_kernel<true>, g1, dim3(256), 0, s, xyz, N, w.r2sq, fps1, vlist, nv, Y, L2, 1, clist, ncr, off, rank);
+    } else {
+        hipLaunchKernelGGL(l2_kernel<false>, g0, dim3(256), 0, s, xyz, N, w.r2sq, fps1, vlist, nv, Y, L2, 0, clist, ncr, off, rank);
+        if (nv > 1) hipLaunchKernelGGL(l2_kernel<false>, g1, dim3(256), 0, s, xyz, N, w.r2sq, fps1, vlist, nv, Y, L2, 1, clist, ncr, off, rank);
+    }
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
 }
@@ -655,6 +776,18 @@ int pn_z(const float *xyz, int N, int nv, const PnWeights &w, const float *L2, f
     if (nv > 1) {      // sized for the worst case (every centre crowded); surplus workgroups leave at once
         const int64_t t1 = ((int64_t)(nv - 1) * N + 31) / 32;
         hipLaunchKernelGGL(z_kernel, dim3((unsigned)((t1 + 3) / 4)), dim3(256), 0, s, xyz, N, nv, L2, w.sa3_w_img, w.sa3_wx, w.sa3_b, Z, Z16, 1, clist, ncr);
+    }
+    DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
+}
+
+int pn_z16(const float *xyz, int N, int nv, const PnWeights &w, const uint32_t *L2_16, float *Z, uint32_t *Z16, const int *clist, const int *ncr,
+           hipStream_t s) {
+    const int64_t t0 = (N + 63) / 64;
+    hipLaunchKernelGGL(z16_kernel, dim3((unsigned)((t0 + 3) / 4)), dim3(256), 0, s, xyz, N, nv, L2_16, w.sa3_w_img16, w.sa3_wx, w.sa3_b, Z, Z16, 0, clist, ncr);
+    if (nv > 1) {      // sized for the worst case (every centre crowded); surplus workgroups leave at once
+        const int64_t t1 = ((int64_t)(nv - 1) * N + 63) / 64;
+        hipLaunchKernelGGL(z16_kernel, dim3((unsigned)((t1 + 3) / 4)), dim3(256), 0, s, xyz, N, nv, L2_16, w.sa3_w_img16, w.sa3_wx, w.sa3_b, Z, Z16, 1, clist, ncr);
     }
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;

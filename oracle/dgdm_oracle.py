@@ -342,8 +342,21 @@ def set_abstraction(sd: SD, p: str, xyz: torch.Tensor, points: Optional[torch.Te
     feat = feat.permute(0, 3, 2, 1)                       # (B, C+D, nsample, npoint)
     i = 0
     while f"{p}.mlp_convs.{i}.weight" in sd:
-        feat = F.conv2d(feat, sd[f"{p}.mlp_convs.{i}.weight"], sd[f"{p}.mlp_convs.{i}.bias"])
         b = f"{p}.mlp_bns.{i}"
+        if _CONTRACTION == 'bf16' and npoint is None and i == 0:
+            # bf16-contraction mode, sa3 (the 259 -> 256 layer on the 512 sa2 features of every row): BatchNorm folded into the
+            # conv in float64; the 256 feature channels go through a bf16 contraction (operands rounded, float32 accumulation),
+            # the 3 coordinate channels and the bias stay float32 - the split csrc/pointnet.hip z16_kernel makes.
+            w = sd[f"{p}.mlp_convs.{i}.weight"].double().reshape(-1, feat.shape[1])
+            sc = sd[b + ".weight"].double() / torch.sqrt(sd[b + ".running_var"].double() + 1e-5)
+            wf = (sc[:, None] * w).float()
+            bf_ = (sc * (sd[f"{p}.mlp_convs.{i}.bias"].double() - sd[b + ".running_mean"].double()) + sd[b + ".bias"].double()).float()
+            rows = feat.permute(0, 2, 3, 1).reshape(-1, feat.shape[1])                     # (B * nsample * npoint, 259)
+            out = _BfLinear.apply(rows[:, C:], wf[:, C:]) + F.linear(rows[:, :C], wf[:, :C], bf_)
+            feat = F.relu(out).reshape(feat.shape[0], feat.shape[2], feat.shape[3], -1).permute(0, 3, 1, 2)
+            i += 1
+            continue
+        feat = F.conv2d(feat, sd[f"{p}.mlp_convs.{i}.weight"], sd[f"{p}.mlp_convs.{i}.bias"])
         feat = F.batch_norm(feat, sd[b + ".running_mean"], sd[b + ".running_var"], sd[b + ".weight"], sd[b + ".bias"],
                             training=False, eps=1e-5)
         feat = F.relu(feat)

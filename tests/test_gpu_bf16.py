@@ -117,13 +117,15 @@ def test_bf16_full_size_properties(dev):
     assert bool(torch.isfinite(b).all())
     e0, e1 = util.rel_l2((-b[0]).cpu(), a[0].cpu()), util.rel_l2(b[1].cpu(), a[1].cpu())
     assert e0 < 8e-2 and e1 < 8e-2, (e0, e1)
-    # g3's tables were built in float32 mode, so the rows above went float32 Z -> float32 xobj -> rounded by the trunk.  A handle
-    # that is in bf16 mode when its tables are built keeps bf16 copies of Z / M0 and gathers bf16 rows instead (half the bytes):
-    # rounding commutes with max, so the gradient must be the same bit for bit.
+    # g3's tables were built in float32 mode (its switch came later), so above only the trunk ran in bf16.  A handle that is in
+    # bf16 mode when its tables are built also runs PointNet++'s sa3 contraction in bf16 and keeps the sa2/sa3 feature tables as
+    # bf16 rows (exact: their consumers round to bf16 and rounding commutes with max): the gradient moves by the sa3 rounding only.
     g16 = engine.Guidance(dyn3, B, G, P, (-1.0, 1.0), 2, T, 512, sub, max_objects=1, contraction_dtype="bf16")
     g16.set_objects(synth.synth_object_3d(70)[None].to(dev))
     b16 = g16.grad(x3.expand(2, -1, -1).contiguous(), 3, [mk('shift_right', 0), mk('rotate', 0)], None, st2)
-    assert torch.equal(b16, b)
+    d0, d1 = util.rel_l2(b16[0].cpu(), b[0].cpu()), util.rel_l2(b16[1].cpu(), b[1].cpu())
+    print(f"bf16 tables vs float32 tables under the bf16 trunk: {d0:.2e} {d1:.2e}")
+    assert d0 < 3e-2 and d1 < 3e-2, (d0, d1)
 
 
 def test_ensemble_groups_equal_single_chains(dev):
