@@ -318,6 +318,7 @@ __global__ __launch_bounds__(256) void l2_kernel(const float *__restrict__ xyz, 
                                                  float *__restrict__ L2 /*[nv][N][256]*/, int mode, const int *__restrict__ clist,
                                                  const int *__restrict__ ncr, const int *__restrict__ off, const short *__restrict__ rank) {
     __shared__ int sel[4][64];
+    __shared__ short rks[4][1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int c, slot;
     if (mode == 0) {
@@ -337,17 +338,19 @@ __global__ __launch_bounds__(256) void l2_kernel(const float *__restrict__ xyz, 
         if (slot >= nv) return;
     }
     const int *perm = fps1 + (size_t)vlist[slot] * 512;
+    // rank[c][k] >= 0 <=> point k lies in c's ball (nbr_fill_kernel made that decision with the reference's distance formula),
+    // and its value is the point's row in c's block of the pair list: the centre's row of the table, copied to LDS, replaces
+    // three coordinate gathers and the distance arithmetic per candidate
     const short *rk = rank + (size_t)c * N;
-    const float cx = xyz[3 * c], cy = xyz[3 * c + 1], cz = xyz[3 * c + 2];
-    const float cn = sq3(cx, cy, cz);
+    for (int i = lane; i < N; i += 64) rks[wave][i] = rk[i];
+    __builtin_amdgcn_wave_barrier();
     int cnt = 0;
     for (int base = 0; base < 512 && cnt < 64; base += 64) {
-        const int pk = perm[base + lane];
-        const float x = xyz[3 * pk], y = xyz[3 * pk + 1], z = xyz[3 * pk + 2];
-        const bool in = !(sqdist_expanded(cx, cy, cz, cn, x, y, z, sq3(x, y, z)) > r2);
+        const int r = rks[wave][perm[base + lane]];
+        const bool in = r >= 0;
         const unsigned long long m = __ballot(in);
         const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
-        if (in && pos < 64) sel[wave][pos] = rk[pk];      // row of (c, pk) inside c's block of the pair list
+        if (in && pos < 64) sel[wave][pos] = r;
         cnt += __popcll(m);
     }
     cnt = min(cnt, 64);
