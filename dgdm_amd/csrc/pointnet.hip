@@ -360,11 +360,12 @@ __global__ __launch_bounds__(256) void l2_kernel(const float *__restrict__ xyz, 
         const uint2 *slab = reinterpret_cast<const uint2 *>(reinterpret_cast<const uint32_t *>(Y) + (size_t)off[c] * 128) + lane;
         uint2 best = make_uint2(0u, 0u);
         int i = 0;
-        for (; i + 4 <= cnt; i += 4) {
-            const uint2 a = slab[(size_t)sel[wave][i] * 64], b = slab[(size_t)sel[wave][i + 1] * 64];
-            const uint2 d = slab[(size_t)sel[wave][i + 2] * 64], e = slab[(size_t)sel[wave][i + 3] * 64];
-            best.x = pkmax_u16(pkmax_u16(best.x, pkmax_u16(a.x, b.x)), pkmax_u16(d.x, e.x));
-            best.y = pkmax_u16(pkmax_u16(best.y, pkmax_u16(a.y, b.y)), pkmax_u16(d.y, e.y));
+        for (; i + 8 <= cnt; i += 8) {                  // eight rows in flight: the gather is latency bound
+            uint2 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = slab[(size_t)sel[wave][i + k] * 64];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { best.x = pkmax_u16(best.x, v[k].x); best.y = pkmax_u16(best.y, v[k].y); }
         }
         for (; i < cnt; ++i) {
             const uint2 a = slab[(size_t)sel[wave][i] * 64];
@@ -377,15 +378,14 @@ __global__ __launch_bounds__(256) void l2_kernel(const float *__restrict__ xyz, 
     float4 best = make_float4(0.f, 0.f, 0.f, 0.f);       // Y >= 0 (ReLU); an empty ball cannot happen for a centre of the set,
                                                          // and a centre outside the variant's set is never read
     int i = 0;
-    for (; i + 4 <= cnt; i += 4) {
-        const float4 a = *reinterpret_cast<const float4 *>(slab + (size_t)sel[wave][i] * 256);
-        const float4 b = *reinterpret_cast<const float4 *>(slab + (size_t)sel[wave][i + 1] * 256);
-        const float4 d = *reinterpret_cast<const float4 *>(slab + (size_t)sel[wave][i + 2] * 256);
-        const float4 e = *reinterpret_cast<const float4 *>(slab + (size_t)sel[wave][i + 3] * 256);
-        best.x = fmaxf(fmaxf(best.x, fmaxf(a.x, b.x)), fmaxf(d.x, e.x));
-        best.y = fmaxf(fmaxf(best.y, fmaxf(a.y, b.y)), fmaxf(d.y, e.y));
-        best.z = fmaxf(fmaxf(best.z, fmaxf(a.z, b.z)), fmaxf(d.z, e.z));
-        best.w = fmaxf(fmaxf(best.w, fmaxf(a.w, b.w)), fmaxf(d.w, e.w));
+    for (; i + 8 <= cnt; i += 8) {                      // eight rows in flight: the gather is latency bound
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4 *>(slab + (size_t)sel[wave][i + k] * 256);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            best.x = fmaxf(best.x, v[k].x); best.y = fmaxf(best.y, v[k].y); best.z = fmaxf(best.z, v[k].z); best.w = fmaxf(best.w, v[k].w);
+        }
     }
     for (; i < cnt; ++i) {
         const float4 a = *reinterpret_cast<const float4 *>(slab + (size_t)sel[wave][i] * 256);
