@@ -38,8 +38,12 @@ class Diffusion(nn.Module):
                  action_groups: Optional[Dict[str, slice]] = None, float32_matmul_precision: str = "high", class_cond: bool = False,
                  classifier_model=None, grid_size: int = 360, num_pos: int = 5, object_vertices: Optional[torch.Tensor] = None,
                  object_ids: Optional[List[int]] = None, num_cpus: int = 32, sub_batch_size: int = 1024, pts_x_dim: int = 7,
-                 pts_z_dim: int = 3, render_video: bool = False, seed: int = 0):
+                 pts_z_dim: int = 3, render_video: bool = False, seed: int = 0, contraction_dtype: str = "f32"):
         super().__init__()
+        if contraction_dtype not in ("f32", "bf16"):
+            raise ValueError(f"contraction dtype {contraction_dtype!r} not supported")
+        # not a reference argument: 'bf16' runs the trunk / eps-net / sa3 contractions with bf16 operands
+        self.contraction_dtype = contraction_dtype
         if mode not in ("point", "point_3d"):
             raise ValueError('model type not supported')
         self.ema_nets = nn.ModuleDict({"noise_pred_net": noise_pred_net})
@@ -75,6 +79,12 @@ class Diffusion(nn.Module):
     def device(self) -> torch.device:
         return next(self.noise_pred_net.parameters()).device
 
+    def _net(self):
+        h = self.noise_pred_net.handle()
+        if getattr(h, "contraction_dtype", "f32") != self.contraction_dtype:
+            h.set_contraction_dtype(self.contraction_dtype)
+        return h
+
     def _dyn(self):
         m = self.classifier_model
         return m.module if hasattr(m, "module") else m            # nn.DataParallel wrapper of generator/train.py:86,88
@@ -99,7 +109,8 @@ class Diffusion(nn.Module):
         if g is None or g.cfg.max_chains < max_chains or g.cfg.max_objects < objects.shape[0]:
             g = engine.Guidance(dyn, batch, self.grid_size, self.num_pos, ori_range, max(max_chains, 1),
                                 self.noise_scheduler.config.num_train_timesteps, npts,
-                                self.sub_batch_size if self.mode == 'point_3d' else 0, max_objects=max(objects.shape[0], 1))
+                                self.sub_batch_size if self.mode == 'point_3d' else 0, max_objects=max(objects.shape[0], 1),
+                                contraction_dtype=self.contraction_dtype)
             self._guidance[key] = g
             g._bank = None
         if g._bank is None or g._bank.shape != objects.shape or not torch.equal(g._bank, objects.detach().cpu()):
@@ -182,7 +193,7 @@ class Diffusion(nn.Module):
         objs = torch.as_tensor(self.object_vertices)
         n = objs.shape[0]
         g = self._guidance_for(batch_size, ori_range, objs, n)
-        out = sampler.guided_chains(self.noise_pred_net.handle(), g, self.noise_scheduler, self.mode, noise.to(self.device),
+        out = sampler.guided_chains(self._net(), g, self.noise_scheduler, self.mode, noise.to(self.device),
                                     [(i, opt_obj) for i in range(n)],
                                     unguided=None if unguided_sample is None else unguided_sample.to(self.device))
         self._emit(save_dir, 'vis_guided', f"{opt_obj}_orirange={ori_range[0]:.3f}_{ori_range[1]:.3f}", out,
@@ -193,7 +204,7 @@ class Diffusion(nn.Module):
     def guided_sample_multi_object(self, batch_idx, batch_size, noise, save_dir, opt_obj='rotate', ori_range=[-1.0, 1.0]):
         objs = torch.as_tensor(self.object_vertices)
         g = self._guidance_for(batch_size, ori_range, objs, objs.shape[0])
-        out = sampler.guided_multi_object(self.noise_pred_net.handle(), g, self.noise_scheduler, self.mode, noise.to(self.device),
+        out = sampler.guided_multi_object(self._net(), g, self.noise_scheduler, self.mode, noise.to(self.device),
                                           list(range(objs.shape[0])), opt_obj)
         self._emit(save_dir, 'vis_guided', f"{opt_obj}_orirange={ori_range[0]:.3f}_{ori_range[1]:.3f}", out[None], ["allobj"])
         return out
@@ -230,7 +241,7 @@ class Diffusion(nn.Module):
         noise = torch.from_numpy(rs.randn(B, self.num_points, self.input_dim)).float().to(dev)
         ts = self.num_inference_steps * torch.ones((B,), dtype=torch.int64)
         sample = self.noise_scheduler.add_noise(data, noise, ts)
-        net = self.noise_pred_net.handle()
+        net = self._net()
         noise_pred_loss = 0.0
         for t in self.noise_scheduler.timesteps:
             eps = net.forward(sample, torch.full((B,), int(t), device=dev))

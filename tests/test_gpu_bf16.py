@@ -197,3 +197,28 @@ def test_bf16_unet_vs_oracle(dev):
             assert util.rel_l2(f32, ref32) < 2e-5
             assert e16 < 1e-2, (L, t, e16)
             assert e32 < 4e-2, (L, t, e32)
+
+
+def test_diffusion_class_bf16_switch(dev):
+    """`Diffusion(contraction_dtype='bf16')` (not a reference argument) drives the same loops with bf16 contractions: the guided
+    samples stay close to the float32 ones on a well-conditioned 2-D chain and the eps-net handle carries the switch."""
+    from dgdm_amd.generator.diffusion import Diffusion
+    from dgdm_amd.generator.diffusion_utils import ConditionalUnet1D
+    from dgdm_amd.dynamics.profile_forward_2d import ProfileForward2DModel
+    from dgdm_amd.scheduler import DDIMScheduler
+    nv, B, L = 100, 4, 14
+    outs = {}
+    for dt in ("f32", "bf16"):
+        net = ConditionalUnet1D(input_dim=1, global_cond_dim=0, down_dims=[128, 256], diffusion_step_embed_dim=32)
+        net.load_state_dict(util.unet_sd(11))
+        dyn = ProfileForward2DModel(params_ch=L, object_ch=2 * nv)
+        dyn.load_state_dict(util.dyn2d_sd(22, nv))
+        d = Diffusion(noise_pred_net=net.to(dev), noise_scheduler=DDIMScheduler(num_train_timesteps=15), num_inference_steps=5, mode='point',
+                      num_points=L, class_cond=True, classifier_model=dyn.to(dev).eval(), grid_size=24, num_pos=3,
+                      object_vertices=torch.stack([synth.synth_object_2d(0, nv)]), object_ids=[0], contraction_dtype=dt)
+        outs[dt] = d.guided_sample(0, B, synth.synth_noise(0, B, L).to(dev), None, opt_obj='shift_left').cpu()
+        assert d._net().contraction_dtype == dt
+    assert outs["bf16"].shape == outs["f32"].shape == (1, B, L, 1)
+    assert float((outs["bf16"] - outs["f32"]).abs().max()) < 0.2 and not torch.equal(outs["bf16"], outs["f32"])
+    with pytest.raises(ValueError):
+        Diffusion(noise_pred_net=net, noise_scheduler=DDIMScheduler(num_train_timesteps=15), num_inference_steps=5, contraction_dtype="fp8")
