@@ -2,22 +2,28 @@
 """Benchmark of the guided-sampling hot path (BASELINE.json metric: guided samples/sec over the full DDIM chain,
 plus ms per denoise step) on MI355X.
 
-Workload (default, BASELINE config 3 shape; config 4 at N = 8): 3-D dynamics-guided sampling.  One *step* of this
+Workload (default, BASELINE configs[2] shape; configs[3] at N = 8): 3-D dynamics-guided sampling.  One *step* of this
 benchmark is one batch of `--pairs` independent (object x objective) pairs per GPU, each a complete guided chain of
 B = 32 fingers: PointNet++ object tables, then S = 5 x [eps-net, cond_fn over R = 32*45*25 = 36 000 replicated rows with
 sub_bs = 512 FPS-start partition, guidance combine, DDIM step].  Every pair has its own synthetic 512-point object, so
 nothing is shared between pairs; the tables are rebuilt inside the timed region for every pair.  The FPS start
-indices (the torch.randint draws of pointnet2_utils.py:83) are the path's random input: they are drawn on the host
-in the reference's order by a background thread one step ahead and handed over as host buffers, so the timed region
-contains their host->device copy but not the Mersenne-Twister draw.
-`--workload 2d` runs BASELINE config 2 (B = 64, G = 360, P = 5, R = 576 000 rows per pair, 100-vertex contours).
+indices (the torch.randint draws of pointnet2_utils.py:83) are the path's random input: they are drawn on the host by a
+background thread one step ahead and handed over as host buffers, so the timed region contains their host->device copy but
+not the Mersenne-Twister draw.  Every pair has a global index (step, rank, slot) -> its object, objective and its own start
+stream are functions of that index only, so the work of a pair does not depend on how many ranks share the batch.
+`--workload 2d` runs BASELINE configs[1] (B = 64, G = 360, P = 5, R = 576 000 rows per pair, 100-vertex contours).
 
-Contract: `python bench.py --gpus N --steps K --warmup W`; one rank per GPU (RANK/LOCAL_RANK/WORLD_SIZE from the
-environment when N > 1); W untimed steps, exactly K timed steps between barrier + synchronize; rank 0 prints ONE JSON line.
+Contract: `python bench.py --gpus N --steps K --warmup W`.  One rank per GPU.  Under a launcher (torchrun: RANK / LOCAL_RANK /
+WORLD_SIZE in the environment) this process is one rank; without one and N > 1 it starts the N rank processes itself (fresh
+interpreters, before anything here touches a GPU) and waits for them.  W untimed steps, exactly K timed steps between
+barrier + synchronize, MAX over ranks; rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import threading
 import time
@@ -34,6 +40,8 @@ from dgdm_amd.dist import gather_pairs                     # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # same guide: v_mfma_f32_32x32x16_bf16, dense (not the 2:1-sparsity figure)
+DEFAULT_PAIRS = {"3d": 32, "2d": 4, "3d_ensemble": 8}
+STREAM_SEED = 1234
 
 
 def parse():
@@ -51,8 +59,32 @@ def parse():
     return p.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------------------------- launcher
+def spawn_ranks(n: int) -> int:
+    """`--gpus N` without a launcher: N fresh rank processes of this script (children, never an exec of this process), one per
+    GPU, rendezvous on 127.0.0.1.  The parent touches no GPU; rank 0's stdout is the benchmark's JSON line."""
+    have = torch.cuda.device_count()          # counts devices without initialising the runtime
+    if have < n:
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------------- workload
 class Workload:
-    def __init__(self, kind, pairs, dev, rank, contraction="f32"):
+    def __init__(self, kind, pairs, dev, rank, world, contraction="f32"):
         self.kind, self.dev, self.contraction = kind, dev, contraction
         self.n_obj = 4 if kind == "3d_ensemble" else 1    # dynamics-gradient evaluations per chain and denoise step
         self.ensemble = kind == "3d_ensemble"
@@ -76,24 +108,30 @@ class Workload:
         self.sched = DDIMScheduler(num_train_timesteps=self.T)
         self.sched.set_timesteps(self.S)
         self.noise = synth.synth_noise(0, self.B, self.L).to(dev)
-        self.rank = rank
-        objectives = [o for o in synth.OBJECTIVES_12 if o != 'convergence']     # 'convergence' needs the sim-side unguided pass
-        self.chains = lambda step: [(i, objectives[(step * pairs + i) % len(objectives)]) for i in range(pairs)]
+        self.rank, self.world = rank, world
+        self.objectives = [o for o in synth.OBJECTIVES_12 if o != 'convergence']     # 'convergence' needs the sim-side unguided pass
         self.rows = self.guid.rows
 
+    def pair_ids(self, step):
+        """Global indices of this rank's pairs in `step`: the batch of world*pairs pairs is block-partitioned over the ranks."""
+        base = (step * self.world + self.rank) * self.pairs
+        return [base + i for i in range(self.pairs)]
+
+    def chains(self, step):
+        return [(i, self.objectives[g % len(self.objectives)]) for i, g in enumerate(self.pair_ids(step))]
+
     def objects(self, step):
-        """Synthetic objects of this step's pairs (distinct for every pair, rank and step), already on the device."""
-        n = self.pairs * self.n_obj
-        base = (self.rank * 100_000 + step) * n
+        """Synthetic objects of this step's pairs (one per gradient chain, a function of the global pair index), on the device."""
         mk = synth.synth_object_3d if self.kind == "3d" else synth.synth_object_2d
-        return torch.stack([mk(base + i, self.N) for i in range(n)]).to(self.dev)
+        return torch.stack([mk(g * self.n_obj + j, self.N) for g in self.pair_ids(step) for j in range(self.n_obj)]).to(self.dev)
 
     def draw(self, step):
         if self.kind != "3d":
             return None
+        streams = [sampler.pair_stream(self.N, self.sub, STREAM_SEED, g) for g in self.pair_ids(step)]
         if self.ensemble:
-            return sampler.draw_ensemble_starts(self.guid, self.pairs, self.n_obj, self.S)
-        return sampler.draw_chain_starts(self.guid, self.chains(step), self.S)
+            return sampler.draw_ensemble_starts(self.guid, self.pairs, self.n_obj, self.S, streams)
+        return sampler.draw_chain_starts(self.guid, self.chains(step), self.S, streams=streams)
 
     def run(self, step, objs, predrawn):
         self.guid.set_objects(objs)                      # 3-D: builds the PointNet++ tables of every pair (timed)
@@ -139,8 +177,70 @@ def timed_loop(wl, steps, warmup, dist):
     return time.perf_counter() - t0, out
 
 
+# ---------------------------------------------------------------------------------------------------------------- roofline
+def pmc_traffic(workload, contraction, kernel):
+    """HBM bytes per launch of the dominant kernel as RECORDED by this round's rocprofv3 PMC passes of this same command
+    (scripts/profile_round.sh -> profiles/r02_*_pmc_hbm.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, counter unit KB).
+    FETCH_SIZE is the raw counter: on gfx950 it can under-count wide coalesced reads by 2x (MI355X_MICROARCH.md §HBM), so the
+    true read traffic lies between 1x and 2x of `fetch_bytes_raw`.  None when no recording exists."""
+    tag = workload + ("_bf16" if contraction == "bf16" else "")
+    f = os.path.join(ROOT, "profiles", f"r02_{tag}_pmc_hbm.json")
+    if not os.path.exists(f):
+        return None
+    d = json.load(open(f))
+    key = next((k for k in d["fetch"] if kernel + "<" in k), None)
+    if key is None or key not in d["write"]:
+        return None
+    fe, wr = d["fetch"][key]["avg_KB"] * 1024.0, d["write"][key]["avg_KB"] * 1024.0
+    return {"bytes_per_launch": fe + wr, "fetch_bytes_raw": fe, "write_bytes": wr, "recorded": os.path.relpath(f, ROOT),
+            "recorded_at": d.get("head")}
+
+
+def stage_profile(wl, secs_per_step, contraction):
+    """One more (untimed) step with HIP events around every stage's launches on their stream (dgdm_prof_*): the roofline of
+    the dominant kernel, the step-level fraction, and the share of each stage in the step."""
+    engine.prof_enable(True)
+    objs, pre = wl.objects(0), wl.draw(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    wl.run(0, objs, pre)
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    st = engine.prof_read_stages()
+    engine.prof_enable(False)
+    n, ms, flops = st["trunk"]
+    if not n:
+        return None, None
+    peak = BF16_MFMA_PEAK_TFLOPS if contraction == "bf16" else F32_MFMA_PEAK_TFLOPS
+    kname = "trunk_bf16_kernel" if contraction == "bf16" else "trunk_kernel"
+    ach = flops / (ms * 1e-3) / 1e12
+    need = st["trunk"][2] + st["unet"][2]                  # necessary FLOPs of one step: trunk (real rows) + eps-net (useful MACs)
+    roof = {"bound": "mfma", "kernel": kname + " (fused dynamics trunk fwd+bwd)", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+            "frac": ach / peak, "traffic": pmc_traffic(wl.kind, contraction, kname), "launches": n, "avg_launch_ms": ms / n,
+            "algorithmic_flops_per_launch": flops / n, "share_of_step": (ms * 1e-3) / secs_per_step,
+            "step_frac": need / secs_per_step / 1e12 / peak,
+            "step_necessary_tflop": need / 1e12,
+            "step_frac_note": "necessary FLOPs of one step (trunk on the real rows + eps-net useful MACs; table-build FLOPs not counted) / "
+                              "wall time of the step / peak of the trunk's MFMA dtype"}
+    shares = {k: {"regions": v[0], "ms_per_step": v[1], "share_of_profiled_step": v[1] / wall_ms} for k, v in st.items() if v[0]}
+    shares["_profiled_step_wall_ms"] = wall_ms
+    return roof, shares
+
+
+# ---------------------------------------------------------------------------------------------------------------- CPU legs
+def _median3(fn):
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return statistics.median(ts), ts
+
+
 def cpu_baseline(wl):
-    """The CPU oracle (a restatement of the reference's as-written dataflow) on this box's host cores, bounded sample."""
+    """The CPU oracle (a restatement of the reference's as-written dataflow, pinned to the reference by tests/golden) on this
+    box's host cores, on a bounded sample of the workload: median of 3 runs, plus one end-to-end chain on a
+    reduced grid as a sanity check of the extrapolation."""
     from oracle import dgdm_oracle as orc
     # torch CPU kernels on these small/medium tensors get slower beyond a few dozen threads (256 threads: >10x slower
     # than 32 on the MI355X host), so the baseline uses at most 32 - the count is reported in `cores`
@@ -151,76 +251,121 @@ def cpu_baseline(wl):
     B, L = wl.B, wl.L
     x = wl.noise.cpu()
     ts = torch.full((B,), int(so.timesteps[0]), dtype=torch.int64)
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        orc.unet1d_forward(wl.unet_sd, x, ts)
-    t_unet = time.perf_counter() - t0
+
+    def unet():
+        with torch.no_grad():
+            orc.unet1d_forward(wl.unet_sd, x, ts)
+    t_unet, _ = _median3(unet)
     cells = wl.G * wl.P * wl.P
     if wl.kind == "3d":
         # one full 512-row sub-batch of cond_fn (fwd + autograd), as generator/diffusion.py:495-498 runs 71 of per step
         s = orc.Setup('point_3d', wl.unet_sd, wl.dyn_sd, so, L, wl.G, wl.P, wl.sub)
         obj = synth.synth_object_3d(0, wl.N)
-        xr = x.clone().requires_grad_(True)
         ori, pos = orc._pose_grid(s, B, (-1.0, 1.0))
-        n = wl.sub                                       # one full sub-batch of 512 rows (10-20 s on 32 threads)
+        n = wl.sub
+
+        def sub_batch():
+            xr = x.clone().requires_grad_(True)
+            with torch.enable_grad():
+                pts = orc._pts3d(s, xr).repeat(cells, 1, 1)[:n]
+                logits = orc.dyn3d_forward(wl.dyn_sd, pts, ori[:n], pos[:n], ts.repeat(cells)[:n].float() / wl.T,
+                                           obj.t().unsqueeze(0).expand(n, -1, -1), None)
+                torch.autograd.grad(orc.deltas_to_objective(logits, 'rotate').sum(), xr)
+        t_sub, runs = _median3(sub_batch)
+        chain = wl.S * (B * cells * t_sub / n + t_unet)
+        sample = (f"median of 3 runs of 1 of the {(B * cells + n - 1) // n} sub-batches ({n} of {B * cells} replicated rows) of one cond_fn call "
+                  f"(PointNet++ + trunk forward, autograd backward) + 1 eps-net forward, extrapolated to {B * cells} rows x {wl.S} steps")
+        # sanity: a whole guided chain on a reduced grid (G=2, P=2 -> 256 rows per cond_fn = one sub-batch per step)
+        Gs, Ps = 2, 2
+        s2 = orc.Setup('point_3d', wl.unet_sd, wl.dyn_sd, so, L, Gs, Ps, wl.sub)
+        torch.manual_seed(0)
         t0 = time.perf_counter()
-        with torch.enable_grad():
-            pts = orc._pts3d(s, xr).repeat(cells, 1, 1)[:n]
-            logits = orc.dyn3d_forward(wl.dyn_sd, pts, ori[:n], pos[:n], ts.repeat(cells)[:n].float() / wl.T,
-                                       obj.t().unsqueeze(0).expand(n, -1, -1), None)
-            torch.autograd.grad(orc.deltas_to_objective(logits, 'rotate').sum(), xr)
-        t_rows = (time.perf_counter() - t0) / n
-        chain = wl.S * (B * cells * t_rows + t_unet)
-        sample = (f"1 of the {(B * cells + n - 1) // n} sub-batches ({n} of {B * cells} replicated rows) of one cond_fn call (PointNet++ + trunk "
-                  f"forward, autograd backward) + 1 eps-net forward, extrapolated to {B * cells} rows x {wl.S} steps")
+        orc.guided_sample(s2, x, obj, 'rotate')
+        t_chain = time.perf_counter() - t0
+        rows_small = B * Gs * Ps * Ps
+        check = {"what": f"one full guided chain end to end at G={Gs}, P={Ps} ({rows_small} rows per cond_fn, {wl.S} steps)",
+                 "seconds": t_chain, "predicted_from_sample_s": wl.S * (rows_small * t_sub / n + t_unet)}
     else:
         s = orc.Setup('point', wl.unet_sd, wl.dyn_sd, so, L, wl.G, wl.P)
         obj = synth.synth_object_2d(0, wl.N)
         Bs = 4                                          # 4 of 64 fingers against the full 9000-cell grid (36 000 rows)
+        t_c, runs = _median3(lambda: orc.cond_fn(s, x[:Bs], ts[:Bs], 'rotate', obj))
+        chain = wl.S * (t_c * (B / Bs) + t_unet)
+        sample = (f"median of 3 runs of cond_fn on {Bs} of {B} fingers x all {cells} cells (36000 rows) + 1 eps-net forward, "
+                  f"extrapolated x{B // Bs} x{wl.S} steps")
         t0 = time.perf_counter()
-        orc.cond_fn(s, x[:Bs], ts[:Bs], 'rotate', obj)
-        t_c = (time.perf_counter() - t0) * (B / Bs)
-        chain = wl.S * (t_c + t_unet)
-        sample = f"cond_fn on {Bs} of {B} fingers x all {cells} cells (36000 rows) + 1 eps-net forward, extrapolated x{B // Bs} x{wl.S} steps"
+        orc.guided_sample(s, x[:Bs], obj, 'rotate')     # a whole chain for those 4 fingers at the full grid
+        t_chain = time.perf_counter() - t0
+        check = {"what": f"one full guided chain end to end for {Bs} fingers at the full grid ({wl.S} steps)", "seconds": t_chain,
+                 "predicted_from_sample_s": wl.S * (t_c + t_unet)}
     return {"value": B / chain, "unit": "guided samples/s", "cores": cores, "kind": "port", "sample": sample,
-            "ms_per_denoise_step": chain / wl.S * 1e3}
+            "ms_per_denoise_step": chain / wl.S * 1e3, "runs_s": runs, "end_to_end_check": check}
 
 
-def pmc_traffic(workload, kernel="trunk_kernel"):
-    """HBM bytes per trunk launch from the committed rocprofv3 PMC passes of this same command (profiles/r01_*_pmc_hbm.json:
-    separate --pmc FETCH_SIZE / WRITE_SIZE runs, counter unit KB).  FETCH_SIZE is the raw counter: on gfx950 it can under-count
-    wide coalesced reads by 2x (MI355X_MICROARCH.md §HBM), so the true read traffic lies between 1x and 2x of `fetch_bytes_raw`."""
-    f = os.path.join(ROOT, "profiles", f"r01_{workload}_pmc_hbm.json")
-    if not os.path.exists(f):
-        return None
-    d = json.load(open(f))
-    key = next((k for k in d["fetch"] if kernel + "<" in k), None)
-    if key is None:
-        return None
-    fe, wr = d["fetch"][key]["avg_KB"] * 1024.0, d["write"][key]["avg_KB"] * 1024.0
-    return {"bytes_per_launch": fe + wr, "fetch_bytes_raw": fe, "write_bytes": wr, "source": os.path.relpath(f, ROOT)}
+def config0(dev):
+    """BASELINE configs[0]: 2-D unconditional sampling, B = 4, L = 14, T = S = 1000 (generator/diffusion.py:249-256 with the
+    parser defaults dynamics/parser.py:29,31) - the reference's CPU-runnable plumbing case: the CPU oracle chain (median of 3)
+    next to the HIP unguided loop on the same noise."""
+    from oracle import dgdm_oracle as orc
+    B, L, T = 4, 14, 1000
+    usd = synth.synth_state_dict(synth.unet_spec(), 11)
+    noise = synth.synth_noise(0, B, L)
+    so = orc.DDIM(T)
+    so.set_timesteps(T)
+    s = orc.Setup('point', usd, None, so, L, 1, 1)
+    cpu_s, runs = _median3(lambda: orc.unguided_sample(s, noise))
+    net = engine.Unet1d(usd)
+    sch = DDIMScheduler(num_train_timesteps=T)
+    sch.set_timesteps(T)
+    x = noise.to(dev)
+    sampler.unguided_sample(net, sch, x)                # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sampler.unguided_sample(net, sch, x)
+    torch.cuda.synchronize()
+    hip_s = time.perf_counter() - t0
+    return {"workload": "2d_unconditional (BASELINE configs[0]: B=4, L=14, T=S=1000)", "dtype": "f32",
+            "cpu_oracle_chain_s": cpu_s, "cpu_runs_s": runs, "cpu_cores": torch.get_num_threads(), "cpu_samples_per_s": B / cpu_s,
+            "hip_chain_s": hip_s, "hip_samples_per_s": B / hip_s, "hip_ms_per_denoise_step": hip_s / T * 1e3}
+
+
+# ---------------------------------------------------------------------------------------------------------------- main
+def workload_text(kind, pairs):
+    if kind == "3d_ensemble":
+        return ("3-D guided sampling with a 4x guidance ensemble (BASELINE configs[4], guided_sample_multi_object semantics): per GPU "
+                f"and step {pairs} chains x B=32 fingers, each step averaging the dynamics gradients of 4 objects (4 cond_fn per chain-step), "
+                "G=45, P=5 -> R=36000 rows per cond_fn, sub_bs=512, 512-point objects, T=15/S=5")
+    if kind == "3d":
+        return (f"3-D dynamics-guided sampling (BASELINE configs[2]; configs[3] at 8 GPUs): per GPU and step {pairs} (object x objective) "
+                "pairs x B=32 fingers, G=45, P=5 -> R=36000 rows per cond_fn, sub_bs=512, 512-point objects, T=15/S=5")
+    return (f"2-D dynamics-guided sampling (BASELINE configs[1]): per GPU and step {pairs} (object x objective) pairs x B=64 fingers, "
+            "G=360, P=5 -> R=576000 rows per cond_fn, 100-vertex objects, T=15/S=5")
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))                   # the parent never touches a GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        print(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s)", file=sys.stderr)
+        sys.exit(2)
     dist = None
-    if a.gpus > 1 or world > 1:
+    if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world)
-    if world > 1:       # ranks share the host: keep torch's CPU pools (input synthesis, FPS start draws) from oversubscribing it
+        # ranks share the host: keep torch's CPU pools (input synthesis, FPS start draws) from oversubscribing it
         torch.set_num_threads(max(1, (os.cpu_count() or 8) // (2 * world)))
     _lib.device_init(local)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    torch.manual_seed(1234 + rank)
-    pairs = a.pairs or {"3d": 32, "2d": 4, "3d_ensemble": 8}[a.workload]
-    wl = Workload(a.workload, pairs, dev, rank, a.contraction)
+    pairs = a.pairs or DEFAULT_PAIRS[a.workload]
+    wl = Workload(a.workload, pairs, dev, rank, world, a.contraction)
 
     engine.prof_enable(False)
     secs, _ = timed_loop(wl, a.steps, a.warmup, dist)
@@ -228,48 +373,23 @@ def main():
         tmax = torch.tensor([secs], device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         secs = float(tmax.item())
-    # second pass, rank 0 only: HIP events around every launch of the dominant kernel (the fused trunk)
-    roof = None
-    if rank == 0:
-        engine.prof_enable(True)
-        objs, pre = wl.objects(0), wl.draw(0)
-        torch.cuda.synchronize()
-        wl.run(0, objs, pre)
-        torch.cuda.synchronize()
-        n, ms, flops = engine.prof_read()
-        engine.prof_enable(False)
-        if n:
-            ach = flops / (ms * 1e-3) / 1e12
-            peak = BF16_MFMA_PEAK_TFLOPS if a.contraction == "bf16" else F32_MFMA_PEAK_TFLOPS
-            kname = "trunk_bf16_kernel" if a.contraction == "bf16" else "trunk_kernel"
-            roof = {"bound": "mfma", "kernel": kname + " (fused dynamics trunk fwd+bwd)", "achieved": ach, "peak": peak,
-                    "unit": "TFLOP/s", "frac": ach / peak, "traffic": pmc_traffic(wl.kind, kname), "launches": n, "avg_launch_ms": ms / n,
-                    "algorithmic_flops_per_launch": flops / n, "share_of_step": (ms * 1e-3) / (secs / a.steps)}
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
+    roof, shares = stage_profile(wl, secs / a.steps, a.contraction)
     samples = wl.B * pairs * world * a.steps
     line = {
         "metric": "guided samples/sec (full DDIM chain)", "value": samples / secs, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": secs / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.contraction, "data": "synthetic (random-init checkpoints, synthetic objects, seeded noise; SURVEY.md §8(d))",
-        "config": {"workload": ("3-D guided sampling with a 4x guidance ensemble (BASELINE configs[4], guided_sample_multi_object semantics): per GPU "
-                                "and step %d chains x B=32 fingers, each step averaging the dynamics gradients of 4 objects (4 cond_fn per chain-step), "
-                                "G=45, P=5 -> R=36000 rows per cond_fn, sub_bs=512, 512-point objects, T=15/S=5"
-                                if a.workload == "3d_ensemble" else
-                                "3-D dynamics-guided sampling (BASELINE configs[2]; configs[3] at 8 GPUs): per GPU and step %d (object x objective) "
-                                "pairs x B=32 fingers, G=45, P=5 -> R=36000 rows per cond_fn, sub_bs=512, 512-point objects, T=15/S=5"
-                                if a.workload == "3d" else
-                                "2-D dynamics-guided sampling (BASELINE configs[1]): per GPU and step %d (object x objective) pairs x B=64 fingers, "
-                                "G=360, P=5 -> R=576000 rows per cond_fn, 100-vertex objects, T=15/S=5") % pairs,
-                   "pairs_per_gpu_per_step": pairs, "fingers_per_pair": wl.B, "denoise_steps": wl.S, "rows_per_cond_fn": wl.rows,
-                   "cond_fn_per_chain_step": wl.n_obj},
+        "config": {"workload": workload_text(a.workload, pairs), "pairs_per_gpu_per_step": pairs, "fingers_per_pair": wl.B,
+                   "denoise_steps": wl.S, "rows_per_cond_fn": wl.rows, "cond_fn_per_chain_step": wl.n_obj},
         "ms_per_denoise_step": secs / a.steps / wl.S * 1e3,
         "ms_per_denoise_step_per_pair": secs / a.steps / wl.S / pairs * 1e3,
     }
     if roof:
         line["roofline"] = roof
+        line["stage_share"] = shares
     if world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(wl)
         line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
@@ -277,13 +397,19 @@ def main():
         other = "2d" if wl.kind == "3d" else "3d"
         del wl
         torch.cuda.empty_cache()
-        # the other BASELINE configurations, two timed steps each (not the headline: `value` above is what the driver reads)
-        extras = []
+        # the other BASELINE configurations (not the headline: `value` above is what the driver reads)
+        extras = [config0(dev)]
         for kind, contraction in ((other, "f32"), ("3d", "bf16"), ("2d", "bf16"), ("3d_ensemble", "bf16")):
-            w2 = Workload(kind, {"3d": 32, "2d": 4, "3d_ensemble": 8}[kind], dev, rank, contraction)
+            w2 = Workload(kind, DEFAULT_PAIRS[kind], dev, rank, world, contraction)
             s2, _ = timed_loop(w2, 2, 1, None)
-            extras.append({"workload": kind, "dtype": contraction, "samples_per_s": w2.B * w2.pairs * 2 / s2, "ms_per_step": s2 / 2 * 1e3,
-                           "ms_per_denoise_step_per_pair": s2 / 2 / w2.S / w2.pairs * 1e3, "cond_fn_per_chain_step": w2.n_obj})
+            e = {"workload": kind, "dtype": contraction, "samples_per_s": w2.B * w2.pairs * 2 / s2, "ms_per_step": s2 / 2 * 1e3,
+                 "ms_per_denoise_step_per_pair": s2 / 2 / w2.S / w2.pairs * 1e3, "cond_fn_per_chain_step": w2.n_obj}
+            r2, sh2 = stage_profile(w2, s2 / 2, contraction)
+            if r2:
+                e["roofline"], e["stage_share"] = r2, sh2
+            if contraction == "f32" and not a.no_cpu_baseline:
+                e["cpu_baseline"] = cpu_baseline(w2)
+            extras.append(e)
             del w2
             torch.cuda.empty_cache()
         line["extra"] = extras

@@ -82,8 +82,10 @@ uint16_t f32_to_bf16(float x);                                              // r
 std::vector<uint16_t> pack_chain_bf16(const float *src, int M, int K);     // A-operand image for trunk_bf16.hip
 std::vector<float> transpose(const float *src, int rows, int cols);   // -> [cols][rows]
 
-// profiling of the dominant kernel
-void prof_begin(hipStream_t s);
-void prof_end(hipStream_t s, double flops);
+// profiling (dgdm_prof_*): HIP events on the launch stream around one stage; `work` = its algorithmic FLOPs (MFMA-bound stages)
+// or bytes (HBM-bound stages), 0 when the host cannot know it
+constexpr int PROF_BUCKETS = DGDM_STAGE_COUNT;
+void prof_begin(hipStream_t s, int stage);
+void prof_end(hipStream_t s, int stage, double work);
 
 }  // namespace dgdm

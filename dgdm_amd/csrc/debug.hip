@@ -2,6 +2,7 @@
 // X, Y are row-major [32 rows][256 features] (as every feature table in this library).
 #include "common.h"
 #include "mfma_chain.h"
+#include "models.h"
 
 namespace dgdm {
 __global__ __launch_bounds__(64, 1) void debug_chain_kernel(const float4 *__restrict__ Wimg, const float *__restrict__ bias,
@@ -38,4 +39,20 @@ extern "C" int dgdm_debug_chain_layer(const float *W_host, const float *bias_hos
     DGDM_HIP_CHECK(hipGetLastError());
     DGDM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     return DGDM_OK;
+}
+
+// Index decisions of the PointNet++ pipeline for one cloud (see include/dgdm_hip.h).
+extern "C" int dgdm_debug_pointnet_indices(DgdmDynamics *m, const float *xyz_dev, int N, const int32_t *perm_dev, int perm_len,
+                                           int32_t *fps512_dev, int32_t *fps128_dev, int32_t *fps128_flags_dev, int32_t *ball1_dev,
+                                           int32_t *ball2_dev, int32_t *ball2_count_dev, int32_t *crowded_dev, void *stream) {
+    using namespace dgdm;
+    DGDM_REQUIRE(m && xyz_dev && perm_dev && fps512_dev && fps128_dev && fps128_flags_dev && ball1_dev && ball2_dev && ball2_count_dev && crowded_dev,
+                 DGDM_EINVAL, "dgdm_debug_pointnet_indices: null argument");
+    if (m->kind != 3) { set_error("model type not supported: PointNet++ belongs to the 3-D model"); return DGDM_EMODE; }
+    DGDM_REQUIRE(N >= 128 && N <= 1024 && perm_len > 0 && perm_len <= N, DGDM_EINVAL, "dgdm_debug_pointnet_indices: N %d / perm_len %d unsupported", N, perm_len);
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if ((rc = pn_fps_table(xyz_dev, N, N, 512, fps512_dev, nullptr, s))) return rc;
+    if ((rc = pn_fps_table(xyz_dev, N, N, 128, fps128_dev, fps128_flags_dev, s))) return rc;
+    return pn_debug_indices(xyz_dev, N, m->pn(), perm_dev, perm_len, ball1_dev, ball2_dev, ball2_count_dev, crowded_dev, s);
 }

@@ -200,10 +200,12 @@ extern "C" int dgdm_guidance_set_objects(DgdmGuidance *g, const float *objects_d
     DGDM_REQUIRE(n_objects <= std::max(1, g->cfg.max_objects), DGDM_EINVAL, "%d objects > max_objects %d", n_objects, g->cfg.max_objects);
     hipStream_t s = (hipStream_t)stream;
     int rc;
+    prof_begin(s, DGDM_STAGE_TABLES);
     if (g->m->kind == 2) {
         DevBuf tmp;
         if ((rc = tmp.alloc((size_t)n_objects * 512 * 4))) return rc;
         if ((rc = g->m->object_part_2d(objects_dev, tmp.as<float>(), g->objpart.as<float>(), n_objects, false, s))) return rc;
+        prof_end(s, DGDM_STAGE_TABLES, 0.0);
         DGDM_HIP_CHECK(hipStreamSynchronize(s));
     } else {
         while ((int)g->tables.size() < n_objects) g->tables.emplace_back(new ObjectTables());
@@ -244,6 +246,7 @@ extern "C" int dgdm_guidance_set_objects(DgdmGuidance *g, const float *objects_d
         }
         // which objects may use the table of FPS(128) sequences (no order-dependent selection anywhere)
         std::vector<int> fl((size_t)n_objects * N);
+        prof_end(s, DGDM_STAGE_TABLES, 0.0);
         DGDM_HIP_CHECK(hipMemcpyAsync(fl.data(), g->pool_flags.p, sizeof(int) * no * N, hipMemcpyDeviceToHost, s));
         DGDM_HIP_CHECK(hipStreamSynchronize(s));
         for (int i = 0; i < n_objects; ++i) {
@@ -353,15 +356,19 @@ static int guidance_grad(DgdmGuidance *g, int kind, const float *x_dev, int time
     }
     const float t_scaled = (float)timestep / (float)g->cfg.num_train_timesteps;      // timesteps.float() / T  (diffusion.py:487,496)
     int rc;
+    prof_begin(s, DGDM_STAGE_GUIDE_MISC);
     if ((rc = g->common_pre(x_dev, t_scaled, oidx.data(), n_chains, s))) return rc;
     DGDM_HIP_CHECK(hipMemcpyAsync(g->objdev.p, tob.data(), sizeof(TrunkObjective) * n_chains, hipMemcpyHostToDevice, s));
+    prof_end(s, DGDM_STAGE_GUIDE_MISC, 0.0);
     TrunkParams p;
     g->m->fill_trunk(&p);
     if (kind == 3) {
         DGDM_REQUIRE(starts_host, DGDM_EINVAL, "3-D guidance needs the FPS start indices");
+        prof_begin(s, DGDM_STAGE_XOBJ);
         if ((rc = g->upload_starts(starts_host, n_chains, g->R, s))) return rc;
         bool used16 = false;
         if ((rc = g->run_xobj(oidx.data(), n_chains, g->R, g->bf16, &used16, s))) return rc;
+        prof_end(s, DGDM_STAGE_XOBJ, 0.0);
         p.xobj = g->xobj.as<float>();
         p.xobj16 = used16 ? g->xobj16.as<uint32_t>() : nullptr;
     }
@@ -390,8 +397,11 @@ static int guidance_grad(DgdmGuidance *g, int kind, const float *x_dev, int time
                 ph[3] / nw, ph[4] / nw, ph[5] / nw);
     }
 #endif
-    return dyn_post(g->m->W1, g->partial.as<float>(), g->tiles_per_b, g->m->blob.at(g->m->off.w1c_w), g->m->blob.at(g->m->off.g2_w),
-                    g->m->blob.at(g->m->off.g0_w), g->V.as<float>(), grad_dev, n_chains * g->B, g->m->L, s);
+    prof_begin(s, DGDM_STAGE_GUIDE_MISC);
+    rc = dyn_post(g->m->W1, g->partial.as<float>(), g->tiles_per_b, g->m->blob.at(g->m->off.w1c_w), g->m->blob.at(g->m->off.g2_w),
+                  g->m->blob.at(g->m->off.g0_w), g->V.as<float>(), grad_dev, n_chains * g->B, g->m->L, s);
+    prof_end(s, DGDM_STAGE_GUIDE_MISC, 0.0);
+    return rc;
 }
 
 extern "C" int dgdm_dyn2d_guidance_grad(DgdmGuidance *g, const float *x_dev, int timestep, const DgdmObjective *objectives,

@@ -102,23 +102,23 @@ std::vector<float> transpose(const float *src, int rows, int cols) {
     return t;
 }
 
-// ---------------------------------------------------------------- profiling of the dominant kernel
-struct ProfRec { hipEvent_t a, b; double flops; };
+// ---------------------------------------------------------------- profiling: HIP events around the launches of each stage
+struct ProfRec { hipEvent_t a, b; double work; };
 static bool g_prof_on = false;
-static std::vector<ProfRec> g_prof;
+static std::vector<ProfRec> g_prof[PROF_BUCKETS];
 
-void prof_begin(hipStream_t s) {
+void prof_begin(hipStream_t s, int bucket) {
     if (!g_prof_on) return;
     ProfRec r{};
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
     (void)hipEventRecord(r.a, s);
-    g_prof.push_back(r);
+    g_prof[bucket].push_back(r);
 }
 
-void prof_end(hipStream_t s, double flops) {
-    if (!g_prof_on || g_prof.empty()) return;
-    g_prof.back().flops = flops;
-    (void)hipEventRecord(g_prof.back().b, s);
+void prof_end(hipStream_t s, int bucket, double work) {
+    if (!g_prof_on || g_prof[bucket].empty()) return;
+    g_prof[bucket].back().work = work;
+    (void)hipEventRecord(g_prof[bucket].back().b, s);
 }
 
 }  // namespace dgdm
@@ -144,26 +144,33 @@ extern "C" int dgdm_device_init(int ordinal) {
 
 extern "C" int dgdm_prof_enable(int on) {
     g_prof_on = on != 0;
-    for (auto &r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
-    g_prof.clear();
+    for (auto &b : g_prof) {
+        for (auto &r : b) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+        b.clear();
+    }
+    return DGDM_OK;
+}
+
+extern "C" int dgdm_prof_read_stage(int stage, int64_t *launches, double *total_ms, double *total_work) {
+    DGDM_REQUIRE(stage >= 0 && stage < PROF_BUCKETS, DGDM_EINVAL, "dgdm_prof_read_stage: stage %d outside 0..%d", stage, PROF_BUCKETS - 1);
+    double ms = 0, fl = 0;
+    int64_t n = 0;
+    for (auto &r : g_prof[stage]) {
+        DGDM_HIP_CHECK(hipEventSynchronize(r.b));
+        float t = 0;
+        DGDM_HIP_CHECK(hipEventElapsedTime(&t, r.a, r.b));
+        ms += t; fl += r.work; ++n;
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    g_prof[stage].clear();
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = ms;
+    if (total_work) *total_work = fl;
     return DGDM_OK;
 }
 
 extern "C" int dgdm_prof_read(int64_t *launches, double *total_ms, double *total_flops) {
-    double ms = 0, fl = 0;
-    int64_t n = 0;
-    for (auto &r : g_prof) {
-        DGDM_HIP_CHECK(hipEventSynchronize(r.b));
-        float t = 0;
-        DGDM_HIP_CHECK(hipEventElapsedTime(&t, r.a, r.b));
-        ms += t; fl += r.flops; ++n;
-        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
-    }
-    g_prof.clear();
-    if (launches) *launches = n;
-    if (total_ms) *total_ms = ms;
-    if (total_flops) *total_flops = fl;
-    return DGDM_OK;
+    return dgdm_prof_read_stage(DGDM_STAGE_TRUNK, launches, total_ms, total_flops);
 }
 
 // generator/diffusion.py:430-471 in gradient form

@@ -66,6 +66,10 @@ int pn_z(const float *xyz, int N, int nv, const PnWeights &w, const float *L2, f
          hipStream_t s);
 int pn_m0(const int *fps2, const int *crowded, int N, const float *Z0, float *M0, int *cl2, int *cnt2, const uint32_t *Z0_16, uint32_t *M0_16,
           hipStream_t s);
+// index test hook (dgdm_debug_pointnet_indices): sa1's 32-neighbour lists [N][32], sa2's first-64 lists [N][64] + counts for the
+// candidate order perm[0..M), crowded flags [N]; synchronises
+int pn_debug_indices(const float *xyz, int N, const PnWeights &w, const int *perm, int M, int *ball1, int *ball2, int *ball2_cnt, int *crowded,
+                     hipStream_t s);
 // all_fast: every chain has its tables and no start point with an order-dependent FPS(128) sequence (then one kernel does it all)
 int pn_xobj(const XobjParams &p, bool all_fast, hipStream_t s);
 

@@ -120,6 +120,28 @@ __global__ __launch_bounds__(256) void fps_table_kernel(const float *__restrict_
     }
 }
 
+// query_ball_point (pointnet2_utils.py:95-115) for one centre by one wave: the first 32 in-radius indices in index order,
+// padded with the first one (:112-114), into nbr[0..32) (LDS).  Shared by sa1_kernel and the index test hook.
+__device__ __forceinline__ void ball_first32(const float *__restrict__ xyz, int N, int p, float cx, float cy, float cz, float cn, float r2,
+                                             int *nbr, int lane) {
+    int cnt = 0;
+    for (int base = 0; base < N && cnt < 32; base += 64) {
+        const int k = base + lane;
+        bool in = false;
+        if (k < N) {
+            const float x = xyz[3 * k], y = xyz[3 * k + 1], z = xyz[3 * k + 2];
+            in = !(sqdist_expanded(cx, cy, cz, cn, x, y, z, sq3(x, y, z)) > r2);
+        }
+        const unsigned long long m = __ballot(in);
+        const int rank = cnt + __popcll(m & ((1ull << lane) - 1ull));
+        if (in && rank < 32) nbr[rank] = k;
+        cnt += __popcll(m);
+    }
+    cnt = min(cnt, 32);
+    __builtin_amdgcn_wave_barrier();
+    if (lane >= cnt && lane < 32) nbr[lane] = (cnt > 0) ? nbr[0] : p;   // pad with the first (:112-114)
+}
+
 // ------------------------------------------------------------------------------------------------ T2
 // sa1 feature of every point p as a centre: first 32 in-radius (r=0.2) points in index order, padded with
 // the first; Conv(3->64)+BN+ReLU, Conv(64->128)+BN+ReLU, max  (pointnet2.py:17, pointnet2_utils.py:95-146,203-208)
@@ -136,24 +158,7 @@ __global__ __launch_bounds__(128) void sa1_kernel(const float *__restrict__ xyz,
     for (int p = blockIdx.x; p < N; p += gridDim.x) {
         const float cx = xyz[3 * p], cy = xyz[3 * p + 1], cz = xyz[3 * p + 2];
         const float cn = sq3(cx, cy, cz);
-        if (t < 64) {      // wave 0: ordered compaction of in-radius indices
-            int cnt = 0;
-            for (int base = 0; base < N && cnt < 32; base += 64) {
-                const int k = base + lane;
-                bool in = false;
-                if (k < N) {
-                    const float x = xyz[3 * k], y = xyz[3 * k + 1], z = xyz[3 * k + 2];
-                    in = !(sqdist_expanded(cx, cy, cz, cn, x, y, z, sq3(x, y, z)) > r2);
-                }
-                const unsigned long long m = __ballot(in);
-                const int rank = cnt + __popcll(m & ((1ull << lane) - 1ull));
-                if (in && rank < 32) nbr[rank] = k;
-                cnt += __popcll(m);
-            }
-            cnt = min(cnt, 32);
-            __builtin_amdgcn_wave_barrier();
-            if (lane >= cnt && lane < 32) nbr[lane] = (cnt > 0) ? nbr[0] : p;   // pad with the first (:112-114)
-        }
+        if (t < 64) ball_first32(xyz, N, p, cx, cy, cz, cn, r2, nbr, lane);      // wave 0
         __syncthreads();
         for (int i = t; i < 32 * 64; i += 128) {          // layer 0 on the relative coordinates
             const int s = i >> 6, c = i & 63, k = nbr[s];
@@ -309,6 +314,25 @@ __global__ __launch_bounds__(256) void nbr_fill_kernel(const float *__restrict__
     }
 }
 
+// sa2's ball query for one centre by one wave: the first 64 in-radius candidates in the order `perm` lists the points
+// (query_ball_point scans the re-ordered cloud, pointnet2_utils.py:95-115).  rks = the centre's row of the rank table in LDS
+// (rank >= 0 <=> in the ball; the value is the candidate's row in the centre's block of the pair list).  Writes those rows to
+// sel[0..cnt) and returns cnt <= 64.  Shared by l2_kernel and the index test hook.
+__device__ __forceinline__ int l2_select(const short *rks, const int *__restrict__ perm, int M, int *sel, int lane) {
+    int cnt = 0;
+    for (int base = 0; base < M && cnt < 64; base += 64) {
+        const int j = base + lane;
+        const int r = j < M ? rks[perm[j]] : -1;
+        const bool in = r >= 0;
+        const unsigned long long m = __ballot(in);
+        const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+        if (in && pos < 64) sel[pos] = r;
+        cnt += __popcll(m);
+    }
+    __builtin_amdgcn_wave_barrier();
+    return min(cnt, 64);
+}
+
 // L2[slot][c][256] = max over the first 64 in-radius (r=0.4) positions of variant vlist[slot] of Y[(c, point)].
 // mode 0: slot 0, every centre (blockIdx.y*4 + wave).  mode 1: slots >= 1, crowded centres only (clist[blockIdx.y]); the
 // waves of a workgroup then share the centre so its Y slab stays cache resident.
@@ -344,17 +368,7 @@ __global__ __launch_bounds__(256) void l2_kernel(const float *__restrict__ xyz, 
     const short *rk = rank + (size_t)c * N;
     for (int i = lane; i < N; i += 64) rks[wave][i] = rk[i];
     __builtin_amdgcn_wave_barrier();
-    int cnt = 0;
-    for (int base = 0; base < 512 && cnt < 64; base += 64) {
-        const int r = rks[wave][perm[base + lane]];
-        const bool in = r >= 0;
-        const unsigned long long m = __ballot(in);
-        const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
-        if (in && pos < 64) sel[wave][pos] = r;
-        cnt += __popcll(m);
-    }
-    cnt = min(cnt, 64);
-    __builtin_amdgcn_wave_barrier();
+    const int cnt = l2_select(rks[wave], perm, 512, sel[wave], lane);       // sa1 always hands 512 centres on (pointnet2.py:17)
     if (BF16) {
         // Y and L2 are bf16 operand-order rows (128 dwords): two dwords per lane, v_pk_max_u16 (values are >= 0)
         const uint2 *slab = reinterpret_cast<const uint2 *>(reinterpret_cast<const uint32_t *>(Y) + (size_t)off[c] * 128) + lane;
@@ -800,6 +814,48 @@ int pn_m0(const int *fps2, const int *crowded, int N, const float *Z0, float *M0
           hipStream_t s) {
     hipLaunchKernelGGL(m0_kernel, dim3((N + 3) / 4), dim3(256), 0, s, fps2, crowded, N, Z0, M0, cl2, cnt2, Z0_16, M0_16);
     DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ index test hook
+// The index decisions of the pipeline, written out for bit-exact comparison with the reference's farthest_point_sample /
+// query_ball_point outputs (tests/test_gpu_indices.py).  Same device functions as the production kernels.
+__global__ __launch_bounds__(64) void debug_ball1_kernel(const float *__restrict__ xyz, int N, float r2, int *__restrict__ out /*[N][32]*/) {
+    __shared__ int nbr[32];
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const float cx = xyz[3 * p], cy = xyz[3 * p + 1], cz = xyz[3 * p + 2];
+    ball_first32(xyz, N, p, cx, cy, cz, sq3(cx, cy, cz), r2, nbr, lane);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 32) out[(size_t)p * 32 + lane] = nbr[lane];
+}
+
+// out[c][0..cnt[c]) = point ids of the first 64 in-radius (r = 0.4) candidates of centre POINT c when the cloud is scanned in
+// the order perm[0..M) (l2_kernel's selection: rank-table row in LDS, l2_select, pair list)
+__global__ __launch_bounds__(64) void debug_ball2_kernel(int N, const int *__restrict__ perm, int M, const int *__restrict__ off,
+                                                         const int *__restrict__ pairs, const short *__restrict__ rank,
+                                                         int *__restrict__ out /*[N][64]*/, int *__restrict__ cnt_out /*[N]*/) {
+    __shared__ int sel[64];
+    __shared__ short rks[1024];
+    const int c = blockIdx.x, lane = threadIdx.x;
+    for (int i = lane; i < N; i += 64) rks[i] = rank[(size_t)c * N + i];
+    __builtin_amdgcn_wave_barrier();
+    const int cnt = l2_select(rks, perm, M, sel, lane);
+    out[(size_t)c * 64 + lane] = lane < cnt ? (pairs[off[c] + sel[lane]] & 0xffff) : -1;
+    if (lane == 0) cnt_out[c] = cnt;
+}
+
+int pn_debug_indices(const float *xyz, int N, const PnWeights &w, const int *perm, int M, int *ball1, int *ball2, int *ball2_cnt, int *crowded,
+                     hipStream_t s) {
+    DevBuf clist, off, pairs, rank;
+    int rc;
+    if ((rc = clist.alloc((size_t)(N + 1) * 4)) || (rc = off.alloc((size_t)(N + 1) * 4)) || (rc = pairs.alloc((size_t)N * N * 4)) ||
+        (rc = rank.alloc((size_t)N * N * 2)))
+        return rc;
+    hipLaunchKernelGGL(debug_ball1_kernel, dim3(N), dim3(64), 0, s, xyz, N, w.r1sq, ball1);
+    if ((rc = pn_crowd(xyz, N, w, crowded, clist.as<int>(), clist.as<int>() + N, off.as<int>(), pairs.as<int>(), rank.as<short>(), s))) return rc;
+    hipLaunchKernelGGL(debug_ball2_kernel, dim3(N), dim3(64), 0, s, N, perm, M, off.as<int>(), pairs.as<int>(), rank.as<short>(), ball2, ball2_cnt);
+    DGDM_HIP_CHECK(hipGetLastError());
+    DGDM_HIP_CHECK(hipStreamSynchronize(s));     // temporaries die here
     return DGDM_OK;
 }
 

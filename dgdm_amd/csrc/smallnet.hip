@@ -239,8 +239,10 @@ extern "C" int dgdm_ddim_guided_step(const float *x_dev, const float *eps_dev, c
                                      float sqrt_1m_abar_prev, float guidance_scale, void *stream) {
     DGDM_REQUIRE(x_dev && eps_dev && x_next_dev && n >= 0, DGDM_EINVAL, "dgdm_ddim_guided_step: null argument");
     if (n == 0) return DGDM_OK;
+    dgdm::prof_begin((hipStream_t)stream, DGDM_STAGE_DDIM);
     hipLaunchKernelGGL(dgdm::ddim_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_dev, eps_dev,
                        grad_dev, n_grad, x_next_dev, n, sqrt_abar_t, sqrt_1m_abar_t, sqrt_abar_prev, sqrt_1m_abar_prev, guidance_scale);
+    dgdm::prof_end((hipStream_t)stream, DGDM_STAGE_DDIM, (double)n * 4.0 * (3 + n_grad));
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
 }

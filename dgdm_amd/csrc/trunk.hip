@@ -20,6 +20,7 @@
 // The backward pass needs no activations, only the ReLU sign bits (kept in LDS, 1 bit per unit),
 // because the dynamics weights are frozen (generator/train.py:91-92).
 #include "common.h"
+#include <algorithm>
 #include "mfma_chain.h"
 #include "trunk.h"
 
@@ -271,11 +272,12 @@ static int launch(const TrunkParams &p, hipStream_t s) {
 
 int trunk_launch(int kind, bool rows_mode, bool fwd_only, const TrunkParams &p, hipStream_t s) {
     // algorithmic FLOPs of what this launch executes: MFMA layers only
-    const double rows = 32.0 * p.ntiles;
+    // real rows only (the last cell tile of a finger is padded to 32: 1125 cells -> 36 tiles = 1152 issued rows)
+    const double rows = rows_mode ? (double)p.R : (double)(p.ntiles / std::max(1, p.tiles_per_b)) * p.C;
     const double mid = 2.0 * 256 * 256 * p.n_mid;
     double per_row = (kind == 3) ? (2.0 * 256 * 512 * 2 + mid) : mid;
     if (!fwd_only) per_row += (kind == 3) ? (2.0 * 256 * 512 + mid) : mid;
-    prof_begin(s);
+    prof_begin(s, DGDM_STAGE_TRUNK);
     int rc;
     if (kind == 2) {
         if (rows_mode) rc = fwd_only ? launch<2, true, true>(p, s) : DGDM_EINVAL;
@@ -284,7 +286,7 @@ int trunk_launch(int kind, bool rows_mode, bool fwd_only, const TrunkParams &p, 
         if (rows_mode) rc = fwd_only ? launch<3, true, true>(p, s) : DGDM_EINVAL;
         else rc = fwd_only ? launch<3, false, true>(p, s) : launch<3, false, false>(p, s);
     }
-    prof_end(s, rows * per_row);
+    prof_end(s, DGDM_STAGE_TRUNK, rows * per_row);
     return rc;
 }
 

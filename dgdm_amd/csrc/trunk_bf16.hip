@@ -568,14 +568,14 @@ int trunk_bf16_launch(int kind, const TrunkParams &p, hipStream_t s) {
     if (p.n_mid != (kind == 3 ? 6 : 7)) return DGDM_EINVAL;
     const int waves = (p.ntiles + 1) / 2, grid = (waves + 3) / 4;
     if (grid == 0) return DGDM_OK;
-    const double rows = 32.0 * p.ntiles;
+    const double rows = (double)(p.ntiles / (p.tiles_per_b > 0 ? p.tiles_per_b : 1)) * p.C;      // real rows, not the 32-row tile padding
     const double mid = 2.0 * 256 * 256 * p.n_mid;
     const double per_row = (kind == 3) ? (2.0 * 256 * 512 * 2 + mid) + (2.0 * 256 * 512 + mid) : 2.0 * mid;
-    prof_begin(s);
+    prof_begin(s, DGDM_STAGE_TRUNK);
     if (kind == 2) hipLaunchKernelGGL((trunk_bf16_kernel<2>), dim3(grid), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((trunk_bf16_kernel<3>), dim3(grid), dim3(256), 0, s, p);
     DGDM_HIP_CHECK(hipGetLastError());
-    prof_end(s, rows * per_row);
+    prof_end(s, DGDM_STAGE_TRUNK, rows * per_row);
     return DGDM_OK;
 }
 

@@ -98,6 +98,18 @@ class Dynamics:
         return out
 
 
+def debug_pointnet_indices(dyn: "Dynamics", cloud: torch.Tensor, perm: Optional[torch.Tensor] = None) -> Dict[str, np.ndarray]:
+    """Test hook: the index decisions of the PointNet++ pipeline for one cloud (N, 3) - FPS sequences from every start index,
+    sa1's 32-neighbour lists, sa2's first-64 lists for the candidate order `perm` (default: index order), crowded flags."""
+    x = _f32(cloud)
+    N = x.shape[0]
+    pm = (torch.arange(N) if perm is None else perm).to(device=x.device, dtype=torch.int32).contiguous()
+    mk = lambda *shape: torch.empty(shape, dtype=torch.int32, device=x.device)       # noqa: E731
+    out = dict(fps512=mk(N, 512), fps128=mk(N, 128), fps128_flags=mk(N), ball1=mk(N, 32), ball2=mk(N, 64), ball2_count=mk(N), crowded=mk(N))
+    check(lib().dgdm_debug_pointnet_indices(dyn._h, dptr(x), N, dptr(pm), pm.numel(), *[dptr(v) for v in out.values()], stream_ptr()))
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
 def make_objective(name: str, object_index: int = 0) -> _lib.Objective:
     o = _lib.Objective()
     o.object = object_index
@@ -224,6 +236,19 @@ def finger_decode_3d(samples: torch.Tensor, sample_size: int = 25, scale: float 
 
 def prof_enable(on: bool) -> None:
     check(lib().dgdm_prof_enable(int(on)))
+
+
+STAGES = ("trunk", "unet", "xobj", "tables", "guide_misc", "ddim")      # include/dgdm_hip.h DGDM_STAGE_*
+
+
+def prof_read_stages() -> Dict[str, Tuple[int, float, float]]:
+    """{stage: (bracketed regions, total ms, algorithmic work)} since prof_enable(True); clears the records."""
+    out = {}
+    for i, name in enumerate(STAGES):
+        n, ms, wk = C.c_int64(), C.c_double(), C.c_double()
+        check(lib().dgdm_prof_read_stage(i, C.byref(n), C.byref(ms), C.byref(wk)))
+        out[name] = (n.value, ms.value, wk.value)
+    return out
 
 
 def prof_read() -> Tuple[int, float, float]:

@@ -21,7 +21,9 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from .. import dist as ddist
 from .. import engine, sampler
+from ..dynamics._backed import HipBacked
 from ..dynamics import metrics
 from ..dynamics.metrics import metric2objective, objective_directions     # noqa: F401  (metric2objective: reference import)
 from ..sampler import SCALE_2D, SCALE_2D_CONV, SCALE_3D, SCALE_3D_CONV, StartStream     # noqa: F401  (reference exports)
@@ -98,7 +100,14 @@ class Diffusion(nn.Module):
         """Accepts a Lightning checkpoint ``state_dict`` (keys ``ema_nets.noise_pred_net.*``, optional nested
         ``ema_model`` and ``_orig_mod.`` prefixes from torch.compile; reference :730-748)."""
         flat = {k.replace("_orig_mod.", ""): v for k, v in state_dict.items() if k != "ema_model"}
-        return super().load_state_dict(flat, strict=False)
+        out = super().load_state_dict(flat, strict=False)
+        # nn.Module.load_state_dict copies into the children's parameters in place (it never calls the children's own
+        # load_state_dict), so their packed device copies and every guidance handle bound to them are stale now
+        for m in self.modules():
+            if isinstance(m, HipBacked):
+                m.invalidate()
+        self._guidance.clear()
+        return out
 
     def _guidance_for(self, batch: int, ori_range: Sequence[float], objects: torch.Tensor, max_chains: int) -> engine.Guidance:
         """Guidance handle for (B, ori_range) with `objects` as its bank."""
@@ -106,7 +115,7 @@ class Diffusion(nn.Module):
         npts = objects.shape[1]
         key = (batch, float(ori_range[0]), float(ori_range[1]), npts)
         g = self._guidance.get(key)
-        if g is None or g.cfg.max_chains < max_chains or g.cfg.max_objects < objects.shape[0]:
+        if g is None or g.dyn is not dyn or g.cfg.max_chains < max_chains or g.cfg.max_objects < objects.shape[0]:
             g = engine.Guidance(dyn, batch, self.grid_size, self.num_pos, ori_range, max(max_chains, 1),
                                 self.noise_scheduler.config.num_train_timesteps, npts,
                                 self.sub_batch_size if self.mode == 'point_3d' else 0, max_objects=max(objects.shape[0], 1),
@@ -188,25 +197,46 @@ class Diffusion(nn.Module):
         return (np.argmax if directions[primary] > 0 else np.argmin)([o[primary] for o in objectives])
 
     # ------------------------------------------------------------------ a1
+    def _spec(self, batch: int, ori_range: Sequence[float], npts: int) -> ddist.GuidanceSpec:
+        return ddist.GuidanceSpec(self._dyn().handle(), batch, self.grid_size, self.num_pos, ori_range,
+                                  self.noise_scheduler.config.num_train_timesteps, npts,
+                                  self.sub_batch_size if self.mode == 'point_3d' else 0, self.contraction_dtype)
+
     def guided_sample(self, batch_idx, batch_size, noise, save_dir, opt_obj='rotate', ori_range=[-1.0, 1.0], unguided_sample=None):
-        """All objects' chains of generator/diffusion.py:561-576 as one batch.  Returns (n_objects, B, L, 1)."""
+        """All objects' chains of generator/diffusion.py:561-576 as one batch.  Returns (n_objects, B, L, 1).
+
+        Under a process group (torchrun, one rank per GPU) the objects' chains are block-partitioned over the ranks and the
+        final samples all-gathered (dgdm_amd/dist.py) - this is what stands in for the reference's nn.DataParallel
+        (generator/train.py:86,88); every rank returns all objects' samples, identical to the single-process result."""
         objs = torch.as_tensor(self.object_vertices)
         n = objs.shape[0]
-        g = self._guidance_for(batch_size, ori_range, objs, n)
-        out = sampler.guided_chains(self._net(), g, self.noise_scheduler, self.mode, noise.to(self.device),
-                                    [(i, opt_obj) for i in range(n)],
-                                    unguided=None if unguided_sample is None else unguided_sample.to(self.device))
-        self._emit(save_dir, 'vis_guided', f"{opt_obj}_orirange={ori_range[0]:.3f}_{ori_range[1]:.3f}", out,
-                   [str(self.object_ids[i]) if self.object_ids is not None else str(i) for i in range(n)])
+        chains = [(i, opt_obj) for i in range(n)]
+        ug = None if unguided_sample is None else unguided_sample.to(self.device)
+        if ddist.world_rank()[0] > 1:
+            out = ddist.guided_chains_sharded(self._net(), self._spec(batch_size, ori_range, objs.shape[1]), self.noise_scheduler, self.mode,
+                                              noise.to(self.device), objs, chains, unguided=ug,
+                                              build=lambda o, k: self._guidance_for(batch_size, ori_range, o.detach().cpu(), k))
+        else:
+            g = self._guidance_for(batch_size, ori_range, objs, n)
+            out = sampler.guided_chains(self._net(), g, self.noise_scheduler, self.mode, noise.to(self.device), chains, unguided=ug)
+        if ddist.world_rank()[1] == 0:
+            self._emit(save_dir, 'vis_guided', f"{opt_obj}_orirange={ori_range[0]:.3f}_{ori_range[1]:.3f}", out,
+                       [str(self.object_ids[i]) if self.object_ids is not None else str(i) for i in range(n)])
         return out
 
     # ------------------------------------------------------------------ a2
     def guided_sample_multi_object(self, batch_idx, batch_size, noise, save_dir, opt_obj='rotate', ori_range=[-1.0, 1.0]):
         objs = torch.as_tensor(self.object_vertices)
-        g = self._guidance_for(batch_size, ori_range, objs, objs.shape[0])
-        out = sampler.guided_multi_object(self._net(), g, self.noise_scheduler, self.mode, noise.to(self.device),
-                                          list(range(objs.shape[0])), opt_obj)
-        self._emit(save_dir, 'vis_guided', f"{opt_obj}_orirange={ori_range[0]:.3f}_{ori_range[1]:.3f}", out[None], ["allobj"])
+        if ddist.world_rank()[0] > 1:       # objects over ranks, gradients all-gathered every step (dist.guided_multi_object_sharded)
+            out = ddist.guided_multi_object_sharded(self._net(), self._spec(batch_size, ori_range, objs.shape[1]), self.noise_scheduler, self.mode,
+                                                    noise.to(self.device), objs, opt_obj,
+                                                    build=lambda o, k: self._guidance_for(batch_size, ori_range, o.detach().cpu(), k))
+        else:
+            g = self._guidance_for(batch_size, ori_range, objs, objs.shape[0])
+            out = sampler.guided_multi_object(self._net(), g, self.noise_scheduler, self.mode, noise.to(self.device),
+                                              list(range(objs.shape[0])), opt_obj)
+        if ddist.world_rank()[1] == 0:
+            self._emit(save_dir, 'vis_guided', f"{opt_obj}_orirange={ori_range[0]:.3f}_{ori_range[1]:.3f}", out[None], ["allobj"])
         return out
 
     def _emit(self, save_dir, sub, tag, samples, names):

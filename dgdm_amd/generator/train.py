@@ -115,15 +115,25 @@ def train(args):
         for bi in range(n_batches):
             batch = torch.from_numpy(np.stack([dataset[i] for i in range(bi * args.batch_size, (bi + 1) * args.batch_size)]))
             res = model.validation_step(batch, bi)
-            print(f"[dgdm_amd] batch {bi}: " + ", ".join(f"{k}={v:.5f}" for k, v in res["stats"].items()))
+            if int(os.environ.get("RANK", "0")) == 0:
+                print(f"[dgdm_amd] batch {bi}: " + ", ".join(f"{k}={v:.5f}" for k, v in res["stats"].items()))
             results.append(res)
     return model, results
 
 
 def main(argv=None):
+    """Single process: one GPU.  Under torchrun (`torchrun --nproc-per-node N generator/train.py ...`): one rank per GPU, the
+    guided chains sharded over the ranks (dgdm_amd/dist.py) where the reference wraps the classifier in nn.DataParallel (:86,88)."""
     from .. import _lib
-    _lib.device_init(int(os.environ.get("LOCAL_RANK", "0")))
-    train(parse(argv))
+    from .. import dist as ddist
+    world, rank, local = ddist.init_from_env()
+    _lib.device_init(local)
+    try:
+        train(parse(argv))
+    finally:
+        if world > 1:
+            import torch.distributed as td
+            td.destroy_process_group()
 
 
 if __name__ == "__main__":

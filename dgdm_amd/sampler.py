@@ -35,18 +35,27 @@ class StartStream:
 
     One classifier call on ``rows`` rows with sub-batch size ``sub`` draws, per sub-batch, ``torch.randint(0, N, (n,))``
     for sa1 and ``torch.randint(0, 512, (n,))`` for sa2 from the global CPU generator
-    (pointnet2_utils.py:83 reached via generator/diffusion.py:495-498 and :524-526)."""
+    (pointnet2_utils.py:83 reached via generator/diffusion.py:495-498 and :524-526).
 
-    def __init__(self, num_points: int, sub_batch_size: int, forced: Optional[Sequence[torch.Tensor]] = None):
+    ``generator``: a private ``torch.Generator`` instead of the global one (per-pair streams, ``pair_stream``)."""
+
+    def __init__(self, num_points: int, sub_batch_size: int, forced: Optional[Sequence[torch.Tensor]] = None,
+                 generator: Optional[torch.Generator] = None):
         self.N, self.sub = int(num_points), int(sub_batch_size)
         self._forced = list(forced) if forced is not None else None
+        self._gen = generator
+
+    def _randint(self, high: int, n: int) -> torch.Tensor:
+        if self._gen is not None:
+            return torch.randint(0, high, (n,), dtype=torch.long, generator=self._gen)
+        return torch.randint(0, high, (n,), dtype=torch.long)
 
     def _draw(self, high: int, n: int) -> np.ndarray:
         if self._forced is not None:
             s = self._forced.pop(0)
             assert s.shape == (n,), (s.shape, n)
             return s.numpy().astype(np.int64)
-        return torch.randint(0, high, (n,), dtype=torch.long).numpy()
+        return self._randint(high, n).numpy()
 
     def call(self, rows: int) -> np.ndarray:
         """The 2*rows indices one classifier call over `rows` rows consumes, in draw order:
@@ -54,13 +63,27 @@ class StartStream:
         if self._forced is None and self.N == 512:
             # same range for both layers: consecutive randint calls on the CPU generator concatenate
             # (tests/test_host_logic.py::test_start_stream_matches_reference_draws), so one call does it
-            return torch.randint(0, 512, (2 * rows,), dtype=torch.long).numpy()
+            return self._randint(512, 2 * rows).numpy()
         out = np.empty(2 * rows, dtype=np.int64)
         for r0 in range(0, rows, self.sub):
             n = min(self.sub, rows - r0)
             out[2 * r0:2 * r0 + n] = self._draw(self.N, n)
             out[2 * r0 + n:2 * r0 + 2 * n] = self._draw(512, n)
         return out
+
+    def skip(self, rows: int) -> None:
+        """Consume the draws of one classifier call without keeping them (a rank replaying the global stream past chains
+        that belong to other ranks, dgdm_amd/dist.py)."""
+        self.call(rows)
+
+
+def pair_stream(num_points: int, sub_batch_size: int, seed: int, pair_index: int) -> StartStream:
+    """A start stream of its own for pair `pair_index` (seed-derived), for workloads that have no reference draw order to keep
+    (bench.py's synthetic pair batches): the draws of a pair depend on (seed, pair index) only, not on the rank that runs it or on
+    how many ranks there are."""
+    g = torch.Generator()
+    g.manual_seed((int(seed) * 1_000_003 + int(pair_index)) & 0x7FFFFFFFFFFFFFFF)
+    return StartStream(num_points, sub_batch_size, generator=g)
 
 
 def unguided_sample(unet: Unet1d, sched: DDIMScheduler, x: torch.Tensor) -> torch.Tensor:
@@ -96,18 +119,40 @@ def convergence_centers(guid: Guidance, mode: str, unguided: torch.Tensor, objec
     return out
 
 
-def draw_chain_starts(guid: Guidance, chains: Sequence[Tuple[int, str]], n_steps: int, starts: Optional[StartStream] = None):
+def draw_chain_starts(guid: Guidance, chains: Sequence[Tuple[int, str]], n_steps: int, starts: Optional[StartStream] = None,
+                      keep: Optional[range] = None, streams: Optional[Sequence[StartStream]] = None):
     """FPS starts of a batch of 3-D chains in the order the reference's sequential loops consume the generator:
-    chain after chain (generator/diffusion.py:561); inside a chain the centre sweep (:563) and then every step's cond_fn (:574)."""
+    chain after chain (generator/diffusion.py:561); inside a chain the centre sweep (:563) and then every step's cond_fn (:574).
+
+    keep: only the chains of this index range are returned (sweep list / step array of len(keep) chains); the draws of the
+    others are consumed and dropped, so that a rank holding a block of the chains sees exactly the numbers a single process
+    would have handed those chains (dgdm_amd/dist.py).  streams: one StartStream per chain instead of the shared one (then
+    nothing has to be skipped: chains outside `keep` are not touched)."""
     nc = len(chains)
-    starts = starts or StartStream(guid.cfg.num_object_points, guid.cfg.sub_batch_size)
-    sweep: List[Optional[np.ndarray]] = [None] * nc
-    step = np.zeros((n_steps, nc, guid.starts_per_call), dtype=np.int64)
+    keep = range(nc) if keep is None else keep
+    if streams is None:
+        starts = starts or StartStream(guid.cfg.num_object_points, guid.cfg.sub_batch_size)
+    sweep: List[Optional[np.ndarray]] = [None] * len(keep)
+    step = np.zeros((n_steps, len(keep), guid.starts_per_call), dtype=np.int64)
     for c, (_, o) in enumerate(chains):
+        mine = c in keep
+        if streams is not None:
+            if not mine:
+                continue
+            st = streams[c]
+        else:
+            st = starts
+        k = c - keep.start
         if o == 'convergence':
-            sweep[c] = starts.call(guid.sweep_rows)
+            if mine:
+                sweep[k] = st.call(guid.sweep_rows)
+            else:
+                st.skip(guid.sweep_rows)
         for si in range(n_steps):
-            step[si, c] = starts.call(guid.rows)
+            if mine:
+                step[si, k] = st.call(guid.rows)
+            else:
+                st.skip(guid.rows)
     return sweep, step
 
 

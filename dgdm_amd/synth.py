@@ -168,6 +168,19 @@ def synth_state_dict(spec: Spec, seed: int, gain: float = 1.0) -> Dict[str, torc
     return out
 
 
+def scale_output(sd: Dict[str, torch.Tensor], gain: float) -> Dict[str, torch.Tensor]:
+    """Copy of a dynamics state_dict with the output layer scaled by `gain`.
+
+    He-init trunks put out guidance gradients 10^2-10^4 times eps' size (summed coherently over the C = G*P^2 cells), whereas the
+    reference's classifier scales (0.001 / 0.5, generator/diffusion.py:30-33) are tuned for a trained model whose guidance term is
+    of eps' order.  With gain 1 the guided chain is a chaotic map that the reference does not reproduce across its own CPU thread
+    counts (tests/golden/g9_*: 0.2 .. 4.5 finger L2); the full-grid parity fixtures therefore also use calibrated gains."""
+    out = dict(sd)
+    out["output.weight"] = sd["output.weight"] * gain
+    out["output.bias"] = sd["output.bias"] * gain
+    return out
+
+
 def _is_bn_key(key: str) -> bool:
     # linears.<3i+1>.* are BatchNorm1d, linears.<3i>.* are Linear
     idx = int(key.split(".")[1])

@@ -212,18 +212,44 @@ int dgdm_finger_decode_3d(const float *samples_dev, int batch, int num_ctrl, int
                           float *surface_dev, void *stream);
 
 /* ------------------------------------------------------------------ measurement hooks
- * When enabled, every launch of the trunk kernel (the dominant kernel) is
- * bracketed by hipEvents on its own stream.  dgdm_prof_read synchronises those events and
- * returns launches, total milliseconds and the algorithmic FLOPs they covered.                  */
+ * When enabled, the launches of every stage of the path are bracketed by hipEvents on the stream they are launched on.
+ * dgdm_prof_read_stage synchronises those events and returns, for one stage, the number of bracketed regions, their total
+ * milliseconds and the algorithmic work they covered (FLOPs for the MFMA-bound stages, 0 where the host cannot know it).
+ * dgdm_prof_read = dgdm_prof_read_stage(DGDM_STAGE_TRUNK): the dominant kernel.                               */
+enum {
+    DGDM_STAGE_TRUNK = 0,   /* trunk_kernel / trunk_bf16_kernel: fused dynamics trunk forward + backward (work = FLOPs, real rows only) */
+    DGDM_STAGE_UNET,        /* unet_kernel: one eps-net forward (work = useful FLOPs)                                          */
+    DGDM_STAGE_XOBJ,        /* 3-D: FPS-start upload + per-row PointNet++ embedding gather (xobj kernels)                      */
+    DGDM_STAGE_TABLES,      /* dgdm_guidance_set_objects: per-object PointNet++ tables (3-D) / object encoder (2-D)            */
+    DGDM_STAGE_GUIDE_MISC,  /* small kernels of cond_fn around the trunk: encoders, first-layer tables, partial-sum fold       */
+    DGDM_STAGE_DDIM,        /* guidance combine + scheduler step                                                               */
+    DGDM_STAGE_COUNT
+};
 int dgdm_prof_enable(int on);
 /* Test hook (3-D): when on, every row runs its own FPS(128) instead of reading the per-object table of
  * order-independent sequences; results must be identical.  Also reports, per object of the
  * bank, whether the table path is admissible (out_fast_ok[n_objects], may be NULL).                   */
 int dgdm_guidance_debug_fps_path(DgdmGuidance *g, int force_per_row, int32_t *out_fast_ok);
 int dgdm_prof_read(int64_t *launches, double *total_ms, double *total_flops);
+int dgdm_prof_read_stage(int stage, int64_t *launches, double *total_ms, double *total_work);
 /* Unit-test hook for the register-resident MFMA chain (csrc/mfma_chain.h): one 32-row tile through one 256 -> 256 layer,
  * Y = X W^T + bias.  W_host [256][256] row-major, bias_host [256] (host memory); X_dev, Y_dev [32][256] (device).  Synchronises. */
 int dgdm_debug_chain_layer(const float *W_host, const float *bias_host, const float *X_dev, float *Y_dev, void *stream);
+
+/* Test hook for the index work of PointNet++ on ONE cloud xyz_dev [N][3] (128 <= N <= 1024), through the same device code as the
+ * production kernels; every output is int32 device memory; synchronises.
+ *   fps512_dev [N][512], fps128_dev [N][128]: farthest_point_sample (dynamics/models/pointnet2_utils.py:71-92) from every start index
+ *                                             (row v = the sequence torch.randint's draw v would give);
+ *   fps128_flags_dev [N]: 1 = that 128-sequence met an exact distance tie between different coordinates (it is then order-dependent
+ *                                             and the production path re-runs FPS per row instead of using the table);
+ *   ball1_dev [N][32]: query_ball_point(0.2, 32, xyz, centre = point p) (pointnet2_utils.py:95-115), padded with the first index;
+ *   ball2_dev [N][64] + ball2_count_dev [N]: query_ball_point(0.4, 64, ...) for centre point c when the candidates are scanned in the
+ *                                             order perm_dev[0..perm_len) (sa2 sees the cloud re-ordered by sa1's FPS); entries past the
+ *                                             count are -1 (the reference pads with the first);
+ *   crowded_dev [N]: 1 = more than 64 points in that ball.                                                          */
+int dgdm_debug_pointnet_indices(DgdmDynamics *m, const float *xyz_dev, int N, const int32_t *perm_dev, int perm_len,
+                                int32_t *fps512_dev, int32_t *fps128_dev, int32_t *fps128_flags_dev, int32_t *ball1_dev,
+                                int32_t *ball2_dev, int32_t *ball2_count_dev, int32_t *crowded_dev, void *stream);
 
 #ifdef __cplusplus
 }

@@ -18,7 +18,8 @@ How the reference is executed:
 * Weights: ``dgdm_amd.synth`` fills the reference modules' ``state_dict`` deterministically, so
   fixtures carry seeds, not weights.  The key/shape specs are asserted against the modules.
 
-Usage:  python tests/golden/make_golden.py   (from the repo root, takes ~2 min)
+Usage:  python tests/golden/make_golden.py [g2 ... g8 g9_2d g9_3d[:part,part]]   (from the repo root; g2-g8 take ~2 min,
+        g9_2d ~1 min, g9_3d ~1.5 h: the full-grid reference chains)
 """
 import os
 import sys
@@ -156,6 +157,8 @@ class _Wrap(nn.Module):   # stands in for nn.DataParallel: only `.module`-free c
 
 
 def make_diffusion(mode, unet, dyn, T, S, L, G, P, objects, sub_bs):
+    for p in dyn.parameters():        # generator/train.py:91-92 freezes the classifier (no autograd graph through PointNet++)
+        p.requires_grad = False
     sched = DDIMScheduler(num_train_timesteps=T)
     d = Diffusion(noise_pred_net=unet, noise_scheduler=sched, num_inference_steps=S, mode=mode, input_dim=1,
                   num_points=L, class_cond=True, classifier_model=_Wrap(dyn), grid_size=G, num_pos=P,
@@ -454,6 +457,143 @@ def g7_convergence():
     np.savez_compressed(os.path.join(OUT, "g7_convergence.npz"), dyn2d_seed=DYN2D_SEED, dyn3d_seed=DYN3D_SEED, **out)
 
 
+def _unguided(d, noise, B):
+    xs = noise.clone()
+    for t in d.noise_scheduler.timesteps:
+        with torch.no_grad():
+            e = d.noise_pred_net(xs, t * torch.ones(B, dtype=torch.int64))
+        xs = d.noise_scheduler.step(e, t, xs).prev_sample
+    return xs
+
+
+def _spread(a, b):
+    """Largest per-finger L2 distance between two sample batches (B, L, 1)."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.sqrt(((a - b).reshape(a.shape[0], -1) ** 2).sum(1)).max())
+
+
+def _scaled_output(dyn, gain):
+    """The synthetic He-init dynamics nets put out guidance gradients 10^2-10^4 times larger than eps (a trained model's are of
+    eps' order: that is what the reference's classifier scales 0.001 / 0.5 are tuned for), which makes the guided chain a chaotic
+    map that the reference itself does not reproduce across thread counts (see the 'raw' entries).  `gain` scales the output
+    layer so that scale * sqrt(1 - abar) * grad is of the order of eps.  dgdm_amd.synth.scale_output does the same to a state_dict."""
+    with torch.no_grad():
+        dyn.output.weight.mul_(gain)
+        dyn.output.bias.mul_(gain)
+    return dyn
+
+
+G9_2D = [  # (name, opt_obj, output gain)
+    ("rotate", "rotate", 1.0 / 12.0), ("shift_left", "shift_left", 0.02), ("clockwise_up", "clockwise_up", 0.02),
+    ("convergence", "convergence", 2e-4), ("rotate_raw", "rotate", 1.0), ("convergence_raw", "convergence", 1.0),
+]
+
+
+def g9_2d():
+    """Full per-finger grid of BASELINE configs[1] (G=360, P=5 -> C=9000 cells per finger, 100-vertex object) at B=4:
+    the reference's own guided_sample / guided_sample_multi_object, free-running, with per-step traces.  Every chain is run
+    twice (8 and 1 CPU threads): the distance between the two end points is the reference's own reproducibility floor."""
+    import time
+    out = {}
+    unet = make_unet()
+    nv = 100
+    objs2 = torch.stack([synth.synth_object_2d(40 + i, nv) for i in range(2)])
+    B, G, P, L, T, S = 4, 360, 5, 14, 15, 5
+    out["dims"] = np.array([B, G, P, L, T, S, nv])
+    out["objs"] = objs2.numpy()
+    noise = synth.synth_noise(0, B, L)
+    names = []
+    for name, o, gain in G9_2D + [("multi", "rotate_clockwise", 0.02)]:
+        d = make_diffusion('point', unet, _scaled_output(make_dyn2d(2 * nv), gain), T, S, L, G, P, objs2, 1024)
+        xs = _unguided(d, noise, B)
+        out["unguided"] = xs.numpy()
+        out[f"{name}_gain"], out[f"{name}_opt_obj"] = np.float64(gain), o
+        if name == "multi":
+            d.object_vertices, d.object_ids = objs2, [0, 1]
+            run = lambda: d.guided_sample_multi_object(0, B, noise, "/tmp/dgdm_golden", opt_obj=o, ori_range=[-1.0, 1.0])       # noqa: E731
+        else:
+            d.object_vertices, d.object_ids = objs2[:1], [0]
+            run = lambda: d.guided_sample(0, B, noise, "/tmp/dgdm_golden", opt_obj=o, ori_range=[-1.0, 1.0], unguided_sample=xs)   # noqa: E731
+        if o == 'convergence':
+            out[f"{name}_centers"] = d.get_convergence_centers(xs, objs2[0], B, ori_range=[-1.0, 1.0]).numpy()
+        for threads in (8, 1):
+            torch.set_num_threads(threads)
+            t0 = time.time()
+            tr = StepTrace(d)
+            res = run_chain(run)
+            tr.close()
+            if threads == 8:
+                tr.pack(f"{name}_trace", out)
+                out[f"{name}_guided"] = np.concatenate(res, axis=0) if name == "multi" else res[0]
+            else:
+                out[f"{name}_guided_1thread"] = np.concatenate(res, axis=0) if name == "multi" else res[0]
+            print("  2d", name, threads, "threads", f"{time.time() - t0:.1f}s", flush=True)
+        torch.set_num_threads(8)
+        out[f"{name}_floor"] = np.float64(_spread(out[f"{name}_guided"], out[f"{name}_guided_1thread"]))
+        print("  2d", name, "gain", gain, "reference 8-vs-1-thread spread (finger L2)", out[f"{name}_floor"], flush=True)
+        names.append(name)
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "g9_2d.npz"), unet_seed=UNET_SEED, dyn2d_seed=DYN2D_SEED, **out)
+
+
+def _pack_starts16(spy):
+    flat, lens = spy.packed()
+    assert flat.size == 0 or (flat.min() >= 0 and flat.max() < 32768)
+    return flat.astype(np.int16), lens.astype(np.int32)
+
+
+G9_3D = {  # part -> (opt_obj, output gain, CPU threads, multi-object)
+    "rotate": ("rotate", 0.03, 8, False), "rotate_alt": ("rotate", 0.03, 4, False),
+    "convergence": ("convergence", 0.002, 8, False), "convergence_alt": ("convergence", 0.002, 4, False),
+    "multi": ("shift_up", 0.002, 8, True),
+    "rotate_raw": ("rotate", 1.0, 8, False), "rotate_raw_alt": ("rotate", 1.0, 4, False),
+}
+
+
+def g9_3d(parts=("rotate", "rotate_alt", "convergence", "multi", "convergence_alt", "rotate_raw", "rotate_raw_alt")):
+    """Full per-finger grid of BASELINE configs[2] (G=45, P=5 -> C=1125 cells per finger, sub_bs=512, 512-point objects) at
+    B=2 (R=2250 rows, 5 sub-batches per cond_fn): the reference's own loops, free-running, with per-step traces and the FPS
+    start indices they drew.  '<part>_alt' repeats a chain with 4 CPU threads on the same draws (the reference's own
+    reproducibility floor).  Each part goes to its own file as soon as it is done (10-25 min per part on 8 cores)."""
+    import time
+    unet = make_unet()
+    objs3 = torch.stack([synth.synth_object_3d(50 + i) for i in range(2)])
+    B, G, P, L, T, S = 2, 45, 5, 42, 15, 5
+    noise = synth.synth_noise(0, B, L)
+    for part in parts:
+        o, gain, threads, multi = G9_3D[part]
+        d = make_diffusion('point_3d', unet, _scaled_output(make_dyn3d(), gain), T, S, L, G, P, objs3, 512)
+        xs = _unguided(d, noise, B)
+        out = dict(dims=np.array([B, G, P, L, T, S, 512]), objs=objs3.numpy(), unguided=xs.numpy(), unet_seed=UNET_SEED,
+                   dyn3d_seed=DYN3D_SEED, gain=np.float64(gain), opt_obj=o, threads=threads)
+        torch.set_num_threads(threads)
+        torch.manual_seed(0)
+        t0 = time.time()
+        tr = StepTrace(d)
+        with RandintSpy() as spy:
+            if multi:
+                d.object_vertices, d.object_ids = objs3, [0, 1]
+                res = run_chain(lambda: d.guided_sample_multi_object(0, B, noise, "/tmp/dgdm_golden", opt_obj=o, ori_range=[-1.0, 1.0]))
+            else:
+                d.object_vertices, d.object_ids = objs3[:1], [0]
+                res = run_chain(lambda: d.guided_sample(0, B, noise, "/tmp/dgdm_golden", opt_obj=o, ori_range=[-1.0, 1.0], unguided_sample=xs))
+        tr.close()
+        torch.set_num_threads(8)
+        tr.pack("trace", out)
+        out["guided"] = np.concatenate(res, axis=0) if multi else res[0]
+        out["starts"], out["start_lens"] = _pack_starts16(spy)
+        print("  3d", part, f"{time.time() - t0:.0f}s", flush=True)
+        if part.endswith("_alt"):
+            ref = np.load(os.path.join(OUT, f"g9_3d_{part[:-4]}.npz"))
+            assert np.array_equal(out["starts"], ref["starts"])
+            fl = _spread(out["guided"], ref["guided"])
+            print("  3d", part[:-4], "reference 8-vs-4-thread spread (finger L2)", fl, flush=True)
+            np.savez_compressed(os.path.join(OUT, f"g9_3d_{part}.npz"), guided=out["guided"], trace_grad=out["trace_grad"],
+                                trace_x=out["trace_x"], threads=threads, floor=np.float64(fl))
+        else:
+            np.savez_compressed(os.path.join(OUT, f"g9_3d_{part}.npz"), **out)
+
+
 def synth_metrics(seed, n_ori=360):
     """Synthetic stand-in for what the simulator returns per (object, gripper) pair (dynamics/sim_test_mj.py:210-232):
     three-class profiles and the motion statistics metric2objective reads.  Inputs only; the outputs come from the reference."""
@@ -519,8 +659,13 @@ if __name__ == "__main__":
     os.makedirs("/tmp/dgdm_golden", exist_ok=True)
     only = sys.argv[1:]
     for name, fn in (("g2", g2_unet), ("g3", g3_dyn2d), ("g4", g4_pointnet), ("g5", g5_dyn3d), ("g6", g6_chains),
-                     ("g7", g7_convergence), ("g8", g8_harness)):
-        if only and name not in only:
+                     ("g7", g7_convergence), ("g8", g8_harness), ("g9_2d", g9_2d), ("g9_3d", g9_3d)):
+        if only and name not in [a.split(":")[0] for a in only]:
+            continue
+        sub = [a.split(":", 1)[1].split(",") for a in only if a.startswith(name + ":")]
+        if sub:
+            fn(tuple(sub[0]))
+            print("wrote", name, sub[0], flush=True)
             continue
         fn()
         print("wrote", name, flush=True)

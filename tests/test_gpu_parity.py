@@ -176,7 +176,7 @@ def test_dyn3d_cond_fn_golden(dev):
 
 
 # ------------------------------------------------------------------------------------------------ a1-a3, a6: chains
-def _teacher_forced(net, gd, s, mode, g, key, chains, final, step_starts, dev, n_grad=1, scale=None, multi_obj=None, rowcoef=None):
+def _teacher_forced(net, gd, s, mode, g, key, chains, final, step_starts, dev, n_grad=1, scale=None, multi_obj=None, rowcoef=None, errs=None):
     """Replays the reference's recorded trajectory (tests/golden: trace*_x/_eps/_grad): at every step the HIP eps-net, cond_fn
     and scheduler step see exactly the inputs the reference saw.  This is the precise check; free-running chains at these
     tiny R (24-72 rows) can be thrown off by a single ReLU sign flip."""
@@ -192,6 +192,8 @@ def _teacher_forced(net, gd, s, mode, g, key, chains, final, step_starts, dev, n
         if multi_obj is None:
             st = step_starts[si].reshape(-1) if step_starts is not None else None
             gr = gd.grad(x.reshape(1, B, L), t, [engine.make_objective(o, oi)], rowcoef, st)
+            if errs is not None:
+                errs.append(util.rel_l2(gr.cpu().reshape(B, L, 1), gs[si]))
             assert util.rel_l2(gr.cpu().reshape(B, L, 1), gs[si]) < REL, (key, si)
             g_ref = torch.from_numpy(gs[si]).to(dev).reshape(1, -1)
         else:
@@ -199,11 +201,14 @@ def _teacher_forced(net, gd, s, mode, g, key, chains, final, step_starts, dev, n
             st = step_starts[si].reshape(-1) if step_starts is not None else None
             gr = gd.grad(x.reshape(1, B, L).expand(n, -1, -1).contiguous(), t, [engine.make_objective(o, k) for k in multi_obj], None, st)
             for k in range(n):
+                if errs is not None:
+                    errs.append(util.rel_l2(gr[k].cpu().reshape(B, L, 1), gs[si * n + k]))
                 assert util.rel_l2(gr[k].cpu().reshape(B, L, 1), gs[si * n + k]) < REL, (key, si, k)
             g_ref = torch.from_numpy(gs[si * n:(si + 1) * n]).to(dev).reshape(n, -1)
         nxt = engine.ddim_guided_step(x, torch.from_numpy(es[si]).to(dev), g_ref, g_ref.shape[0], s.coefficients(t), scale).cpu()
         want = xs[si + 1] if si + 1 < S else final
-        assert finger_l2(nxt, want) < 1e-5, (key, si)      # x_t reaches ~15 here: 1e-5 is a few float32 ulps over 14-42 entries
+        # x_t reaches ~15 on the small golden chains: 1e-5 is a few float32 ulps over 14-42 entries (scaled up where |x| is larger)
+        assert finger_l2(nxt, want) < 1e-5 * max(1.0, float(np.abs(want).max()) / 15.0), (key, si)
 
 
 def test_chains_golden_2d(dev):
