@@ -5,6 +5,8 @@
 #include <algorithm>
 #include <cstring>
 #include <unordered_map>
+#include <atomic>
+#include <thread>
 
 using namespace dgdm;
 
@@ -30,6 +32,8 @@ struct ObjectTables {       // 3-D, per object
     bool   fast_ok = false; // no flag set: rows can take their centres from fps2 instead of running FPS
     DevBuf crowded, clist;  // [N] int each + clist[N] = count: centres whose ball query truncates (pointnet.hip crowd_kernel)
     DevBuf M0, cl2, cnt2;   // [N][256] float, [N][128] int, [N] int: variant-independent part of the sa3 max (pointnet.hip m0_kernel)
+    DevBuf cl2s;            // [N][128] cl2 as positions in clist (xobj_group_kernel)
+    int    ncr = 0;         // number of crowded centres (read back by set_objects)
     DevBuf Z16, M0_16;      // bf16 operand-order copies, built when the handle is in bf16 mode at set_objects time
     bool   has16 = false;
 };
@@ -51,7 +55,8 @@ struct DgdmGuidance {
     DevBuf tmpF1[NBUILD], tmpU[NBUILD], tmpY[NBUILD], tmpL2[NBUILD], tmpOff[NBUILD], tmpPairs[NBUILD], tmpRank[NBUILD], vlist;      // 3-D table-build temporaries
     hipStream_t bstream[NBUILD] = {nullptr, nullptr, nullptr};
     hipEvent_t bev[NBUILD] = {nullptr, nullptr, nullptr}, bstart = nullptr;
-    DevBuf V, genc, atab, chainbias, timepart, ttmp, partial, objdev, objidx, xobj, xobj16, starts, order, xchains, todo;
+    DevBuf V, genc, atab, chainbias, timepart, ttmp, partial, objdev, objidx, xobj, xobj16, starts, order, xchains, todo, groupoff;
+    int xobj_mode = 0;              // test hook: 0 = group kernel where possible, 2 = per-row table kernel (xobj_fast_kernel)
     int n_objects = 0;
     bool force_slow_xobj = false;   // test hook: always run the per-row FPS kernel
     void *pinned = nullptr; size_t pinned_bytes = 0; hipEvent_t pinned_ev = nullptr;
@@ -132,7 +137,8 @@ extern "C" int dgdm_guidance_create(DgdmGuidance **out, DgdmDynamics *model, con
             (rc = g->order.alloc((size_t)nc * g->R * sizeof(int))) || (rc = g->xchains.alloc(sizeof(XobjChain) * nc)) ||
             (rc = g->todo.alloc(((size_t)nc * g->R + 1) * sizeof(int))))
             return rc;
-        g->pinned_bytes = (size_t)nc * g->R * 3 * sizeof(int);
+        g->pinned_bytes = ((size_t)nc * g->R * 3 + (size_t)nc * (cfg->num_object_points + 1)) * sizeof(int);
+        if ((rc = g->groupoff.alloc((size_t)nc * (cfg->num_object_points + 1) * sizeof(int)))) return rc;
         DGDM_HIP_CHECK(hipHostMalloc(&g->pinned, g->pinned_bytes, hipHostMallocDefault));
         DGDM_HIP_CHECK(hipEventCreateWithFlags(&g->pinned_ev, hipEventDisableTiming));
     }
@@ -151,7 +157,8 @@ extern "C" int dgdm_guidance_set_contraction_dtype(DgdmGuidance *g, int dtype) {
 
 extern "C" int dgdm_guidance_debug_fps_path(DgdmGuidance *g, int force_per_row, int32_t *out_fast_ok) {
     DGDM_REQUIRE(g, DGDM_EINVAL, "dgdm_guidance_debug_fps_path: null handle");
-    g->force_slow_xobj = force_per_row != 0;
+    g->force_slow_xobj = force_per_row == 1;            // 1: every row runs its own FPS; 2: per-row table kernel; 0: default (group kernel)
+    g->xobj_mode = force_per_row == 2 ? 2 : 0;
     if (out_fast_ok)
         for (int i = 0; i < g->n_objects && i < (int)g->tables.size(); ++i) out_fast_ok[i] = g->tables[i]->fast_ok ? 1 : 0;
     return DGDM_OK;
@@ -167,7 +174,8 @@ int DgdmGuidance::build_object(int oi, int slot, hipStream_t s) {
     int rc;
     if ((rc = t.Z.alloc((size_t)N * N * 256 * 4)) ||
         (rc = t.crowded.alloc((size_t)N * sizeof(int))) || (rc = t.clist.alloc((size_t)(N + 1) * sizeof(int))) ||
-        (rc = t.M0.alloc((size_t)N * 256 * 4)) || (rc = t.cl2.alloc((size_t)N * 128 * sizeof(int))) || (rc = t.cnt2.alloc((size_t)N * sizeof(int))))
+        (rc = t.M0.alloc((size_t)N * 256 * 4)) || (rc = t.cl2.alloc((size_t)N * 128 * sizeof(int))) || (rc = t.cnt2.alloc((size_t)N * sizeof(int))) ||
+        (rc = t.cl2s.alloc((size_t)N * 128 * sizeof(int))))
         return rc;
     t.has16 = bf16;
     if (bf16 && ((rc = t.Z16.alloc((size_t)N * N * 128 * 4)) || (rc = t.M0_16.alloc((size_t)N * 128 * 4)))) return rc;
@@ -192,7 +200,7 @@ int DgdmGuidance::build_object(int oi, int slot, hipStream_t s) {
         if ((rc = pn_z16(xyz, N, N, w, tL2.as<uint32_t>(), t.Z.as<float>(), z16, t.clist.as<int>(), t.clist.as<int>() + N, s))) return rc;          // T6
     } else if ((rc = pn_z(xyz, N, N, w, tL2.as<float>(), t.Z.as<float>(), z16, t.clist.as<int>(), t.clist.as<int>() + N, s))) return rc;
     return pn_m0(t.fps2, t.crowded.as<int>(), N, t.Z.as<float>(), t.M0.as<float>(), t.cl2.as<int>(), t.cnt2.as<int>(), z16,
-                 bf16 ? t.M0_16.as<uint32_t>() : nullptr, s);                                                                                       // T7
+                 bf16 ? t.M0_16.as<uint32_t>() : nullptr, t.clist.as<int>(), t.clist.as<int>() + N, t.cl2s.as<int>(), s);                         // T7
 }
 
 extern "C" int dgdm_guidance_set_objects(DgdmGuidance *g, const float *objects_dev, int n_objects, void *stream) {
@@ -253,7 +261,9 @@ extern "C" int dgdm_guidance_set_objects(DgdmGuidance *g, const float *objects_d
             bool ok = N >= 128;
             for (int k = 0; k < N; ++k) ok = ok && fl[(size_t)i * N + k] == 0;
             g->tables[i]->fast_ok = ok;
+            DGDM_HIP_CHECK(hipMemcpyAsync(&g->tables[i]->ncr, g->tables[i]->clist.as<int>() + N, sizeof(int), hipMemcpyDeviceToHost, s));
         }
+        DGDM_HIP_CHECK(hipStreamSynchronize(s));
     }
     g->n_objects = n_objects;
     return DGDM_OK;
@@ -280,35 +290,48 @@ int DgdmGuidance::common_pre(const float *x_dev, float t_scaled, const int *obji
 int DgdmGuidance::upload_starts(const int64_t *starts_host, int n_chains, int64_t rows, hipStream_t s) {
     const int N = cfg.num_object_points;
     const int64_t sb = cfg.sub_batch_size;
-    DGDM_REQUIRE((size_t)n_chains * rows * 3 * sizeof(int) <= pinned_bytes, DGDM_EINVAL, "starts staging too small");
+    DGDM_REQUIRE(((size_t)n_chains * rows * 3 + (size_t)n_chains * (N + 1)) * sizeof(int) <= pinned_bytes, DGDM_EINVAL, "starts staging too small");
     DGDM_HIP_CHECK(hipEventSynchronize(pinned_ev));            // previous copy out of the staging buffer has finished
     int *dst = static_cast<int *>(pinned);
-    for (int c = 0; c < n_chains; ++c) {
-        const int64_t *src = starts_host + (size_t)c * 2 * rows;
-        int *d = dst + (size_t)c * 2 * rows;
-        for (int64_t r0 = 0; r0 < rows; r0 += sb) {
-            const int64_t n = std::min(sb, rows - r0);
-            const int64_t *s1 = src + 2 * r0, *s2 = s1 + n;
-            for (int64_t k = 0; k < n; ++k) {
-                const int64_t a = s1[k], b = s2[k];
-                DGDM_REQUIRE(a >= 0 && a < N && b >= 0 && b < 512, DGDM_EINVAL, "FPS start out of range (sa1 %lld of %d, sa2 %lld of 512)", (long long)a, N, (long long)b);
-                d[2 * (r0 + k)] = (int)a; d[2 * (r0 + k) + 1] = (int)b;
-            }
-        }
-    }
-    // rows of every chain sorted by s1 (counting sort): rows of one variant gather from the same Z slab
     int *ord = dst + (size_t)n_chains * 2 * rows;
-    std::vector<int> cnt(N + 1);
-    for (int c = 0; c < n_chains; ++c) {
-        const int *d = dst + (size_t)c * 2 * rows;
-        int *o = ord + (size_t)c * rows;
-        std::fill(cnt.begin(), cnt.end(), 0);
-        for (int64_t r = 0; r < rows; ++r) ++cnt[d[2 * r] + 1];
-        for (int k = 0; k < N; ++k) cnt[k + 1] += cnt[k];
-        for (int64_t r = 0; r < rows; ++r) o[cnt[d[2 * r]]++] = (int)r;
+    int *goff = ord + (size_t)n_chains * rows;                 // [n_chains][N+1]: where each s1-group starts in the chain's sorted rows
+    // per chain: int64 draws -> (s1, s2) int32 pairs in row order; rows sorted by s1 (counting sort) so that the rows of one
+    // variant gather from the same Z slab; group offsets.  Chains are independent: a few host threads share them.
+    std::atomic<int> bad{0};
+    auto work = [&](int c0, int c1) {
+        std::vector<int> cnt(N + 1);
+        for (int c = c0; c < c1; ++c) {
+            const int64_t *src = starts_host + (size_t)c * 2 * rows;
+            int *d = dst + (size_t)c * 2 * rows;
+            for (int64_t r0 = 0; r0 < rows; r0 += sb) {
+                const int64_t n = std::min(sb, rows - r0);
+                const int64_t *s1 = src + 2 * r0, *s2 = s1 + n;
+                for (int64_t k = 0; k < n; ++k) {
+                    const int64_t a = s1[k], b = s2[k];
+                    if (!(a >= 0 && a < N && b >= 0 && b < 512)) { bad.store(1); return; }
+                    d[2 * (r0 + k)] = (int)a; d[2 * (r0 + k) + 1] = (int)b;
+                }
+            }
+            int *o = ord + (size_t)c * rows;
+            std::fill(cnt.begin(), cnt.end(), 0);
+            for (int64_t r = 0; r < rows; ++r) ++cnt[d[2 * r] + 1];
+            for (int k = 0; k < N; ++k) cnt[k + 1] += cnt[k];
+            memcpy(goff + (size_t)c * (N + 1), cnt.data(), sizeof(int) * (N + 1));
+            for (int64_t r = 0; r < rows; ++r) o[cnt[d[2 * r]]++] = (int)r;
+        }
+    };
+    const int nthreads = (int)std::min<int64_t>(8, std::max<int64_t>(1, (int64_t)n_chains * rows / 65536));
+    if (nthreads <= 1) {
+        work(0, n_chains);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; ++t) pool.emplace_back(work, (int)((int64_t)n_chains * t / nthreads), (int)((int64_t)n_chains * (t + 1) / nthreads));
+        for (auto &th : pool) th.join();
     }
+    DGDM_REQUIRE(!bad.load(), DGDM_EINVAL, "FPS start out of range (sa1 must be in [0, %d), sa2 in [0, 512))", N);
     DGDM_HIP_CHECK(hipMemcpyAsync(starts.p, pinned, (size_t)n_chains * rows * 2 * sizeof(int), hipMemcpyHostToDevice, s));
     DGDM_HIP_CHECK(hipMemcpyAsync(order.p, ord, (size_t)n_chains * rows * sizeof(int), hipMemcpyHostToDevice, s));
+    DGDM_HIP_CHECK(hipMemcpyAsync(groupoff.p, goff, (size_t)n_chains * (N + 1) * sizeof(int), hipMemcpyHostToDevice, s));
     DGDM_HIP_CHECK(hipEventRecord(pinned_ev, s));
     return DGDM_OK;
 }
@@ -329,7 +352,6 @@ int DgdmGuidance::run_xobj(const int *objidx_host, int n_chains, int64_t rows, b
         if (rc) return rc;
     }
     if (used16) *used16 = want16;
-    DGDM_HIP_CHECK(hipMemcpyAsync(xchains.p, ch.data(), sizeof(XobjChain) * n_chains, hipMemcpyHostToDevice, s));
     XobjParams xp{};
     xp.chains = xchains.as<XobjChain>(); xp.starts = starts.as<int>(); xp.order = order.as<int>(); xp.xobj = xobj.as<float>();
     xp.xobj16 = want16 ? xobj16.as<uint32_t>() : nullptr;
@@ -337,6 +359,21 @@ int DgdmGuidance::run_xobj(const int *objidx_host, int n_chains, int64_t rows, b
     xp.todo = todo.as<int>(); xp.todo_count = todo.as<int>() + (size_t)cfg.max_chains * R; xp.todo_capacity = (int64_t)cfg.max_chains * R;
     bool all_fast = true;
     for (int i = 0; i < n_chains; ++i) all_fast = all_fast && tables[objidx_host[i]]->fast_ok;
+    // group kernel: every chain needs its tables and a slab chunk that fits LDS (it handles tie-flagged start points itself)
+    bool groups = !force_slow_xobj && xobj_mode == 0;
+    int items = 0;
+    for (int i = 0; i < n_chains && groups; ++i) {
+        const ObjectTables &t = *tables[objidx_host[i]];
+        const int lpr = xobj_group_lpr(t.ncr, want16);
+        groups = lpr > 0 && cfg.num_object_points >= 128;
+        ch[i].clist = t.clist.as<int>(); ch[i].cl2s = t.cl2s.as<int>(); ch[i].ncr = t.ncr; ch[i].lpr = lpr; ch[i].item_base = items;
+        items += cfg.num_object_points * ((want16 ? 32 : 64) / std::max(1, lpr));
+    }
+    DGDM_HIP_CHECK(hipMemcpyAsync(xchains.p, ch.data(), sizeof(XobjChain) * n_chains, hipMemcpyHostToDevice, s));     // pageable: staged before return
+    if (groups) {
+        xp.group_off = groupoff.as<int>(); xp.nchain = n_chains; xp.total_items = items; xp.use_table = 1;
+        return pn_xobj_groups(xp, s);
+    }
     return pn_xobj(xp, all_fast, s);
 }
 

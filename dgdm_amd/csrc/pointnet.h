@@ -34,6 +34,12 @@ struct XobjChain {
     const int   *cl2;             // [N][128] crowded centres of fps2[q], padded with the last one
     const int   *cnt2;            // [N] their number
     int          N;
+    // (chain, s1)-group kernel (xobj_group_kernel): the object's crowded centres, their slot in that list per fps2 sequence
+    const int   *clist;           // [ncr] crowded centre point ids (crowd_kernel)
+    const int   *cl2s;            // [N][128] cl2 as positions in clist (m0_kernel), padded like cl2
+    int          ncr;             // number of crowded centres (host copy)
+    int          lpr;             // lanes per row of the group kernel: 64 / 32 / 16 / 8  <=>  1 / 2 / 4 / 8 feature chunks
+    int          item_base;       // first work item of this chain: items = (s1, chunk) pairs, chunk fastest
 };
 
 struct XobjParams {
@@ -48,6 +54,8 @@ struct XobjParams {
     int             *todo;        // [total_rows] rows xobj_fast_kernel left to xobj_kernel, or null (then xobj_kernel does everything)
     int             *todo_count;  // device counter of that list
     int64_t          todo_capacity;
+    const int       *group_off;   // [nchain][N+1] offsets of the s1-groups in `order` (rows of a chain sorted by s1), or null
+    int              nchain, total_items;
 };
 
 int pn_fps_table(const float *xyz, int N, int nv, int npoint, int *out, int *flags, hipStream_t s, int nobj = 1);
@@ -65,7 +73,11 @@ int pn_z16(const float *xyz, int N, int nv, const PnWeights &w, const uint32_t *
 int pn_z(const float *xyz, int N, int nv, const PnWeights &w, const float *L2, float *Z, uint32_t *Z16, const int *clist, const int *ncr,
          hipStream_t s);
 int pn_m0(const int *fps2, const int *crowded, int N, const float *Z0, float *M0, int *cl2, int *cnt2, const uint32_t *Z0_16, uint32_t *M0_16,
-          hipStream_t s);
+          const int *clist, const int *ncr, int *cl2s, hipStream_t s);
+// lanes per row for an object with `ncr` crowded centres (0 = the group kernel cannot hold its slab: use the per-row kernels)
+int xobj_group_lpr(int ncr, bool bf16);
+// one workgroup per (chain, s1, feature chunk): the variant's crowded Z rows staged once in LDS, all rows of the group reduced from there
+int pn_xobj_groups(const XobjParams &p, hipStream_t s);
 // index test hook (dgdm_debug_pointnet_indices): sa1's 32-neighbour lists [N][32], sa2's first-64 lists [N][64] + counts for the
 // candidate order perm[0..M), crowded flags [N]; synchronises
 int pn_debug_indices(const float *xyz, int N, const PnWeights &w, const int *perm, int M, int *ball1, int *ball2, int *ball2_cnt, int *crowded,

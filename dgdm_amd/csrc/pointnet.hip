@@ -558,7 +558,12 @@ __global__ __launch_bounds__(256, 1) void z16_kernel(const float *__restrict__ x
 // loop can run in groups of four without a tail.  One wave per start point q.  max is exact, so the split is bit-neutral.
 __global__ __launch_bounds__(256) void m0_kernel(const int *__restrict__ fps2 /*[N][128]*/, const int *__restrict__ crowded, int N,
                                                  const float *__restrict__ Z0 /*[N][256]*/, float *__restrict__ M0, int *__restrict__ cl2,
-                                                 int *__restrict__ cnt2, const uint32_t *__restrict__ Z0_16, uint32_t *__restrict__ M0_16) {
+                                                 int *__restrict__ cnt2, const uint32_t *__restrict__ Z0_16, uint32_t *__restrict__ M0_16,
+                                                 const int *__restrict__ clist, const int *__restrict__ ncr, int *__restrict__ cl2s) {
+    // position of every crowded centre in clist (ascending point ids, crowd_kernel): cl2s = cl2 in those terms
+    __shared__ short slot_of[1024];
+    for (int i = threadIdx.x; i < *ncr; i += blockDim.x) slot_of[clist[i]] = (short)i;
+    __syncthreads();
     const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= N) return;
     const int idA = fps2[(size_t)q * 128 + lane], idB = fps2[(size_t)q * 128 + 64 + lane];
@@ -574,6 +579,13 @@ __global__ __launch_bounds__(256) void m0_kernel(const int *__restrict__ fps2 /*
     if (cnt > 0) last = mB ? __shfl(idB, 63 - __clzll(mB)) : __shfl(idA, 63 - __clzll(mA));
     for (int j = cnt + lane; j < 128; j += 64) dst[j] = last;
     if (lane == 0) cnt2[q] = cnt;
+    {
+        int *ds = cl2s + (size_t)q * 128;
+        if (crA) ds[__popcll(mA & below)] = slot_of[idA];
+        if (crB) ds[nA + __popcll(mB & below)] = slot_of[idB];
+        const int ls = cnt > 0 ? slot_of[last] : 0;
+        for (int j = cnt + lane; j < 128; j += 64) ds[j] = ls;
+    }
     const float *zt = Z0 + lane * 4;
     float4 best = make_float4(0.f, 0.f, 0.f, 0.f);      // Z >= 0 (ReLU)
     for (int i = 0; i < 64; ++i) {
@@ -745,6 +757,180 @@ __global__ __launch_bounds__(256) void xobj_kernel(const XobjParams p) {
     R::store(p, (size_t)w, lane, best);
 }
 
+// ------------------------------------------------------------------------------------------------ per (chain, s1) group
+// All rows of a chain that drew the same sa1 start s1 reduce rows of the SAME slab Z[s1][crowded centres].  One workgroup per
+// (chain, s1, feature chunk): the slab chunk [ncr][F] goes from HBM/L2 to LDS once (<= 78 KB, two workgroups per CU so one
+// loads while the other reduces), then every row of the group takes max(M0[q], its crowded centres' rows) out of LDS -
+// ~38 KB of LDS reads per row instead of ~38 KB of L2 gathers.  LPR lanes (16 B each) cover one row's chunk: 64/LPR rows per
+// wave at a time; a row's slot list (cl2s[q], padded with its last entry, so over-reading is idempotent) sits in registers and
+// is broadcast inside the row's lane group.  Same max, same operands: bit-identical to xobj_fast_kernel.
+constexpr int XG_LDS_BYTES = 78 * 1024;
+
+int xobj_group_lpr(int ncr, bool bf16) {
+    const int W = bf16 ? 128 : 256;                                   // dwords per table row
+    for (int lpr = W / 4; lpr >= 8; lpr >>= 1)                         // F = 4 * lpr dwords per centre and chunk
+        if ((size_t)ncr * lpr * 16 <= (size_t)XG_LDS_BYTES) return lpr;
+    return 0;
+}
+
+template <bool BF16, int LPR>
+__device__ __forceinline__ void xobj_group_body(const XobjParams &p, const XobjChain &ch, int chain, int s1, int chunk, uint32_t *slab) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    constexpr int W = BF16 ? 128 : 256, F = 4 * LPR, RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int f0 = chunk * F;
+    const int *goff = p.group_off + (size_t)chain * (ch.N + 1);
+    const int g0 = goff[s1], gn = goff[s1 + 1] - g0;
+    if (gn == 0) return;                                               // no row of this chain drew s1 (workgroup-uniform)
+    const uint32_t *Zs = (BF16 ? ch.Z16 : reinterpret_cast<const uint32_t *>(ch.Z)) + ((size_t)(ch.slot_of_start ? ch.slot_of_start[s1] : s1) * ch.N) * W + f0;
+    // ---- row metadata of this wave's rows, one row per lane (row k = wave + 4 * lane): issued before the slab loads so that the
+    //      chain of dependent lookups (row id -> s2 -> start point q -> flag, count) overlaps them
+    const int *ord = p.order + (size_t)chain * p.R + g0;
+    const int *st = p.starts + (size_t)chain * 2 * p.R;
+    const int myk = wave + 4 * lane;
+    const bool have = myk < gn;                                        // groups of more than 256 rows: see the tail loop
+    const int r_v = have ? ord[myk] : 0;
+    const int q_v = have ? ch.fps1[(size_t)s1 * 512 + st[2 * r_v + 1]] : 0;      // start point of sa2's FPS
+    const int slow_v = have ? ch.flags[q_v] : 1;                       // order-dependent sequence: xobj_kernel's row
+    const int cnt_v = have ? ch.cnt2[q_v] : 0;
+    // ---- stage the slab chunk: piece i = (centre i / LPR, 16-byte part i % LPR)
+    const int pieces = ch.ncr * LPR;
+    for (int i0 = threadIdx.x; i0 < pieces; i0 += 256 * 8) {
+        u4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + 256 * k;
+            if (i < pieces) v[k] = *reinterpret_cast<const u4 *>(Zs + (size_t)ch.clist[i / LPR] * W + (i % LPR) * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + 256 * k;
+            if (i < pieces) *reinterpret_cast<u4 *>(slab + (size_t)i * 4) = v[k];
+        }
+    }
+    if (chunk == 0 && have && slow_v) p.todo[atomicAdd(p.todo_count, 1)] = (int)((int64_t)chain * p.R + r_v);
+    __syncthreads();
+    // ---- one row at a time per wave (uniform control flow); the wave's 64 lanes read RPW slots' pieces per ds_read_b128
+    const int sg = lane / LPR, fl = lane % LPR;
+    const uint32_t *M0 = (BF16 ? ch.M0_16 : reinterpret_cast<const uint32_t *>(ch.M0)) + f0 + fl * 4;
+    uint32_t *out = (BF16 ? p.xobj16 : reinterpret_cast<uint32_t *>(p.xobj)) + (size_t)chain * p.R * W + f0 + fl * 4;
+    const int nmine = min(64, (gn - wave + 3) / 4);                    // rows of this wave held in lanes
+    auto vmax4 = [](u4 a, u4 b) {
+        u4 o;
+        if (BF16) { o.x = pkmax_u16(a.x, b.x); o.y = pkmax_u16(a.y, b.y); o.z = pkmax_u16(a.z, b.z); o.w = pkmax_u16(a.w, b.w); }
+        else {
+            o.x = __float_as_uint(fmaxf(__uint_as_float(a.x), __uint_as_float(b.x))); o.y = __float_as_uint(fmaxf(__uint_as_float(a.y), __uint_as_float(b.y)));
+            o.z = __float_as_uint(fmaxf(__uint_as_float(a.z), __uint_as_float(b.z))); o.w = __float_as_uint(fmaxf(__uint_as_float(a.w), __uint_as_float(b.w)));
+        }
+        return o;
+    };
+    // software pipeline: the slot list and the M0 piece of row i+1 are loaded while row i is reduced
+    int qn = __builtin_amdgcn_readlane(q_v, 0);
+    int SA = ch.cl2s[(size_t)qn * 128 + lane], SB = ch.cl2s[(size_t)qn * 128 + 64 + lane];
+    u4 m0 = *reinterpret_cast<const u4 *>(M0 + (size_t)qn * W);
+    for (int i = 0; i < nmine; ++i) {
+        const int r = __builtin_amdgcn_readlane(r_v, i), cnt = __builtin_amdgcn_readlane(cnt_v, i), slow = __builtin_amdgcn_readlane(slow_v, i);
+        const int sa = SA, sb = SB;
+        u4 best = m0;
+        if (i + 1 < nmine) {
+            qn = __builtin_amdgcn_readlane(q_v, i + 1);
+            SA = ch.cl2s[(size_t)qn * 128 + lane]; SB = ch.cl2s[(size_t)qn * 128 + 64 + lane];
+            m0 = *reinterpret_cast<const u4 *>(M0 + (size_t)qn * W);
+        }
+        if (slow) continue;
+        // slot j + sg for lane group sg; the list is padded with its last entry to 128, so reading past cnt repeats a member
+        for (int j = 0; j < cnt; j += 4 * RPW) {
+            u4 v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int jj = j + e * RPW;                              // uniform; jj + sg stays inside one 64-entry half (64 % RPW == 0)
+                int slot;
+                if (RPW == 1) slot = jj < 64 ? __builtin_amdgcn_readlane(sa, jj & 63) : __builtin_amdgcn_readlane(sb, jj & 63);
+                else slot = __shfl(jj < 64 ? sa : sb, (jj & 63) + sg);
+                v[e] = *reinterpret_cast<const u4 *>(slab + ((size_t)slot * LPR + fl) * 4);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) best = vmax4(best, v[e]);
+        }
+        if (RPW > 1 && cnt > 0) {                                       // fold the lane groups (each saw every RPW-th slot)
+#pragma unroll
+            for (int o = 32; o >= LPR; o >>= 1) {
+                u4 t;
+                t.x = __shfl_xor(best.x, o); t.y = __shfl_xor(best.y, o); t.z = __shfl_xor(best.z, o); t.w = __shfl_xor(best.w, o);
+                best = vmax4(best, t);
+            }
+        }
+        if (sg == 0) *reinterpret_cast<u4 *>(out + (size_t)r * W) = best;
+    }
+    // ---- groups of more than 256 rows (never at the shipped sizes: 36 000 rows over 512 start indices): remaining rows one by one
+    for (int k = 256 + wave; k < gn; k += 4) {
+        const int r = ord[k], q = ch.fps1[(size_t)s1 * 512 + st[2 * r + 1]];
+        if (ch.flags[q] != 0) {
+            if (chunk == 0 && lane == 0) p.todo[atomicAdd(p.todo_count, 1)] = (int)((int64_t)chain * p.R + r);
+            continue;
+        }
+        const int cnt = ch.cnt2[q];
+        u4 best = *reinterpret_cast<const u4 *>(M0 + (size_t)q * W);
+        for (int j = sg; j < cnt; j += RPW) {
+            const int slot = ch.cl2s[(size_t)q * 128 + j];
+            best = vmax4(best, *reinterpret_cast<const u4 *>(slab + ((size_t)slot * LPR + fl) * 4));
+        }
+        if (RPW > 1) {
+#pragma unroll
+            for (int o = 32; o >= LPR; o >>= 1) {
+                u4 t;
+                t.x = __shfl_xor(best.x, o); t.y = __shfl_xor(best.y, o); t.z = __shfl_xor(best.z, o); t.w = __shfl_xor(best.w, o);
+                best = vmax4(best, t);
+            }
+        }
+        if (sg == 0) *reinterpret_cast<u4 *>(out + (size_t)r * W) = best;
+    }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256, 2) void xobj_group_kernel(const XobjParams p) {
+    extern __shared__ uint32_t xg_slab[];
+    // work item -> (chain, s1, chunk): chains own contiguous item ranges (item_base ascending)
+    const int item = blockIdx.x;
+    int lo = 0, hi = p.nchain - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (p.chains[mid].item_base <= item) lo = mid; else hi = mid - 1;
+    }
+    const int chain = lo;
+    const XobjChain ch = p.chains[chain];
+    const int nchunk = (BF16 ? 32 : 64) / ch.lpr;
+    const int rel = item - ch.item_base, s1 = rel / nchunk, chunk = rel % nchunk;
+    switch (ch.lpr) {
+        case 64: if (!BF16) xobj_group_body<BF16, (BF16 ? 32 : 64)>(p, ch, chain, s1, chunk, xg_slab); break;
+        case 32: xobj_group_body<BF16, 32>(p, ch, chain, s1, chunk, xg_slab); break;
+        case 16: xobj_group_body<BF16, 16>(p, ch, chain, s1, chunk, xg_slab); break;
+        default: xobj_group_body<BF16, 8>(p, ch, chain, s1, chunk, xg_slab); break;
+    }
+}
+
+int pn_xobj_groups(const XobjParams &p, hipStream_t s) {
+    if (p.total_items <= 0) return DGDM_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        DGDM_HIP_CHECK(hipFuncSetAttribute((const void *)xobj_group_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, XG_LDS_BYTES));
+        DGDM_HIP_CHECK(hipFuncSetAttribute((const void *)xobj_group_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, XG_LDS_BYTES));
+        attr_set = true;
+    }
+    DGDM_HIP_CHECK(hipMemsetAsync(p.todo_count, 0, sizeof(int), s));
+    if (p.xobj16) hipLaunchKernelGGL(xobj_group_kernel<true>, dim3((unsigned)p.total_items), dim3(256), XG_LDS_BYTES, s, p);
+    else hipLaunchKernelGGL(xobj_group_kernel<false>, dim3((unsigned)p.total_items), dim3(256), XG_LDS_BYTES, s, p);
+    DGDM_HIP_CHECK(hipGetLastError());
+    // the rows it recorded (tie-flagged start points) run their own FPS
+    XobjParams q = p;
+    q.skip_fast = 1;
+    const int64_t cap = std::min<int64_t>(p.total_rows, p.todo_capacity);
+    if (p.xobj16) hipLaunchKernelGGL(xobj_kernel<true>, dim3((unsigned)((cap + 3) / 4)), dim3(256), 0, s, q);
+    else hipLaunchKernelGGL(xobj_kernel<false>, dim3((unsigned)((cap + 3) / 4)), dim3(256), 0, s, q);
+    DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 int pn_fps_table(const float *xyz, int N, int nv, int npoint, int *out, int *flags, hipStream_t s, int nobj) {
     hipLaunchKernelGGL(fps_table_kernel, dim3((nv + 3) / 4, nobj), dim3(256), (size_t)3 * N * sizeof(float), s, xyz, N, nv, npoint, out, flags);
@@ -811,8 +997,8 @@ int pn_z16(const float *xyz, int N, int nv, const PnWeights &w, const uint32_t *
 }
 
 int pn_m0(const int *fps2, const int *crowded, int N, const float *Z0, float *M0, int *cl2, int *cnt2, const uint32_t *Z0_16, uint32_t *M0_16,
-          hipStream_t s) {
-    hipLaunchKernelGGL(m0_kernel, dim3((N + 3) / 4), dim3(256), 0, s, fps2, crowded, N, Z0, M0, cl2, cnt2, Z0_16, M0_16);
+          const int *clist, const int *ncr, int *cl2s, hipStream_t s) {
+    hipLaunchKernelGGL(m0_kernel, dim3((N + 3) / 4), dim3(256), 0, s, fps2, crowded, N, Z0, M0, cl2, cnt2, Z0_16, M0_16, clist, ncr, cl2s);
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
 }

@@ -153,10 +153,12 @@ class Guidance:
         torch.cuda.current_stream().synchronize()     # `o` may be a temporary
         self.n_objects = o.shape[0]
 
-    def debug_fps_path(self, force_per_row: bool):
-        """Test hook: force the per-row FPS kernel; returns which objects are admissible for the table path."""
+    def debug_fps_path(self, mode):
+        """Test hook: which kernels build the per-row PointNet++ embeddings.  0 / False: default ((chain, s1)-group kernel where
+        the slab fits LDS); 1 / True: every row runs its own FPS(128); 2: per-row table kernel.  All three must agree bit for bit.
+        Returns which objects are admissible for the table path."""
         ok = (C.c_int32 * max(1, self.n_objects))()
-        check(lib().dgdm_guidance_debug_fps_path(self._h, int(force_per_row), ok))
+        check(lib().dgdm_guidance_debug_fps_path(self._h, int(mode), ok))
         return [bool(v) for v in ok][:self.n_objects]
 
     def rowcoef(self, centers: torch.Tensor) -> np.ndarray:

@@ -119,7 +119,7 @@ def unet1d_forward(sd: SD, sample: torch.Tensor, timestep: torch.Tensor) -> torc
     half = dsed // 2
     fr = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1)))     # :30-37
     arg = timestep.expand(x.shape[0])[:, None] * fr[None, :]
-    g = torch.cat((arg.sin(), arg.cos()), dim=-1)
+    g = torch.cat((arg.sin(), arg.cos()), dim=-1).to(sd["diffusion_step_encoder.1.weight"].dtype)      # no-op in float32
     g = F.linear(g, sd["diffusion_step_encoder.1.weight"], sd["diffusion_step_encoder.1.bias"])
     g = F.linear(F.mish(g), sd["diffusion_step_encoder.3.weight"], sd["diffusion_step_encoder.3.bias"])
     n_down = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("down_modules."))
@@ -164,7 +164,9 @@ def timestep_embedding(t: torch.Tensor, dim: int, max_period: int = 10000) -> to
 
 
 def _mlp2(sd: SD, p: str, x: torch.Tensor, act: Callable) -> torch.Tensor:
-    x = act(F.linear(x, sd[p + ".0.weight"], sd[p + ".0.bias"]))
+    # the cast is a no-op for a float32 state_dict; with a float64 copy of the weights it makes the whole model run in float64
+    # on the same float32 embedding inputs (the triangulation of tests/test_gpu_fullgrid.py: which float32 result is nearer)
+    x = act(F.linear(x.to(sd[p + ".0.weight"].dtype), sd[p + ".0.weight"], sd[p + ".0.bias"]))
     return F.linear(x, sd[p + ".2.weight"], sd[p + ".2.bias"])
 
 
@@ -333,9 +335,11 @@ def set_abstraction(sd: SD, p: str, xyz: torch.Tensor, points: Optional[torch.Te
         if points is not None:
             feat = torch.cat([feat, points.view(B, 1, N, -1)], dim=-1)
     else:                                                 # sample_and_group :118-146
-        fps = farthest_point_sample(xyz, npoint, starts.draw(N, B))
+        # .float() is a no-op on the float32 path; with float64 inputs (the float64 yardstick of tests/test_gpu_fullgrid.py)
+        # it keeps the discrete decisions - which points FPS picks, which fall inside a ball - the float32 ones
+        fps = farthest_point_sample(xyz.float(), npoint, starts.draw(N, B))
         new_xyz = _gather(xyz, fps)
-        idx = query_ball_point(radius, nsample, xyz, new_xyz)
+        idx = query_ball_point(radius, nsample, xyz.float(), new_xyz.float())
         feat = _gather(xyz, idx) - new_xyz.view(B, npoint, 1, C)
         if points is not None:
             feat = torch.cat([feat, _gather(points, idx)], dim=-1)

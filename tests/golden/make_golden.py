@@ -527,9 +527,14 @@ def g9_2d():
                 out[f"{name}_guided"] = np.concatenate(res, axis=0) if name == "multi" else res[0]
             else:
                 out[f"{name}_guided_1thread"] = np.concatenate(res, axis=0) if name == "multi" else res[0]
+                n_first = 2 if name == "multi" else 1        # cond_fn calls of the first step: identical inputs in both runs
+                out[f"{name}_grad0_1thread"] = torch.stack(tr.grad[:n_first]).numpy()
             print("  2d", name, threads, "threads", f"{time.time() - t0:.1f}s", flush=True)
         torch.set_num_threads(8)
         out[f"{name}_floor"] = np.float64(_spread(out[f"{name}_guided"], out[f"{name}_guided_1thread"]))
+        g8, g1 = out[f"{name}_trace_grad"][:out[f"{name}_grad0_1thread"].shape[0]].astype(np.float64), out[f"{name}_grad0_1thread"].astype(np.float64)
+        out[f"{name}_grad_floor"] = np.float64(np.linalg.norm(g8 - g1) / np.linalg.norm(g8))
+        print("  2d", name, "reference first-step gradient, 8 vs 1 thread: rel L2", out[f"{name}_grad_floor"], flush=True)
         print("  2d", name, "gain", gain, "reference 8-vs-1-thread spread (finger L2)", out[f"{name}_floor"], flush=True)
         names.append(name)
     out["names"] = np.array(names)
@@ -592,6 +597,113 @@ def g9_3d(parts=("rotate", "rotate_alt", "convergence", "multi", "convergence_al
                                 trace_x=out["trace_x"], threads=threads, floor=np.float64(fl))
         else:
             np.savez_compressed(os.path.join(OUT, f"g9_3d_{part}.npz"), **out)
+
+
+def _guided_sample_with_centers(s, noise, obj, opt_obj, centers, starts):
+    """orc.guided_sample with given convergence centres (loop body of generator/diffusion.py:570-576)."""
+    B = noise.shape[0]
+    scale = orc.classifier_scale(s.mode, opt_obj)
+    x = noise.clone()
+    for t in s.sched.timesteps:
+        ts = t * torch.ones(B, dtype=torch.int64)
+        with torch.no_grad():
+            eps = orc.unet1d_forward(s.unet, x, ts)
+        gr = orc.cond_fn(s, x, ts, opt_obj, obj, (-1.0, 1.0), centers, starts)
+        eps = eps - (1 - s.sched.alphas_cumprod[t]).sqrt() * gr * scale
+        x = s.sched.step(eps, t, x)
+    return x
+
+
+def g9_f64(parts=None):
+    """Float64 first-step gradients for the g9 chains (same inputs as the recorded step 0: x = the start noise, the recorded FPS
+    draws): the yardstick that tells float32 rounding noise from error.  The reference's modules cannot run in float64 as they are
+    (cond_fn builds float32 inputs), so this uses the oracle - pinned to the reference in float32 by tests/test_oracle_golden.py
+    (<= 2e-6) - with a float64 copy of the same weights.  Writes tests/golden/g9_f64.npz (merging with what is there)."""
+    import time
+    from tests import util as tu
+    path = os.path.join(OUT, "g9_f64.npz")
+    out = dict(np.load(path)) if os.path.exists(path) else {}
+    f64 = lambda sd: {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}      # noqa: E731
+    g = np.load(os.path.join(OUT, "g9_2d.npz"))
+    B, G, P, L, T, S, nv = [int(v) for v in g["dims"]]
+    sch = orc.DDIM(T)
+    sch.set_timesteps(S)
+    t = torch.full((B,), int(sch.timesteps[0]), dtype=torch.int64)
+    for name in [str(n) for n in g["names"]]:
+        if parts and ("2d/" + name) not in parts:
+            continue
+        o, gain = str(g[f"{name}_opt_obj"]), float(g[f"{name}_gain"])
+        sd = f64(synth.scale_output(synth.synth_state_dict(synth.dyn2d_spec(14, 2 * nv), DYN2D_SEED), gain))
+        s64 = orc.Setup('point', None, sd, sch, L, G, P)
+        x = torch.from_numpy(g[f"{name}_trace_x"][0]).double()
+        objs = [0, 1] if name == "multi" else [0]
+        c = torch.from_numpy(g[f"{name}_centers"]) if o == 'convergence' else None
+        out[f"2d/{name}"] = np.stack([orc.cond_fn(s64, x, t, o, torch.from_numpy(g["objs"][oi]).double(), (-1.0, 1.0), c).numpy() for oi in objs])
+        # 2-D is cheap: the float64 gradient at EVERY recorded step (inputs = the reference's recorded x of that step)
+        allsteps = []
+        for si, tt in enumerate(sch.timesteps):
+            xs = torch.from_numpy(g[f"{name}_trace_x"][si]).double()
+            ts = torch.full((B,), int(tt), dtype=torch.int64)
+            allsteps += [orc.cond_fn(s64, xs, ts, o, torch.from_numpy(g["objs"][oi]).double(), (-1.0, 1.0), c).numpy() for oi in objs]
+        out[f"2d/{name}_steps"] = np.stack(allsteps)
+        # the whole chain in float64 (eps-net, dynamics, objective, scheduler arithmetic; same float32-valued weights, noise,
+        # scheduler coefficients): the end point exact arithmetic gives - what both float32 implementations approximate
+        sc = orc.Setup('point', f64(synth.synth_state_dict(synth.unet_spec(), UNET_SEED)), sd, sch, L, G, P)
+        noise = synth.synth_noise(0, B, L).double()
+        if name == "multi":
+            out[f"2d/{name}_chain"] = orc.guided_sample_multi_object(sc, noise, [torch.from_numpy(g["objs"][oi]).double() for oi in objs], o).numpy()
+        else:
+            ug = orc.unguided_sample(sc, noise)
+            out[f"2d/{name}_chain"] = orc.guided_sample(sc, noise, torch.from_numpy(g["objs"][0]).double(), o, unguided=ug).numpy()
+        print("  f64 2d", name, "reference float32 chain vs float64 chain (finger L2)", _spread(g[f"{name}_guided"], out[f"2d/{name}_chain"]), flush=True)
+    for part in ("rotate", "convergence", "multi", "rotate_raw"):
+        f = os.path.join(OUT, f"g9_3d_{part}.npz")
+        if not os.path.exists(f) or (parts and ("3d/" + part) not in parts and ("3d/" + part + "_chain") not in parts):
+            continue
+        g = np.load(f)
+        B, G, P, L, T, S, N = [int(v) for v in g["dims"]]
+        o, gain = str(g["opt_obj"]), float(g["gain"])
+        sd = f64(synth.scale_output(synth.synth_state_dict(synth.dyn3d_spec(42), DYN3D_SEED), gain))
+        sch = orc.DDIM(T)
+        sch.set_timesteps(S)
+        s64 = orc.Setup('point_3d', None, sd, sch, L, G, P, 512)
+        t = torch.full((B,), int(sch.timesteps[0]), dtype=torch.int64)
+        x = torch.from_numpy(g["trace_x"][0]).double()
+        calls = tu.unpack_starts(g["starts"].astype(np.int64), g["start_lens"])
+        n_sub = 2 * ((B * G * P * P + 511) // 512)              # randint calls per cond_fn
+        c = None
+        if o == 'convergence':                                   # the centre sweep drew first (B*G rows: one sub-batch)
+            sweep, calls = calls[:2], calls[2:]
+            ug = torch.from_numpy(g["unguided"])
+            s32 = orc.Setup('point_3d', None, synth.scale_output(synth.synth_state_dict(synth.dyn3d_spec(42), DYN3D_SEED), gain), sch, L, G, P, 512)
+            c = orc.get_convergence_centers(s32, ug, torch.from_numpy(g["objs"][0]), (-1.0, 1.0), orc.StartLog(list(sweep)))
+        objs = [0, 1] if part == "multi" else [0]
+        t0 = time.time()
+        res = []
+        for k, oi in enumerate(objs):
+            log = orc.StartLog(list(calls[k * n_sub:(k + 1) * n_sub]))
+            res.append(orc.cond_fn(s64, x, t, o, torch.from_numpy(g["objs"][oi]).double(), (-1.0, 1.0), c, log).numpy())
+        out[f"3d/{part}"] = np.stack(res)
+        print("  f64 3d", part, f"{time.time() - t0:.0f}s", flush=True)
+        np.savez_compressed(path, **out)
+        if parts and ("3d/" + part + "_chain") in parts:          # the whole chain in float64 on the recorded draws (25-50 min)
+            t0 = time.time()
+            sc = orc.Setup('point_3d', f64(synth.synth_state_dict(synth.unet_spec(), UNET_SEED)), sd, sch, L, G, P, 512)
+            noise = synth.synth_noise(0, B, L).double()
+            log = orc.StartLog(tu.unpack_starts(g["starts"].astype(np.int64), g["start_lens"]))
+            if part == "multi":
+                ch = orc.guided_sample_multi_object(sc, noise, [torch.from_numpy(g["objs"][oi]).double() for oi in objs], o, starts=log)
+            else:
+                # the centre sweep decides discretely (three-class profile): take the float32 centres the recorded run used
+                if o == 'convergence':
+                    log = orc.StartLog(tu.unpack_starts(g["starts"].astype(np.int64), g["start_lens"])[2:])
+                    ch = _guided_sample_with_centers(sc, noise, torch.from_numpy(g["objs"][0]).double(), o, c, log)
+                else:
+                    ch = orc.guided_sample(sc, noise, torch.from_numpy(g["objs"][0]).double(), o, starts=log)
+            out[f"3d/{part}_chain"] = ch.numpy()
+            print("  f64 3d chain", part, f"{time.time() - t0:.0f}s reference float32 chain vs float64 chain (finger L2)", _spread(g["guided"], ch.numpy()), flush=True)
+            np.savez_compressed(path, **out)
+    np.savez_compressed(path, **out)
 
 
 def synth_metrics(seed, n_ori=360):
@@ -659,7 +771,7 @@ if __name__ == "__main__":
     os.makedirs("/tmp/dgdm_golden", exist_ok=True)
     only = sys.argv[1:]
     for name, fn in (("g2", g2_unet), ("g3", g3_dyn2d), ("g4", g4_pointnet), ("g5", g5_dyn3d), ("g6", g6_chains),
-                     ("g7", g7_convergence), ("g8", g8_harness), ("g9_2d", g9_2d), ("g9_3d", g9_3d)):
+                     ("g7", g7_convergence), ("g8", g8_harness), ("g9_2d", g9_2d), ("g9_3d", g9_3d), ("g9_f64", g9_f64)):
         if only and name not in [a.split(":")[0] for a in only]:
             continue
         sub = [a.split(":", 1)[1].split(",") for a in only if a.startswith(name + ":")]

@@ -5,18 +5,34 @@ Per-finger statistics depend on the cell count C = G*P^2, not on B, so the fixtu
   2-D  B=4, G=360, P=5 (C = 9000 cells per finger as in configs[1]; R = 36 000 rows per cond_fn), 100-vertex object
   3-D  B=2, G=45,  P=5 (C = 1125 cells per finger as in configs[2]; R = 2250 rows = 5 sub-batches of sub_bs = 512), 512-point object
 
-Every fixture chain was run twice by the reference (8 CPU threads and 1 (2-D) / 4 (3-D) threads, same seeds and FPS draws); the
-distance between those two end points is stored as ``floor``: the reference's own reproducibility.  With the synthetic He-init
-dynamics weights as they are (``gain`` 1, the '*_raw' chains) the guidance term is 10^2..10^4 times eps, the chain is chaotic and
-the reference parts from itself by 0.2 .. 4.5 - no implementation can be compared free-running there, only step by step.  The
-other chains scale the dynamics output layer (``dgdm_amd.synth.scale_output``) so that the guidance term is of eps' order, as
-the reference's classifier scales assume; there the reference reproduces itself to 1e-5 .. 7e-5 and the HIP path must be within
+What "parity" can mean for a free-running chain.  Both sides compute in float32 with different summation orders, and the chain
+amplifies differences.  Two yardsticks are stored with the fixtures:
+  * ``floor``: the reference run twice (8 CPU threads vs 1 (2-D) / 4 (3-D) threads, same seeds and FPS draws) - how far the
+    reference is from ITSELF (its cond_fn gradient turns out thread-invariant in 2-D; the spread comes from the eps-net);
+  * ``chain64`` (tests/golden/g9_f64.npz): the same chain evaluated entirely in float64 by the oracle (pinned to the reference in
+    float32) - the end point exact arithmetic gives.  dist(reference float32, chain64) is how far the REFERENCE is from exact.
+With the synthetic He-init dynamics weights as they are (``gain`` 1, the '*_raw' chains) the guidance term is 10^2..10^4 times
+eps, the chain is chaotic and the reference is 0.2 .. 6 away from itself and from the exact chain: nothing can be compared
+free-running there.  The other chains scale the dynamics output layer (``dgdm_amd.synth.scale_output``) so that the guidance
+term is of eps' order, as the reference's classifier scales assume.  Asserted:
 
-    finger L2  <  1e-4                       (north_star)      when floor <  3e-5
-    finger L2  <  max(1e-4, 3 * floor)                          when floor >= 3e-5 (the reference itself is not better than that)
+    dist(HIP, chain64)    <=  max(1e-4, 1.5 * dist(reference, chain64))     HIP is as close to exact as the reference is
+    dist(HIP, reference)  <   1e-4    (north_star)                          wherever the reference itself is within 1e-4 of exact
+                                                                            (2-D: rotate, shift_left, clockwise_up, multi)
+'convergence' (classifier scale 10 and a gradient that is the difference of two large window sums) stays ill-conditioned even
+when its guidance term is of eps' size: the reference is 0.33 from exact, so it only takes part in the first assertion.
 
-Every chain - chaotic or not - is also replayed step by step on the reference's recorded trajectory (eps-net, cond_fn gradient,
-scheduler step: relative 2e-5), which is the precise check.  The measured numbers are printed (pytest -s) and tabulated in DESIGN.md.
+Every chain - chaotic or not - is also replayed step by step on the reference's recorded trajectory (eps-net 2e-5, scheduler step
+a few ulps, cond_fn gradient see below), which is the precise check.
+
+Gradient tolerance at these grids.  A float32 sum over 9000 (1125) cells per finger carries rounding noise of its own: against a
+float64 evaluation of the same model on the same inputs (tests/golden/g9_f64.npz, made with the oracle's float64 mode) the
+REFERENCE's float32 gradient is off by 1.8e-5 .. 2.4e-5 relative ('convergence', a difference of two large window sums: 4e-4), and
+it is bit-identical across its own thread counts, so that is arithmetic, not scheduling.  Two float32 implementations with
+different summation orders can therefore not agree to the 2e-5 the small golden cases use.  The yardstick is the float64 result:
+    first step:  rel(HIP, float64)       <=  max(2e-5, 1.5 * rel(reference, float64))     (HIP is as close to exact as the reference)
+    every step:  rel(HIP, reference)     <=  max(2e-5, 2.5 * rel(reference, float64))     (triangle inequality on the above)
+The measured numbers are printed (pytest -s), merged into gpurun_out/fullgrid_parity.json and tabulated in DESIGN.md §7.
 """
 import json
 import os
@@ -34,11 +50,39 @@ NORTH_STAR = 1e-4
 REPORT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "fullgrid_parity.json")
 
 
-def tolerance(floor):
-    """See the module docstring; None = the reference does not reproduce itself (chaotic chain): no free-running comparison."""
-    if floor > 5e-2:
-        return None
-    return NORTH_STAR if floor < 3e-5 else max(NORTH_STAR, 3.0 * floor)
+def chain64(key):
+    f = util.load("g9_f64.npz")
+    return f[key + "_chain"] if (key + "_chain") in f.files else None
+
+
+def check_end_point(tag, out, ref, c64, floor):
+    """The two assertions of the module docstring; returns the report row."""
+    d_ref = finger_l2(ref, c64) if c64 is not None else None
+    d_hip = finger_l2(out, c64) if c64 is not None else None
+    err = finger_l2(out, ref)
+    row = dict(reference_thread_floor=floor, reference_vs_chain64=d_ref, hip_vs_chain64=d_hip, hip_vs_reference=err)
+    if d_ref is not None and d_ref < 1.0:              # beyond that the chain is chaotic: clamp(-1, 1) bounds every distance
+        assert d_hip <= max(NORTH_STAR, 1.5 * d_ref), (tag, row)
+    if d_ref is not None and d_ref < NORTH_STAR:
+        assert err < NORTH_STAR, (tag, row)
+    if d_ref is None and floor is not None and floor < 3e-5:      # no float64 chain stored: fall back on the thread floor
+        assert err < NORTH_STAR, (tag, row)
+    return row
+
+
+def grad_noise(key, ref_grads):
+    """rel(reference float32, float64) of the first-step gradient(s), the float64 gradients themselves, and the tolerance for
+    every recorded cond_fn call: max(2e-5, 2.5 * rel(reference, float64)) with the call's own float64 gradient where the fixture
+    has one (2-D: every step) and the first step's figure otherwise."""
+    f = util.load("g9_f64.npz")
+    if key not in f.files:
+        return None, None, 2e-5
+    g64 = f[key]
+    noise = util.rel_l2(ref_grads[:g64.shape[0]], g64)
+    if key + "_steps" in f.files:
+        steps = f[key + "_steps"]
+        return noise, g64, [max(2e-5, 2.5 * util.rel_l2(ref_grads[i], steps[i])) for i in range(steps.shape[0])]
+    return noise, g64, max(2e-5, 2.5 * noise)
 
 
 def _report(rows):
@@ -68,10 +112,12 @@ def test_fullgrid_2d(dev):
         gd = engine.Guidance(dyn, B, G, P, (-1.0, 1.0), 2, T, nv, 0, max_objects=2)
         gd.set_objects(objs.to(dev))
         ref = g[f"{name}_guided"]
-        errs = []
+        errs, grads = [], []
+        noise64, g64, rel = grad_noise(f"2d/{name}", g[f"{name}_trace_grad"])
         if name == "multi":
             out = sampler.guided_multi_object(net, gd, s, 'point', noise, [0, 1], o).cpu()
-            _teacher_forced(net, gd, s, 'point', g, f"{name}_trace", [(0, o)], ref, None, dev, scale=sampler.SCALE_2D, multi_obj=[0, 1], errs=errs)
+            _teacher_forced(net, gd, s, 'point', g, f"{name}_trace", [(0, o)], ref, None, dev, scale=sampler.SCALE_2D, multi_obj=[0, 1], errs=errs,
+                            rel=rel, grads=grads)
         else:
             out = sampler.guided_chains(net, gd, s, 'point', noise, [(0, o)], unguided=ug)[0].cpu()
             rc = None
@@ -79,16 +125,19 @@ def test_fullgrid_2d(dev):
                 centers = sampler.convergence_centers(gd, 'point', ug, [0])
                 assert np.array_equal(centers[0].numpy(), g[f"{name}_centers"])
                 rc = torch.from_numpy(gd.rowcoef(centers[0])).to(dev).reshape(1, -1)
-            _teacher_forced(net, gd, s, 'point', g, f"{name}_trace", [(0, o)], ref, None, dev, scale=sampler.classifier_scale('point', o), rowcoef=rc, errs=errs)
-        err, tol = finger_l2(out, ref), tolerance(floor)
-        rows[f"2d/{name}"] = dict(opt_obj=o, gain=gain, reference_floor=floor, hip_vs_reference=err, tolerance=tol, max_step_grad_rel=max(errs))
-        print(f"2d {name:16s} gain {gain:.4g} reference floor {floor:.2e} HIP vs reference {err:.2e} tol {tol} max per-step grad rel {max(errs):.1e}")
-        if tol is not None:
-            assert err < tol, (name, err, tol, floor)
+            _teacher_forced(net, gd, s, 'point', g, f"{name}_trace", [(0, o)], ref, None, dev, scale=sampler.classifier_scale('point', o), rowcoef=rc,
+                            errs=errs, rel=rel, grads=grads)
+        hip64 = util.rel_l2(torch.stack(grads[:g64.shape[0]]), g64)
+        assert hip64 <= max(2e-5, 1.5 * noise64), (name, hip64, noise64)
+        row = check_end_point(f"2d/{name}", out, ref, chain64(f"2d/{name}"), floor)
+        row.update(opt_obj=o, gain=gain, max_step_grad_rel=max(errs), grad0_reference_vs_f64=noise64, grad0_hip_vs_f64=hip64)
+        rows[f"2d/{name}"] = row
+        print(f"2d {name:16s} gain {gain:.4g} | end point: HIP vs reference {row['hip_vs_reference']:.2e}; vs float64 chain: reference "
+              f"{row['reference_vs_chain64']:.2e} HIP {row['hip_vs_chain64']:.2e}; reference thread floor {floor:.2e} | gradient: max per-step HIP vs "
+              f"reference {max(errs):.1e}; first step vs float64: reference {noise64:.1e} HIP {hip64:.1e}")
     _report(rows)
-    # the north-star bound proper must hold on the well-conditioned chains
-    assert all(r["hip_vs_reference"] < NORTH_STAR for k, r in rows.items() if r["reference_floor"] < 3e-5)
-    assert sum(r["reference_floor"] < 3e-5 for r in rows.values()) >= 3
+    # the north-star bound proper was checked on at least the four well-conditioned chains
+    assert sum(r["reference_vs_chain64"] < NORTH_STAR and r["hip_vs_reference"] < NORTH_STAR for r in rows.values()) >= 4
 
 
 def _load3d(part):
@@ -117,12 +166,13 @@ def test_fullgrid_3d(dev, part):
     assert finger_l2(ug.cpu(), g["unguided"]) < NORTH_STAR
     forced = lambda: sampler.StartStream(N, 512, util.unpack_starts(g["starts"].astype(np.int64), g["start_lens"]))      # noqa: E731
     ref = g["guided"]
-    errs = []
+    errs, grads = [], []
+    noise64, g64, rel = grad_noise(f"3d/{part}", g["trace_grad"])
     if part == "multi":
         out = sampler.guided_multi_object(net, gd, s, 'point_3d', noise, [0, 1], o, starts=forced()).cpu()
         st = forced()
         step = np.stack([np.stack([st.call(gd.rows), st.call(gd.rows)]) for _ in range(S)])
-        _teacher_forced(net, gd, s, 'point_3d', g, "trace", [(0, o)], ref, step, dev, scale=sampler.SCALE_3D, multi_obj=[0, 1], errs=errs)
+        _teacher_forced(net, gd, s, 'point_3d', g, "trace", [(0, o)], ref, step, dev, scale=sampler.SCALE_3D, multi_obj=[0, 1], errs=errs, rel=rel, grads=grads)
     else:
         out = sampler.guided_chains(net, gd, s, 'point_3d', noise, [(0, o)], unguided=ug, starts=forced())[0].cpu()
         sweep, step = sampler.draw_chain_starts(gd, [(0, o)], S, forced())
@@ -130,10 +180,17 @@ def test_fullgrid_3d(dev, part):
         if o == 'convergence':
             centers = sampler.convergence_centers(gd, 'point_3d', ug, [0], sweep[0])
             rc = torch.from_numpy(gd.rowcoef(centers[0])).to(dev).reshape(1, -1)
-        _teacher_forced(net, gd, s, 'point_3d', g, "trace", [(0, o)], ref, step, dev, scale=sampler.classifier_scale('point_3d', o), rowcoef=rc, errs=errs)
-    err = finger_l2(out, ref)
-    tol = tolerance(floor) if floor is not None else NORTH_STAR
-    _report({f"3d/{part}": dict(opt_obj=o, gain=gain, reference_floor=floor, hip_vs_reference=err, tolerance=tol, max_step_grad_rel=max(errs))})
-    print(f"3d {part:12s} gain {gain:.4g} reference floor {floor} HIP vs reference {err:.2e} tol {tol} max per-step grad rel {max(errs):.1e}")
-    if tol is not None:
-        assert err < tol, (part, err, tol, floor)
+        _teacher_forced(net, gd, s, 'point_3d', g, "trace", [(0, o)], ref, step, dev, scale=sampler.classifier_scale('point_3d', o), rowcoef=rc,
+                        errs=errs, rel=rel, grads=grads)
+    hip64 = None
+    if g64 is not None:
+        hip64 = util.rel_l2(torch.stack(grads[:g64.shape[0]]), g64)
+        assert hip64 <= max(2e-5, 1.5 * noise64), (part, hip64, noise64)
+    row = check_end_point(f"3d/{part}", out, ref, chain64(f"3d/{part}"), floor)
+    row.update(opt_obj=o, gain=gain, max_step_grad_rel=max(errs), grad0_reference_vs_f64=noise64, grad0_hip_vs_f64=hip64)
+    _report({f"3d/{part}": row})
+    print(f"3d {part:12s} gain {gain:.4g} | end point: HIP vs reference {row['hip_vs_reference']:.2e}; vs float64 chain: reference "
+          f"{row['reference_vs_chain64']} HIP {row['hip_vs_chain64']}; reference thread floor {floor} | gradient: max per-step HIP vs reference "
+          f"{max(errs):.1e}; first step vs float64: reference {noise64} HIP {hip64}")
+    if row["reference_vs_chain64"] is None and floor is not None and 3e-5 <= floor < 5e-2:
+        assert row["hip_vs_reference"] < max(NORTH_STAR, 3.0 * floor), (part, row)      # until a float64 chain is stored: 3x the reference's own spread

@@ -60,7 +60,7 @@ def test_ball_query_on_reordered_cloud_vs_oracle(dev):
     """sa2's query scans the cloud in sa1's FPS order (pointnet2_utils.py:132-134 on new_xyz of sa1): for a few variants s1 the
     first-64 lists of every centre must equal the oracle's query on the re-ordered cloud, mapped back to point ids."""
     dyn = engine.Dynamics(3, util.dyn3d_sd(33), 42)
-    cloud = synth.synth_object_3d(7)          # a box: dense faces -> many crowded centres
+    cloud = synth.synth_object_3d(8)          # 146 of its 512 centres have more than 64 points in their r = 0.4 ball
     base = engine.debug_pointnet_indices(dyn, cloud.to(dev))
     assert base["crowded"].sum() > 0, "the case is only interesting when some query truncates at 64"
     for s1 in (0, 77, 511):

@@ -176,11 +176,14 @@ def test_dyn3d_cond_fn_golden(dev):
 
 
 # ------------------------------------------------------------------------------------------------ a1-a3, a6: chains
-def _teacher_forced(net, gd, s, mode, g, key, chains, final, step_starts, dev, n_grad=1, scale=None, multi_obj=None, rowcoef=None, errs=None):
+def _teacher_forced(net, gd, s, mode, g, key, chains, final, step_starts, dev, n_grad=1, scale=None, multi_obj=None, rowcoef=None, errs=None, rel=None, grads=None):
     """Replays the reference's recorded trajectory (tests/golden: trace*_x/_eps/_grad): at every step the HIP eps-net, cond_fn
     and scheduler step see exactly the inputs the reference saw.  This is the precise check; free-running chains at these
     tiny R (24-72 rows) can be thrown off by a single ReLU sign flip."""
     xs, es, gs = g[key + "_x"], g[key + "_eps"], g[key + "_grad"]
+    # gradient tolerance: REL, or what a full-grid fixture calibrated against float64 - one value or one per recorded cond_fn call
+    rel = REL if rel is None else rel
+    rel_of = (lambda i: rel[i]) if isinstance(rel, (list, tuple, np.ndarray)) else (lambda i: rel)
     S = xs.shape[0]
     B, L = xs.shape[1], xs.shape[2]
     oi, o = chains[0]
@@ -194,7 +197,9 @@ def _teacher_forced(net, gd, s, mode, g, key, chains, final, step_starts, dev, n
             gr = gd.grad(x.reshape(1, B, L), t, [engine.make_objective(o, oi)], rowcoef, st)
             if errs is not None:
                 errs.append(util.rel_l2(gr.cpu().reshape(B, L, 1), gs[si]))
-            assert util.rel_l2(gr.cpu().reshape(B, L, 1), gs[si]) < REL, (key, si)
+            if grads is not None:
+                grads.append(gr.cpu().reshape(B, L, 1))
+            assert util.rel_l2(gr.cpu().reshape(B, L, 1), gs[si]) < rel_of(si), (key, si)
             g_ref = torch.from_numpy(gs[si]).to(dev).reshape(1, -1)
         else:
             n = len(multi_obj)
@@ -203,7 +208,9 @@ def _teacher_forced(net, gd, s, mode, g, key, chains, final, step_starts, dev, n
             for k in range(n):
                 if errs is not None:
                     errs.append(util.rel_l2(gr[k].cpu().reshape(B, L, 1), gs[si * n + k]))
-                assert util.rel_l2(gr[k].cpu().reshape(B, L, 1), gs[si * n + k]) < REL, (key, si, k)
+                if grads is not None:
+                    grads.append(gr[k].cpu().reshape(B, L, 1))
+                assert util.rel_l2(gr[k].cpu().reshape(B, L, 1), gs[si * n + k]) < rel_of(si * n + k), (key, si, k)
             g_ref = torch.from_numpy(gs[si * n:(si + 1) * n]).to(dev).reshape(n, -1)
         nxt = engine.ddim_guided_step(x, torch.from_numpy(es[si]).to(dev), g_ref, g_ref.shape[0], s.coefficients(t), scale).cpu()
         want = xs[si + 1] if si + 1 < S else final
@@ -316,3 +323,31 @@ def test_dyn3d_cond_fn_oracle_fps_paths(dev):
                                               [n for r0 in range(0, gd.rows, sub) for n in (min(sub, gd.rows - r0),) * 2]))
         ref = orc.cond_fn(s, x[c], torch.full((B,), 3, dtype=torch.int64), o, objs[oi], (-1.0, 1.0), None, log)
         assert util.rel_l2(fast[c].reshape(B, L, 1), ref) < REL, (c, o)
+
+
+def test_xobj_kernels_agree(dev):
+    """The three ways of building the per-row embeddings - (chain, s1)-group kernel (LDS slab; 1, 2 or 8 feature chunks depending
+    on how many crowded centres the object has), per-row table kernel, per-row FPS - give bit-identical gradients; float32 and
+    bf16 table formats; objects with 0 / 146 / 506 crowded centres and one with exact duplicate points (tie-flagged start points)."""
+    B, G, P, L, T, sub = 2, 12, 3, 42, 15, 64
+    dyn = engine.Dynamics(3, util.dyn3d_sd(44), L)
+    dup = synth.synth_object_3d(32).clone()
+    dup[9] = dup[400]
+    dup[10] = dup[400]
+    objs = torch.stack([synth.synth_object_3d(1), synth.synth_object_3d(8), synth.synth_object_3d(2), dup])
+    nc = objs.shape[0]
+    x = torch.stack([synth.synth_noise(70 + i, B, L) for i in range(nc)]).clamp(-1, 1).reshape(nc, B, L).to(dev)
+    objectives = [engine.make_objective(o, i) for i, o in enumerate(('rotate', 'shift_up', 'clockwise_left', 'rotate'))]
+    for dtype in ("f32", "bf16"):
+        gd = engine.Guidance(dyn, B, G, P, (-1.0, 1.0), nc, T, 512, sub, max_objects=nc, contraction_dtype=dtype)
+        gd.set_objects(objs.to(dev))
+        torch.manual_seed(5)
+        st = sampler.StartStream(512, sub)
+        starts = np.concatenate([st.call(gd.rows) for _ in range(nc)])
+        res = {}
+        for mode in (0, 2, 1):
+            gd.debug_fps_path(mode)
+            res[mode] = gd.grad(x, 3, objectives, None, starts).cpu()
+        gd.debug_fps_path(0)
+        assert torch.equal(res[0], res[2]) and torch.equal(res[0], res[1]), dtype
+        assert float(res[0].abs().max()) > 0
