@@ -7,9 +7,9 @@ benchmark is one batch of `--pairs` independent (object x objective) pairs per G
 B = 32 fingers: PointNet++ object tables, then S = 5 x [eps-net, cond_fn over R = 32*45*25 = 36 000 replicated rows with
 sub_bs = 512 FPS-start partition, guidance combine, DDIM step].  Every pair has its own synthetic 512-point object, so
 nothing is shared between pairs; the tables are rebuilt inside the timed region for every pair.  The FPS start
-indices (the torch.randint draws of pointnet2_utils.py:83) are the path's random input: they are drawn on the host by a
-background thread one step ahead and handed over as host buffers, so the timed region contains their host->device copy but
-not the Mersenne-Twister draw.  Every pair has a global index (step, rank, slot) -> its object, objective and its own start
+indices (the torch.randint draws of pointnet2_utils.py:83) are the path's random input: they are drawn on the host before the
+clock starts and handed over as host int64 buffers (the boundary's contract), so the timed region contains their conversion and
+host->device copy but not the Mersenne-Twister draw.  Every pair has a global index (step, rank, slot) -> its object, objective and its own start
 stream are functions of that index only, so the work of a pair does not depend on how many ranks share the batch.
 `--workload 2d` runs BASELINE configs[1] (B = 64, G = 360, P = 5, R = 576 000 rows per pair, 100-vertex contours).
 
@@ -143,14 +143,19 @@ class Workload:
 
 
 def timed_loop(wl, steps, warmup, dist):
-    """Returns (seconds for `steps` steps, last output).  Inputs of step k+1 are prepared while step k runs."""
+    """Returns (seconds for `steps` steps, last output).  The synthetic inputs of every step - objects (uploaded) and the FPS
+    start draws (host int64 arrays, as the reference's torch.randint hands them over) - exist before the clock starts, like a
+    dataset would; when they would not fit in host memory (> 6 GB of draws) the inputs of step k+1 are prepared while step k runs."""
     total = warmup + steps
     prepared = {}
 
     def prepare(k):
         prepared[k] = (wl.objects(k), wl.draw(k))
 
-    prepare(0)
+    per_step = 8 * 2 * wl.rows * wl.pairs * wl.n_obj * wl.S if wl.kind == "3d" else 0
+    ahead = per_step * total <= 6 * 2 ** 30
+    for k in range(total if ahead else 1):
+        prepare(k)
     out = None
     t0 = None
     for k in range(total):
@@ -161,7 +166,7 @@ def timed_loop(wl, steps, warmup, dist):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
         th = None
-        if k + 1 < total:
+        if not ahead and k + 1 < total:
             th = threading.Thread(target=prepare, args=(k + 1,))
             th.start()
         objs, pre = prepared.pop(k)

@@ -51,10 +51,10 @@ struct DgdmGuidance {
     std::vector<std::unique_ptr<ObjectTables>> tables;   // 3-D
     bool bf16 = false;                           // contractions of the trunk on bf16 MFMA (dgdm_guidance_set_contraction_dtype)
     static constexpr int NBUILD = 3;             // objects whose tables are built concurrently (own stream + temporaries each)
-    DevBuf pool_xyz, pool_fps1, pool_fps2, pool_flags;   // [n_objects] x per-object FPS tables (ObjectTables point into these)
+    DevBuf pool_xyz, pool_fps1, pool_fps2, pool_flags, pool_ncr;   // [n_objects] x per-object FPS tables (ObjectTables point into these), crowded-centre counts
     DevBuf tmpF1[NBUILD], tmpU[NBUILD], tmpY[NBUILD], tmpL2[NBUILD], tmpOff[NBUILD], tmpPairs[NBUILD], tmpRank[NBUILD], vlist;      // 3-D table-build temporaries
-    hipStream_t bstream[NBUILD] = {nullptr, nullptr, nullptr};
-    hipEvent_t bev[NBUILD] = {nullptr, nullptr, nullptr}, bstart = nullptr;
+    hipStream_t bstream[NBUILD] = {nullptr, nullptr, nullptr}, fstream = nullptr;    // fstream: sa2's FPS table, beside the builds
+    hipEvent_t bev[NBUILD] = {nullptr, nullptr, nullptr}, bstart = nullptr, fstart = nullptr, fdone = nullptr;
     DevBuf V, genc, atab, chainbias, timepart, ttmp, partial, objdev, objidx, xobj, xobj16, starts, order, xchains, todo, groupoff;
     int xobj_mode = 0;              // test hook: 0 = group kernel where possible, 2 = per-row table kernel (xobj_fast_kernel)
     int n_objects = 0;
@@ -68,6 +68,9 @@ struct DgdmGuidance {
             if (bev[i]) (void)hipEventDestroy(bev[i]);
         }
         if (bstart) (void)hipEventDestroy(bstart);
+        if (fstart) (void)hipEventDestroy(fstart);
+        if (fdone) (void)hipEventDestroy(fdone);
+        if (fstream) (void)hipStreamDestroy(fstream);
     }
     int build_pose_table(const std::vector<float> &ori, const std::vector<float> &pos, DevBuf *dst, DevBuf *dst_tiled, hipStream_t s);
     int common_pre(const float *x_dev, float t_scaled, const int *objidx_host, int n_chains, hipStream_t s);
@@ -190,7 +193,8 @@ int DgdmGuidance::build_object(int oi, int slot, hipStream_t s) {
     DevBuf &tOff = tmpOff[slot], &tPairs = tmpPairs[slot], &tRank = tmpRank[slot];
     if ((rc = tOff.alloc((size_t)(N + 1) * sizeof(int))) || (rc = tPairs.alloc((size_t)N * N * sizeof(int))) || (rc = tRank.alloc((size_t)N * N * sizeof(short))))
         return rc;
-    if ((rc = pn_crowd(xyz, N, w, t.crowded.as<int>(), t.clist.as<int>(), t.clist.as<int>() + N, tOff.as<int>(), tPairs.as<int>(), tRank.as<short>(), s))) return rc;
+    if ((rc = pn_crowd(xyz, N, w, t.crowded.as<int>(), t.clist.as<int>(), t.clist.as<int>() + N, tOff.as<int>(), tPairs.as<int>(), tRank.as<short>(), s,
+                       pool_ncr.as<int>() + oi))) return rc;
     // bf16 mode: the sa3 contraction (T6) runs on the bf16 matrix pipe and rounds its input, so T4 writes and T5 reduces bf16
     // rows (the temporaries tY / tL2 are simply used at half size); float32 mode: everything float32
     if ((rc = pn_pairs(xyz, N, tU.as<float>(), w, tPairs.as<int>(), tOff.as<int>(), tY.as<float>(), bf16 ? tY.as<uint32_t>() : nullptr, s))) return rc;   // T4
@@ -199,6 +203,7 @@ int DgdmGuidance::build_object(int oi, int slot, hipStream_t s) {
     if (bf16) {
         if ((rc = pn_z16(xyz, N, N, w, tL2.as<uint32_t>(), t.Z.as<float>(), z16, t.clist.as<int>(), t.clist.as<int>() + N, s))) return rc;          // T6
     } else if ((rc = pn_z(xyz, N, N, w, tL2.as<float>(), t.Z.as<float>(), z16, t.clist.as<int>(), t.clist.as<int>() + N, s))) return rc;
+    DGDM_HIP_CHECK(hipStreamWaitEvent(s, fdone, 0));          // fps2 (sa2's FPS table) is built beside the other stages, on its own stream
     return pn_m0(t.fps2, t.crowded.as<int>(), N, t.Z.as<float>(), t.M0.as<float>(), t.cl2.as<int>(), t.cnt2.as<int>(), z16,
                  bf16 ? t.M0_16.as<uint32_t>() : nullptr, t.clist.as<int>(), t.clist.as<int>() + N, t.cl2s.as<int>(), s);                         // T7
 }
@@ -234,11 +239,21 @@ extern "C" int dgdm_guidance_set_objects(DgdmGuidance *g, const float *objects_d
         // T1 for every object at once, on the caller's stream: fps1[obj][start][512], fps2[obj][start point][128] + tie flags
         const size_t no = (size_t)n_objects;
         if ((rc = g->pool_xyz.alloc(no * N * 3 * 4)) || (rc = g->pool_fps1.alloc(no * N * 512 * sizeof(int))) ||
-            (rc = g->pool_fps2.alloc(no * N * 128 * sizeof(int))) || (rc = g->pool_flags.alloc(no * N * sizeof(int))))
+            (rc = g->pool_fps2.alloc(no * N * 128 * sizeof(int))) || (rc = g->pool_flags.alloc(no * N * sizeof(int))) ||
+            (rc = g->pool_ncr.alloc(no * sizeof(int))))
             return rc;
+        if (!g->fstream) {
+            DGDM_HIP_CHECK(hipStreamCreateWithFlags(&g->fstream, hipStreamNonBlocking));
+            DGDM_HIP_CHECK(hipEventCreateWithFlags(&g->fstart, hipEventDisableTiming));
+            DGDM_HIP_CHECK(hipEventCreateWithFlags(&g->fdone, hipEventDisableTiming));
+        }
         DGDM_HIP_CHECK(hipMemcpyAsync(g->pool_xyz.p, objects_dev, no * N * 3 * 4, hipMemcpyDeviceToDevice, s));
+        // sa2's FPS table (fps2) is only read by the last build stage (m0): it runs on its own stream beside sa1's table and the builds
+        DGDM_HIP_CHECK(hipEventRecord(g->fstart, s));
+        DGDM_HIP_CHECK(hipStreamWaitEvent(g->fstream, g->fstart, 0));
+        if ((rc = pn_fps_table(g->pool_xyz.as<float>(), N, N, 128, g->pool_fps2.as<int>(), g->pool_flags.as<int>(), g->fstream, n_objects))) return rc;
+        DGDM_HIP_CHECK(hipEventRecord(g->fdone, g->fstream));
         if ((rc = pn_fps_table(g->pool_xyz.as<float>(), N, N, 512, g->pool_fps1.as<int>(), nullptr, s, n_objects))) return rc;
-        if ((rc = pn_fps_table(g->pool_xyz.as<float>(), N, N, 128, g->pool_fps2.as<int>(), g->pool_flags.as<int>(), s, n_objects))) return rc;
         for (int i = 0; i < n_objects; ++i) {
             ObjectTables &t = *g->tables[i];
             t.xyz = g->pool_xyz.as<float>() + (size_t)i * N * 3; t.fps1 = g->pool_fps1.as<int>() + (size_t)i * N * 512;
@@ -252,18 +267,19 @@ extern "C" int dgdm_guidance_set_objects(DgdmGuidance *g, const float *objects_d
             DGDM_HIP_CHECK(hipEventRecord(g->bev[i], g->bstream[i]));
             DGDM_HIP_CHECK(hipStreamWaitEvent(s, g->bev[i], 0));
         }
-        // which objects may use the table of FPS(128) sequences (no order-dependent selection anywhere)
-        std::vector<int> fl((size_t)n_objects * N);
+        DGDM_HIP_CHECK(hipStreamWaitEvent(s, g->fdone, 0));
+        // which objects may use the table of FPS(128) sequences (no order-dependent selection anywhere); crowded-centre counts
+        std::vector<int> fl((size_t)n_objects * N), ncrs(n_objects);
         prof_end(s, DGDM_STAGE_TABLES, 0.0);
         DGDM_HIP_CHECK(hipMemcpyAsync(fl.data(), g->pool_flags.p, sizeof(int) * no * N, hipMemcpyDeviceToHost, s));
+        DGDM_HIP_CHECK(hipMemcpyAsync(ncrs.data(), g->pool_ncr.p, sizeof(int) * no, hipMemcpyDeviceToHost, s));
         DGDM_HIP_CHECK(hipStreamSynchronize(s));
         for (int i = 0; i < n_objects; ++i) {
             bool ok = N >= 128;
             for (int k = 0; k < N; ++k) ok = ok && fl[(size_t)i * N + k] == 0;
             g->tables[i]->fast_ok = ok;
-            DGDM_HIP_CHECK(hipMemcpyAsync(&g->tables[i]->ncr, g->tables[i]->clist.as<int>() + N, sizeof(int), hipMemcpyDeviceToHost, s));
+            g->tables[i]->ncr = ncrs[i];
         }
-        DGDM_HIP_CHECK(hipStreamSynchronize(s));
     }
     g->n_objects = n_objects;
     return DGDM_OK;

@@ -12,7 +12,8 @@ using namespace dgdm;
 namespace {
 
 // MFMA image of a convolution (csrc/unet.hip conv_mfma): [Cout/16][ntaps][Cin/16][64 lanes][4];
-// lane (i = l & 15, q = l >> 4), component c  ->  W(co = 16 mt + i, ci = 16 g + 4 c + q, tap taps[t]).
+// lane (i = l & 15, q = l >> 4), component c  ->  W(co = 16 mt + i, ci = 16 g + 4 q + c, tap taps[t]): K-step c of a group takes
+// channel 4 q + c from lane group q, so a lane's four B values are four CONSECUTIVE channels - one ds_read_b128 (unet.hip).
 // `at(co, ci, k)` reads the torch tensor: Conv1d is [Cout][Cin][KW], ConvTranspose1d is [Cin][Cout][KW].
 template <class At>
 std::vector<float> conv_image(int cout, int cin, const std::vector<int> &taps, At at) {
@@ -23,12 +24,13 @@ std::vector<float> conv_image(int cout, int cin, const std::vector<int> &taps, A
             for (int gg = 0; gg < g; ++gg)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int c = 0; c < 4; ++c)
-                        o[((((size_t)m * nt + t) * g + gg) * 64 + lane) * 4 + c] = at(16 * m + (lane & 15), 16 * gg + 4 * c + (lane >> 4), taps[t]);
+                        o[((((size_t)m * nt + t) * g + gg) * 64 + lane) * 4 + c] = at(16 * m + (lane & 15), 16 * gg + 4 * (lane >> 4) + c, taps[t]);
     return o;
 }
 
 // bf16 image for conv_mfma_bf16: [Cout/16][ntaps][Cin/32][64 lanes][8]; lane (i = l & 15, kg = l >> 4), slot j ->
-// bf16(W(co = 16 mt + i, ci = 32 g + 8 kg + j, tap taps[t])).  Appended to `dst`; returns the element offset.
+// bf16(W(co = 16 mt + i, ci = 32 g + 4 kg + j (j < 4) | 32 g + 16 + 4 kg + j - 4 (j >= 4), tap taps[t])): a lane's eight K values are
+// two runs of four consecutive channels 16 apart, so both of its ds_read_b128 have the conflict-free bank pattern of the float32 path.  Appended to `dst`; returns the element offset.
 template <class At>
 size_t conv_image16(std::vector<uint16_t> &dst, int cout, int cin, const std::vector<int> &taps, At at) {
     const size_t off = dst.size();
@@ -40,7 +42,7 @@ size_t conv_image16(std::vector<uint16_t> &dst, int cout, int cin, const std::ve
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 8; ++j)
                         dst[off + ((((size_t)m * nt + t) * g + gg) * 64 + lane) * 8 + j] =
-                            f32_to_bf16(at(16 * m + (lane & 15), 32 * gg + 8 * (lane >> 4) + j, taps[t]));
+                            f32_to_bf16(at(16 * m + (lane & 15), 32 * gg + (j < 4 ? 4 * (lane >> 4) + j : 16 + 4 * (lane >> 4) + j - 4), taps[t]));
     return off;
 }
 

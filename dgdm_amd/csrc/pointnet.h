@@ -61,7 +61,8 @@ struct XobjParams {
 int pn_fps_table(const float *xyz, int N, int nv, int npoint, int *out, int *flags, hipStream_t s, int nobj = 1);
 int pn_sa1(const float *xyz, int N, const PnWeights &w, float *F1, hipStream_t s);
 // crowded/clist/ncr: centres whose ball holds > 64 points; off [N+1], pairs [<= N*N], rank [N][N]: the in-radius pair list (T4/T5)
-int pn_crowd(const float *xyz, int N, const PnWeights &w, int *crowded, int *clist, int *ncr, int *off, int *pairs, short *rank, hipStream_t s);
+int pn_crowd(const float *xyz, int N, const PnWeights &w, int *crowded, int *clist, int *ncr, int *off, int *pairs, short *rank, hipStream_t s,
+             int *ncr_copy = nullptr);
 // Y16 (optional): write bf16 operand-order rows there INSTEAD of the float32 rows (bf16 mode)
 int pn_pairs(const float *xyz, int N, const float *U, const PnWeights &w, const int *pairs, const int *off, float *Y, uint32_t *Y16, hipStream_t s);
 int pn_l2(const float *xyz, int N, const PnWeights &w, const int *fps1, const int *vlist, int nv, const float *Y, float *L2,

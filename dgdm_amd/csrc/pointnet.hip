@@ -22,6 +22,7 @@
 //   balls : ((-2 * (a.b)) + |a|^2) + |b|^2  >  r^2           (pointnet2_utils.py:45-47,110)
 #include "common.h"
 #include "mfma_chain.h"
+#include <type_traits>
 #include "pointnet.h"
 
 // No implicit a*b+c -> fma contraction in this file: the scheduler update, FPS and ball-query distances must round
@@ -41,14 +42,30 @@ __device__ __forceinline__ float sqdist_expanded(float cx, float cy, float cz, f
     return __fadd_rn(__fadd_rn(__fmul_rn(-2.f, dot), cn), pn);
 }
 
-// wave-wide argmax, first index wins ties (torch.max semantics, pointnet2_utils.py:91)
+// wave-wide argmax, first index wins ties (torch.max semantics, pointnet2_utils.py:91); every lane receives the result.
+// Two DPP reductions (v_max_f32 / v_min_u32 with data-parallel-primitive operands: no LDS crossbar traffic, unlike __shfl_xor,
+// which is ds_bpermute_b32): the maximum, then the smallest index among the lanes that hold it.
+template <class T, class Op>
+__device__ __forceinline__ T dpp_reduce(T v, Op op) {
+    auto step = [&](auto ctrl, auto rmask) {
+        constexpr int C = decltype(ctrl)::value, M = decltype(rmask)::value;
+        const int o = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), C, M, 0xf, false);
+        v = op(v, __builtin_bit_cast(T, o));
+    };
+    step(std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xf>{});     // quad_perm [1,0,3,2]: lane ^ 1
+    step(std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xf>{});     // quad_perm [2,3,0,1]: lane ^ 2
+    step(std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xf>{});    // row_half_mirror: the other quad of the 8
+    step(std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xf>{});    // row_mirror: the other half of the row of 16
+    step(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});    // row_bcast15 into rows 1 and 3
+    step(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});    // row_bcast31 into rows 2 and 3
+    return __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));   // lane 63 has seen all 64
+}
+
 __device__ __forceinline__ void wave_argmax(float &v, int &i) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float ov = __shfl_xor(v, off);
-        const int oi = __shfl_xor(i, off);
-        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
-    }
+    const float m = dpp_reduce(v, [](float a, float b) { return fmaxf(a, b); });
+    const unsigned cand = (v == m) ? (unsigned)i : 0xffffffffu;
+    i = (int)dpp_reduce(cand, [](unsigned a, unsigned b) { return a < b ? a : b; });
+    v = m;
 }
 
 // farthest_point_sample (pointnet2_utils.py:71-92) by one wave over M <= 64*PPL points whose
@@ -251,7 +268,8 @@ __global__ __launch_bounds__(256, 1) void pair_kernel(const float *__restrict__ 
 // (more than 64 in-radius points: the ball query truncates, and which 64 survive depends on the variant's order) need
 // one value per variant.  crowded[c] in {0,1}; clist = the crowded centres, *ncr their number.
 __global__ __launch_bounds__(1024) void crowd_kernel(const float *__restrict__ xyz, int N, float r2, int *__restrict__ crowded,
-                                                     int *__restrict__ clist, int *__restrict__ ncr, int *__restrict__ off /*[N+1]*/) {
+                                                     int *__restrict__ clist, int *__restrict__ ncr, int *__restrict__ off /*[N+1]*/,
+                                                     int *__restrict__ ncr_copy /* optional second home of the count (host readback pool) */) {
     __shared__ int wcount[16], wsum[16];
     const int c = threadIdx.x, lane = c & 63, wave = c >> 6;
     bool cr = false;
@@ -285,6 +303,7 @@ __global__ __launch_bounds__(1024) void crowd_kernel(const float *__restrict__ x
         int tot = 0, stot = 0;
         for (int w = 0; w < 16; ++w) { tot += wcount[w]; stot += wsum[w]; }
         *ncr = tot;
+        if (ncr_copy) *ncr_copy = tot;
         off[N] = stot;
     }
 }
@@ -951,8 +970,9 @@ int pn_pairs(const float *xyz, int N, const float *U, const PnWeights &w, const 
     return DGDM_OK;
 }
 
-int pn_crowd(const float *xyz, int N, const PnWeights &w, int *crowded, int *clist, int *ncr, int *off, int *pairs, short *rank, hipStream_t s) {
-    hipLaunchKernelGGL(crowd_kernel, dim3(1), dim3(1024), 0, s, xyz, N, w.r2sq, crowded, clist, ncr, off);
+int pn_crowd(const float *xyz, int N, const PnWeights &w, int *crowded, int *clist, int *ncr, int *off, int *pairs, short *rank, hipStream_t s,
+             int *ncr_copy) {
+    hipLaunchKernelGGL(crowd_kernel, dim3(1), dim3(1024), 0, s, xyz, N, w.r2sq, crowded, clist, ncr, off, ncr_copy);
     hipLaunchKernelGGL(nbr_fill_kernel, dim3((N + 3) / 4), dim3(256), 0, s, xyz, N, w.r2sq, off, pairs, rank);
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;

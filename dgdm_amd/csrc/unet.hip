@@ -1,13 +1,16 @@
 // ConditionalUnet1D forward (generator/diffusion_utils.py:123-285), one workgroup per sample, one launch per forward.
 //
-// The whole network runs inside the launch: activations live in LDS as [position + 2][channels + 4]
+// The whole network runs inside the launch: activations live in LDS as [position + 2][channels + 8]
 // (channel-contiguous rows, two zero halo rows on each side, <= 130 KiB for the shipped shapes), weights stream from
 // L2, GroupNorm statistics are wave-shuffle reductions, Mish / FiLM / residual adds are fused into the passes that
 // already touch the data.  One launch per denoise step instead of ~90 eager ops.
 //
 // Convolutions are implicit GEMMs on v_mfma_f32_16x16x4_f32 (exact f32): D[co][pos] += W[co][ci,tap] * in[ci][pos+tap-pad],
 // weights as the A operand from a pre-arranged global image (one coalesced float4 per lane feeds 4 K-steps),
-// activations as the B operand straight from LDS (row stride C+4 floats = 4 mod 32 banks: conflict-free).  Each wave
+// activations as the B operand straight from LDS: K-step c of a 16-channel group takes channel 4q + c from lane group q, so a
+// lane's operands of four K-steps are four consecutive channels = ONE ds_read_b128 (it was four ds_read_b32, each a 2-way bank
+// conflict: rows j and j + 8 of a tile met in one bank with the old row stride of C + 4 floats).  Row stride C + 8 floats
+// (8 mod 64 dword banks) makes every 16-lane group of that b128 read hit 64 distinct banks.  Each wave
 // owns pairs of 16-channel output tiles and all position tiles, so a weight fragment is loaded once and reused for
 // every position tile.  The two convolutions that touch a single channel (1 -> d0 input conv, d0 -> 1 output conv) run
 // on the VALU.
@@ -18,6 +21,7 @@
 namespace dgdm {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int UNET_ROW_PAD = 8;      // LDS activation rows are C + 8 floats: see the header comment (bank mapping of the B-operand reads)
 // Activations live in LDS.  The device functions below are real calls (not inlined into the kernel), so a plain `float *`
 // parameter would be a generic pointer: every access a flat_load/flat_store with 64-bit address arithmetic on the VALU
 // (measured: 5.9 VALU instructions per MFMA in this kernel).  Address-space-3 pointers give ds_read/ds_write with
@@ -48,7 +52,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // Generic strided multi-tap convolution as implicit GEMM.
 //   out[(l*ostride + ooff) + 2][co] (+)= bias[co] + sum_{t < ntaps} sum_ci W_t[co][ci] * in[l*istride + ioff0 + t*iostep + 2][ci],  l < Lout
-// img: [Cout/16][ntaps][Cin/16][64 lanes] float4; lane (i = l&15, q = l>>4), component c -> W_t[16 mt + i][16 g + 4 c + q].
+// img: [Cout/16][ntaps][Cin/16][64 lanes] float4; lane (i = l&15, q = l>>4), component c -> W_t[16 mt + i][16 g + 4 q + c].
 // MODE 0: store, 1: add to what is in `out` (residual).
 struct ConvArgs {
     const float4 *img;
@@ -65,7 +69,7 @@ __device__ void conv_mfma(const ConvArgs a, const lds_f *in, int CPi, lds_f *out
     const int groups = a.cin >> 4, mtiles = a.cout >> 4;
     int base[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) base[nt] = (min(nt * 16 + j, Lout - 1) * a.istride + 2) * CPi + q;
+    for (int nt = 0; nt < NT; ++nt) base[nt] = (min(nt * 16 + j, Lout - 1) * a.istride + 2) * CPi + 4 * q;
     const int iters = a.ntaps * groups;
     for (int mp = wave; mp * MT < mtiles; mp += nwave) {
         int mt[MT];
@@ -95,17 +99,15 @@ __device__ void conv_mfma(const ConvArgs a, const lds_f *in, int CPi, lds_f *out
 #pragma unroll
             for (int m = 0; m < MT; ++m) nxt2[m] = w[m][(size_t)pre * 64];
             const int off = (a.ioff0 + t * a.iostep) * CPi + g * 16;
-            float bv[4][NT];
+            f32x4 bv[NT];
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bv[c][nt] = in[base[nt] + off + 4 * c];
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = *(const lds_f4 *)(in + base[nt] + off);
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) acc[m][nt] = mfma16(av[m][c], bv[c][nt], acc[m][nt]);
+                    for (int m = 0; m < MT; ++m) acc[m][nt] = mfma16(av[m][c], bv[nt][c], acc[m][nt]);
             if (++g == groups) { g = 0; ++t; }
         }
         // D layout: column (position) = lane & 15, rows (channels) = 4*(lane >> 4) + r
@@ -129,8 +131,8 @@ __device__ void conv_mfma(const ConvArgs a, const lds_f *in, int CPi, lds_f *out
 
 // The same convolution with bf16 operands (BASELINE configs[4], "bf16 contractions"): v_mfma_f32_16x16x32_bf16, K-step = 32 input
 // channels of one tap.  img16: [Cout/16][ntaps][Cin/32][64 lanes][8 bf16]; lane (i = l & 15, kg = l >> 4), slot j ->
-// W_t[16 mt + i][32 g + 8 kg + j] (rounded to bf16 on the host).  The activations stay float32 in LDS; a lane reads its 8
-// consecutive channels with two ds_read_b128 and rounds them with four v_cvt_pk_bf16_f32.  Accumulation, bias and everything
+// W_t[16 mt + i][32 g + 4 kg + j] for j < 4, [32 g + 16 + 4 kg + j - 4] for j >= 4 (rounded to bf16 on the host).  The activations stay
+// float32 in LDS; a lane reads its two runs of 4 consecutive channels with two ds_read_b128 and rounds them with four v_cvt_pk_bf16_f32.  Accumulation, bias and everything
 // around the convolution are float32.
 typedef __bf16 bf16x8_u __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_u __attribute__((ext_vector_type(2)));
@@ -149,7 +151,7 @@ __device__ void conv_mfma_bf16(const ConvArgs a, const lds_f *in, int CPi, lds_f
     const int groups = a.cin >> 5, mtiles = a.cout >> 4;
     int base[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) base[nt] = (min(nt * 16 + j, Lout - 1) * a.istride + 2) * CPi + 8 * q;
+    for (int nt = 0; nt < NT; ++nt) base[nt] = (min(nt * 16 + j, Lout - 1) * a.istride + 2) * CPi + 4 * q;
     const int iters = a.ntaps * groups;
     for (int mp = wave; mp * MT < mtiles; mp += nwave) {
         int mt[MT];
@@ -181,7 +183,7 @@ __device__ void conv_mfma_bf16(const ConvArgs a, const lds_f *in, int CPi, lds_f
             bf16x8_u bv[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const f32x4 lo = *(const lds_f4 *)(in + base[nt] + off), hi = *(const lds_f4 *)(in + base[nt] + off + 4);
+                const f32x4 lo = *(const lds_f4 *)(in + base[nt] + off), hi = *(const lds_f4 *)(in + base[nt] + off + 16);
                 const u32x4_u pk = {pack2_bf16(lo[0], lo[1]), pack2_bf16(lo[2], lo[3]), pack2_bf16(hi[0], hi[1]), pack2_bf16(hi[2], hi[3])};
                 bv[nt] = __builtin_bit_cast(bf16x8_u, pk);
             }
@@ -301,7 +303,7 @@ struct Bufs { lds_f *A, *B, *C, *D, *film, *cond, *tmp, *xin; int bf16; };
 // ConditionalResidualBlock1D.forward (diffusion_utils.py:101-120): x(in, cin channels) -> out; t1 scratch.
 // `out` may be a wider buffer (row stride CPout >= cout + 4): the concat buffer of the up path.
 __device__ void res_block(const UnetRes &w, const lds_f *in, lds_f *t1, lds_f *out, int CPout, int L, int cond_dim, int groups, const Bufs s) {
-    const int CPi = w.cin + 4, CPo = w.cout + 4;
+    const int CPi = w.cin + UNET_ROW_PAD, CPo = w.cout + UNET_ROW_PAD;
     matvec(w.cond_wt, w.cond_b, s.cond, s.film, cond_dim, 2 * w.cout);     // cond_encoder: Mish already applied to s.cond
     if (w.cin == 1) {   // first block: single input channel held in s.xin[pos + 2]; conv k5 and the 1x1 residual on the VALU
         for (int i = threadIdx.x; i < L * w.cout; i += blockDim.x) {
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(512) void unet_kernel(const UnetParams *__restrict_
     for (int i = t; i < L + 4; i += blockDim.x) s.xin[i] = (i >= 2 && i < 2 + L) ? sample[(size_t)b * L + i - 2] : 0.f;
     __syncthreads();
 
-    const int CP0 = p.d0 + 4, CP1 = p.d1 + 4, CPcat = 2 * p.d1 + 4;
+    const int CP0 = p.d0 + UNET_ROW_PAD, CP1 = p.d1 + UNET_ROW_PAD, CPcat = 2 * p.d1 + UNET_ROW_PAD;
     res_block(p.res[0], nullptr, s.B, s.C, CP0, L, p.dsed, G, s);     // down0.0   1 -> d0
     res_block(p.res[1], s.C, s.B, s.D, CP0, L, p.dsed, G, s);         // down0.1   d0 -> d0   (its skip is never consumed, :264-278)
     conv<0>(conv_args(p.down_w, p.down_b, p.d0, p.d0, 3, 1, 2, p.bf16), s.D, CP0, s.B, CP0, L2);       // Downsample1d (:42)
@@ -425,8 +427,8 @@ int unet_launch(const UnetParams &p, const UnetParams *p_dev, const float *sampl
     DGDM_REQUIRE(2 * L2 == L, DGDM_EINVAL, "U-Net needs an even number of control points (got %d): the skip concat of the reference "
                  "requires ConvTranspose1d(4,2,1) to restore L", L);
     DGDM_REQUIRE(L <= 64, DGDM_EINVAL, "U-Net kernel supports up to 64 control points (got %d)", L);
-    const int bufS = std::max((L + 4) * (p.d0 + 4), (L2 + 4) * (p.d1 + 4));
-    const int bufA = std::max((L + 4) * (p.d0 + 4), (L2 + 4) * (2 * p.d1 + 4));
+    const int bufS = std::max((L + 4) * (p.d0 + UNET_ROW_PAD), (L2 + 4) * (p.d1 + UNET_ROW_PAD));
+    const int bufA = std::max((L + 4) * (p.d0 + UNET_ROW_PAD), (L2 + 4) * (2 * p.d1 + UNET_ROW_PAD));
     const size_t lds_floats = (size_t)bufA + 3 * (size_t)bufS + 2 * p.cmax + p.dsed + 4 * p.dsed + (L + 4) + 16;
     DGDM_REQUIRE(lds_floats * 4 <= 160 * 1024, DGDM_EINVAL, "U-Net activations (%zu B) exceed the 160 KiB LDS", lds_floats * 4);
     static bool attr_set = false;

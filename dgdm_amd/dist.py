@@ -135,7 +135,7 @@ def gather_rows(local: torch.Tensor, n_items: int, group=None) -> torch.Tensor:
 
 
 def guided_multi_object_sharded(unet, spec: GuidanceSpec, sched, mode: str, noise: torch.Tensor, objects: torch.Tensor, opt_obj: str,
-                                starts=None, group=None, build: Optional[Callable] = None) -> torch.Tensor:
+                                starts=None, group=None, build: Optional[Callable] = None, on_step=None) -> torch.Tensor:
     """``sampler.guided_multi_object`` (generator/diffusion.py:637-647: ONE chain whose step uses the mean of n_obj cond_fn
     gradients) with the objects block-partitioned over the ranks.  Unlike the per-object chains this loop has a real exchange
     step: every denoise step the ranks all-gather their objects' gradients [n_obj, B, L] (a few KB over RCCL) and then all take
@@ -154,7 +154,7 @@ def guided_multi_object_sharded(unet, spec: GuidanceSpec, sched, mode: str, nois
     objectives = [engine.make_objective(opt_obj, k) for k in range(len(mine))]
     scale = sampler.classifier_scale(mode, opt_obj, multi=True)
     x = noise.reshape(B, L).contiguous().to(torch.float32)
-    for t in sched.timesteps:
+    for i, t in enumerate(sched.timesteps):
         t = int(t)
         eps = unet.forward(x.reshape(B, L, 1), torch.full((B,), t, dtype=torch.int32, device=x.device)).reshape(B, L)
         st = None
@@ -167,4 +167,6 @@ def guided_multi_object_sharded(unet, spec: GuidanceSpec, sched, mode: str, nois
             g = torch.zeros((0, B, L), dtype=torch.float32, device=x.device)
         g = gather_rows(g, n_obj, group)
         x = engine.ddim_guided_step(x, eps, g, n_obj, sched.coefficients(t), scale)
+        if on_step is not None:
+            on_step(i, x.reshape(B, L, 1))
     return x.reshape(B, L, 1)

@@ -7,9 +7,12 @@ What is kept: constructor keywords, ``noise_pred_net`` / ``ema_nets`` naming (so
 
 * the objects of ``guided_sample`` are advanced as one batch of chains (dgdm_amd/sampler.py) instead of one after
   the other; the FPS start draws are replayed in the reference's order so the numbers are the same;
-* the MuJoCo / Ray evaluation and wandb tables that follow each loop in the reference (:577-619, :678-709) are not
-  part of this package: the final samples are returned and, if ``save_dir`` is given, written as ``.npy`` where
-  the reference starts its simulation (out of scope);
+* the MuJoCo / Ray simulation that follows each loop in the reference (:577-580, :678-683) is not part of this package
+  (SURVEY.md §2 #10): the final samples are returned and, if ``save_dir`` is given, written as ``.npy`` where the reference
+  starts its simulation.  The rest of the harness is here (``artefacts.py``): the per-step PNG dumps (``val_vis/``,
+  ``val_vis_noise/``, ``vis_guided/<tag>/allobj_*``) and - when a simulator callable with the reference's ``sim_test_batch``
+  signature is given as ``Diffusion(simulator=...)`` - the unguided / guided / multi-object tables, written as JSON under
+  ``tables/`` where the reference calls ``logger.log_table`` (a wandb logger passed as ``table_logger`` receives them too);
 * Lightning is not required: the class is a plain ``nn.Module`` with the few hooks ``generator/train.py`` uses.
 """
 from __future__ import annotations
@@ -23,6 +26,7 @@ import torch.nn as nn
 
 from .. import dist as ddist
 from .. import engine, sampler
+from . import artefacts
 from ..dynamics._backed import HipBacked
 from ..dynamics import metrics
 from ..dynamics.metrics import metric2objective, objective_directions     # noqa: F401  (metric2objective: reference import)
@@ -40,12 +44,18 @@ class Diffusion(nn.Module):
                  action_groups: Optional[Dict[str, slice]] = None, float32_matmul_precision: str = "high", class_cond: bool = False,
                  classifier_model=None, grid_size: int = 360, num_pos: int = 5, object_vertices: Optional[torch.Tensor] = None,
                  object_ids: Optional[List[int]] = None, num_cpus: int = 32, sub_batch_size: int = 1024, pts_x_dim: int = 7,
-                 pts_z_dim: int = 3, render_video: bool = False, seed: int = 0, contraction_dtype: str = "f32"):
+                 pts_z_dim: int = 3, render_video: bool = False, seed: int = 0, contraction_dtype: str = "f32", simulator=None,
+                 render_plots: bool = True, table_logger=None):
         super().__init__()
         if contraction_dtype not in ("f32", "bf16"):
             raise ValueError(f"contraction dtype {contraction_dtype!r} not supported")
         # not a reference argument: 'bf16' runs the trunk / eps-net / sa3 contractions with bf16 operands
         self.contraction_dtype = contraction_dtype
+        # not reference arguments either: the simulator callable (sim_test_batch / sim_test_batch_3d signature) that feeds the
+        # harness tables, whether the per-step PNGs are drawn (they cost a device->host copy per step, as in the reference), and
+        # an optional wandb-style logger that receives the tables besides the JSON files
+        self.simulator, self.render_plots, self.table_logger = simulator, render_plots, table_logger
+        self.current_epoch = 0
         if mode not in ("point", "point_3d"):
             raise ValueError('model type not supported')
         self.ema_nets = nn.ModuleDict({"noise_pred_net": noise_pred_net})
@@ -220,24 +230,51 @@ class Diffusion(nn.Module):
             g = self._guidance_for(batch_size, ori_range, objs, n)
             out = sampler.guided_chains(self._net(), g, self.noise_scheduler, self.mode, noise.to(self.device), chains, unguided=ug)
         if ddist.world_rank()[1] == 0:
-            self._emit(save_dir, 'vis_guided', f"{opt_obj}_orirange={ori_range[0]:.3f}_{ori_range[1]:.3f}", out,
-                       [str(self.object_ids[i]) if self.object_ids is not None else str(i) for i in range(n)])
+            tag = f"{opt_obj}_orirange={ori_range[0]:.3f}_{ori_range[1]:.3f}"
+            ids = [self.object_ids[i] if self.object_ids is not None else i for i in range(n)]
+            self._emit(save_dir, 'vis_guided', tag, out, [str(i) for i in ids])
+            if self.simulator is not None and save_dir:                  # :577-619
+                arr = out.detach().cpu().numpy()
+                sims = [self.simulator(arr[i], [ids[i]], os.path.join(save_dir, 'vis_guided', tag, str(ids[i])), render=self.render_video,
+                                       num_cpus=self.num_cpus, num_rot=int((ori_range[1] - ori_range[0]) * 180), ori_range=ori_range) for i in range(n)]
+                artefacts.guided_table(self, self._tables(save_dir), sims, opt_obj, ori_range)
         return out
 
     # ------------------------------------------------------------------ a2
     def guided_sample_multi_object(self, batch_idx, batch_size, noise, save_dir, opt_obj='rotate', ori_range=[-1.0, 1.0]):
         objs = torch.as_tensor(self.object_vertices)
+        tag = f"{opt_obj}_orirange={ori_range[0]:.3f}_{ori_range[1]:.3f}"
+        rank0 = ddist.world_rank()[1] == 0
+        on_step = None
+        if save_dir and self.render_plots and rank0:                     # per-step, per-gripper PNGs (:648-674)
+            def on_step(i, x):
+                for gi, row in enumerate(x.detach().cpu().numpy()):
+                    artefacts.plot_fingers(os.path.join(save_dir, 'vis_guided', tag, 'allobj_%d_%d.png' % (batch_idx * batch_size + gi, i)),
+                                           row[:, 0], self.mode, self.pts_x_dim, self.pts_z_dim, stacked=False)
         if ddist.world_rank()[0] > 1:       # objects over ranks, gradients all-gathered every step (dist.guided_multi_object_sharded)
             out = ddist.guided_multi_object_sharded(self._net(), self._spec(batch_size, ori_range, objs.shape[1]), self.noise_scheduler, self.mode,
                                                     noise.to(self.device), objs, opt_obj,
-                                                    build=lambda o, k: self._guidance_for(batch_size, ori_range, o.detach().cpu(), k))
+                                                    build=lambda o, k: self._guidance_for(batch_size, ori_range, o.detach().cpu(), k), on_step=on_step)
         else:
             g = self._guidance_for(batch_size, ori_range, objs, objs.shape[0])
             out = sampler.guided_multi_object(self._net(), g, self.noise_scheduler, self.mode, noise.to(self.device),
-                                              list(range(objs.shape[0])), opt_obj)
-        if ddist.world_rank()[1] == 0:
-            self._emit(save_dir, 'vis_guided', f"{opt_obj}_orirange={ori_range[0]:.3f}_{ori_range[1]:.3f}", out[None], ["allobj"])
+                                              list(range(objs.shape[0])), opt_obj, on_step=on_step)
+        if rank0:
+            self._emit(save_dir, 'vis_guided', tag, out[None], ["allobj"])
+            if self.simulator is not None and save_dir:                  # :675-709: every gripper on all objects
+                arr = out.detach().cpu().numpy()
+                ids = list(self.object_ids) if self.object_ids is not None else list(range(objs.shape[0]))
+                sims = [self.simulator(arr[i:i + 1], ids, os.path.join(save_dir, 'vis_guided', tag, 'allobj_%d' % i), render=self.render_video,
+                                       num_cpus=self.num_cpus, num_rot=int((ori_range[1] - ori_range[0]) * 180), ori_range=ori_range)
+                        for i in range(arr.shape[0])]
+                artefacts.multi_object_table(self, self._tables(save_dir), sims, len(ids), opt_obj, ori_range)
         return out
+
+    def _object_ids(self) -> list:
+        return list(self.object_ids) if self.object_ids is not None else list(range(torch.as_tensor(self.object_vertices).shape[0]))
+
+    def _tables(self, save_dir) -> "artefacts.TableLog":
+        return artefacts.TableLog(save_dir, self.table_logger)
 
     def _emit(self, save_dir, sub, tag, samples, names):
         """Where the reference hands `sample.cpu().numpy()` to its simulator (:578-580, :675-683), the samples are kept and saved."""
@@ -273,24 +310,51 @@ class Diffusion(nn.Module):
         sample = self.noise_scheduler.add_noise(data, noise, ts)
         net = self._net()
         noise_pred_loss = 0.0
-        for t in self.noise_scheduler.timesteps:
+        rank0 = ddist.world_rank()[1] == 0
+        plots = bool(self.save_dir) and self.render_plots and rank0
+        for i, t in enumerate(self.noise_scheduler.timesteps):
             eps = net.forward(sample, torch.full((B,), int(t), device=dev))
             noise_pred_loss += float(torch.mean((eps - noise) ** 2))
             sample = self.noise_scheduler.step(eps, t, sample).prev_sample
+            if plots and batch_idx == 0:                                 # val_vis/<epoch>_<step>.png, sample 0 (:203-231)
+                artefacts.plot_fingers(os.path.join(self.save_dir, 'val_vis', '%d_%d.png' % (self.current_epoch, i)),
+                                       sample[0, :, 0].detach().cpu().numpy(), self.mode, self.pts_x_dim, self.pts_z_dim, stacked=True)
         stats = {"val/noise pred loss": noise_pred_loss / self.num_inference_steps,
                  "val/denoise loss": float(torch.mean((sample - data) ** 2)),
                  "val/accuracy": float(torch.mean((torch.abs(sample - data) < 0.01).float()))}
         out: Dict[str, Any] = {"stats": stats}
         if batch_idx != 0:
             return out
-        unguided = sampler.unguided_sample(net, self.noise_scheduler, noise)
-        self._emit(self.save_dir, 'val_vis_noise', 'unguided', unguided[None], ["unguided"])
+        imgs: List[str] = []                                             # last-step PNG of every gripper (:273, :292)
+        last = len(self.noise_scheduler.timesteps) - 1
+
+        def on_step(i, x, eps):                                          # val_vis_noise/<epoch>_<gripper>_<step>.png (:258-292)
+            for gi, row in enumerate(x.detach().cpu().numpy()):
+                f = artefacts.plot_fingers(os.path.join(self.save_dir, 'val_vis_noise', '%d_%d_%d.png' % (self.current_epoch, batch_idx * B + gi, i)),
+                                           row[:, 0], self.mode, self.pts_x_dim, self.pts_z_dim, stacked=False)
+                if i == last:
+                    imgs.append(f)
+        unguided = sampler.unguided_sample(net, self.noise_scheduler, noise, on_step=on_step if plots else None)
+        if rank0:
+            self._emit(self.save_dir, 'val_vis_noise', 'unguided', unguided[None], ["unguided"])
         out["unguided"] = unguided
         if self.class_cond:
             if self.object_vertices is None:
                 raise ValueError('object vertices not provided')
+            sim_unguided, tables = None, self._tables(self.save_dir)
+            if rank0 and self.save_dir:
+                if self.simulator is not None:                           # one roll-out of the unguided grippers on every object (:301-305)
+                    sim_unguided = self.simulator(unguided.detach().cpu().numpy(), self._object_ids(), os.path.join(self.save_dir, 'val_vis_noise'),
+                                                  render=self.render_video, num_cpus=self.num_cpus)
+                else:
+                    tables.skipped("no simulator callable was given to Diffusion(simulator=...): the objective tables of "
+                                   "generator/diffusion.py:304-336, 592-619, 697-709 need simulator roll-outs (dynamics/sim_test_mj*.py)")
             for opt_obj in OBJECTIVE_SWEEP:
                 rng = [-1.0, 1.0]
+                if sim_unguided is not None:
+                    if not imgs:
+                        imgs = [None] * B
+                    artefacts.unguided_table(self, tables, sim_unguided, imgs, len(self._object_ids()), B, opt_obj, rng, self.mode == 'point_3d')
                 if opt_obj != 'convergence':
                     out[f"multi/{opt_obj}"] = self.guided_sample_multi_object(batch_idx, B, noise, self.save_dir, opt_obj=opt_obj, ori_range=rng)
                 out[f"guided/{opt_obj}"] = self.guided_sample(batch_idx, B, noise, self.save_dir, opt_obj=opt_obj, ori_range=rng,

@@ -86,14 +86,17 @@ def pair_stream(num_points: int, sub_batch_size: int, seed: int, pair_index: int
     return StartStream(num_points, sub_batch_size, generator=g)
 
 
-def unguided_sample(unet: Unet1d, sched: DDIMScheduler, x: torch.Tensor) -> torch.Tensor:
-    """S x [eps-net ; DDIM step]  (generator/diffusion.py:193-201, :249-256)."""
+def unguided_sample(unet: Unet1d, sched: DDIMScheduler, x: torch.Tensor, on_step=None) -> torch.Tensor:
+    """S x [eps-net ; DDIM step]  (generator/diffusion.py:193-201, :249-256).  on_step(i, x_i, eps_i): the harness's per-step hook
+    (plots, noise-prediction loss); it forces a device->host copy per step, as the reference's own plotting does."""
     B = x.shape[0]
     x = x.clone()
-    for t in sched.timesteps:
+    for i, t in enumerate(sched.timesteps):
         ts = torch.full((B,), int(t), dtype=torch.int32, device=x.device)
         eps = unet.forward(x, ts)
         x = engine.ddim_guided_step(x, eps, None, 0, sched.coefficients(int(t)), 0.0)
+        if on_step is not None:
+            on_step(i, x, eps)
     return x
 
 
@@ -201,7 +204,7 @@ def guided_chains(unet: Unet1d, guid: Guidance, sched: DDIMScheduler, mode: str,
 
 
 def guided_multi_object(unet: Unet1d, guid: Guidance, sched: DDIMScheduler, mode: str, noise: torch.Tensor,
-                        object_indices: Sequence[int], opt_obj: str, starts: Optional[StartStream] = None) -> torch.Tensor:
+                        object_indices: Sequence[int], opt_obj: str, starts: Optional[StartStream] = None, on_step=None) -> torch.Tensor:
     """``Diffusion.guided_sample_multi_object`` loop (:637-647): one chain, gradient = mean over the objects."""
     n_obj, (B, L, _) = len(object_indices), noise.shape
     dev = noise.device
@@ -213,13 +216,15 @@ def guided_multi_object(unet: Unet1d, guid: Guidance, sched: DDIMScheduler, mode
         starts = starts or StartStream(guid.cfg.num_object_points, guid.cfg.sub_batch_size)
     scale = classifier_scale(mode, opt_obj, multi=True)
     x = noise.reshape(B, L).contiguous().to(torch.float32)
-    for t in sched.timesteps:
+    for i, t in enumerate(sched.timesteps):
         t = int(t)
         ts = torch.full((B,), t, dtype=torch.int32, device=dev)
         eps = unet.forward(x.reshape(B, L, 1), ts).reshape(B, L)
         st = np.concatenate([starts.call(guid.rows) for _ in object_indices]) if is3d else None      # object after object (:641-643)
         g = guid.grad(x.reshape(1, B, L).expand(n_obj, -1, -1).contiguous(), t, objectives, None, st)
         x = engine.ddim_guided_step(x, eps, g, n_obj, sched.coefficients(t), scale)
+        if on_step is not None:                              # the harness's per-step plots (generator/diffusion.py:648-674)
+            on_step(i, x.reshape(B, L, 1))
     return x.reshape(B, L, 1)
 
 

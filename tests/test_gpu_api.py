@@ -161,6 +161,13 @@ def test_cli_entry_point(dev, tmp_path):
     assert len(results) == 2 and "guided/rotate" in results[0] and results[0]["guided/rotate"].shape == (6, 2, 42, 1)
     assert os.path.exists(os.path.join(tmp_path, "vis_guided", "rotate_orirange=-1.000_1.000", "BABY_CAR.npy"))
     assert float(results[0]["guided/rotate"].abs().max()) <= 1.0 + 1e-6
+    # the harness's artefact tree (generator/diffusion.py:203-231, 258-292, 648-674): per-step PNGs under the reference's names
+    for rel in ("val_vis/0_0.png", "val_vis/0_4.png", "val_vis_noise/0_0_0.png", "val_vis_noise/0_1_4.png",
+                "vis_guided/rotate_orirange=-1.000_1.000/allobj_0_0.png", "vis_guided/shift_up_orirange=-1.000_1.000/allobj_1_4.png"):
+        f = os.path.join(tmp_path, rel)
+        assert os.path.exists(f) and open(f, "rb").read(4) == b"\x89PNG", rel
+    assert not os.path.exists(os.path.join(tmp_path, "vis_guided", "convergence_orirange=-1.000_1.000", "allobj_0_0.png"))      # :337: no multi-object loop
+    assert "simulator" in open(os.path.join(tmp_path, "tables", "SKIPPED.txt")).read()          # tables need simulator roll-outs
     # the decoded finger surfaces are written next to the control values and agree with the CPU decode of those values
     from oracle import finger_decode_oracle as dec
     d = os.path.join(tmp_path, "vis_guided", "rotate_orirange=-1.000_1.000")
@@ -190,3 +197,35 @@ def test_checkpoint_formats(dev, tmp_path):
     _, synthetic = train(parse(shlex.split(common)))
     for k in ("unguided", "guided/shift_up", "multi/rotate"):
         assert torch.equal(from_files[0][k], synthetic[0][k]), k
+
+
+def test_harness_tables_with_a_simulator(dev, tmp_path):
+    """With a simulator callable (the reference's sim_test_batch signature; here a stand-in that returns synthetic metrics)
+    validation_step writes the three table families where the reference calls logger.log_table."""
+    import json
+    from tests.test_artefacts import synth_metrics
+    calls = []
+
+    def simulator(samples, object_ids, save_dir, render=False, num_cpus=1, **kw):
+        n = len(samples) * len(object_ids)
+        calls.append((np.asarray(samples).shape, list(object_ids), save_dir, kw))
+        return ([f"{save_dir}/g{i}.png" for i in range(n)], [synth_metrics(7 + i) for i in range(n)], [f"p{i}" for i in range(n)],
+                [f"px{i}" for i in range(n)], [f"py{i}" for i in range(n)], [f"f{i}" for i in range(n)], [[] for _ in range(n)],
+                [f"{save_dir}/d{i}" for i in range(n)])
+
+    B, G, P, L, nv = 2, 4, 2, 14, 100
+    objs = torch.stack([synth.synth_object_2d(i, nv) for i in range(2)])
+    d, _ = _diffusion('point', dev, B, G, P, L, objs)
+    d.simulator, d.save_dir, d.render_plots = simulator, str(tmp_path), False
+    data = synth.synth_noise(3, B, L).clamp(-1, 1)
+    out = d.validation_step(data, 0)
+    assert "guided/rotate" in out and out["guided/rotate"].shape == (2, B, L, 1)
+    tables = sorted(os.listdir(tmp_path / "tables"))
+    assert len([t for t in tables if t.startswith("val__unguided_sample__")]) == 12
+    assert len([t for t in tables if t.startswith("val__guided_sample__allobj_")]) == 11          # no multi-object chain for 'convergence'
+    assert len([t for t in tables if t.startswith("val__guided_sample__") and "allobj" not in t]) == 12
+    t = json.load(open(tmp_path / "tables" / "val__guided_sample__rotate_orirange=-1.000_1.000.json"))
+    assert t["columns"][0] == "object_idx" and t["data"][0][0] == -1
+    # the simulator saw: the unguided grippers on all objects once, then per objective every object's chain and every multi-object gripper
+    assert calls[0][0] == (B, L, 1) and calls[0][1] == [0, 1]
+    assert sum(1 for c in calls if c[0] == (1, L, 1)) == 11 * B and sum(1 for c in calls if len(c[1]) == 1) == 12 * 2
