@@ -56,6 +56,7 @@ struct DgdmGuidance {
     hipStream_t bstream[NBUILD] = {nullptr, nullptr, nullptr}, fstream = nullptr;    // fstream: sa2's FPS table, beside the builds
     hipEvent_t bev[NBUILD] = {nullptr, nullptr, nullptr}, bstart = nullptr, fstart = nullptr, fdone = nullptr;
     DevBuf V, genc, atab, chainbias, timepart, ttmp, partial, objdev, objidx, xobj, xobj16, starts, order, xchains, todo, groupoff;
+    int l2_gather_mode = 0;         // test hook (mode 4): build the sa2 features of the crowded centres with l2_kernel's global gathers
     int xobj_mode = 0;              // test hook: 0 = group kernel where possible, 2 = per-row table kernel (xobj_fast_kernel)
     int n_objects = 0;
     bool force_slow_xobj = false;   // test hook: always run the per-row FPS kernel
@@ -162,6 +163,7 @@ extern "C" int dgdm_guidance_debug_fps_path(DgdmGuidance *g, int force_per_row, 
     DGDM_REQUIRE(g, DGDM_EINVAL, "dgdm_guidance_debug_fps_path: null handle");
     g->force_slow_xobj = force_per_row == 1;            // 1: every row runs its own FPS; 2: per-row table kernel; 0: default (group kernel)
     g->xobj_mode = force_per_row == 2 ? 2 : 0;
+    g->l2_gather_mode = force_per_row == 4 ? 1 : 0;     // takes effect at the next dgdm_guidance_set_objects
     if (out_fast_ok)
         for (int i = 0; i < g->n_objects && i < (int)g->tables.size(); ++i) out_fast_ok[i] = g->tables[i]->fast_ok ? 1 : 0;
     return DGDM_OK;
@@ -199,7 +201,7 @@ int DgdmGuidance::build_object(int oi, int slot, hipStream_t s) {
     // rows (the temporaries tY / tL2 are simply used at half size); float32 mode: everything float32
     if ((rc = pn_pairs(xyz, N, tU.as<float>(), w, tPairs.as<int>(), tOff.as<int>(), tY.as<float>(), bf16 ? tY.as<uint32_t>() : nullptr, s))) return rc;   // T4
     if ((rc = pn_l2(xyz, N, w, t.fps1, vlist.as<int>(), N, tY.as<float>(), tL2.as<float>(), t.clist.as<int>(), t.clist.as<int>() + N,
-                    tOff.as<int>(), tRank.as<short>(), bf16, s))) return rc;                                               // T5
+                    tOff.as<int>(), tRank.as<short>(), bf16, s, l2_gather_mode ? 0 : 1))) return rc;                       // T5
     if (bf16) {
         if ((rc = pn_z16(xyz, N, N, w, tL2.as<uint32_t>(), t.Z.as<float>(), z16, t.clist.as<int>(), t.clist.as<int>() + N, s))) return rc;          // T6
     } else if ((rc = pn_z(xyz, N, N, w, tL2.as<float>(), t.Z.as<float>(), z16, t.clist.as<int>(), t.clist.as<int>() + N, s))) return rc;

@@ -65,8 +65,11 @@ int pn_crowd(const float *xyz, int N, const PnWeights &w, int *crowded, int *cli
              int *ncr_copy = nullptr);
 // Y16 (optional): write bf16 operand-order rows there INSTEAD of the float32 rows (bf16 mode)
 int pn_pairs(const float *xyz, int N, const float *U, const PnWeights &w, const int *pairs, const int *off, float *Y, uint32_t *Y16, hipStream_t s);
+// crowded_mode 1: the variants >= 1 of the crowded centres by l2c_kernel (needs vlist = identity: slot v = start index v, and K <= 255
+// points per ball); 0: l2_kernel throughout
 int pn_l2(const float *xyz, int N, const PnWeights &w, const int *fps1, const int *vlist, int nv, const float *Y, float *L2,
-          const int *clist, const int *ncr, const int *off, const short *rank, bool bf16 /* Y and L2 are bf16 operand-order rows */, hipStream_t s);
+          const int *clist, const int *ncr, const int *off, const short *rank, bool bf16 /* Y and L2 are bf16 operand-order rows */, hipStream_t s,
+          int crowded_mode = 0);
 // bf16 mode T6: bf16 contraction from L2_16 rows; writes the float32 rows and their bf16 copy
 int pn_z16(const float *xyz, int N, int nv, const PnWeights &w, const uint32_t *L2_16, float *Z, uint32_t *Z16, const int *clist, const int *ncr,
            hipStream_t s);

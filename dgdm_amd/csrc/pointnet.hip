@@ -427,6 +427,148 @@ __global__ __launch_bounds__(256) void l2_kernel(const float *__restrict__ xyz, 
     *reinterpret_cast<float4 *>(L2 + ((size_t)slot * N + c) * 256 + lane * 4) = best;
 }
 
+// T5 for the crowded centres, all variants at once.  l2_kernel's mode 1 makes every (variant, crowded centre) pair gather its 64
+// rows of Y from L2: 511 variants x 64 KB per centre, ~5 GB of L2 traffic per object - the bound of the whole table build.  Here
+// one workgroup owns a crowded centre: its block of Y ([K][256] floats, K = points in the ball, 65..~190 on the shipped clouds) is
+// staged in LDS once (in feature chunks of F floats when K KB do not fit), the first-64 selections of all variants are computed
+// once (l2_select, kept as bytes: K <= 255) and every variant's max is taken out of LDS.  Same operands, same max: bit-identical
+// to l2_kernel.  Centres with K > 255 (none on 512-point clouds so far) are left to l2_kernel (kmax tells the host).
+constexpr int L2C_YBYTES = 120 * 1024, L2C_THREADS = 512;
+
+template <bool BF16, int LPR>
+__device__ __forceinline__ void l2c_reduce(const uint32_t *ych, const unsigned char *selv, int cnt, uint32_t *dst, int lane) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    constexpr int RPW = 64 / LPR;
+    const int sg = lane / LPR, fl = lane % LPR;
+    u4 best = {0u, 0u, 0u, 0u};                                   // Y >= 0 (ReLU): 0 is the identity of both max flavours
+    auto vmax4 = [](u4 a, u4 b) {
+        u4 o;
+        if (BF16) { o.x = pkmax_u16(a.x, b.x); o.y = pkmax_u16(a.y, b.y); o.z = pkmax_u16(a.z, b.z); o.w = pkmax_u16(a.w, b.w); }
+        else {
+            o.x = __float_as_uint(fmaxf(__uint_as_float(a.x), __uint_as_float(b.x))); o.y = __float_as_uint(fmaxf(__uint_as_float(a.y), __uint_as_float(b.y)));
+            o.z = __float_as_uint(fmaxf(__uint_as_float(a.z), __uint_as_float(b.z))); o.w = __float_as_uint(fmaxf(__uint_as_float(a.w), __uint_as_float(b.w)));
+        }
+        return o;
+    };
+    // selv is padded to 64 entries with its last member, so lane groups that run past cnt re-read a member (idempotent)
+    // lane group sg takes entries j + 4 sg .. j + 4 sg + 3: one dword of four selection bytes per step
+    for (int j = 0; j < cnt; j += 4 * RPW) {
+        const uint32_t four = *reinterpret_cast<const uint32_t *>(selv + min(j + 4 * sg, 60));
+        u4 v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = *reinterpret_cast<const u4 *>(ych + ((size_t)((four >> (8 * e)) & 255u) * LPR + fl) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) best = vmax4(best, v[e]);
+    }
+    if (RPW > 1) {
+#pragma unroll
+        for (int o = 32; o >= LPR; o >>= 1) {
+            u4 t;
+            t.x = __shfl_xor(best.x, o); t.y = __shfl_xor(best.y, o); t.z = __shfl_xor(best.z, o); t.w = __shfl_xor(best.w, o);
+            best = vmax4(best, t);
+        }
+    }
+    if (sg == 0) *reinterpret_cast<u4 *>(dst + fl * 4) = best;
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(L2C_THREADS, 1) void l2c_kernel(int N, const int *__restrict__ fps1 /*[N][512]*/, int nv, const uint32_t *__restrict__ Y,
+                                                             uint32_t *__restrict__ L2 /*[nv][N][W]*/, const int *__restrict__ clist,
+                                                             const int *__restrict__ ncr, const int *__restrict__ off,
+                                                             const short *__restrict__ rank) {
+    constexpr int W = BF16 ? 128 : 256;                           // dwords per row of Y / L2
+    extern __shared__ uint32_t l2c_lds[];
+    short *rks = reinterpret_cast<short *>(l2c_lds);              // [1024]
+    unsigned char *sel = reinterpret_cast<unsigned char *>(l2c_lds + 512);        // [512][64]
+    unsigned char *cnts = sel + 512 * 64;                         // [512]
+    uint32_t *ych = l2c_lds + 512 + 512 * 16 + 128;               // [K][F]
+    if ((int)blockIdx.x >= *ncr) return;
+    const int c = clist[blockIdx.x];
+    const int K = off[c + 1] - off[c];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = L2C_THREADS / 64;
+    for (int i = threadIdx.x; i < N; i += L2C_THREADS) rks[i] = rank[(size_t)c * N + i];
+    __syncthreads();
+    __shared__ int selw[L2C_THREADS / 64][64];
+    if (K > 255) {
+        // a ball with more points than a byte can index (never on the shipped 512-point clouds): gather from global memory as
+        // l2_kernel does, W / 64 dwords per lane
+        constexpr int D = W / 64;
+        for (int v = 1 + wave; v < nv; v += nwave) {
+            const int cnt = l2_select(rks, fps1 + (size_t)v * 512, 512, selw[wave], lane);
+            uint32_t best[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) best[d] = 0u;
+            for (int i = 0; i < cnt; ++i) {
+                const uint32_t *row = Y + ((size_t)off[c] + selw[wave][i]) * W + lane * D;
+#pragma unroll
+                for (int d = 0; d < D; ++d)
+                    best[d] = BF16 ? pkmax_u16(best[d], row[d]) : __float_as_uint(fmaxf(__uint_as_float(best[d]), __uint_as_float(row[d])));
+            }
+            uint32_t *dst = L2 + ((size_t)v * N + c) * W + lane * D;
+#pragma unroll
+            for (int d = 0; d < D; ++d) dst[d] = best[d];
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
+    // ---- the first-64 selection of every variant (slot v reads the cloud in the order fps1[v])
+    // (the 512 candidates of the next variant are loaded while the current one is scanned: alone in its CU's LDS, the workgroup
+    //  has only its own 8 waves to hide the L2 latency of those loads)
+    {
+        int pv[8], pn[8];
+        const int v0 = 1 + wave;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pn[i] = v0 < nv ? fps1[(size_t)v0 * 512 + 64 * i + lane] : 0;
+        for (int v = v0; v < nv; v += nwave) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pv[i] = pn[i];
+            const int vn = v + nwave;
+            if (vn < nv) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pn[i] = fps1[(size_t)vn * 512 + 64 * i + lane];
+            }
+            int cnt = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {                                 // l2_select on the registers
+                if (cnt >= 64) break;
+                const int r = rks[pv[i]];
+                const bool in = r >= 0;
+                const unsigned long long m = __ballot(in);
+                const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+                if (in && pos < 64) selw[wave][pos] = r;
+                cnt += __popcll(m);
+            }
+            cnt = min(cnt, 64);
+            __builtin_amdgcn_wave_barrier();
+            sel[(size_t)v * 64 + lane] = (unsigned char)selw[wave][lane < cnt ? lane : max(cnt - 1, 0)];   // a crowded centre has cnt = 64
+            if (lane == 0) cnts[v] = (unsigned char)cnt;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // ---- feature chunks of F dwords: F = 4 * LPR, the widest that holds K rows in the Y area
+    int lpr = W / 4;
+    while ((size_t)K * lpr * 16 > (size_t)L2C_YBYTES) lpr >>= 1;
+    const uint32_t *Yc = Y + (size_t)off[c] * W;
+    for (int f0 = 0; f0 < W; f0 += 4 * lpr) {
+        __syncthreads();                                          // selections written / previous chunk consumed
+        const int pieces = K * lpr;
+        for (int i = threadIdx.x; i < pieces; i += L2C_THREADS)
+            *reinterpret_cast<uint4 *>(ych + (size_t)i * 4) = *reinterpret_cast<const uint4 *>(Yc + (size_t)(i / lpr) * W + f0 + (i % lpr) * 4);
+        __syncthreads();
+        for (int v = 1 + wave; v < nv; v += nwave) {
+            uint32_t *dst = L2 + ((size_t)v * N + c) * W + f0;
+            const unsigned char *sv = sel + (size_t)v * 64;
+            const int cnt = cnts[v];
+            switch (lpr) {
+                case 64: if (!BF16) l2c_reduce<BF16, (BF16 ? 32 : 64)>(ych, sv, cnt, dst, lane); break;
+                case 32: l2c_reduce<BF16, 32>(ych, sv, cnt, dst, lane); break;
+                case 16: l2c_reduce<BF16, 16>(ych, sv, cnt, dst, lane); break;
+                default: l2c_reduce<BF16, 8>(ych, sv, cnt, dst, lane); break;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ T6
 // Z[row][256] = ReLU(W3'[:,3:] L2[row] + W3'[:,0:3] xyz_c + b3'),  row = slot*N + c   (sa3, pointnet2.py:19)
 // mode 0: slot 0, all N centres.  mode 1: slots 1..nv-1, crowded centres only (work item k -> slot 1 + k / ncr, centre clist[k % ncr]).
@@ -978,9 +1120,32 @@ int pn_crowd(const float *xyz, int N, const PnWeights &w, int *crowded, int *cli
     return DGDM_OK;
 }
 
+int pn_l2c(int N, const int *fps1, int nv, const float *Y, float *L2, const int *clist, const int *ncr, const int *off, const short *rank, bool bf16,
+           hipStream_t s) {
+    static bool attr_set = false;
+    const size_t lds = (size_t)(512 + 512 * 16 + 128) * 4 + L2C_YBYTES;
+    if (!attr_set) {
+        DGDM_HIP_CHECK(hipFuncSetAttribute((const void *)l2c_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DGDM_HIP_CHECK(hipFuncSetAttribute((const void *)l2c_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    if (bf16) hipLaunchKernelGGL(l2c_kernel<true>, dim3(N), dim3(L2C_THREADS), lds, s, N, fps1, nv, reinterpret_cast<const uint32_t *>(Y),
+                                 reinterpret_cast<uint32_t *>(L2), clist, ncr, off, rank);
+    else hipLaunchKernelGGL(l2c_kernel<false>, dim3(N), dim3(L2C_THREADS), lds, s, N, fps1, nv, reinterpret_cast<const uint32_t *>(Y),
+                            reinterpret_cast<uint32_t *>(L2), clist, ncr, off, rank);
+    DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
+}
+
 int pn_l2(const float *xyz, int N, const PnWeights &w, const int *fps1, const int *vlist, int nv, const float *Y, float *L2,
-          const int *clist, const int *ncr, const int *off, const short *rank, bool bf16, hipStream_t s) {
+          const int *clist, const int *ncr, const int *off, const short *rank, bool bf16, hipStream_t s, int crowded_mode) {
     const dim3 g0(1, (N + 3) / 4), g1((unsigned)(((nv - 1 + 3) / 4) * ((N + 7) / 8) * 8));   // g1: worst case (every centre crowded)
+    if (crowded_mode == 1 && N <= 1024 && nv <= 512) {            // slot 0 here, slots >= 1 of the crowded centres by l2c_kernel
+        if (bf16) hipLaunchKernelGGL(l2_kernel<true>, g0, dim3(256), 0, s, xyz, N, w.r2sq, fps1, vlist, nv, Y, L2, 0, clist, ncr, off, rank);
+        else hipLaunchKernelGGL(l2_kernel<false>, g0, dim3(256), 0, s, xyz, N, w.r2sq, fps1, vlist, nv, Y, L2, 0, clist, ncr, off, rank);
+        DGDM_HIP_CHECK(hipGetLastError());
+        return nv > 1 ? pn_l2c(N, fps1, nv, Y, L2, clist, ncr, off, rank, bf16, s) : DGDM_OK;
+    }
     if (bf16) {
         hipLaunchKernelGGL(l2_kernel<true>, g0, dim3(256), 0, s, xyz, N, w.r2sq, fps1, vlist, nv, Y, L2, 0, clist, ncr, off, rank);
         if (nv > 1) hipLaunchKernelGGL(l2_kernel<true>, g1, dim3(256), 0, s, xyz, N, w.r2sq, fps1, vlist, nv, Y, L2, 1, clist, ncr, off, rank);

@@ -15,15 +15,19 @@ namespace dgdm {
 // Y[r][n] = act( sum_k X[r][k] * WT[k][n] + bias[n] + rowbias[r / rb_div][n] ) (+ Y[r][n] if accumulate)
 // WT is the weight stored [in][out] ("kn"), so a wave reads 64 consecutive outputs per k.
 // The k loop is an in-order fmaf chain per output, like a sequential dot product.
-template <int ACT>
+// RB rows per workgroup (8 for a handful of rows, 32 otherwise: every weight value loaded from L2 feeds RB fmas); the k loop
+// runs four at a time - four weight loads in flight, the activations as one ds_read_b128 per row - with the same ascending-k
+// fmaf order per output as a one-at-a-time loop, so the result does not depend on RB or the unrolling.
+template <int ACT, int RB>
 __global__ __launch_bounds__(256) void linear_kernel(const float *__restrict__ X, int ldx, const float *__restrict__ WT,
                                                      const float *__restrict__ bias, const float *__restrict__ rowbias,
                                                      int rb_div, float *__restrict__ Y, int ldy, int rows, int K, int N,
                                                      int accumulate) {
-    constexpr int RB = 8, KC = 128;
-    __shared__ float xs[RB][KC];
+    constexpr int KC = 128;
+    __shared__ __attribute__((aligned(16))) float xs[RB][KC];
     const int r0 = blockIdx.x * RB;
     const int n = blockIdx.y * 256 + threadIdx.x;
+    const int nn = min(n, N - 1);                       // out-of-range columns compute a copy of the last one and drop it
     float acc[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) acc[r] = 0.f;
@@ -35,11 +39,15 @@ __global__ __launch_bounds__(256) void linear_kernel(const float *__restrict__ X
             xs[r][k] = (r0 + r < rows && k < kc) ? X[(size_t)(r0 + r) * ldx + k0 + k] : 0.f;
         }
         __syncthreads();
-        if (n < N) {
-            for (int k = 0; k < kc; ++k) {
-                const float w = WT[(size_t)(k0 + k) * N + n];
+        const float *wp = WT + (size_t)k0 * N + nn;
+        for (int k = 0; k < kc; k += 4) {
+            // k + j >= kc only in the last group of a K that is not a multiple of 4: x is zero there, w is read from a valid row
+            const float w0 = wp[(size_t)k * N], w1 = wp[(size_t)min(k + 1, kc - 1) * N], w2 = wp[(size_t)min(k + 2, kc - 1) * N],
+                        w3 = wp[(size_t)min(k + 3, kc - 1) * N];
 #pragma unroll
-                for (int r = 0; r < RB; ++r) acc[r] = fmaf(xs[r][k], w, acc[r]);
+            for (int r = 0; r < RB; ++r) {
+                const float4 x = *reinterpret_cast<const float4 *>(&xs[r][k]);
+                acc[r] = fmaf(x.w, w3, fmaf(x.z, w2, fmaf(x.y, w1, fmaf(x.x, w0, acc[r]))));
             }
         }
     }
@@ -57,16 +65,23 @@ __global__ __launch_bounds__(256) void linear_kernel(const float *__restrict__ X
     }
 }
 
+template <int RB>
+static void linear_launch(const float *X, int ldx, const float *WT, const float *bias, const float *rowbias, int rb_div, float *Y, int ldy,
+                          int rows, int K, int N, int act, bool accumulate, hipStream_t s) {
+    dim3 grid((rows + RB - 1) / RB, (N + 255) / 256);
+    if (act == ACT_NONE)
+        hipLaunchKernelGGL((linear_kernel<ACT_NONE, RB>), grid, dim3(256), 0, s, X, ldx, WT, bias, rowbias, rb_div, Y, ldy, rows, K, N, (int)accumulate);
+    else if (act == ACT_RELU)
+        hipLaunchKernelGGL((linear_kernel<ACT_RELU, RB>), grid, dim3(256), 0, s, X, ldx, WT, bias, rowbias, rb_div, Y, ldy, rows, K, N, (int)accumulate);
+    else
+        hipLaunchKernelGGL((linear_kernel<ACT_SILU, RB>), grid, dim3(256), 0, s, X, ldx, WT, bias, rowbias, rb_div, Y, ldy, rows, K, N, (int)accumulate);
+}
+
 int linear(const float *X, int ldx, const float *WT, const float *bias, const float *rowbias, int rb_div, float *Y, int ldy,
            int rows, int K, int N, int act, bool accumulate, hipStream_t s) {
     if (rows <= 0) return DGDM_OK;
-    dim3 grid((rows + 7) / 8, (N + 255) / 256);
-    if (act == ACT_NONE)
-        hipLaunchKernelGGL(linear_kernel<ACT_NONE>, grid, dim3(256), 0, s, X, ldx, WT, bias, rowbias, rb_div, Y, ldy, rows, K, N, (int)accumulate);
-    else if (act == ACT_RELU)
-        hipLaunchKernelGGL(linear_kernel<ACT_RELU>, grid, dim3(256), 0, s, X, ldx, WT, bias, rowbias, rb_div, Y, ldy, rows, K, N, (int)accumulate);
-    else
-        hipLaunchKernelGGL(linear_kernel<ACT_SILU>, grid, dim3(256), 0, s, X, ldx, WT, bias, rowbias, rb_div, Y, ldy, rows, K, N, (int)accumulate);
+    if (rows >= 64) linear_launch<32>(X, ldx, WT, bias, rowbias, rb_div, Y, ldy, rows, K, N, act, accumulate, s);
+    else linear_launch<8>(X, ldx, WT, bias, rowbias, rb_div, Y, ldy, rows, K, N, act, accumulate, s);
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
 }

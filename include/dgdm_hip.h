@@ -228,7 +228,8 @@ enum {
 int dgdm_prof_enable(int on);
 /* Test hook (3-D): which kernels build the per-row PointNet++ embeddings - mode 0: default (one workgroup per
  * (chain, s1) group, the variant's crowded-centre rows staged in LDS); 1: every row runs its own FPS(128) instead of reading the
- * per-object table of order-independent sequences; 2: the per-row table kernel.  Results must be identical.  Also reports, per
+ * per-object table of order-independent sequences; 2: the per-row table kernel; 4: like 0, and the NEXT dgdm_guidance_set_objects builds
+ * the crowded centres' sa2 features with per-(variant, centre) global gathers instead of the LDS-staged kernel.  Results must be identical.  Also reports, per
  * object of the bank, whether the table path is admissible (out_fast_ok[n_objects], may be NULL).                          */
 int dgdm_guidance_debug_fps_path(DgdmGuidance *g, int mode, int32_t *out_fast_ok);
 int dgdm_prof_read(int64_t *launches, double *total_ms, double *total_flops);

@@ -352,6 +352,9 @@ def test_xobj_kernels_agree(dev):
         for mode in (0, 2, 1):
             gd.debug_fps_path(mode)
             res[mode] = gd.grad(x, 3, objectives, None, starts).cpu()
+        gd.debug_fps_path(4)                      # tables rebuilt with l2_kernel's per-(variant, centre) gathers instead of l2c_kernel
+        gd.set_objects(objs.to(dev))
+        res[4] = gd.grad(x, 3, objectives, None, starts).cpu()
         gd.debug_fps_path(0)
-        assert torch.equal(res[0], res[2]) and torch.equal(res[0], res[1]), dtype
+        assert torch.equal(res[0], res[2]) and torch.equal(res[0], res[1]) and torch.equal(res[0], res[4]), dtype
         assert float(res[0].abs().max()) > 0
