@@ -56,6 +56,9 @@ def parse():
                    help="arithmetic of the dynamics-trunk contractions: f32 (the parity path, default) or bf16 operands with f32 accumulation")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true", help="skip the secondary workload summary")
+    p.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                   help="collective backend for N > 1: nccl (= RCCL, one GPU per rank; the measured configuration) or gloo (launcher / sharding "
+                        "test on a box with fewer GPUs than ranks: ranks share the GPUs round-robin and the final gather goes through host memory)")
     return p.parse_args()
 
 
@@ -64,8 +67,9 @@ def spawn_ranks(n: int) -> int:
     """`--gpus N` without a launcher: N fresh rank processes of this script (children, never an exec of this process), one per
     GPU, rendezvous on 127.0.0.1.  The parent touches no GPU; rank 0's stdout is the benchmark's JSON line."""
     have = torch.cuda.device_count()          # counts devices without initialising the runtime
-    if have < n:
-        print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible", file=sys.stderr)
+    if have < n and "gloo" not in sys.argv[1:] and "--backend=gloo" not in sys.argv[1:]:
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible (RCCL needs one GPU per rank; --backend gloo shares them for a functional test)",
+              file=sys.stderr)
         return 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -172,7 +176,8 @@ def timed_loop(wl, steps, warmup, dist):
         objs, pre = prepared.pop(k)
         out = wl.run(k, objs, pre)
         if dist is not None and dist.get_world_size() > 1:
-            out = gather_pairs(out, wl.pairs * dist.get_world_size())   # the path's only collective: final samples
+            # the path's only collective: final samples; RCCL on device tensors, or host tensors for the gloo test mode
+            out = gather_pairs(out, wl.pairs * dist.get_world_size())
         if th is not None:
             th.join()
     torch.cuda.synchronize()
@@ -362,8 +367,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
+        if a.backend == "gloo":
+            local = local % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(a.backend, rank=rank, world_size=world)
         # ranks share the host: keep torch's CPU pools (input synthesis, FPS start draws) from oversubscribing it
         torch.set_num_threads(max(1, (os.cpu_count() or 8) // (2 * world)))
     _lib.device_init(local)
@@ -375,7 +382,7 @@ def main():
     engine.prof_enable(False)
     secs, _ = timed_loop(wl, a.steps, a.warmup, dist)
     if dist is not None:
-        tmax = torch.tensor([secs], device=dev)
+        tmax = torch.tensor([secs], device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         secs = float(tmax.item())
     if rank != 0:
@@ -387,6 +394,7 @@ def main():
         "metric": "guided samples/sec (full DDIM chain)", "value": samples / secs, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": secs / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.contraction, "data": "synthetic (random-init checkpoints, synthetic objects, seeded noise; SURVEY.md §8(d))",
+        **({"backend_note": "gloo test mode: ranks share GPUs, not a scaling measurement"} if (world > 1 and a.backend == "gloo") else {}),
         "config": {"workload": workload_text(a.workload, pairs), "pairs_per_gpu_per_step": pairs, "fingers_per_pair": wl.B,
                    "denoise_steps": wl.S, "rows_per_cond_fn": wl.rows, "cond_fn_per_chain_step": wl.n_obj},
         "ms_per_denoise_step": secs / a.steps / wl.S * 1e3,

@@ -29,11 +29,16 @@ def gather_pairs(local: torch.Tensor, n_items: int, group=None) -> torch.Tensor:
         return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     most = max(len(shard_range(n_items, r, world)) for r in range(world))
-    pad = torch.zeros((most,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[:local.shape[0]] = local
+    # RCCL ("nccl") gathers device tensors in place; under gloo (CPU tests, or ranks sharing a GPU) the payload goes through host memory
+    dev = local.device
+    via_host = local.is_cuda and dist.get_backend(group) != "nccl"
+    src = local.cpu() if via_host else local
+    pad = torch.zeros((most,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    pad[:src.shape[0]] = src
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad, group=group)
-    return torch.cat([bufs[r][:len(shard_range(n_items, r, world))] for r in range(world)], dim=0)
+    out = torch.cat([bufs[r][:len(shard_range(n_items, r, world))] for r in range(world)], dim=0)
+    return out.to(dev) if via_host else out
 
 
 def run_sharded(pairs: Sequence[Tuple[int, str]], run_local: Callable[[List[Tuple[int, str]]], torch.Tensor], group=None) -> torch.Tensor:
@@ -58,12 +63,32 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
-        if backend is None:
-            backend = "nccl" if torch.cuda.device_count() > 0 else "gloo"
-        if backend == "nccl":
+        if backend is None:       # DGDM_DIST_BACKEND=gloo: functional runs on a box with fewer GPUs than ranks (ranks then share the GPUs)
+            backend = os.environ.get("DGDM_DIST_BACKEND") or ("nccl" if torch.cuda.device_count() > 0 else "gloo")
+        if torch.cuda.device_count() > 0:
+            local = local % torch.cuda.device_count() if backend != "nccl" else local
             torch.cuda.set_device(local)
         dist.init_process_group(backend, rank=rank, world_size=world)
+    sync_start_stream_seed()
     return world, rank, local
+
+
+def sync_start_stream_seed(group=None) -> int:
+    """One seed for the torch CPU generator on every rank, so that all ranks walk the same FPS start stream
+    (``guided_chains_sharded``).  The reference never seeds that generator (its 3-D results differ from run to run);
+    DGDM_TORCH_SEED pins it - for one process as well - otherwise rank 0's own (random) initial seed is broadcast."""
+    env = os.environ.get("DGDM_TORCH_SEED")
+    seed = int(env) if env else int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        t = torch.tensor([seed], dtype=torch.int64)
+        if dist.get_backend(group) == "nccl":
+            t = t.cuda()
+        dist.broadcast(t, src=0, group=group)
+        seed = int(t.item())
+    elif not env:
+        return seed                      # single process, nothing pinned: leave the generator as torch initialised it
+    torch.manual_seed(seed)
+    return seed
 
 
 def shard_chains(chains: Sequence[Tuple[int, str]], rank: int, world: int):

@@ -77,7 +77,7 @@ def _objects(args, fingers_3d: bool):
 def train(args):
     if args.mode != 'test':
         raise NotImplementedError("only --mode=test (guided sampling) runs on the MI355X path; training is out of scope")
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    dev = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else int(os.environ.get("LOCAL_RANK", "0")))
     pts = finger_control_points(args.num_fingers, args.fingers_3d)
     max_y, min_y = (0.0, -0.1) if args.fingers_3d else (0.015, -0.045)
     dataset = GripperDataset(pts, 0.12, -0.12, max_y, min_y)

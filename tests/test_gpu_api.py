@@ -229,3 +229,51 @@ def test_harness_tables_with_a_simulator(dev, tmp_path):
     # the simulator saw: the unguided grippers on all objects once, then per objective every object's chain and every multi-object gripper
     assert calls[0][0] == (B, L, 1) and calls[0][1] == [0, 1]
     assert sum(1 for c in calls if c[0] == (1, L, 1)) == 11 * B and sum(1 for c in calls if len(c[1]) == 1) == 12 * 2
+
+
+def test_bench_spawns_ranks_itself(dev):
+    """`bench.py --gpus 2` without a launcher starts two rank processes, shards the pairs, gathers and reports n_gpus = 2.  On a
+    1-GPU box the two ranks share the GPU and use gloo for the final gather (RCCL needs one GPU per rank)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--pairs", "2", "--backend", "gloo",
+                        "--no-cpu-baseline", "--no-extra"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 1 and line["value"] > 0 and line["config"]["pairs_per_gpu_per_step"] == 2
+    # without the test backend the launcher refuses to put two RCCL ranks on one GPU
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env, timeout=120)
+        assert r.returncode != 0 and "GPU" in r.stderr
+
+
+def test_sharded_cli_matches_single_process(dev, tmp_path):
+    """The product entry under a launcher: two ranks (sharing this box's GPU, gloo for the gathers) shard the objects' chains and
+    the multi-object loop's gradient evaluations; every sample file equals the single-process run bit for bit - same FPS draws
+    (every rank walks the reference's one generator stream), same arithmetic."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    flags = ("--mode=test --classifier_guidance --fingers_3d --num_fingers=2 --batch_size=2 --grid_size=3 --num_pos=2 --sub_bs=5 "
+             "--object_max_num_vertices=512 --ctrlpts_dim=42 --num_train_timesteps=15 --num_inference_steps=5").split()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["DGDM_TORCH_SEED"] = "20241"       # the reference leaves torch's CPU generator (the FPS start draws) unseeded: pin it for the comparison
+    one, two = str(tmp_path / "one"), str(tmp_path / "two")
+    script = os.path.join(root, "generator", "train.py")
+    r = subprocess.run([sys.executable, script] + flags + [f"--save_dir={one}"], capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+                        script] + flags + [f"--save_dir={two}"], capture_output=True, text=True, env=dict(env, DGDM_DIST_BACKEND="gloo"), timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    files = sorted(os.path.relpath(os.path.join(d, f), one) for d, _, fs in os.walk(one) for f in fs if f.endswith(".npy"))
+    assert len(files) >= 12 * 7
+    bad = [(f, float(np.abs(np.load(os.path.join(one, f)) - np.load(os.path.join(two, f))).max())) for f in files
+           if not np.array_equal(np.load(os.path.join(one, f)), np.load(os.path.join(two, f)))]
+    if bad:
+        import json
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        json.dump({"n_files": len(files), "bad": bad}, open(os.path.join(root, "gpurun_out", "sharded_bad.json"), "w"))
+    assert not bad, (len(bad), len(files), bad[:4])
