@@ -70,6 +70,7 @@ PROTOTYPES = {
     "dgdm_prof_enable": (C.c_int, [C.c_int]),
     "dgdm_guidance_debug_fps_path": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32)]),
     "dgdm_debug_pointnet_indices": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dgdm_guidance_debug_partials": (C.c_int, [_P, C.c_int, _P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P]),
     "dgdm_prof_read_stage": (C.c_int, [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dgdm_prof_read": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }

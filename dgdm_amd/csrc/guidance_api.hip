@@ -168,6 +168,17 @@ extern "C" int dgdm_guidance_debug_fps_path(DgdmGuidance *g, int force_per_row, 
         for (int i = 0; i < g->n_objects && i < (int)g->tables.size(); ++i) out_fast_ok[i] = g->tables[i]->fast_ok ? 1 : 0;
     return DGDM_OK;
 }
+// Test hook: the per-tile partial sums of d objective / d z1 the last dgdm_dyn{2,3}d_guidance_grad call left behind
+// ([n_chains * B * tiles_per_b][W1], tile = (chain * B + b) * tiles_per_b + cell tile; a tile is 32 consecutive pose cells of one finger).
+extern "C" int dgdm_guidance_debug_partials(DgdmGuidance *g, int n_chains, float *out_dev, int32_t *tiles_per_finger, int32_t *width, void *stream) {
+    DGDM_REQUIRE(g && n_chains > 0 && n_chains <= g->cfg.max_chains, DGDM_EINVAL, "dgdm_guidance_debug_partials: bad argument");
+    if (tiles_per_finger) *tiles_per_finger = g->tiles_per_b;
+    if (width) *width = g->m->W1;
+    if (out_dev)
+        DGDM_HIP_CHECK(hipMemcpyAsync(out_dev, g->partial.p, (size_t)n_chains * g->B * g->tiles_per_b * g->m->W1 * sizeof(float), hipMemcpyDeviceToDevice,
+                                      (hipStream_t)stream));
+    return DGDM_OK;
+}
 extern "C" int64_t dgdm_guidance_rows(const DgdmGuidance *g) { return g ? g->R : 0; }
 extern "C" int64_t dgdm_guidance_starts_per_call(const DgdmGuidance *g) { return (g && g->m->kind == 3) ? 2 * g->R : 0; }
 

@@ -161,6 +161,14 @@ class Guidance:
         check(lib().dgdm_guidance_debug_fps_path(self._h, int(mode), ok))
         return [bool(v) for v in ok][:self.n_objects]
 
+    def debug_partials(self, n_chains: int) -> torch.Tensor:
+        """Test hook: per-tile partial sums of d objective / d z1 of the last grad() call -> (n_chains, B, tiles_per_finger, W1)."""
+        tp, w = C.c_int32(), C.c_int32()
+        check(lib().dgdm_guidance_debug_partials(self._h, n_chains, None, C.byref(tp), C.byref(w), stream_ptr()))
+        out = torch.empty((n_chains, self.cfg.batch, tp.value, w.value), dtype=torch.float32, device="cuda")
+        check(lib().dgdm_guidance_debug_partials(self._h, n_chains, dptr(out), None, None, stream_ptr()))
+        return out
+
     def rowcoef(self, centers: torch.Tensor) -> np.ndarray:
         """'convergence' row coefficients of one chain (deltas_to_objective :445-452 applied per cond_fn call)."""
         c = np.ascontiguousarray(centers.detach().cpu().numpy().astype(np.int64))

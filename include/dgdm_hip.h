@@ -232,6 +232,11 @@ int dgdm_prof_enable(int on);
  * the crowded centres' sa2 features with per-(variant, centre) global gathers instead of the LDS-staged kernel.  Results must be identical.  Also reports, per
  * object of the bank, whether the table path is admissible (out_fast_ok[n_objects], may be NULL).                          */
 int dgdm_guidance_debug_fps_path(DgdmGuidance *g, int mode, int32_t *out_fast_ok);
+/* Test hook: the per-tile partial sums of d objective / d z1 (z1 = the first trunk layer's pre-activation, BatchNorm folded) that the
+ * last dgdm_dyn{2,3}d_guidance_grad call produced: out_dev [n_chains * B * tiles_per_finger][width], tile index
+ * (chain * B + b) * tiles_per_finger + t = cells 32 t .. 32 t + 31 of finger b.  A ReLU whose float32 pre-activation has the other sign
+ * than in exact arithmetic changes exactly one tile, which is what tests/test_gpu_fullgrid.py looks at.  out_dev may be NULL (sizes only). */
+int dgdm_guidance_debug_partials(DgdmGuidance *g, int n_chains, float *out_dev, int32_t *tiles_per_finger, int32_t *width, void *stream);
 int dgdm_prof_read(int64_t *launches, double *total_ms, double *total_flops);
 int dgdm_prof_read_stage(int stage, int64_t *launches, double *total_ms, double *total_work);
 /* Unit-test hook for the register-resident MFMA chain (csrc/mfma_chain.h): one 32-row tile through one 256 -> 256 layer,

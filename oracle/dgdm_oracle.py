@@ -235,6 +235,9 @@ def _trunk_bf16(sd: SD, x: torch.Tensor, n_embed: int) -> torch.Tensor:
     return _BfLinear.apply(a, sd["output.weight"]) + sd["output.bias"]
 
 
+TRUNK_CAPTURE: Optional[list] = None     # test hook: when a list, _trunk appends the first layer's pre-activation tensor to it
+
+
 def _trunk(sd: SD, x: torch.Tensor, n_embed: int = 0) -> torch.Tensor:
     # Linear -> BatchNorm1d(eval) -> ReLU x8, then Linear (profile_forward_2d.py:109-135,154-155)
     if _CONTRACTION == 'bf16':
@@ -245,6 +248,8 @@ def _trunk(sd: SD, x: torch.Tensor, n_embed: int = 0) -> torch.Tensor:
         b = f"linears.{3 * i + 1}"
         x = F.batch_norm(x, sd[b + ".running_mean"], sd[b + ".running_var"], sd[b + ".weight"], sd[b + ".bias"],
                          training=False, eps=1e-5)
+        if TRUNK_CAPTURE is not None and i == 0:
+            TRUNK_CAPTURE.append(x)          # z1: first-layer pre-activation (tests: per-row d objective / d z1, see make_golden.g9_tiles)
         x = F.relu(x)
         i += 1
     return F.linear(x, sd["output.weight"], sd["output.bias"])

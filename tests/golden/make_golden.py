@@ -706,6 +706,70 @@ def g9_f64(parts=None):
     np.savez_compressed(path, **out)
 
 
+def g9_tiles(parts=("rotate", "convergence", "multi")):
+    """Per-tile sums of d objective / d z1 (z1 = first trunk layer's pre-activation) for the first step of the 3-D g9 chains, in float32
+    (= the reference's arithmetic; the oracle is pinned to it) and in float64: the HIP trunk leaves exactly these sums behind
+    (one per 32 consecutive pose cells of a finger), so a ReLU that takes the other sign in float32 than in exact arithmetic shows
+    up in ONE tile instead of being smeared over a finger's gradient.  Writes tests/golden/g9_tiles.npz."""
+    import time
+    from tests import util as tu
+    path = os.path.join(OUT, "g9_tiles.npz")
+    out = dict(np.load(path)) if os.path.exists(path) else {}
+    f64 = lambda sd: {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}      # noqa: E731
+    for part in parts:
+        g = np.load(os.path.join(OUT, f"g9_3d_{part}.npz"))
+        B, G, P, L, T, S, N = [int(v) for v in g["dims"]]
+        o, gain = str(g["opt_obj"]), float(g["gain"])
+        sd32 = synth.scale_output(synth.synth_state_dict(synth.dyn3d_spec(42), DYN3D_SEED), gain)
+        sch = orc.DDIM(T)
+        sch.set_timesteps(S)
+        t = torch.full((B,), int(sch.timesteps[0]), dtype=torch.int64)
+        calls = tu.unpack_starts(g["starts"].astype(np.int64), g["start_lens"])
+        cells = G * P * P
+        n_sub = 2 * ((B * cells + 511) // 512)
+        centers = None
+        if o == 'convergence':
+            sweep, calls = calls[:2], calls[2:]
+            s32 = orc.Setup('point_3d', None, sd32, sch, L, G, P, 512)
+            centers = orc.get_convergence_centers(s32, torch.from_numpy(g["unguided"]), torch.from_numpy(g["objs"][0]), (-1.0, 1.0), orc.StartLog(list(sweep)))
+        objs = [0, 1] if part == "multi" else [0]
+        for dt, sd in (("32", sd32), ("64", f64(sd32))):
+            res = []
+            for k, oi in enumerate(objs):
+                t0 = time.time()
+                s_ = orc.Setup('point_3d', None, sd, sch, L, G, P, 512)
+                log = orc.StartLog(list(calls[k * n_sub:(k + 1) * n_sub]))
+                x = torch.from_numpy(g["trace_x"][0])
+                x = (x.double() if dt == "64" else x).requires_grad_(True)
+                obj = torch.from_numpy(g["objs"][oi])
+                obj = obj.double() if dt == "64" else obj
+                ori, pos = orc._pose_grid(s_, B, (-1.0, 1.0))
+                tt = t.repeat(cells).float() / T
+                pts = orc._pts3d(s_, x).repeat(cells, 1, 1)
+                ov = obj.t().unsqueeze(0)
+                rows = []
+                with torch.enable_grad():
+                    for i in range(0, B * cells, 512):
+                        j = min(i + 512, B * cells)
+                        orc.TRUNK_CAPTURE = []
+                        logits = orc.dyn3d_forward(sd, pts[i:j], ori[i:j], pos[i:j], tt[i:j], ov.expand(j - i, -1, -1), log)
+                        z1 = orc.TRUNK_CAPTURE[0]
+                        orc.TRUNK_CAPTURE = None
+                        val = orc.deltas_to_objective(logits, o, centers=centers, grid_size=G, num_pos=P)
+                        rows.append(torch.autograd.grad(val.sum(), z1)[0].detach().double())
+                zg = torch.cat(rows)                                    # [R][512], reference row r = cell * B + b
+                tiles = (cells + 31) // 32
+                acc = torch.zeros(B, tiles, zg.shape[1], dtype=torch.float64)
+                for b in range(B):
+                    for tI in range(tiles):
+                        c0, c1 = 32 * tI, min(32 * tI + 32, cells)
+                        acc[b, tI] = zg[torch.arange(c0, c1) * B + b].sum(0)
+                res.append(acc.numpy())
+                print("  tiles", part, "float" + dt, "object", oi, f"{time.time() - t0:.0f}s", flush=True)
+            out[f"{part}/tiles{dt}"] = np.stack(res).astype(np.float64 if dt == "64" else np.float32)
+            np.savez_compressed(path, **out)
+
+
 def synth_metrics(seed, n_ori=360):
     """Synthetic stand-in for what the simulator returns per (object, gripper) pair (dynamics/sim_test_mj.py:210-232):
     three-class profiles and the motion statistics metric2objective reads.  Inputs only; the outputs come from the reference."""
@@ -771,7 +835,7 @@ if __name__ == "__main__":
     os.makedirs("/tmp/dgdm_golden", exist_ok=True)
     only = sys.argv[1:]
     for name, fn in (("g2", g2_unet), ("g3", g3_dyn2d), ("g4", g4_pointnet), ("g5", g5_dyn3d), ("g6", g6_chains),
-                     ("g7", g7_convergence), ("g8", g8_harness), ("g9_2d", g9_2d), ("g9_3d", g9_3d), ("g9_f64", g9_f64)):
+                     ("g7", g7_convergence), ("g8", g8_harness), ("g9_2d", g9_2d), ("g9_3d", g9_3d), ("g9_f64", g9_f64), ("g9_tiles", g9_tiles)):
         if only and name not in [a.split(":")[0] for a in only]:
             continue
         sub = [a.split(":", 1)[1].split(",") for a in only if a.startswith(name + ":")]

@@ -172,7 +172,7 @@ def test_fullgrid_3d(dev, part):
         out = sampler.guided_multi_object(net, gd, s, 'point_3d', noise, [0, 1], o, starts=forced()).cpu()
         st = forced()
         step = np.stack([np.stack([st.call(gd.rows), st.call(gd.rows)]) for _ in range(S)])
-        _teacher_forced(net, gd, s, 'point_3d', g, "trace", [(0, o)], ref, step, dev, scale=sampler.SCALE_3D, multi_obj=[0, 1], errs=errs, rel=rel, grads=grads)
+        _teacher_forced(net, gd, s, 'point_3d', g, "trace", [(0, o)], ref, step, dev, scale=sampler.SCALE_3D, multi_obj=[0, 1], errs=errs, rel=1.0, grads=grads)
     else:
         out = sampler.guided_chains(net, gd, s, 'point_3d', noise, [(0, o)], unguided=ug, starts=forced())[0].cpu()
         sweep, step = sampler.draw_chain_starts(gd, [(0, o)], S, forced())
@@ -181,10 +181,13 @@ def test_fullgrid_3d(dev, part):
             centers = sampler.convergence_centers(gd, 'point_3d', ug, [0], sweep[0])
             rc = torch.from_numpy(gd.rowcoef(centers[0])).to(dev).reshape(1, -1)
         _teacher_forced(net, gd, s, 'point_3d', g, "trace", [(0, o)], ref, step, dev, scale=sampler.classifier_scale('point_3d', o), rowcoef=rc,
-                        errs=errs, rel=rel, grads=grads)
-    hip64 = None
+                        errs=errs, rel=1.0, grads=grads)
+    hip64 = util.rel_l2(torch.stack(grads[:g64.shape[0]]), g64) if g64 is not None else None
+    print(f"3d {part:12s} per-call gradient HIP vs reference {[float('%.2e' % e) for e in errs]}; first step vs float64: reference {noise64} HIP {hip64}; "
+          f"end point HIP vs reference {finger_l2(out, ref):.2e}")
+    tol = rel if isinstance(rel, list) else [rel] * len(errs)
+    assert all(e < t for e, t in zip(errs, tol)), (part, errs, tol)
     if g64 is not None:
-        hip64 = util.rel_l2(torch.stack(grads[:g64.shape[0]]), g64)
         assert hip64 <= max(2e-5, 2.0 * noise64), (part, hip64, noise64)
     row = check_end_point(f"3d/{part}", out, ref, chain64(f"3d/{part}"), floor)
     row.update(opt_obj=o, gain=gain, max_step_grad_rel=max(errs), grad0_reference_vs_f64=noise64, grad0_hip_vs_f64=hip64)
@@ -194,3 +197,57 @@ def test_fullgrid_3d(dev, part):
           f"{max(errs):.1e}; first step vs float64: reference {noise64} HIP {hip64}")
     if row["reference_vs_chain64"] is None and floor is not None and 3e-5 <= floor < 5e-2:
         assert row["hip_vs_reference"] < max(NORTH_STAR, 3.0 * floor), (part, row)      # until a float64 chain is stored: 3x the reference's own spread
+
+
+@pytest.mark.parametrize("part", ["rotate", "convergence", "multi"])
+def test_fullgrid_3d_tiles(dev, part):
+    """Where a 3-D gradient differs from the reference by more than rounding, it is a ReLU tie, not arithmetic.
+
+    At C = 1125 cells per finger a float32 gradient is exact to ~1e-6 EXCEPT for rows in which some ReLU's pre-activation is so
+    close to zero that float32 and exact arithmetic disagree about its sign: one such unit changes one row's contribution by a
+    few per cent, i.e. the finger's gradient by ~5e-5.  That happens to the reference too (its float32 first-step gradient of the
+    'rotate' chain is 3.5e-5 from float64 on one finger and 1e-6 on the other).  The HIP trunk leaves per-tile partial sums of
+    d objective / d z1 behind (32 consecutive pose cells of one finger), so the event can be localised: compared with the float64
+    sums (tests/golden/g9_tiles.npz) nearly all tiles must agree to rounding, and the few that do not must be off by at most
+    one row's worth.  The reference's own float32 sums are held to the same count."""
+    f = os.path.join(util.GOLDEN, "g9_tiles.npz")
+    t = np.load(f) if os.path.exists(f) else None
+    if t is None or f"{part}/tiles64" not in t.files:
+        pytest.skip("tests/golden/g9_tiles.npz has no entry for this chain")
+    g = _load3d(part)
+    B, G, P, L, T, S, N = [int(v) for v in g["dims"]]
+    o, gain = str(g["opt_obj"]), float(g["gain"])
+    dyn = engine.Dynamics(3, synth.scale_output(util.dyn3d_sd(g["dyn3d_seed"]), gain), L)
+    objs = torch.from_numpy(g["objs"])
+    gd = engine.Guidance(dyn, B, G, P, (-1.0, 1.0), 2, T, N, 512, max_objects=2)
+    gd.set_objects(objs.to(dev))
+    s = sched(T, S)
+    st = sampler.StartStream(N, 512, util.unpack_starts(g["starts"].astype(np.int64), g["start_lens"]))
+    x = torch.from_numpy(g["trace_x"][0]).to(dev).reshape(1, B, L)
+    rc = None
+    if part == "multi":
+        starts = np.concatenate([st.call(gd.rows), st.call(gd.rows)])
+        gd.grad(x.expand(2, -1, -1).contiguous(), int(s.timesteps[0]), [engine.make_objective(o, 0), engine.make_objective(o, 1)], None, starts)
+        hip = gd.debug_partials(2).cpu().double().numpy()
+    else:
+        if o == 'convergence':
+            net = engine.Unet1d(util.unet_sd(g["unet_seed"]))
+            ug = sampler.unguided_sample(net, s, synth.synth_noise(0, B, L).to(dev))
+            centers = sampler.convergence_centers(gd, 'point_3d', ug, [0], st.call(gd.sweep_rows))
+            rc = torch.from_numpy(gd.rowcoef(centers[0])).to(dev).reshape(1, -1)
+        gd.grad(x, int(s.timesteps[0]), [engine.make_objective(o, 0)], rc, st.call(gd.rows))
+        hip = gd.debug_partials(1).cpu().double().numpy()
+    t64, t32 = t[f"{part}/tiles64"].astype(np.float64), t[f"{part}/tiles32"].astype(np.float64)
+    assert hip.shape == t64.shape, (hip.shape, t64.shape)
+    scale = np.sqrt((t64 ** 2).sum(-1)).mean()                           # a typical tile's norm: errors are relative to that
+    e_hip = np.sqrt(((hip - t64) ** 2).sum(-1)).reshape(-1) / scale
+    e_ref = np.sqrt(((t32 - t64) ** 2).sum(-1)).reshape(-1) / scale
+    clean = 1e-5
+    n_hip, n_ref = int((e_hip >= clean).sum()), int((e_ref >= clean).sum())
+    _report({f"3d_tiles/{part}": dict(tiles=int(e_hip.size), hip_median=float(np.median(e_hip)), ref_median=float(np.median(e_ref)),
+                                      hip_outlier_tiles=n_hip, ref_outlier_tiles=n_ref, hip_max=float(e_hip.max()), ref_max=float(e_ref.max()))})
+    print(f"3d tiles {part:12s} {e_hip.size} tiles | HIP vs float64: median {np.median(e_hip):.1e}, tiles >= {clean:g}: {n_hip} (max {e_hip.max():.1e}) | "
+          f"reference float32 vs float64: median {np.median(e_ref):.1e}, tiles >= {clean:g}: {n_ref} (max {e_ref.max():.1e})")
+    assert np.median(e_hip) < 3e-6                                       # rounding-level agreement on the bulk
+    assert n_hip <= max(6, 3 * n_ref + 3), (n_hip, n_ref)                # ReLU ties are rare and not more frequent than in the reference
+    assert e_hip.max() < 0.5                                             # an outlier is at most about one row's contribution
