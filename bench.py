@@ -317,6 +317,7 @@ def config0(dev):
     parser defaults dynamics/parser.py:29,31) - the reference's CPU-runnable plumbing case: the CPU oracle chain (median of 3)
     next to the HIP unguided loop on the same noise."""
     from oracle import dgdm_oracle as orc
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))      # same policy as cpu_baseline (tiny ops get slower with more threads)
     B, L, T = 4, 14, 1000
     usd = synth.synth_state_dict(synth.unet_spec(), 11)
     noise = synth.synth_noise(0, B, L)

@@ -985,43 +985,48 @@ __device__ __forceinline__ void xobj_group_body(const XobjParams &p, const XobjC
         }
         return o;
     };
-    // software pipeline: the slot list and the M0 piece of row i+1 are loaded while row i is reduced
-    int qn = __builtin_amdgcn_readlane(q_v, 0);
-    int SA = ch.cl2s[(size_t)qn * 128 + lane], SB = ch.cl2s[(size_t)qn * 128 + 64 + lane];
-    u4 m0 = *reinterpret_cast<const u4 *>(M0 + (size_t)qn * W);
-    for (int i = 0; i < nmine; ++i) {
-        const int r = __builtin_amdgcn_readlane(r_v, i), cnt = __builtin_amdgcn_readlane(cnt_v, i), slow = __builtin_amdgcn_readlane(slow_v, i);
-        const int sa = SA, sb = SB;
-        u4 best = m0;
-        if (i + 1 < nmine) {
-            qn = __builtin_amdgcn_readlane(q_v, i + 1);
-            SA = ch.cl2s[(size_t)qn * 128 + lane]; SB = ch.cl2s[(size_t)qn * 128 + 64 + lane];
-            m0 = *reinterpret_cast<const u4 *>(M0 + (size_t)qn * W);
-        }
-        if (slow) continue;
-        // slot j + sg for lane group sg; the list is padded with its last entry to 128, so reading past cnt repeats a member
-        for (int j = 0; j < cnt; j += 4 * RPW) {
-            u4 v[4];
+    // rows in batches of four: the four slot lists and M0 pieces are requested together (the per-row lookups are L2-latency bound)
+    for (int i0 = 0; i0 < nmine; i0 += 4) {
+        int SA[4], SB[4];
+        u4 m0[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int jj = j + e * RPW;                              // uniform; jj + sg stays inside one 64-entry half (64 % RPW == 0)
-                int slot;
-                if (RPW == 1) slot = jj < 64 ? __builtin_amdgcn_readlane(sa, jj & 63) : __builtin_amdgcn_readlane(sb, jj & 63);
-                else slot = __shfl(jj < 64 ? sa : sb, (jj & 63) + sg);
-                v[e] = *reinterpret_cast<const u4 *>(slab + ((size_t)slot * LPR + fl) * 4);
+        for (int u = 0; u < 4; ++u) {
+            const int qn = __builtin_amdgcn_readlane(q_v, min(i0 + u, nmine - 1));
+            SA[u] = ch.cl2s[(size_t)qn * 128 + lane]; SB[u] = ch.cl2s[(size_t)qn * 128 + 64 + lane];
+            m0[u] = *reinterpret_cast<const u4 *>(M0 + (size_t)qn * W);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u;
+            if (i >= nmine) break;
+            const int r = __builtin_amdgcn_readlane(r_v, i), cnt = __builtin_amdgcn_readlane(cnt_v, i), slow = __builtin_amdgcn_readlane(slow_v, i);
+            const int sa = SA[u], sb = SB[u];
+            u4 best = m0[u];
+            if (slow) continue;
+            // slot j + sg for lane group sg; the list is padded with its last entry to 128, so reading past cnt repeats a member
+            for (int j = 0; j < cnt; j += 4 * RPW) {
+                u4 v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int jj = j + e * RPW;                              // uniform; jj + sg stays inside one 64-entry half (64 % RPW == 0)
+                    int slot;
+                    if (RPW == 1) slot = jj < 64 ? __builtin_amdgcn_readlane(sa, jj & 63) : __builtin_amdgcn_readlane(sb, jj & 63);
+                    else slot = __shfl(jj < 64 ? sa : sb, (jj & 63) + sg);
+                    v[e] = *reinterpret_cast<const u4 *>(slab + ((size_t)slot * LPR + fl) * 4);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) best = vmax4(best, v[e]);
             }
+            if (RPW > 1 && cnt > 0) {                                       // fold the lane groups (each saw every RPW-th slot)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) best = vmax4(best, v[e]);
-        }
-        if (RPW > 1 && cnt > 0) {                                       // fold the lane groups (each saw every RPW-th slot)
-#pragma unroll
-            for (int o = 32; o >= LPR; o >>= 1) {
-                u4 t;
-                t.x = __shfl_xor(best.x, o); t.y = __shfl_xor(best.y, o); t.z = __shfl_xor(best.z, o); t.w = __shfl_xor(best.w, o);
-                best = vmax4(best, t);
+                for (int o = 32; o >= LPR; o >>= 1) {
+                    u4 t;
+                    t.x = __shfl_xor(best.x, o); t.y = __shfl_xor(best.y, o); t.z = __shfl_xor(best.z, o); t.w = __shfl_xor(best.w, o);
+                    best = vmax4(best, t);
+                }
             }
+            if (sg == 0) *reinterpret_cast<u4 *>(out + (size_t)r * W) = best;
         }
-        if (sg == 0) *reinterpret_cast<u4 *>(out + (size_t)r * W) = best;
     }
     // ---- groups of more than 256 rows (never at the shipped sizes: 36 000 rows over 512 start indices): remaining rows one by one
     for (int k = 256 + wave; k < gn; k += 4) {

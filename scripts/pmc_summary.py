@@ -33,4 +33,4 @@ def one(d, counter):
 
 
 if __name__ == "__main__":
-    print(json.dumps({"fetch": one(sys.argv[1], "FETCH_SIZE"), "write": one(sys.argv[2], "WRITE_SIZE")}, indent=1))
+    print(json.dumps({"head": sys.argv[3] if len(sys.argv) > 3 else None, "fetch": one(sys.argv[1], "FETCH_SIZE"), "write": one(sys.argv[2], "WRITE_SIZE")}, indent=1))
