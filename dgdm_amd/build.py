@@ -12,6 +12,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libdgdm_hip.so")
 SOURCES = ["host_util.hip", "smallnet.hip", "unet.hip", "trunk.hip", "trunk_bf16.hip", "pointnet.hip", "models_api.hip", "guidance_api.hip", "decode.hip", "debug.hip"]
+# unet.hip: its block functions as real calls cost 200 VGPRs and a register save/restore through scratch at every call (152 MB of
+# scratch writes per 1024-sample launch in the round-2 PMC pass); fully inlined the kernel needs 126 VGPRs
+PER_FILE_FLAGS = {"unet.hip": ["-mllvm", "-amdgpu-function-calls=false"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("DGDM_EXTRA_FLAGS", "").split()
 
 
@@ -33,7 +36,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         o = os.path.join(CSRC, "build", src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([hipcc] + FLAGS + PER_FILE_FLAGS.get(src, []) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
