@@ -104,7 +104,11 @@ def train(args):
                       pts_z_dim=args.ctrlpts_z_dim, sub_batch_size=args.sub_bs, render_video=args.render_video, seed=args.seed)
     ck = _load_or_synth(args.diffusion_checkpoint_path, [("ema_nets.noise_pred_net." + k, s) for k, s in synth.unet_spec()], 11,
                         "diffusion checkpoint")
-    model.load_state_dict(ck)
+    res = model.load_state_dict(ck)
+    lost = [k for k in res.missing_keys if k.startswith("ema_nets.noise_pred_net.")]
+    if lost or res.unexpected_keys:
+        raise KeyError(f"diffusion checkpoint does not match ConditionalUnet1D: missing {lost[:5]}{'...' if len(lost) > 5 else ''}, "
+                       f"unexpected {list(res.unexpected_keys)[:5]}")
     model.eval().to(dev)
     model.save_dir = args.save_dir or None
     if model.save_dir:

@@ -183,20 +183,31 @@ def test_checkpoint_formats(dev, tmp_path):
     torch.compile's '_orig_mod.' infixes (generator/diffusion.py:730-753)."""
     from dgdm_amd.generator.train import train
     from dynamics.parser import parse
-    usd, dsd = util.unet_sd(11), util.dyn3d_sd(23)         # the seeds train() falls back to without files: 11 and 22 + fingers_3d
+    usd, dsd = util.unet_sd(12), util.dyn3d_sd(24)         # NOT the seeds train() falls back to without files (11 and 22 + fingers_3d)
     dyn_path, dif_path = os.path.join(tmp_path, "dynamics_3d.pt"), os.path.join(tmp_path, "diffusion_3d.ckpt")
     torch.save({"module." + k: v for k, v in dsd.items()}, dyn_path)
     sd = {"ema_nets.noise_pred_net._orig_mod." + k: v for k, v in usd.items()}
     sd["ema_model"] = {"noise_pred_net._orig_mod." + k: v.clone() for k, v in usd.items()}
     torch.save({"state_dict": sd, "epoch": 3, "global_step": 99}, dif_path)
+    # the same weights without any of the wrappers' prefixes
+    dyn_plain, dif_plain = os.path.join(tmp_path, "dynamics_plain.pt"), os.path.join(tmp_path, "diffusion_plain.ckpt")
+    torch.save(dict(dsd), dyn_plain)
+    torch.save({"state_dict": {"ema_nets.noise_pred_net." + k: v for k, v in usd.items()}}, dif_plain)
     common = ("--mode=test --classifier_guidance --fingers_3d --num_fingers=2 --batch_size=2 --grid_size=3 --num_pos=2 --sub_bs=5 "
               "--object_max_num_vertices=512 --ctrlpts_dim=42 --num_train_timesteps=15 --num_inference_steps=5")
-    torch.manual_seed(0)
-    _, from_files = train(parse(shlex.split(common + f" --checkpoint_path={dyn_path} --diffusion_checkpoint_path={dif_path}")))
-    torch.manual_seed(0)
-    _, synthetic = train(parse(shlex.split(common)))
+    runs = {}
+    for name, extra in (("wrapped", f" --checkpoint_path={dyn_path} --diffusion_checkpoint_path={dif_path}"),
+                        ("plain", f" --checkpoint_path={dyn_plain} --diffusion_checkpoint_path={dif_plain}"), ("fallback", "")):
+        torch.manual_seed(0)
+        _, runs[name] = train(parse(shlex.split(common + extra)))
     for k in ("unguided", "guided/shift_up", "multi/rotate"):
-        assert torch.equal(from_files[0][k], synthetic[0][k]), k
+        assert torch.equal(runs["wrapped"][0][k], runs["plain"][0][k]), k            # both formats carry the same weights
+        assert not torch.equal(runs["wrapped"][0][k], runs["fallback"][0][k]), k     # ... and they were really used, not the fallback
+    # a checkpoint that does not fit the network is an error, not a silent partial load
+    bad = os.path.join(tmp_path, "bad.ckpt")
+    torch.save({"state_dict": {"ema_nets.noise_pred_net." + k: v for k, v in list(usd.items())[:-3]}}, bad)
+    with pytest.raises(KeyError, match="does not match"):
+        train(parse(shlex.split(common + f" --checkpoint_path={dyn_plain} --diffusion_checkpoint_path={bad}")))
 
 
 def test_harness_tables_with_a_simulator(dev, tmp_path):
@@ -277,3 +288,28 @@ def test_sharded_cli_matches_single_process(dev, tmp_path):
         os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
         json.dump({"n_files": len(files), "bad": bad}, open(os.path.join(root, "gpurun_out", "sharded_bad.json"), "w"))
     assert not bad, (len(bad), len(files), bad[:4])
+
+
+def test_reload_invalidates_device_weights(dev):
+    """Diffusion.load_state_dict after a first sample: nn.Module copies into the children's parameters in place, so the packed device
+    copies of the eps-net (and any guidance handle bound to a reloaded classifier) must be rebuilt - the second sample uses the new weights."""
+    B, G, P, L, nv = 2, 4, 2, 14, 100
+    objs = torch.stack([synth.synth_object_2d(i, nv) for i in range(2)])
+    d, _ = _diffusion('point', dev, B, G, P, L, objs)
+    noise = synth.synth_noise(0, B, L).to(dev)
+    first = d.guided_sample(0, B, noise, None, opt_obj='shift_up').clone()
+    again = d.guided_sample(0, B, noise, None, opt_obj='shift_up')
+    assert torch.equal(first, again)
+    d.load_state_dict({"ema_nets.noise_pred_net." + k: v for k, v in util.unet_sd(99).items()})
+    assert not d._guidance                                               # handles bound to the old device weights are gone
+    other = d.guided_sample(0, B, noise, None, opt_obj='shift_up')
+    assert not torch.equal(first, other)
+    ref_net = d.noise_pred_net.handle()
+    from dgdm_amd import engine
+    direct = engine.Unet1d(util.unet_sd(99)).forward(noise, torch.full((B,), 3, device=dev))
+    assert torch.equal(ref_net.forward(noise, torch.full((B,), 3, device=dev)), direct)
+    # the classifier: new weights -> new handle -> the cached guidance is rebuilt on it
+    dyn = d._dyn()
+    dyn.load_state_dict(util.dyn2d_sd(77, nv))
+    third = d.guided_sample(0, B, noise, None, opt_obj='shift_up')
+    assert not torch.equal(third, other)
