@@ -32,6 +32,23 @@ typedef __attribute__((address_space(3))) f32x4 lds_f4;
 // also counts on lgkmcnt, so every wait for an LDS operand would wait for the weight prefetch as well.
 typedef const __attribute__((address_space(1))) f32x4 glb_f4;
 
+// Experiment build only (DGDM_EXTRA_FLAGS=-DDGDM_UNET_CLOCKS): thread 0 of every workgroup stamps the shader clock at every phase
+// boundary; dgdm_debug_unet_clocks copies the stamps out (scripts/unet_phases.py prints the mean time per phase).
+#ifdef DGDM_UNET_CLOCKS
+__device__ long long unet_clk[1024 * 64];
+#define UCLK()                                                                                              \
+    do {                                                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x < 1024 && clk_i < 64) unet_clk[blockIdx.x * 64 + clk_i] = (long long)__builtin_readcyclecounter(); \
+        ++clk_i;                                                                                            \
+    } while (0)
+#define UCLK_ARG , int &clk_i
+#define UCLK_PASS , clk_i
+#else
+#define UCLK() do {} while (0)
+#define UCLK_ARG
+#define UCLK_PASS
+#endif
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 __device__ __forceinline__ float mish(float x) {
@@ -289,22 +306,32 @@ __device__ void gn_mish_film(lds_f *buf, int CP, int C, int L, int groups, const
     }
 }
 
-// y[n] = b[n] + sum_k WT[k][n] x[k],  x in LDS
-__device__ void matvec(const float *__restrict__ WT, const float *__restrict__ b, const lds_f *x, lds_f *y, int K, int N) {
-    for (int n = threadIdx.x; n < N; n += blockDim.x) {
-        float acc = 0.f;
-        for (int k = 0; k < K; ++k) acc = fmaf(WT[(size_t)k * N + n], x[k], acc);
-        y[n] = acc + b[n];
+// sum_k WT[k][n] x[k] (x in LDS, K a multiple of 8): eight weight loads in flight per step, the same ascending-k fmaf chain
+__device__ __forceinline__ float dot_kn(const float *__restrict__ WT, int N, int n, const lds_f *x, int K) {
+    float acc = 0.f;
+    for (int k = 0; k < K; k += 8) {
+        float w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = WT[(size_t)(k + j) * N + n];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = fmaf(w[j], x[k + j], acc);
     }
+    return acc;
 }
 
-struct Bufs { lds_f *A, *B, *C, *D, *film, *cond, *tmp, *xin; int bf16; };
+// y[n] = b[n] + sum_k WT[k][n] x[k],  x in LDS
+__device__ void matvec(const float *__restrict__ WT, const float *__restrict__ b, const lds_f *x, lds_f *y, int K, int N) {
+    for (int n = threadIdx.x; n < N; n += blockDim.x) y[n] = dot_kn(WT, N, n, x, K) + b[n];
+}
+
+struct Bufs { lds_f *A, *B, *C, *D, *film, *cond, *tmp, *xin; int bf16; };      // film: [8 blocks][2 * cmax] FiLM scale|shift, all computed up front
 
 // ConditionalResidualBlock1D.forward (diffusion_utils.py:101-120): x(in, cin channels) -> out; t1 scratch.
 // `out` may be a wider buffer (row stride CPout >= cout + 4): the concat buffer of the up path.
-__device__ void res_block(const UnetRes &w, const lds_f *in, lds_f *t1, lds_f *out, int CPout, int L, int cond_dim, int groups, const Bufs s) {
+__device__ void res_block(const UnetRes &w, const lds_f *in, lds_f *t1, lds_f *out, int CPout, int L, int cond_dim, int groups, const Bufs s,
+                          const lds_f *film UCLK_ARG) {
     const int CPi = w.cin + UNET_ROW_PAD, CPo = w.cout + UNET_ROW_PAD;
-    matvec(w.cond_wt, w.cond_b, s.cond, s.film, cond_dim, 2 * w.cout);     // cond_encoder: Mish already applied to s.cond
+    // the block's FiLM vector (cond_encoder: Mish -> Linear(cond_dim, 2 cout)) was computed with the other seven before the first block
     if (w.cin == 1) {   // first block: single input channel held in s.xin[pos + 2]; conv k5 and the 1x1 residual on the VALU
         for (int i = threadIdx.x; i < L * w.cout; i += blockDim.x) {
             const int l = i / w.cout, co = i - l * w.cout;
@@ -318,13 +345,17 @@ __device__ void res_block(const UnetRes &w, const lds_f *in, lds_f *t1, lds_f *o
     }
     zero_halo(t1, CPo, w.cout, L);
     __syncthreads();
-    gn_mish_film(t1, CPo, w.cout, L, groups, w.g0_w, w.g0_b, s.film);
+    UCLK();
+    gn_mish_film(t1, CPo, w.cout, L, groups, w.g0_w, w.g0_b, film);
     __syncthreads();
+    UCLK();
     conv<0>(conv_args(w.c1_w, w.c1_b, w.cout, w.cout, 5, 2, 1, s.bf16), t1, CPo, out, CPout, L);
     zero_halo(out, CPout, w.cout, L);
     __syncthreads();
+    UCLK();
     gn_mish_film(out, CPout, w.cout, L, groups, w.g1_w, w.g1_b, nullptr);
     __syncthreads();
+    UCLK();
     if (w.cin == 1) {
         for (int i = threadIdx.x; i < L * w.cout; i += blockDim.x) {
             const int l = i / w.cout, co = i - l * w.cout;
@@ -339,6 +370,7 @@ __device__ void res_block(const UnetRes &w, const lds_f *in, lds_f *t1, lds_f *o
         }
     }
     __syncthreads();
+    UCLK();
 }
 
 // `pp` points at the UnetParams in device memory: passing the struct by value and handing references to its members to the
@@ -356,11 +388,15 @@ __global__ __launch_bounds__(512) void unet_kernel(const UnetParams *__restrict_
     s.C = s.B + bufS;
     s.D = s.C + bufS;
     s.film = s.D + bufS;
-    s.cond = s.film + 2 * p.cmax;
+    s.cond = s.film + 8 * 2 * p.cmax;
     s.tmp = s.cond + p.dsed;
     s.xin = s.tmp + 4 * p.dsed;
     s.bf16 = p.bf16;
     const int G = p.groups;
+#ifdef DGDM_UNET_CLOCKS
+    int clk_i = 0;
+#endif
+    UCLK();
 
     // ---- diffusion_step_encoder: SinusoidalPosEmb -> Linear -> Mish -> Linear   (diffusion_utils.py:25-37,149-154)
     {
@@ -382,24 +418,40 @@ __global__ __launch_bounds__(512) void unet_kernel(const UnetParams *__restrict_
     }
     for (int i = t; i < L + 4; i += blockDim.x) s.xin[i] = (i >= 2 && i < 2 + L) ? sample[(size_t)b * L + i - 2] : 0.f;
     __syncthreads();
+    // all eight cond_encoders at once (they only depend on the step embedding): one phase with 6 independent dot products per
+    // thread instead of eight phases of 32 dependent L2 loads each in front of the blocks' first convolutions
+    {
+        lds_f *films = s.film;
+        const int stride = 2 * p.cmax;
+        for (int i = t; i < 8 * stride; i += blockDim.x) {
+            const int blk = i / stride, n = i - blk * stride, N = 2 * p.res[blk].cout;
+            if (n < N) {
+                films[i] = dot_kn(p.res[blk].cond_wt, N, n, s.cond, p.dsed) + p.res[blk].cond_b[n];
+            }
+        }
+    }
+    __syncthreads();
+    UCLK();      // step encoder + FiLM vectors done
 
     const int CP0 = p.d0 + UNET_ROW_PAD, CP1 = p.d1 + UNET_ROW_PAD, CPcat = 2 * p.d1 + UNET_ROW_PAD;
-    res_block(p.res[0], nullptr, s.B, s.C, CP0, L, p.dsed, G, s);     // down0.0   1 -> d0
-    res_block(p.res[1], s.C, s.B, s.D, CP0, L, p.dsed, G, s);         // down0.1   d0 -> d0   (its skip is never consumed, :264-278)
+    res_block(p.res[0], nullptr, s.B, s.C, CP0, L, p.dsed, G, s, s.film + 0 * 2 * p.cmax UCLK_PASS);     // down0.0   1 -> d0
+    res_block(p.res[1], s.C, s.B, s.D, CP0, L, p.dsed, G, s, s.film + 1 * 2 * p.cmax UCLK_PASS);         // down0.1   d0 -> d0   (its skip is never consumed, :264-278)
     conv<0>(conv_args(p.down_w, p.down_b, p.d0, p.d0, 3, 1, 2, p.bf16), s.D, CP0, s.B, CP0, L2);       // Downsample1d (:42)
     zero_halo(s.B, CP0, p.d0, L2);
     __syncthreads();
-    res_block(p.res[2], s.B, s.C, s.D, CP1, L2, p.dsed, G, s);        // down1.0   d0 -> d1
-    res_block(p.res[3], s.D, s.B, s.C, CP1, L2, p.dsed, G, s);        // down1.1   -> skip, stays in C until the concat
-    res_block(p.res[4], s.C, s.B, s.D, CP1, L2, p.dsed, G, s);        // mid0
-    res_block(p.res[5], s.D, s.B, s.A, CPcat, L2, p.dsed, G, s);      // mid1 -> channels [0, d1) of the concat buffer
+    UCLK();      // downsample conv
+    res_block(p.res[2], s.B, s.C, s.D, CP1, L2, p.dsed, G, s, s.film + 2 * 2 * p.cmax UCLK_PASS);        // down1.0   d0 -> d1
+    res_block(p.res[3], s.D, s.B, s.C, CP1, L2, p.dsed, G, s, s.film + 3 * 2 * p.cmax UCLK_PASS);        // down1.1   -> skip, stays in C until the concat
+    res_block(p.res[4], s.C, s.B, s.D, CP1, L2, p.dsed, G, s, s.film + 4 * 2 * p.cmax UCLK_PASS);        // mid0
+    res_block(p.res[5], s.D, s.B, s.A, CPcat, L2, p.dsed, G, s, s.film + 5 * 2 * p.cmax UCLK_PASS);      // mid1 -> channels [0, d1) of the concat buffer
     for (int i = t; i < (L2 + 4) * p.d1; i += blockDim.x) {           // torch.cat((x, h.pop()), dim=1) (:275): skip -> channels [d1, 2 d1)
         const int r = i / p.d1, c = i - r * p.d1;
         s.A[r * CPcat + p.d1 + c] = s.C[r * CP1 + c];
     }
     __syncthreads();
-    res_block(p.res[6], s.A, s.B, s.D, CP0, L2, p.dsed, G, s);        // up0.0   2*d1 -> d0
-    res_block(p.res[7], s.D, s.B, s.C, CP0, L2, p.dsed, G, s);        // up0.1
+    UCLK();      // concat copy
+    res_block(p.res[6], s.A, s.B, s.D, CP0, L2, p.dsed, G, s, s.film + 6 * 2 * p.cmax UCLK_PASS);        // up0.0   2*d1 -> d0
+    res_block(p.res[7], s.D, s.B, s.C, CP0, L2, p.dsed, G, s, s.film + 7 * 2 * p.cmax UCLK_PASS);        // up0.1
     {   // Upsample1d: ConvTranspose1d(d0, d0, 4, 2, 1) (:51): out[2 li] = W1 in[li] + W3 in[li-1];  out[2 li + 1] = W2 in[li] + W0 in[li+1]
         ConvArgs e = conv_args(p.up_w_even, p.up_b, p.d0, p.d0, 2, 0, 1, p.bf16);
         e.ioff0 = 0; e.iostep = -1; e.ostride = 2; e.ooff = 0;
@@ -409,16 +461,20 @@ __global__ __launch_bounds__(512) void unet_kernel(const UnetParams *__restrict_
         conv<0>(o, s.C, CP0, s.A, CP0, L2);
         zero_halo(s.A, CP0, p.d0, L);                                 // 2*L2 == L (checked by the launcher)
         __syncthreads();
+        UCLK();  // upsample convs
     }
     conv<0>(conv_args(p.fin_w, p.fin_b, p.d0, p.d0, 5, 2, 1, p.bf16), s.A, CP0, s.B, CP0, L);          // final_conv.0
     __syncthreads();
+    UCLK();      // final conv
     gn_mish_film(s.B, CP0, p.d0, L, G, p.fin_gw, p.fin_gb, nullptr);
     __syncthreads();
+    UCLK();      // final GroupNorm
     for (int l = t; l < L; l += blockDim.x) {                         // final_conv.1: Conv1d(d0, 1, 1)
         float acc = 0.f;
         for (int c = 0; c < p.d0; ++c) acc = fmaf(p.out_w[c], s.B[(l + 2) * CP0 + c], acc);
         eps[(size_t)b * L + l] = acc + p.out_b[0];
     }
+    UCLK();          // output conv
 }
 
 int unet_launch(const UnetParams &p, const UnetParams *p_dev, const float *sample, const int *timestep, float *eps, int B, int L, hipStream_t s) {
@@ -429,7 +485,7 @@ int unet_launch(const UnetParams &p, const UnetParams *p_dev, const float *sampl
     DGDM_REQUIRE(L <= 64, DGDM_EINVAL, "U-Net kernel supports up to 64 control points (got %d)", L);
     const int bufS = std::max((L + 4) * (p.d0 + UNET_ROW_PAD), (L2 + 4) * (p.d1 + UNET_ROW_PAD));
     const int bufA = std::max((L + 4) * (p.d0 + UNET_ROW_PAD), (L2 + 4) * (2 * p.d1 + UNET_ROW_PAD));
-    const size_t lds_floats = (size_t)bufA + 3 * (size_t)bufS + 2 * p.cmax + p.dsed + 4 * p.dsed + (L + 4) + 16;
+    const size_t lds_floats = (size_t)bufA + 3 * (size_t)bufS + 8 * 2 * p.cmax + p.dsed + 4 * p.dsed + (L + 4) + 16;
     DGDM_REQUIRE(lds_floats * 4 <= 160 * 1024, DGDM_EINVAL, "U-Net activations (%zu B) exceed the 160 KiB LDS", lds_floats * 4);
     static bool attr_set = false;
     if (!attr_set) {
@@ -442,3 +498,9 @@ int unet_launch(const UnetParams &p, const UnetParams *p_dev, const float *sampl
 }
 
 }  // namespace dgdm
+
+#ifdef DGDM_UNET_CLOCKS
+extern "C" int dgdm_debug_unet_clocks(long long *out_host, int n) {
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(dgdm::unet_clk), sizeof(long long) * (size_t)n) == hipSuccess ? 0 : -3;
+}
+#endif
