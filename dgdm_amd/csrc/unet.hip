@@ -21,6 +21,9 @@
 namespace dgdm {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef UNET_THREADS
+#define UNET_THREADS 512
+#endif
 constexpr int UNET_ROW_PAD = 8;      // LDS activation rows are C + 8 floats: see the header comment (bank mapping of the B-operand reads)
 // Activations live in LDS.  The device functions below are real calls (not inlined into the kernel), so a plain `float *`
 // parameter would be a generic pointer: every access a flat_load/flat_store with 64-bit address arithmetic on the VALU
@@ -375,7 +378,7 @@ __device__ void res_block(const UnetRes &w, const lds_f *in, lds_f *t1, lds_f *o
 
 // `pp` points at the UnetParams in device memory: passing the struct by value and handing references to its members to the
 // (non-inlined) block functions made the compiler copy all 1.1 KB of it to scratch in every thread.
-__global__ __launch_bounds__(512) void unet_kernel(const UnetParams *__restrict__ pp, int bufA, int bufS, const float *__restrict__ sample,
+__global__ __launch_bounds__(UNET_THREADS) void unet_kernel(const UnetParams *__restrict__ pp, int bufA, int bufS, const float *__restrict__ sample,
                                                    const int *__restrict__ timestep, float *__restrict__ eps, int L) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     lds_f *lds = (lds_f *)lds_raw;
@@ -492,7 +495,7 @@ int unet_launch(const UnetParams &p, const UnetParams *p_dev, const float *sampl
         DGDM_HIP_CHECK(hipFuncSetAttribute((const void *)unet_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(unet_kernel, dim3(B), dim3(512), lds_floats * 4, s, p_dev, bufA, bufS, sample, timestep, eps, L);
+    hipLaunchKernelGGL(unet_kernel, dim3(B), dim3(UNET_THREADS), lds_floats * 4, s, p_dev, bufA, bufS, sample, timestep, eps, L);
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
 }
