@@ -190,8 +190,14 @@ def guided_chains(unet: Unet1d, guid: Guidance, sched: DDIMScheduler, mode: str,
     x = noise.reshape(1, B, L).expand(nc, -1, -1).contiguous().to(torch.float32)
     for si, t in enumerate(sched.timesteps):
         t = int(t)
-        ts = torch.full((nc * B,), t, dtype=torch.int32, device=dev)
-        eps = unet.forward(x.reshape(nc * B, L, 1), ts).reshape(nc, B, L)
+        if si == 0 and nc > 1:
+            # every chain starts from the same noise (generator/diffusion.py:570: `sample = noise.clone()` per object), so the first
+            # eps-net call has nc identical copies of the B fingers as its batch: evaluate it once (same input, same kernel, same bits)
+            ts = torch.full((B,), t, dtype=torch.int32, device=dev)
+            eps = unet.forward(x[0].reshape(B, L, 1), ts).reshape(1, B, L).expand(nc, -1, -1).contiguous()
+        else:
+            ts = torch.full((nc * B,), t, dtype=torch.int32, device=dev)
+            eps = unet.forward(x.reshape(nc * B, L, 1), ts).reshape(nc, B, L)
         g = guid.grad(x, t, objectives, rowcoef, step_starts[si].reshape(-1) if is3d else None)
         if trace is not None:
             trace.append((eps.clone(), g.clone()))
@@ -262,8 +268,12 @@ def guided_multi_object_groups(unet: Unet1d, guid: Guidance, sched: DDIMSchedule
     x = noise.reshape(1, B, L).expand(K, -1, -1).contiguous().to(torch.float32)
     for si, t in enumerate(sched.timesteps):
         t = int(t)
-        ts = torch.full((K * B,), t, dtype=torch.int32, device=dev)
-        eps = unet.forward(x.reshape(K * B, L, 1), ts).reshape(K, B, L)
+        if si == 0 and K > 1:        # all K chains start from the same noise: one eps-net evaluation (see guided_chains)
+            ts = torch.full((B,), t, dtype=torch.int32, device=dev)
+            eps = unet.forward(x[0].reshape(B, L, 1), ts).reshape(1, B, L).expand(K, -1, -1).contiguous()
+        else:
+            ts = torch.full((K * B,), t, dtype=torch.int32, device=dev)
+            eps = unet.forward(x.reshape(K * B, L, 1), ts).reshape(K, B, L)
         g = guid.grad(x.repeat(n_obj, 1, 1), t, objectives, None, predrawn[si].reshape(-1) if is3d else None)     # (n_obj*K, B, L)
         x = engine.ddim_guided_step(x, eps, g, n_obj, sched.coefficients(t), scale)
     return x.reshape(K, B, L, 1)
