@@ -340,6 +340,45 @@ def config0(dev):
             "hip_chain_s": hip_s, "hip_samples_per_s": B / hip_s, "hip_ms_per_denoise_step": hip_s / T * 1e3}
 
 
+def sweep_leg(dev):
+    """The workload of the reference's shipped generator/guided_sample_3d.sh: ONE set of 6 objects, 16 fingers, and on it the whole
+    validation sweep of generator/diffusion.py:307-339 - 12 objectives, each a multi-object chain (not for 'convergence') and the 6
+    per-object chains, 5 denoise steps each.  Unlike the headline workload (a fresh object per pair) the objects are reused 71 times,
+    which is what the per-object tables are for; the second figure forces the per-step gather kernels (test hook mode 3) to show what
+    the embedding table X[s1][q] (built once the objects have served more than 5 calls) is worth."""
+    B, G, P, L, N, sub, T, S, n_obj = 16, 45, 5, 42, 512, 512, 15, 5, 6
+    net = engine.Unet1d(synth.synth_state_dict(synth.unet_spec(), 11))
+    dyn = engine.Dynamics(3, synth.synth_state_dict(synth.dyn3d_spec(L), 33), L)
+    sched = DDIMScheduler(num_train_timesteps=T)
+    sched.set_timesteps(S)
+    noise = synth.synth_noise(0, B, L).to(dev)
+    objs = torch.stack([synth.synth_object_3d(900 + i, N) for i in range(n_obj)]).to(dev)
+    out = {}
+    for label, mode in (("with_embedding_tables", 0), ("gather_kernels_only", 3)):
+        times = []
+        for rep in range(2):                       # first repetition warms the allocator up
+            guid = engine.Guidance(dyn, B, G, P, (-1.0, 1.0), n_obj, T, N, sub, max_objects=n_obj)
+            guid.debug_fps_path(mode)
+            torch.manual_seed(0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            guid.set_objects(objs)
+            ug = sampler.unguided_sample(net, sched, noise)
+            n = 0
+            for o in synth.OBJECTIVES_12:
+                if o != 'convergence':
+                    sampler.guided_multi_object(net, guid, sched, 'point_3d', noise, list(range(n_obj)), o)
+                    n += B
+                sampler.guided_chains(net, guid, sched, 'point_3d', noise, [(i, o) for i in range(n_obj)], unguided=ug)
+                n += B * n_obj
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+            del guid
+        out[label] = {"seconds": times[-1], "samples_per_s": n / times[-1]}
+    return {"workload": "3d_sweep (generator/guided_sample_3d.sh: 6 objects x 12 objectives, B=16, G=45, P=5, sub_bs=512, T=15/S=5; objects reused)",
+            "dtype": "f32", "samples": n, **out}
+
+
 # ---------------------------------------------------------------------------------------------------------------- main
 def workload_text(kind, pairs):
     if kind == "3d_ensemble":
@@ -412,7 +451,7 @@ def main():
         del wl
         torch.cuda.empty_cache()
         # the other BASELINE configurations (not the headline: `value` above is what the driver reads)
-        extras = [config0(dev)]
+        extras = [config0(dev), sweep_leg(dev)]
         for kind, contraction in ((other, "f32"), ("3d", "bf16"), ("2d", "bf16"), ("3d_ensemble", "bf16")):
             w2 = Workload(kind, DEFAULT_PAIRS[kind], dev, rank, world, contraction)
             s2, _ = timed_loop(w2, 2, 1, None)

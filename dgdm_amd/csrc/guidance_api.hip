@@ -33,6 +33,8 @@ struct ObjectTables {       // 3-D, per object
     DevBuf crowded, clist;  // [N] int each + clist[N] = count: centres whose ball query truncates (pointnet.hip crowd_kernel)
     DevBuf M0, cl2, cnt2;   // [N][256] float, [N][128] int, [N] int: variant-independent part of the sa3 max (pointnet.hip m0_kernel)
     DevBuf cl2s;            // [N][128] cl2 as positions in clist (xobj_group_kernel)
+    DevBuf X, X16;          // [N][N][256] float32 / [N][N][128] bf16 dwords: the finished embedding per (s1, start point) (pointnet.hip xtab_kernel)
+    bool   has_x = false, has_x16 = false;
     int    ncr = 0;         // number of crowded centres (read back by set_objects)
     DevBuf Z16, M0_16;      // bf16 operand-order copies, built when the handle is in bf16 mode at set_objects time
     bool   has16 = false;
@@ -56,6 +58,11 @@ struct DgdmGuidance {
     hipStream_t bstream[NBUILD] = {nullptr, nullptr, nullptr}, fstream = nullptr;    // fstream: sa2's FPS table, beside the builds
     hipEvent_t bev[NBUILD] = {nullptr, nullptr, nullptr}, bstart = nullptr, fstart = nullptr, fdone = nullptr;
     DevBuf V, genc, atab, chainbias, timepart, ttmp, partial, objdev, objidx, xobj, xobj16, starts, order, xchains, todo, groupoff;
+    DevBuf xidx, xidxchains, xtabptrs;       // embedding-table path: row index per reference row, per-chain lookup info, per-chain table base pointers
+    bool xtab_enabled = true;       // test hook: modes 1-3 read materialised rows (per-step gather kernels) instead of the embedding table
+    int xtab_policy = 0;            // 0: build the embedding tables once the objects have served more than XTAB_AFTER cond_fn calls; 1: at set_objects (test hook mode 5)
+    int grads_since_set = 0;
+    static constexpr int XTAB_AFTER = 5;
     int l2_gather_mode = 0;         // test hook (mode 4): build the sa2 features of the crowded centres with l2_kernel's global gathers
     int xobj_mode = 0;              // test hook: 0 = group kernel where possible, 2 = per-row table kernel (xobj_fast_kernel)
     int n_objects = 0;
@@ -75,8 +82,11 @@ struct DgdmGuidance {
     }
     int build_pose_table(const std::vector<float> &ori, const std::vector<float> &pos, DevBuf *dst, DevBuf *dst_tiled, hipStream_t s);
     int common_pre(const float *x_dev, float t_scaled, const int *objidx_host, int n_chains, hipStream_t s);
-    int upload_starts(const int64_t *starts_host, int n_chains, int64_t rows, hipStream_t s);
+    int upload_starts(const int64_t *starts_host, int n_chains, int64_t rows, hipStream_t s, bool need_order = true);
+    // true + p filled when every chain's object has its embedding table in the wanted format: then no per-step gather runs at all
+    int use_xtab(const int *objidx_host, int n_chains, int64_t rows, bool want16, dgdm::TrunkParams *p, bool *ok, hipStream_t s);
     int build_object(int oi, int slot, hipStream_t s);
+    int build_xtab(int oi, hipStream_t s);
     int run_xobj(const int *objidx_host, int n_chains, int64_t rows, bool want16, bool *used16, hipStream_t s);
 };
 
@@ -142,7 +152,9 @@ extern "C" int dgdm_guidance_create(DgdmGuidance **out, DgdmDynamics *model, con
             (rc = g->todo.alloc(((size_t)nc * g->R + 1) * sizeof(int))))
             return rc;
         g->pinned_bytes = ((size_t)nc * g->R * 3 + (size_t)nc * (cfg->num_object_points + 1)) * sizeof(int);
-        if ((rc = g->groupoff.alloc((size_t)nc * (cfg->num_object_points + 1) * sizeof(int)))) return rc;
+        if ((rc = g->groupoff.alloc((size_t)nc * (cfg->num_object_points + 1) * sizeof(int))) || (rc = g->xidx.alloc((size_t)nc * g->R * sizeof(int))) ||
+            (rc = g->xidxchains.alloc(sizeof(XidxChain) * nc)) || (rc = g->xtabptrs.alloc(sizeof(void *) * nc)))
+            return rc;
         DGDM_HIP_CHECK(hipHostMalloc(&g->pinned, g->pinned_bytes, hipHostMallocDefault));
         DGDM_HIP_CHECK(hipEventCreateWithFlags(&g->pinned_ev, hipEventDisableTiming));
     }
@@ -164,6 +176,9 @@ extern "C" int dgdm_guidance_debug_fps_path(DgdmGuidance *g, int force_per_row, 
     g->force_slow_xobj = force_per_row == 1;            // 1: every row runs its own FPS; 2: per-row table kernel; 0: default (group kernel)
     g->xobj_mode = force_per_row == 2 ? 2 : 0;
     g->l2_gather_mode = force_per_row == 4 ? 1 : 0;     // takes effect at the next dgdm_guidance_set_objects
+    g->xtab_enabled = force_per_row == 0 || force_per_row == 4 || force_per_row == 5;      // modes 1-3 read materialised rows; 3 = the group gather kernel
+    g->xtab_policy = force_per_row == 5 ? 1 : 0;         // 5: the next set_objects builds the embedding tables right away
+    if (force_per_row == 3) g->xobj_mode = 0;
     if (out_fast_ok)
         for (int i = 0; i < g->n_objects && i < (int)g->tables.size(); ++i) out_fast_ok[i] = g->tables[i]->fast_ok ? 1 : 0;
     return DGDM_OK;
@@ -217,8 +232,30 @@ int DgdmGuidance::build_object(int oi, int slot, hipStream_t s) {
         if ((rc = pn_z16(xyz, N, N, w, tL2.as<uint32_t>(), t.Z.as<float>(), z16, t.clist.as<int>(), t.clist.as<int>() + N, s))) return rc;          // T6
     } else if ((rc = pn_z(xyz, N, N, w, tL2.as<float>(), t.Z.as<float>(), z16, t.clist.as<int>(), t.clist.as<int>() + N, s))) return rc;
     DGDM_HIP_CHECK(hipStreamWaitEvent(s, fdone, 0));          // fps2 (sa2's FPS table) is built beside the other stages, on its own stream
-    return pn_m0(t.fps2, t.crowded.as<int>(), N, t.Z.as<float>(), t.M0.as<float>(), t.cl2.as<int>(), t.cnt2.as<int>(), z16,
-                 bf16 ? t.M0_16.as<uint32_t>() : nullptr, t.clist.as<int>(), t.clist.as<int>() + N, t.cl2s.as<int>(), s);                         // T7
+    if ((rc = pn_m0(t.fps2, t.crowded.as<int>(), N, t.Z.as<float>(), t.M0.as<float>(), t.cl2.as<int>(), t.cnt2.as<int>(), z16,
+                    bf16 ? t.M0_16.as<uint32_t>() : nullptr, t.clist.as<int>(), t.clist.as<int>() + N, t.cl2s.as<int>(), s))) return rc;          // T7
+    t.has_x = t.has_x16 = false;
+    return xtab_policy == 1 ? build_xtab(oi, s) : DGDM_OK;       // eager only on request: see guidance_grad for when it pays
+}
+
+// T8: the embedding table of object oi in the format the trunk of the object's build mode reads (float32 for the parity path, bf16
+// operand-order rows when the object was built in bf16 mode)
+int DgdmGuidance::build_xtab(int oi, hipStream_t s) {
+    const int N = cfg.num_object_points;
+    ObjectTables &t = *tables[oi];
+    if (N < 128) return DGDM_OK;
+    const bool b16 = t.has16;
+    int rc;
+    if (b16) { if ((rc = t.X16.alloc((size_t)N * N * 128 * 4))) return rc; }
+    else if ((rc = t.X.alloc((size_t)N * N * 256 * 4))) return rc;
+    XtabObj xo{};
+    xo.xyz = t.xyz; xo.fps1 = t.fps1; xo.Z = t.Z.as<float>(); xo.M0 = t.M0.as<float>();
+    xo.Z16 = b16 ? t.Z16.as<uint32_t>() : nullptr; xo.M0_16 = b16 ? t.M0_16.as<uint32_t>() : nullptr;
+    xo.clist = t.clist.as<int>(); xo.ncr = t.clist.as<int>() + N; xo.cl2s = t.cl2s.as<int>(); xo.cnt2 = t.cnt2.as<int>(); xo.flags = t.flags;
+    xo.crowded = t.crowded.as<int>(); xo.X = b16 ? nullptr : t.X.as<float>(); xo.X16 = b16 ? t.X16.as<uint32_t>() : nullptr; xo.N = N;
+    if ((rc = pn_xtab(xo, b16, s))) return rc;
+    (b16 ? t.has_x16 : t.has_x) = true;
+    return DGDM_OK;
 }
 
 extern "C" int dgdm_guidance_set_objects(DgdmGuidance *g, const float *objects_dev, int n_objects, void *stream) {
@@ -295,6 +332,7 @@ extern "C" int dgdm_guidance_set_objects(DgdmGuidance *g, const float *objects_d
         }
     }
     g->n_objects = n_objects;
+    g->grads_since_set = 0;
     return DGDM_OK;
 }
 
@@ -316,7 +354,7 @@ int DgdmGuidance::common_pre(const float *x_dev, float t_scaled, const int *obji
 }
 
 // Reference draw order per chain: for each sub-batch i, sa1's torch.randint(rows_i) then sa2's  ->  device [chain][row][2]
-int DgdmGuidance::upload_starts(const int64_t *starts_host, int n_chains, int64_t rows, hipStream_t s) {
+int DgdmGuidance::upload_starts(const int64_t *starts_host, int n_chains, int64_t rows, hipStream_t s, bool need_order) {
     const int N = cfg.num_object_points;
     const int64_t sb = cfg.sub_batch_size;
     DGDM_REQUIRE(((size_t)n_chains * rows * 3 + (size_t)n_chains * (N + 1)) * sizeof(int) <= pinned_bytes, DGDM_EINVAL, "starts staging too small");
@@ -341,6 +379,7 @@ int DgdmGuidance::upload_starts(const int64_t *starts_host, int n_chains, int64_
                     d[2 * (r0 + k)] = (int)a; d[2 * (r0 + k) + 1] = (int)b;
                 }
             }
+            if (!need_order) continue;                      // embedding-table path: rows are looked up where they are
             int *o = ord + (size_t)c * rows;
             std::fill(cnt.begin(), cnt.end(), 0);
             for (int64_t r = 0; r < rows; ++r) ++cnt[d[2 * r] + 1];
@@ -359,9 +398,35 @@ int DgdmGuidance::upload_starts(const int64_t *starts_host, int n_chains, int64_
     }
     DGDM_REQUIRE(!bad.load(), DGDM_EINVAL, "FPS start out of range (sa1 must be in [0, %d), sa2 in [0, 512))", N);
     DGDM_HIP_CHECK(hipMemcpyAsync(starts.p, pinned, (size_t)n_chains * rows * 2 * sizeof(int), hipMemcpyHostToDevice, s));
-    DGDM_HIP_CHECK(hipMemcpyAsync(order.p, ord, (size_t)n_chains * rows * sizeof(int), hipMemcpyHostToDevice, s));
-    DGDM_HIP_CHECK(hipMemcpyAsync(groupoff.p, goff, (size_t)n_chains * (N + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+    if (need_order) {
+        DGDM_HIP_CHECK(hipMemcpyAsync(order.p, ord, (size_t)n_chains * rows * sizeof(int), hipMemcpyHostToDevice, s));
+        DGDM_HIP_CHECK(hipMemcpyAsync(groupoff.p, goff, (size_t)n_chains * (N + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+    }
     DGDM_HIP_CHECK(hipEventRecord(pinned_ev, s));
+    return DGDM_OK;
+}
+
+int DgdmGuidance::use_xtab(const int *objidx_host, int n_chains, int64_t rows, bool want16, TrunkParams *p, bool *ok, hipStream_t s) {
+    *ok = false;
+    if (!xtab_enabled || force_slow_xobj || xobj_mode != 0) return DGDM_OK;
+    std::vector<XidxChain> xc(n_chains);
+    std::vector<const void *> base(n_chains);
+    for (int i = 0; i < n_chains; ++i) {
+        DGDM_REQUIRE(objidx_host[i] >= 0 && objidx_host[i] < n_objects, DGDM_EINVAL, "chain %d refers to object %d of %d", i, objidx_host[i], n_objects);
+        const ObjectTables &t = *tables[objidx_host[i]];
+        if (!(want16 ? t.has_x16 : t.has_x)) return DGDM_OK;          // built in the other format (or not at all): gather kernels
+        xc[i].fps1 = t.fps1; xc[i].N = cfg.num_object_points; xc[i].m0_only = t.ncr == 0;
+        // an object without crowded centres has X[s1][q] = M0[q]: its table is M0 itself (xtab_kernel wrote nothing)
+        base[i] = want16 ? (t.ncr == 0 ? (const void *)t.M0_16.p : (const void *)t.X16.p) : (t.ncr == 0 ? (const void *)t.M0.p : (const void *)t.X.p);
+    }
+    DGDM_HIP_CHECK(hipMemcpyAsync(xidxchains.p, xc.data(), sizeof(XidxChain) * n_chains, hipMemcpyHostToDevice, s));      // pageable: staged before return
+    DGDM_HIP_CHECK(hipMemcpyAsync(xtabptrs.p, base.data(), sizeof(void *) * n_chains, hipMemcpyHostToDevice, s));
+    int rc;
+    if ((rc = pn_xidx(xidxchains.as<XidxChain>(), starts.as<int>(), rows, n_chains, xidx.as<int>(), s))) return rc;
+    p->xidx = xidx.as<int>();
+    if (want16) p->xtab16 = xtabptrs.as<const uint32_t *>();
+    else p->xtab = xtabptrs.as<const float *>();
+    *ok = true;
     return DGDM_OK;
 }
 
@@ -431,12 +496,31 @@ static int guidance_grad(DgdmGuidance *g, int kind, const float *x_dev, int time
     if (kind == 3) {
         DGDM_REQUIRE(starts_host, DGDM_EINVAL, "3-D guidance needs the FPS start indices");
         prof_begin(s, DGDM_STAGE_XOBJ);
-        if ((rc = g->upload_starts(starts_host, n_chains, g->R, s))) return rc;
-        bool used16 = false;
-        if ((rc = g->run_xobj(oidx.data(), n_chains, g->R, g->bf16, &used16, s))) return rc;
+        // with the embedding tables of set_objects in place a row's embedding is a table row: only the (s1, s2) pairs go to the device
+        // The table X[s1][q] of an object costs about what 7 of these calls spend gathering its rows (it holds all 262 144 (s1, q)
+        // pairs; one call touches 36 000 of them): it pays as soon as the objects serve more than one 5-step chain - the
+        // reference's validation sweep runs 12 objectives x 5 steps (+ the multi-object chains) on the same objects - and it would
+        // cost 2 % when every pair brings its own object (bench.py).  So it is built when the call count says the objects are being
+        // reused: on call XTAB_AFTER + 1 since set_objects.
+        bool tab = g->xtab_enabled && !g->force_slow_xobj && g->xobj_mode == 0;
+        if (tab && ++g->grads_since_set == DgdmGuidance::XTAB_AFTER + 1)
+            for (int i = 0; i < g->n_objects; ++i) {
+                ObjectTables &t = *g->tables[i];
+                if (!(t.has16 ? t.has_x16 : t.has_x) && (rc = g->build_xtab(i, s))) return rc;
+            }
+        for (int i = 0; i < n_chains && tab; ++i) {
+            DGDM_REQUIRE(oidx[i] >= 0 && oidx[i] < g->n_objects, DGDM_EINVAL, "chain %d refers to object %d of %d", i, oidx[i], g->n_objects);
+            tab = g->bf16 ? g->tables[oidx[i]]->has_x16 : g->tables[oidx[i]]->has_x;
+        }
+        if ((rc = g->upload_starts(starts_host, n_chains, g->R, s, !tab))) return rc;
+        if (tab && (rc = g->use_xtab(oidx.data(), n_chains, g->R, g->bf16, &p, &tab, s))) return rc;
+        if (!tab) {
+            bool used16 = false;
+            if ((rc = g->run_xobj(oidx.data(), n_chains, g->R, g->bf16, &used16, s))) return rc;
+            p.xobj = g->xobj.as<float>();
+            p.xobj16 = used16 ? g->xobj16.as<uint32_t>() : nullptr;
+        }
         prof_end(s, DGDM_STAGE_XOBJ, 0.0);
-        p.xobj = g->xobj.as<float>();
-        p.xobj16 = used16 ? g->xobj16.as<uint32_t>() : nullptr;
     }
     p.Atab = g->atab.as<float>(); p.Ptab = g->ptab.as<float>(); p.PtabT = g->ptab_t.as<float>(); p.obj = g->objdev.as<TrunkObjective>(); p.rowcoef = rowcoef_dev;
     p.partial = g->partial.as<float>();
@@ -493,9 +577,15 @@ extern "C" int dgdm_guidance_orientation_sweep(DgdmGuidance *g, const float *x_d
     g->m->fill_trunk(&p);
     if (kind == 3) {
         DGDM_REQUIRE(starts_host, DGDM_EINVAL, "3-D sweep needs the FPS start indices");
-        if ((rc = g->upload_starts(starts_host, n_chains, g->Rs, s))) return rc;
-        if ((rc = g->run_xobj(object_of_chain, n_chains, g->Rs, false, nullptr, s))) return rc;      // the sweep stays float32
-        p.xobj = g->xobj.as<float>();
+        // the sweep stays float32: table rows when the float32 tables exist, the gather kernels otherwise (e.g. a bf16-mode handle)
+        bool tab = g->xtab_enabled && !g->force_slow_xobj && g->xobj_mode == 0;
+        for (int i = 0; i < n_chains && tab; ++i) tab = object_of_chain[i] >= 0 && object_of_chain[i] < g->n_objects && g->tables[object_of_chain[i]]->has_x;
+        if ((rc = g->upload_starts(starts_host, n_chains, g->Rs, s, !tab))) return rc;
+        if (tab && (rc = g->use_xtab(object_of_chain, n_chains, g->Rs, false, &p, &tab, s))) return rc;
+        if (!tab) {
+            if ((rc = g->run_xobj(object_of_chain, n_chains, g->Rs, false, nullptr, s))) return rc;
+            p.xobj = g->xobj.as<float>();
+        }
     }
     p.Atab = g->atab.as<float>(); p.Ptab = g->ptab_sweep.as<float>(); p.PtabT = g->ptab_sweep_t.as<float>(); p.logits = logits_dev;
     p.B = g->B; p.C = g->G; p.tiles_per_b = g->sweep_tiles_per_b; p.ntiles = n_chains * g->B * g->sweep_tiles_per_b; p.R = g->Rs;

@@ -58,6 +58,23 @@ struct XobjParams {
     int              nchain, total_items;
 };
 
+// Per-object table of finished embeddings (xtab_kernel): X[s1][q] = max(M0[q], max over the crowded centres of fps2[q] of Z[s1][centre]) -
+// everything a reference row contributes to the trunk depends on its two FPS draws only through (s1, q = fps1[s1][s2]).
+struct XtabObj {
+    const float *xyz; const int *fps1;            // [N][3], [N][512]
+    const float *Z, *M0; const uint32_t *Z16, *M0_16;
+    const int *clist, *ncr;                       // crowded centres (device count)
+    const int *cl2s, *cnt2, *flags, *crowded;
+    float *X; uint32_t *X16;                      // [N][N][256] float32 or [N][N][128] bf16 operand-order dwords (one of them)
+    int N;
+};
+// builds X (or X16) for one object; start points whose FPS(128) sequence is order-dependent (flags) get their rows from a per-row FPS
+int pn_xtab(const XtabObj &o, bool bf16, hipStream_t s);
+// per reference row the row of X its embedding is: idx[chain][r] = s1 * N + q (or q alone for chains whose object has no crowded centre:
+// their table is M0 itself)
+struct XidxChain { const int *fps1; int N; int m0_only; };
+int pn_xidx(const XidxChain *chains_dev, const int *starts, int64_t R, int nchain, int *idx, hipStream_t s);
+
 int pn_fps_table(const float *xyz, int N, int nv, int npoint, int *out, int *flags, hipStream_t s, int nobj = 1);
 int pn_sa1(const float *xyz, int N, const PnWeights &w, float *F1, hipStream_t s);
 // crowded/clist/ncr: centres whose ball holds > 64 points; off [N+1], pairs [<= N*N], rank [N][N]: the in-radius pair list (T4/T5)

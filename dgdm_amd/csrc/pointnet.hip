@@ -1097,6 +1097,203 @@ int pn_xobj_groups(const XobjParams &p, hipStream_t s) {
     return DGDM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ T8: the embedding table X
+// A reference row's embedding depends on its draws (s1, s2) only through s1 and the start POINT q = fps1[s1][s2] of sa2's FPS:
+//   X[s1][q] = max( M0[q], max over the crowded centres c of fps2[q] of Z[s1][c] ).
+// 512 x 512 rows per object, built once per object by the same slab-in-LDS reduction xobj_group_kernel does per denoise step
+// (one workgroup per (s1, feature chunk): the variant's crowded rows staged once, then ALL 512 start points reduced from LDS);
+// afterwards a cond_fn call needs no gather at all - the trunk reads row X[s1 * N + q] directly.  One chain uses 36 000 rows per
+// step, 180 000 over the 5 steps, of these 262 144 - so the table costs about what 1.5 chains' worth of per-step gathers did, and
+// an object usually serves 12 objectives.  Objects without crowded centres need no table: X[s1][q] = M0[q].
+template <bool BF16, int LPR>
+__device__ __forceinline__ void xtab_body(const XtabObj &o, int ncr, int s1, int chunk, uint32_t *slab) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    constexpr int W = BF16 ? 128 : 256, F = 4 * LPR, RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int f0 = chunk * F, N = o.N;
+    const uint32_t *Zs = (BF16 ? o.Z16 : reinterpret_cast<const uint32_t *>(o.Z)) + ((size_t)s1 * N) * W + f0;
+    const int pieces = ncr * LPR;
+    for (int i0 = threadIdx.x; i0 < pieces; i0 += 256 * 8) {
+        u4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + 256 * k;
+            if (i < pieces) v[k] = *reinterpret_cast<const u4 *>(Zs + (size_t)o.clist[i / LPR] * W + (i % LPR) * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + 256 * k;
+            if (i < pieces) *reinterpret_cast<u4 *>(slab + (size_t)i * 4) = v[k];
+        }
+    }
+    __syncthreads();
+    const int sg = lane / LPR, fl = lane % LPR;
+    const uint32_t *M0 = (BF16 ? o.M0_16 : reinterpret_cast<const uint32_t *>(o.M0)) + f0 + fl * 4;
+    uint32_t *out = (BF16 ? o.X16 : reinterpret_cast<uint32_t *>(o.X)) + ((size_t)s1 * N) * W + f0 + fl * 4;
+    auto vmax4 = [](u4 a, u4 b) {
+        u4 r;
+        if (BF16) { r.x = pkmax_u16(a.x, b.x); r.y = pkmax_u16(a.y, b.y); r.z = pkmax_u16(a.z, b.z); r.w = pkmax_u16(a.w, b.w); }
+        else {
+            r.x = __float_as_uint(fmaxf(__uint_as_float(a.x), __uint_as_float(b.x))); r.y = __float_as_uint(fmaxf(__uint_as_float(a.y), __uint_as_float(b.y)));
+            r.z = __float_as_uint(fmaxf(__uint_as_float(a.z), __uint_as_float(b.z))); r.w = __float_as_uint(fmaxf(__uint_as_float(a.w), __uint_as_float(b.w)));
+        }
+        return r;
+    };
+    // start points q = wave, wave + 4, ...: 64 of them per pass, their counts / tie flags one per lane, then four at a time
+    for (int kb = 0; kb < N; kb += 256) {
+        const int myq = kb + wave + 4 * lane;
+        const int cnt_v = myq < N ? o.cnt2[myq] : 0;
+        const int slow_v = myq < N ? o.flags[myq] : 1;
+        const int nmine = min(64, (N - kb - wave + 3) / 4);
+        for (int i0 = 0; i0 < nmine; i0 += 4) {
+            int SA[4], SB[4];
+            u4 m0[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int qn = kb + wave + 4 * min(i0 + u, nmine - 1);
+                SA[u] = o.cl2s[(size_t)qn * 128 + lane]; SB[u] = o.cl2s[(size_t)qn * 128 + 64 + lane];
+                m0[u] = *reinterpret_cast<const u4 *>(M0 + (size_t)qn * W);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u;
+                if (i >= nmine) break;
+                const int q = kb + wave + 4 * i;
+                const int cnt = __builtin_amdgcn_readlane(cnt_v, i), slow = __builtin_amdgcn_readlane(slow_v, i);
+                if (slow) continue;                                     // xtab_slow_kernel's row
+                const int sa = SA[u], sb = SB[u];
+                u4 best = m0[u];
+                for (int j = 0; j < cnt; j += 4 * RPW) {
+                    u4 v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int jj = j + e * RPW;
+                        int slot;
+                        if (RPW == 1) slot = jj < 64 ? __builtin_amdgcn_readlane(sa, jj & 63) : __builtin_amdgcn_readlane(sb, jj & 63);
+                        else slot = __shfl(jj < 64 ? sa : sb, (jj & 63) + sg);
+                        v[e] = *reinterpret_cast<const u4 *>(slab + ((size_t)slot * LPR + fl) * 4);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) best = vmax4(best, v[e]);
+                }
+                if (RPW > 1 && cnt > 0) {
+#pragma unroll
+                    for (int x = 32; x >= LPR; x >>= 1) {
+                        u4 t;
+                        t.x = __shfl_xor(best.x, x); t.y = __shfl_xor(best.y, x); t.z = __shfl_xor(best.z, x); t.w = __shfl_xor(best.w, x);
+                        best = vmax4(best, t);
+                    }
+                }
+                if (sg == 0) *reinterpret_cast<u4 *>(out + (size_t)q * W) = best;
+            }
+        }
+    }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256, 2) void xtab_kernel(const XtabObj o) {
+    extern __shared__ uint32_t xt_slab[];
+    constexpr int W = BF16 ? 128 : 256, MAXCH = W / 32;
+    const int ncr = *o.ncr;
+    if (ncr == 0) return;                                               // the object's table is M0 itself
+    int lpr = W / 4;
+    while (lpr > 8 && (size_t)ncr * lpr * 16 > (size_t)XG_LDS_BYTES) lpr >>= 1;
+    const int nchunk = (W / 4) / lpr;
+    const int s1 = blockIdx.x / MAXCH, chunk = blockIdx.x % MAXCH;
+    if (chunk >= nchunk) return;
+    switch (lpr) {
+        case 64: if (!BF16) xtab_body<BF16, (BF16 ? 32 : 64)>(o, ncr, s1, chunk, xt_slab); break;
+        case 32: xtab_body<BF16, 32>(o, ncr, s1, chunk, xt_slab); break;
+        case 16: xtab_body<BF16, 16>(o, ncr, s1, chunk, xt_slab); break;
+        default: xtab_body<BF16, 8>(o, ncr, s1, chunk, xt_slab); break;
+    }
+}
+
+// Rows X[s1][q] of the start points q whose FPS(128) sequence depends on the ordering (exact distance ties: flags[q]): FPS on the
+// cloud as re-ordered by variant s1, started at q's position, as the reference does for every row.  One workgroup per s1.
+template <bool BF16>
+__global__ __launch_bounds__(256) void xtab_slow_kernel(const XtabObj o) {
+    typedef RowOps<BF16> R;
+    __shared__ float coords[4][3][512];
+    __shared__ int centres[4][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, s1 = blockIdx.x, N = o.N;
+    if (*o.ncr == 0) return;
+    const int *perm = o.fps1 + (size_t)s1 * 512;
+    XobjChain ch{};
+    ch.Z = o.Z; ch.Z16 = o.Z16;
+    int seen = 0;
+    for (int q = 0; q < N; ++q) {
+        if (o.flags[q] == 0) continue;                                  // uniform
+        if ((seen++ & 3) != wave) continue;
+        // position of q in the variant's order (any of them if the point repeats: the sequence of POINTS is the same)
+        int s2 = -1;
+        for (int base = 0; base < 512 && s2 < 0; base += 64) {
+            const unsigned long long m = __ballot(perm[base + lane] == q);
+            if (m) s2 = base + __ffsll((long long)m) - 1;
+        }
+        if (s2 < 0) continue;                                           // q is not among this variant's 512 centres: no row refers to it
+        float *lx = coords[wave][0], *ly = coords[wave][1], *lz = coords[wave][2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = lane + 64 * i, pid = perm[j];
+            lx[j] = o.xyz[3 * pid]; ly[j] = o.xyz[3 * pid + 1]; lz[j] = o.xyz[3 * pid + 2];
+        }
+        __builtin_amdgcn_wave_barrier();
+        fps_wave<8, false>(lx, ly, lz, 512, s2, 128, centres[wave], lane);
+        __builtin_amdgcn_wave_barrier();
+        const int idA = perm[centres[wave][lane]], idB = perm[centres[wave][64 + lane]];
+        const int rowA = (o.crowded[idA] ? s1 * N : 0) + idA, rowB = (o.crowded[idB] ? s1 * N : 0) + idB;
+        typename R::V best = R::zero();
+#pragma unroll 4
+        for (int i = 0; i < 64; i += 2) {
+            const int c0 = __shfl(rowA, i), c1 = __shfl(rowA, i + 1), c2 = __shfl(rowB, i), c3 = __shfl(rowB, i + 1);
+            const typename R::V a = R::load(ch, false, (size_t)c0, lane), b = R::load(ch, false, (size_t)c1, lane);
+            const typename R::V d = R::load(ch, false, (size_t)c2, lane), e = R::load(ch, false, (size_t)c3, lane);
+            best = R::vmax(R::vmax(best, R::vmax(a, b)), R::vmax(d, e));
+        }
+        if (BF16) reinterpret_cast<uint2 *>(o.X16 + ((size_t)s1 * N + q) * 128)[lane] = *reinterpret_cast<uint2 *>(&best);
+        else reinterpret_cast<float4 *>(o.X + ((size_t)s1 * N + q) * 256)[lane] = *reinterpret_cast<float4 *>(&best);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+int pn_xtab(const XtabObj &o, bool bf16, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        DGDM_HIP_CHECK(hipFuncSetAttribute((const void *)xtab_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, XG_LDS_BYTES));
+        DGDM_HIP_CHECK(hipFuncSetAttribute((const void *)xtab_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, XG_LDS_BYTES));
+        attr_set = true;
+    }
+    if (bf16) {
+        hipLaunchKernelGGL(xtab_kernel<true>, dim3(o.N * 4), dim3(256), XG_LDS_BYTES, s, o);
+        hipLaunchKernelGGL(xtab_slow_kernel<true>, dim3(o.N), dim3(256), 0, s, o);
+    } else {
+        hipLaunchKernelGGL(xtab_kernel<false>, dim3(o.N * 8), dim3(256), XG_LDS_BYTES, s, o);
+        hipLaunchKernelGGL(xtab_slow_kernel<false>, dim3(o.N), dim3(256), 0, s, o);
+    }
+    DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
+}
+
+__global__ __launch_bounds__(256) void xidx_kernel(const XidxChain *__restrict__ chains, const int *__restrict__ starts, int64_t R, int64_t total,
+                                                   int *__restrict__ idx) {
+    const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (w >= total) return;
+    const int chain = (int)(w / R);
+    const XidxChain ch = chains[chain];
+    const int s1 = starts[2 * w], s2 = starts[2 * w + 1];
+    const int q = ch.fps1[(size_t)s1 * 512 + s2];
+    idx[w] = ch.m0_only ? q : s1 * ch.N + q;
+}
+
+int pn_xidx(const XidxChain *chains_dev, const int *starts, int64_t R, int nchain, int *idx, hipStream_t s) {
+    const int64_t total = R * nchain;
+    if (total <= 0) return DGDM_OK;
+    hipLaunchKernelGGL(xidx_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, chains_dev, starts, R, total, idx);
+    DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 int pn_fps_table(const float *xyz, int N, int nv, int npoint, int *out, int *flags, hipStream_t s, int nobj) {
     hipLaunchKernelGGL(fps_table_kernel, dim3((nv + 3) / 4, nobj), dim3(256), (size_t)3 * N * sizeof(float), s, xyz, N, nv, npoint, out, flags);

@@ -25,6 +25,11 @@ struct TrunkParams {
     const float  *b2;         // folded bias of layer 2
     const float  *xobj;       // [nchain][R][256]  PointNet++ embedding per reference row
     const uint32_t *xobj16;   // bf16 trunk only: the same rows in bf16 operand order [nchain][R][128 dwords] (mfma_chain.h), or null
+    // table mode, 3-D: instead of materialised rows, the per-object embedding tables (pointnet.h xtab): row r of chain c is
+    // xtab[c] + xidx[c * R + r] * 256 floats (xtab16: * 128 dwords).  Null: read xobj / xobj16.
+    const float *const *xtab;
+    const uint32_t *const *xtab16;
+    const int    *xidx;
     // first-layer tables
     const float  *Atab;       // table mode: [nchain*B][W1]; rows mode: [rows][W1]
     const float  *Ptab;       // [C][W1]  (table mode)

@@ -245,9 +245,11 @@ __device__ __forceinline__ void front3d(const wrsrc_t rs, const int voff, float4
     u32x4_t xin[8][2];
     const float *xrow = p.xobj + ((size_t)tr.chain * p.R + tr.r) * 256;
     f32x16 acc2[8];
-    if (p.xobj16) {
-        // the embedding was produced in bf16 operand order (pointnet.hip xobj kernels): the row IS the B operand
-        const u32x4_t *row16 = reinterpret_cast<const u32x4_t *>(p.xobj16 + ((size_t)tr.chain * p.R + tr.r) * 128) + (h4 >> 1);
+    if (p.xobj16 || p.xtab16) {
+        // the embedding was produced in bf16 operand order (pointnet.hip xobj kernels / embedding table): the row IS the B operand
+        const uint32_t *r16 = p.xtab16 ? p.xtab16[tr.chain] + (size_t)p.xidx[(size_t)tr.chain * p.R + tr.r] * 128
+                                       : p.xobj16 + ((size_t)tr.chain * p.R + tr.r) * 128;
+        const u32x4_t *row16 = reinterpret_cast<const u32x4_t *>(r16) + (h4 >> 1);
 #pragma unroll
         for (int o = 0; o < 8; ++o) { xin[o][0] = row16[4 * o]; xin[o][1] = row16[4 * o + 1]; }
 #pragma unroll

@@ -154,9 +154,11 @@ class Guidance:
         self.n_objects = o.shape[0]
 
     def debug_fps_path(self, mode):
-        """Test hook: which kernels build the per-row PointNet++ embeddings.  0 / False: default ((chain, s1)-group kernel where
-        the slab fits LDS); 1 / True: every row runs its own FPS(128); 2: per-row table kernel.  All three must agree bit for bit.
-        Returns which objects are admissible for the table path."""
+        """Test hook: where a reference row's PointNet++ embedding comes from.  0 / False: default ((chain, s1)-group gather kernel
+        until the objects have served more than 5 cond_fn calls, then the per-object embedding table and no gather at all); 5: the
+        next set_objects builds the embedding tables right away; 3: always the group gather kernel; 2: per-row table kernel;
+        1 / True: every row runs its own FPS(128); 4: like 0, and the next set_objects builds the crowded centres' features with
+        global gathers.  All must agree bit for bit.  Returns which objects are admissible for the table path."""
         ok = (C.c_int32 * max(1, self.n_objects))()
         check(lib().dgdm_guidance_debug_fps_path(self._h, int(mode), ok))
         return [bool(v) for v in ok][:self.n_objects]

@@ -226,11 +226,14 @@ enum {
     DGDM_STAGE_COUNT
 };
 int dgdm_prof_enable(int on);
-/* Test hook (3-D): which kernels build the per-row PointNet++ embeddings - mode 0: default (one workgroup per
- * (chain, s1) group, the variant's crowded-centre rows staged in LDS); 1: every row runs its own FPS(128) instead of reading the
- * per-object table of order-independent sequences; 2: the per-row table kernel; 4: like 0, and the NEXT dgdm_guidance_set_objects builds
- * the crowded centres' sa2 features with per-(variant, centre) global gathers instead of the LDS-staged kernel.  Results must be identical.  Also reports, per
- * object of the bank, whether the table path is admissible (out_fast_ok[n_objects], may be NULL).                          */
+/* Test hook (3-D): where a reference row's PointNet++ embedding comes from - mode 0: default: one workgroup per
+ * (chain, s1) group with the variant's crowded-centre rows staged in LDS, until the objects of the last dgdm_guidance_set_objects have
+ * served more than 5 guidance calls; from then on the per-object embedding table X[s1][start point] (built at that moment) and no gather
+ * kernel at all; 5: the NEXT set_objects builds the embedding tables right away; 3: always the group kernel; 2: the per-row table kernel;
+ * 1: every row runs its own FPS(128) instead of reading the per-object table of order-independent sequences; 4: like 0, and the NEXT
+ * set_objects builds the crowded centres' sa2 features with per-(variant, centre) global gathers instead of the LDS-staged kernel.
+ * Results must be identical.  Also reports, per object of the bank, whether the table of FPS(128) sequences is admissible
+ * (out_fast_ok[n_objects], may be NULL).                                                                                                */
 int dgdm_guidance_debug_fps_path(DgdmGuidance *g, int mode, int32_t *out_fast_ok);
 /* Test hook: the per-tile partial sums of d objective / d z1 (z1 = the first trunk layer's pre-activation, BatchNorm folded) that the
  * last dgdm_dyn{2,3}d_guidance_grad call produced: out_dev [n_chains * B * tiles_per_finger][width], tile index

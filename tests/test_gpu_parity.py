@@ -330,8 +330,9 @@ def test_dyn3d_cond_fn_oracle_fps_paths(dev):
 
 
 def test_xobj_kernels_agree(dev):
-    """The three ways of building the per-row embeddings - (chain, s1)-group kernel (LDS slab; 1, 2 or 8 feature chunks depending
-    on how many crowded centres the object has), per-row table kernel, per-row FPS - give bit-identical gradients; float32 and
+    """The four ways of getting a row's embedding - the per-object embedding table X[s1][q] (default: no per-step kernel at all), the
+    (chain, s1)-group gather kernel (LDS slab; 1, 2 or 8 feature chunks depending on how many crowded centres the object has), the
+    per-row table kernel, per-row FPS - give bit-identical gradients; float32 and
     bf16 table formats; objects with 0 / 146 / 506 crowded centres and one with exact duplicate points (tie-flagged start points)."""
     B, G, P, L, T, sub = 2, 12, 3, 42, 15, 64
     dyn = engine.Dynamics(3, util.dyn3d_sd(44), L)
@@ -349,12 +350,19 @@ def test_xobj_kernels_agree(dev):
         st = sampler.StartStream(512, sub)
         starts = np.concatenate([st.call(gd.rows) for _ in range(nc)])
         res = {}
-        for mode in (0, 2, 1):
+        for mode in (0, 3, 2, 1):
             gd.debug_fps_path(mode)
             res[mode] = gd.grad(x, 3, objectives, None, starts).cpu()
+        gd.debug_fps_path(5)                      # embedding tables X[s1][q] built by set_objects: no per-step gather kernel at all
+        gd.set_objects(objs.to(dev))
+        res[5] = gd.grad(x, 3, objectives, None, starts).cpu()
         gd.debug_fps_path(4)                      # tables rebuilt with l2_kernel's per-(variant, centre) gathers instead of l2c_kernel
         gd.set_objects(objs.to(dev))
         res[4] = gd.grad(x, 3, objectives, None, starts).cpu()
         gd.debug_fps_path(0)
-        assert torch.equal(res[0], res[2]) and torch.equal(res[0], res[1]) and torch.equal(res[0], res[4]), dtype
+        assert all(torch.equal(res[0], res[m]) for m in (3, 2, 1, 5, 4)), dtype
+        # default policy: the embedding tables appear once the objects have served more than 5 calls; nothing changes numerically
+        gd.set_objects(objs.to(dev))
+        for k in range(8):
+            assert torch.equal(gd.grad(x, 3, objectives, None, starts).cpu(), res[0]), (dtype, k)
         assert float(res[0].abs().max()) > 0
