@@ -65,6 +65,8 @@ PROTOTYPES = {
     "dgdm_guidance_starts_per_call": (C.c_int64, [_P]),
     "dgdm_dyn2d_guidance_grad": (C.c_int, [_P, _P, C.c_int, C.POINTER(Objective), _P, C.c_int, _P, _P]),
     "dgdm_dyn3d_guidance_grad": (C.c_int, [_P, _P, C.c_int, C.POINTER(Objective), _P, _P, C.c_int, _P, _P]),
+    "dgdm_guided_chains_run": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.POINTER(Objective), _P, _P, C.POINTER(C.c_int32), C.POINTER(C.c_float),
+                                         C.POINTER(C.c_float), C.c_int, _P, _P]),
     "dgdm_guidance_orientation_sweep": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P]),
     "dgdm_convergence_rowcoef": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, _P]),
     "dgdm_prof_enable": (C.c_int, [C.c_int]),

@@ -58,6 +58,7 @@ struct DgdmGuidance {
     hipStream_t bstream[NBUILD] = {nullptr, nullptr, nullptr}, fstream = nullptr;    // fstream: sa2's FPS table, beside the builds
     hipEvent_t bev[NBUILD] = {nullptr, nullptr, nullptr}, bstart = nullptr, fstart = nullptr, fdone = nullptr;
     DevBuf V, genc, atab, chainbias, timepart, ttmp, partial, objdev, objidx, xobj, xobj16, starts, order, xchains, todo, groupoff;
+    DevBuf loopx[2], loopeps, loopgrad, loopxrep, loopts;      // workspace of dgdm_guided_chains_run
     DevBuf xidx, xidxchains, xtabptrs;       // embedding-table path: row index per reference row, per-chain lookup info, per-chain table base pointers
     bool xtab_enabled = true;       // test hook: modes 1-3 read materialised rows (per-step gather kernels) instead of the embedding table
     int xtab_policy = 0;            // 0: build the embedding tables once the objects have served more than XTAB_AFTER cond_fn calls; 1: at set_objects (test hook mode 5)
@@ -562,6 +563,72 @@ extern "C" int dgdm_dyn2d_guidance_grad(DgdmGuidance *g, const float *x_dev, int
 extern "C" int dgdm_dyn3d_guidance_grad(DgdmGuidance *g, const float *x_dev, int timestep, const DgdmObjective *objectives,
                                         const float *rowcoef_dev, const int64_t *starts_host, int n_chains, float *grad_dev, void *stream) {
     return guidance_grad(g, 3, x_dev, timestep, objectives, rowcoef_dev, starts_host, n_chains, grad_dev, (hipStream_t)stream);
+}
+
+// ================================================================================================ the denoise loop as one call
+namespace {
+__global__ void fill_i32_kernel(int *p, int v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void repeat_rows_kernel(const float *__restrict__ src, float *__restrict__ dst, int64_t n_src, int reps) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_src * reps) dst[i] = src[i % n_src];
+}
+}  // namespace
+
+extern "C" int dgdm_guided_chains_run(DgdmUnet1d *unet, DgdmGuidance *g, const float *noise_dev, int n_chains, int n_grad,
+                                      const DgdmObjective *objectives, const float *rowcoef_dev, const int64_t *starts_host,
+                                      const int32_t *timesteps, const float *coef, const float *scales, int n_steps, float *x_out_dev,
+                                      void *stream) {
+    DGDM_REQUIRE(unet && g && noise_dev && objectives && timesteps && coef && scales && x_out_dev, DGDM_EINVAL, "dgdm_guided_chains_run: null argument");
+    DGDM_REQUIRE(n_chains > 0 && n_grad > 0 && n_chains * n_grad <= g->cfg.max_chains && n_steps > 0, DGDM_EINVAL,
+                 "dgdm_guided_chains_run: %d chains x %d gradients outside 1..%d", n_chains, n_grad, g->cfg.max_chains);
+    hipStream_t s = (hipStream_t)stream;
+    const int B = g->B, L = g->m->L, kind = g->m->kind;
+    const size_t per_chain = (size_t)B * L, nx = per_chain * n_chains, ng = nx * n_grad;
+    DGDM_REQUIRE(kind == 2 || starts_host, DGDM_EINVAL, "3-D guidance needs the FPS start indices");
+    int rc;
+    if ((rc = g->loopx[0].alloc(nx * 4)) || (rc = g->loopx[1].alloc(nx * 4)) || (rc = g->loopeps.alloc(nx * 4)) || (rc = g->loopgrad.alloc(ng * 4)) ||
+        (rc = g->loopxrep.alloc(ng * 4)) || (rc = g->loopts.alloc((size_t)n_chains * B * sizeof(int))))
+        return rc;
+    // every chain starts from the same noise (generator/diffusion.py:570)
+    hipLaunchKernelGGL(repeat_rows_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, s, noise_dev, g->loopx[0].as<float>(), (int64_t)per_chain, n_chains);
+    bool same_scale = true;
+    for (int c = 1; c < n_chains; ++c) same_scale = same_scale && scales[c] == scales[0];
+    const int64_t spc = kind == 3 ? 2 * g->R : 0;
+    for (int si = 0; si < n_steps; ++si) {
+        float *x = g->loopx[si & 1].as<float>(), *xn = (si + 1 == n_steps) ? x_out_dev : g->loopx[(si + 1) & 1].as<float>();
+        const int t = timesteps[si];
+        // eps-net: at the first step all chains hold the same B fingers - one evaluation, replicated (same input, same bits)
+        const int nb = (si == 0 && n_chains > 1) ? B : n_chains * B;
+        hipLaunchKernelGGL(fill_i32_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, g->loopts.as<int>(), t, nb);
+        if ((rc = dgdm_unet1d_forward(unet, x, g->loopts.as<int>(), g->loopeps.as<float>(), nb, L, s))) return rc;
+        if (nb != n_chains * B) {
+            // replicate in place from the back so that the source block [0, per_chain) is read before it could be overwritten: separate buffer instead
+            hipLaunchKernelGGL(repeat_rows_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, s, g->loopeps.as<float>(), g->loopgrad.as<float>(), (int64_t)per_chain, n_chains);
+            DGDM_HIP_CHECK(hipMemcpyAsync(g->loopeps.p, g->loopgrad.p, nx * 4, hipMemcpyDeviceToDevice, s));
+        }
+        // cond_fn for the n_grad * n_chains gradient chains (object-major: gradient j of chain k is chain j * n_chains + k), x repeated
+        const float *xg = x;
+        if (n_grad > 1) {
+            hipLaunchKernelGGL(repeat_rows_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, x, g->loopxrep.as<float>(), (int64_t)nx, n_grad);
+            xg = g->loopxrep.as<float>();
+        }
+        const int64_t *st = kind == 3 ? starts_host + (size_t)si * n_chains * n_grad * spc : nullptr;
+        if ((rc = guidance_grad(g, kind, xg, t, objectives, rowcoef_dev, st, n_chains * n_grad, g->loopgrad.as<float>(), s))) return rc;
+        const float *cf = coef + 4 * si;
+        if (same_scale) {
+            if ((rc = dgdm_ddim_guided_step(x, g->loopeps.as<float>(), g->loopgrad.as<float>(), n_grad, xn, (int64_t)nx, cf[0], cf[1], cf[2], cf[3], scales[0], s))) return rc;
+        } else {
+            DGDM_REQUIRE(n_grad == 1, DGDM_EINVAL, "per-chain guidance scales with averaged gradients are not supported");
+            for (int c = 0; c < n_chains; ++c)
+                if ((rc = dgdm_ddim_guided_step(x + c * per_chain, g->loopeps.as<float>() + c * per_chain, g->loopgrad.as<float>() + c * per_chain, 1,
+                                                xn + c * per_chain, (int64_t)per_chain, cf[0], cf[1], cf[2], cf[3], scales[c], s))) return rc;
+        }
+    }
+    DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
 }
 
 extern "C" int dgdm_guidance_orientation_sweep(DgdmGuidance *g, const float *x_dev, const int32_t *object_of_chain, const int64_t *starts_host,

@@ -221,6 +221,29 @@ def ddim_guided_step(x: torch.Tensor, eps: torch.Tensor, grad: Optional[torch.Te
     return out
 
 
+def guided_chains_run(unet: "Unet1d", guid: "Guidance", noise: torch.Tensor, n_chains: int, n_grad: int, objectives: Sequence[_lib.Objective],
+                      rowcoef: Optional[torch.Tensor], starts: Optional[np.ndarray], timesteps: Sequence[int],
+                      coefs: Sequence[Tuple[float, float, float, float]], scales: Sequence[float]) -> torch.Tensor:
+    """The whole guided denoise loop in one library call (dgdm_guided_chains_run): noise (B, L) -> (n_chains, B, L)."""
+    x0 = _f32(noise).reshape(noise.shape[0], -1)
+    B, L = x0.shape
+    S = len(timesteps)
+    assert len(objectives) == n_chains * n_grad and len(scales) == n_chains and len(coefs) == S
+    arr = (_lib.Objective * len(objectives))(*objectives)
+    ts = (C.c_int32 * S)(*[int(t) for t in timesteps])
+    cf = (C.c_float * (4 * S))(*[float(v) for c in coefs for v in c])
+    sc = (C.c_float * n_chains)(*[float(v) for v in scales])
+    sp = None
+    if guid.dyn.kind == 3:
+        assert starts is not None and starts.dtype == np.int64 and starts.size == S * n_chains * n_grad * guid.starts_per_call
+        starts = np.ascontiguousarray(starts)
+        sp = starts.ctypes.data
+    out = torch.empty((n_chains, B, L), dtype=torch.float32, device=x0.device)
+    check(lib().dgdm_guided_chains_run(unet._h, guid._h, dptr(x0), n_chains, n_grad, arr, dptr(rowcoef) if rowcoef is not None else None, sp,
+                                       ts, cf, sc, S, dptr(out), stream_ptr()))
+    return out         # `starts` has been consumed: every step converts it into the handle's pinned staging buffer before it returns
+
+
 def ddim_add_noise(x0: torch.Tensor, noise: torch.Tensor, sqrt_abar: float, sqrt_1m_abar: float) -> torch.Tensor:
     x0, noise = _f32(x0), _f32(noise)
     out = torch.empty_like(x0)

@@ -187,6 +187,11 @@ def guided_chains(unet: Unet1d, guid: Guidance, sched: DDIMScheduler, mode: str,
             rc[c] = guid.rowcoef(centers[k])
         rowcoef = torch.from_numpy(rc).to(dev)
     scales = [classifier_scale(mode, o) for _, o in chains]
+    if trace is None:         # the loop itself runs inside the library (one call); the Python loop below is kept for traced runs
+        out = engine.guided_chains_run(unet, guid, noise.reshape(B, L), nc, 1, objectives, rowcoef,
+                                       np.ascontiguousarray(step_starts) if is3d else None, [int(t) for t in sched.timesteps],
+                                       [sched.coefficients(int(t)) for t in sched.timesteps], scales)
+        return out.reshape(nc, B, L, 1)
     x = noise.reshape(1, B, L).expand(nc, -1, -1).contiguous().to(torch.float32)
     for si, t in enumerate(sched.timesteps):
         t = int(t)
@@ -221,6 +226,12 @@ def guided_multi_object(unet: Unet1d, guid: Guidance, sched: DDIMScheduler, mode
     if is3d:
         starts = starts or StartStream(guid.cfg.num_object_points, guid.cfg.sub_batch_size)
     scale = classifier_scale(mode, opt_obj, multi=True)
+    if on_step is None:       # one library call for the whole loop; per step the reference draws object after object (:641-643)
+        S = len(sched.timesteps)
+        st = np.stack([np.concatenate([starts.call(guid.rows) for _ in object_indices]) for _ in range(S)]) if is3d else None
+        out = engine.guided_chains_run(unet, guid, noise.reshape(B, L), 1, n_obj, objectives, None, st, [int(t) for t in sched.timesteps],
+                                       [sched.coefficients(int(t)) for t in sched.timesteps], [scale])
+        return out.reshape(B, L, 1)
     x = noise.reshape(B, L).contiguous().to(torch.float32)
     for i, t in enumerate(sched.timesteps):
         t = int(t)
@@ -249,7 +260,7 @@ def draw_ensemble_starts(guid: Guidance, n_groups: int, n_obj: int, n_steps: int
 
 def guided_multi_object_groups(unet: Unet1d, guid: Guidance, sched: DDIMScheduler, mode: str, noise: torch.Tensor,
                                groups: Sequence[Sequence[int]], opt_objs: Sequence[str], streams: Optional[Sequence[StartStream]] = None,
-                               predrawn: Optional[np.ndarray] = None) -> torch.Tensor:
+                               predrawn: Optional[np.ndarray] = None, python_loop: bool = False) -> torch.Tensor:
     """Several independent ``guided_sample_multi_object`` chains (:637-647) in the same launches: chain k averages the guidance
     gradients of the objects ``groups[k]`` for objective ``opt_objs[k]`` (a guidance ensemble: n_obj dynamics-gradient
     evaluations per denoise step).  All groups have the same size.  Launch order of the gradient chains is object-major,
@@ -265,6 +276,11 @@ def guided_multi_object_groups(unet: Unet1d, guid: Guidance, sched: DDIMSchedule
     if is3d and predrawn is None:
         predrawn = draw_ensemble_starts(guid, K, n_obj, S, streams)
     scale = classifier_scale(mode, opt_objs[0], multi=True)
+    if not python_loop:       # one library call: K chains x n_obj gradients each, gradient chains object-major
+        out = engine.guided_chains_run(unet, guid, noise.reshape(B, L), K, n_obj, objectives, None,
+                                       np.ascontiguousarray(predrawn) if is3d else None, [int(t) for t in sched.timesteps],
+                                       [sched.coefficients(int(t)) for t in sched.timesteps], [scale] * K)
+        return out.reshape(K, B, L, 1)
     x = noise.reshape(1, B, L).expand(K, -1, -1).contiguous().to(torch.float32)
     for si, t in enumerate(sched.timesteps):
         t = int(t)

@@ -175,6 +175,22 @@ int dgdm_dyn3d_guidance_grad(DgdmGuidance *g, const float *x_dev, int timestep, 
                              const float *rowcoef_dev, const int64_t *starts_host, int n_chains, float *grad_dev,
                              void *stream);
 
+/* The whole guided denoise loop in one call: Diffusion.guided_sample's loop body (generator/diffusion.py:570-576) for n_chains chains, or
+ * guided_sample_multi_object's (:637-647) for n_chains chains that each average n_grad gradients - n_steps x [eps-net; cond_fn; guidance
+ * combine; scheduler step] without returning to the host language in between.
+ *   noise_dev    [B][L]             the start sample every chain begins from (:570)
+ *   objectives   [n_grad * n_chains] host array, object-major: gradient j of chain k is entry j * n_chains + k (n_grad = 1: one per chain)
+ *   rowcoef_dev  [n_grad * n_chains][R] or NULL
+ *   starts_host  3-D: [n_steps][n_grad * n_chains][starts_per_call] int64 in the reference's draw order per gradient chain; 2-D: NULL
+ *   timesteps    [n_steps] host; coef [n_steps][4] host = sqrt(abar_t), sqrt(1 - abar_t), sqrt(abar_prev), sqrt(1 - abar_prev) per step
+ *   scales       [n_chains] host: the classifier scale of every chain (:549-560)
+ *   x_out_dev    [n_chains][B][L]   the final samples
+ * The first eps-net call is evaluated once for all chains (they all hold the start sample).  Equivalent, bit for bit, to calling
+ * dgdm_unet1d_forward / dgdm_dyn{2,3}d_guidance_grad / dgdm_ddim_guided_step step by step.                                             */
+int dgdm_guided_chains_run(DgdmUnet1d *unet, DgdmGuidance *g, const float *noise_dev, int n_chains, int n_grad,
+                           const DgdmObjective *objectives, const float *rowcoef_dev, const int64_t *starts_host,
+                           const int32_t *timesteps, const float *coef, const float *scales, int n_steps, float *x_out_dev, void *stream);
+
 /* Forward-only sweep of Diffusion.get_convergence_centers (diffusion.py:506-531): G orientations,
  * pos = 0, t = 0, rows r = g*B + b.  logits_dev [n_chains][B*G][3].  starts_host (3-D) holds
  * 2*B*G indices per chain in draw order with the sub_batch_size partition of :524-526.           */

@@ -366,3 +366,42 @@ def test_xobj_kernels_agree(dev):
         for k in range(8):
             assert torch.equal(gd.grad(x, 3, objectives, None, starts).cpu(), res[0]), (dtype, k)
         assert float(res[0].abs().max()) > 0
+
+
+def test_native_loop_equals_step_by_step(dev):
+    """dgdm_guided_chains_run (the whole denoise loop inside the library) against the same loop driven step by step from Python through
+    dgdm_unet1d_forward / dgdm_dyn*_guidance_grad / dgdm_ddim_guided_step: bit-identical, 2-D and 3-D, per-object chains with mixed
+    classifier scales ('convergence' among them), one multi-object chain, several multi-object chains per launch."""
+    net = engine.Unet1d(util.unet_sd(11))
+    for mode in ('point', 'point_3d'):
+        if mode == 'point':
+            nv, B, G, P, L, T, sub = 100, 3, 7, 3, 14, 15, 0
+            dyn = engine.Dynamics(2, util.dyn2d_sd(22, nv), L, 2 * nv)
+            objs = torch.stack([synth.synth_object_2d(i, nv) for i in range(4)])
+        else:
+            nv, B, G, P, L, T, sub = 512, 2, 4, 2, 42, 15, 9
+            dyn = engine.Dynamics(3, util.dyn3d_sd(33), L)
+            objs = torch.stack([synth.synth_object_3d(i) for i in (1, 8, 2, 31)])
+        gd = engine.Guidance(dyn, B, G, P, (-1.0, 1.0), 8, T, nv, sub, max_objects=4)
+        gd.set_objects(objs.to(dev))
+        s = sched(T, 5)
+        noise = synth.synth_noise(0, B, L).to(dev)
+        ug = sampler.unguided_sample(net, s, noise)
+        chains = [(0, 'rotate'), (1, 'convergence'), (2, 'shift_up'), (3, 'clockwise_left'), (0, 'convergence')]
+        torch.manual_seed(4)
+        a = sampler.guided_chains(net, gd, s, mode, noise, chains, unguided=ug)
+        torch.manual_seed(4)
+        b = sampler.guided_chains(net, gd, s, mode, noise, chains, unguided=ug, trace=[])
+        assert torch.equal(a, b), mode
+        torch.manual_seed(5)
+        a = sampler.guided_multi_object(net, gd, s, mode, noise, [0, 1, 2, 3], 'shift_left')
+        torch.manual_seed(5)
+        b = sampler.guided_multi_object(net, gd, s, mode, noise, [0, 1, 2, 3], 'shift_left', on_step=lambda i, x: None)
+        assert torch.equal(a, b), mode
+        groups, objv = [[0, 1], [2, 3], [1, 3]], ['rotate', 'shift_down', 'counterclockwise_up']
+        pre = None
+        if mode == 'point_3d':
+            pre = sampler.draw_ensemble_starts(gd, 3, 2, 5, [sampler.pair_stream(nv, sub, 7, k) for k in range(3)])
+        a = sampler.guided_multi_object_groups(net, gd, s, mode, noise, groups, objv, predrawn=pre)
+        b = sampler.guided_multi_object_groups(net, gd, s, mode, noise, groups, objv, predrawn=pre, python_loop=True)
+        assert torch.equal(a, b), mode
