@@ -56,3 +56,42 @@ extern "C" int dgdm_debug_pointnet_indices(DgdmDynamics *m, const float *xyz_dev
     if ((rc = pn_fps_table(xyz_dev, N, N, 128, fps128_dev, fps128_flags_dev, s))) return rc;
     return pn_debug_indices(xyz_dev, N, m->pn(), perm_dev, perm_len, ball1_dev, ball2_dev, ball2_count_dev, crowded_dev, s);
 }
+
+// ------------------------------------------------------------------------------------------------ the reference's index functions (include/dgdm_hip.h)
+extern "C" int dgdm_farthest_point_sample(const float *xyz_dev, const int64_t *start_host, int B, int N, int npoint, int32_t *out_dev, void *stream) {
+    using namespace dgdm;
+    DGDM_REQUIRE(xyz_dev && start_host && out_dev && B >= 0 && npoint > 0, DGDM_EINVAL, "dgdm_farthest_point_sample: bad argument");
+    DGDM_REQUIRE(N > 0 && N <= 1024, DGDM_EINVAL, "clouds of %d points unsupported (1..1024)", N);
+    if (B == 0) return DGDM_OK;
+    std::vector<int> st(B);
+    for (int i = 0; i < B; ++i) {
+        DGDM_REQUIRE(start_host[i] >= 0 && start_host[i] < N, DGDM_EINVAL, "FPS start %lld outside [0, %d)", (long long)start_host[i], N);
+        st[i] = (int)start_host[i];
+    }
+    DevBuf d;
+    int rc;
+    if ((rc = d.upload(st.data(), sizeof(int) * B))) return rc;
+    if ((rc = pn_fps_rows(xyz_dev, d.as<int>(), B, N, npoint, out_dev, (hipStream_t)stream))) return rc;
+    DGDM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));           // `d` dies here
+    return DGDM_OK;
+}
+
+extern "C" int dgdm_query_ball_point(float radius_squared, int nsample, const float *xyz_dev, const float *new_xyz_dev, int B, int N, int S, int32_t *out_dev,
+                                     void *stream) {
+    using namespace dgdm;
+    DGDM_REQUIRE(xyz_dev && new_xyz_dev && out_dev && B >= 0 && N > 0 && S >= 0 && nsample > 0, DGDM_EINVAL, "dgdm_query_ball_point: bad argument");
+    if (B == 0 || S == 0) return DGDM_OK;
+    return pn_ball_rows(xyz_dev, new_xyz_dev, B, N, S, radius_squared, nsample, out_dev, (hipStream_t)stream);
+}
+
+extern "C" int dgdm_square_distance(const float *src_dev, const float *dst_dev, int B, int S, int N, float *out_dev, void *stream) {
+    using namespace dgdm;
+    DGDM_REQUIRE(src_dev && dst_dev && out_dev && B >= 0 && S >= 0 && N >= 0, DGDM_EINVAL, "dgdm_square_distance: bad argument");
+    return pn_sqdist_rows(src_dev, dst_dev, B, S, N, out_dev, (hipStream_t)stream);
+}
+
+extern "C" int dgdm_index_points(const float *points_dev, const int32_t *idx_dev, int B, int N, int M, int C, float *out_dev, void *stream) {
+    using namespace dgdm;
+    DGDM_REQUIRE(points_dev && idx_dev && out_dev && B >= 0 && N > 0 && M >= 0 && C > 0, DGDM_EINVAL, "dgdm_index_points: bad argument");
+    return pn_index_rows(points_dev, idx_dev, B, N, M, C, out_dev, (hipStream_t)stream);
+}

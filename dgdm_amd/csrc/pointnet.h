@@ -75,6 +75,12 @@ int pn_xtab(const XtabObj &o, bool bf16, hipStream_t s);
 struct XidxChain { const int *fps1; int N; int m0_only; };
 int pn_xidx(const XidxChain *chains_dev, const int *starts, int64_t R, int nchain, int *idx, hipStream_t s);
 
+// the index functions for arbitrary batches of clouds (C-ABI dgdm_farthest_point_sample / dgdm_query_ball_point / dgdm_square_distance / dgdm_index_points)
+int pn_fps_rows(const float *xyz, const int *start, int B, int N, int npoint, int *out, hipStream_t s);
+int pn_ball_rows(const float *xyz, const float *centres, int B, int N, int S, float r2, int nsample, int *out, hipStream_t s);
+int pn_sqdist_rows(const float *src, const float *dst, int B, int S, int N, float *out, hipStream_t s);
+int pn_index_rows(const float *points, const int *idx, int B, int N, int M, int C, float *out, hipStream_t s);
+
 int pn_fps_table(const float *xyz, int N, int nv, int npoint, int *out, int *flags, hipStream_t s, int nobj = 1);
 int pn_sa1(const float *xyz, int N, const PnWeights &w, float *F1, hipStream_t s);
 // crowded/clist/ncr: centres whose ball holds > 64 points; off [N+1], pairs [<= N*N], rank [N][N]: the in-radius pair list (T4/T5)

@@ -1294,6 +1294,100 @@ int pn_xidx(const XidxChain *chains_dev, const int *starts, int64_t R, int nchai
     return DGDM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ the index functions on their own
+// dynamics/models/pointnet2_utils.py:27-115 for arbitrary batches of clouds (the reference's names, mirrored in
+// dgdm_amd/dynamics/models/pointnet2_utils.py).  The guided path does not call these - it reads the per-object tables above - but they are
+// the same device code (fps_wave, the expanded distance form) with per-cloud inputs.
+__global__ __launch_bounds__(256) void fps_rows_kernel(const float *__restrict__ xyz /*[B][N][3]*/, const int *__restrict__ start /*[B]*/, int B, int N,
+                                                       int npoint, int *__restrict__ out /*[B][npoint]*/) {
+    extern __shared__ float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wave;
+    float *lx = lds + (size_t)wave * 3 * N, *ly = lx + N, *lz = ly + N;
+    if (b < B) {
+        const float *c = xyz + (size_t)b * N * 3;
+        for (int i = lane; i < N; i += 64) { lx[i] = c[3 * i]; ly[i] = c[3 * i + 1]; lz[i] = c[3 * i + 2]; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (b >= B) return;
+    if (N <= 512) fps_wave<8, false>(lx, ly, lz, N, start[b], npoint, out + (size_t)b * npoint, lane);
+    else fps_wave<16, false>(lx, ly, lz, N, start[b], npoint, out + (size_t)b * npoint, lane);
+}
+
+// first `nsample` indices k (ascending) with square_distance(centre, xyz[k]) <= r2, padded with the first one; a group without any member
+// is filled with N, which is what the reference's masked assignment leaves there (group_first is N then)
+__global__ __launch_bounds__(256) void ball_rows_kernel(const float *__restrict__ xyz /*[B][N][3]*/, const float *__restrict__ centres /*[B][S][3]*/, int B,
+                                                        int N, int S, float r2, int nsample, int *__restrict__ out /*[B][S][nsample]*/) {
+    const int lane = threadIdx.x & 63;
+    const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= (int64_t)B * S) return;
+    const int b = (int)(g / S);
+    const float *c = xyz + (size_t)b * N * 3;
+    const float cx = centres[3 * g], cy = centres[3 * g + 1], cz = centres[3 * g + 2];
+    const float cn = sq3(cx, cy, cz);
+    int *dst = out + (size_t)g * nsample;
+    int cnt = 0, first = N;
+    for (int base = 0; base < N && cnt < nsample; base += 64) {
+        const int k = base + lane;
+        bool in = false;
+        if (k < N) {
+            const float x = c[3 * k], y = c[3 * k + 1], z = c[3 * k + 2];
+            in = !(sqdist_expanded(cx, cy, cz, cn, x, y, z, sq3(x, y, z)) > r2);
+        }
+        const unsigned long long m = __ballot(in);
+        if (m && first == N) first = base + __ffsll((long long)m) - 1;
+        const int rank = cnt + __popcll(m & ((1ull << lane) - 1ull));
+        if (in && rank < nsample) dst[rank] = k;
+        cnt += __popcll(m);
+    }
+    cnt = min(cnt, nsample);
+    for (int i = cnt + lane; i < nsample; i += 64) dst[i] = first;
+}
+
+__global__ void sqdist_rows_kernel(const float *__restrict__ src /*[B][S][3]*/, const float *__restrict__ dst /*[B][N][3]*/, int B, int S, int N,
+                                   float *__restrict__ out /*[B][S][N]*/) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * S * N) return;
+    const int n = (int)(i % N);
+    const int64_t bs = i / N;
+    const int b = (int)(bs / S);
+    const float *a = src + 3 * bs, *p = dst + ((size_t)b * N + n) * 3;
+    out[i] = sqdist_expanded(a[0], a[1], a[2], sq3(a[0], a[1], a[2]), p[0], p[1], p[2], sq3(p[0], p[1], p[2]));
+}
+
+__global__ void index_rows_kernel(const float *__restrict__ points /*[B][N][C]*/, const int *__restrict__ idx /*[B][M]*/, int B, int N, int M, int C,
+                                  float *__restrict__ out /*[B][M][C]*/) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * M * C) return;
+    const int c = (int)(i % C);
+    const int64_t bm = i / C;
+    const int b = (int)(bm / M);
+    out[i] = points[((size_t)b * N + idx[bm]) * C + c];
+}
+
+int pn_fps_rows(const float *xyz, const int *start, int B, int N, int npoint, int *out, hipStream_t s) {
+    hipLaunchKernelGGL(fps_rows_kernel, dim3((B + 3) / 4), dim3(256), (size_t)4 * 3 * N * sizeof(float), s, xyz, start, B, N, npoint, out);
+    DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
+}
+int pn_ball_rows(const float *xyz, const float *centres, int B, int N, int S, float r2, int nsample, int *out, hipStream_t s) {
+    hipLaunchKernelGGL(ball_rows_kernel, dim3((unsigned)(((int64_t)B * S + 3) / 4)), dim3(256), 0, s, xyz, centres, B, N, S, r2, nsample, out);
+    DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
+}
+int pn_sqdist_rows(const float *src, const float *dst, int B, int S, int N, float *out, hipStream_t s) {
+    const int64_t n = (int64_t)B * S * N;
+    hipLaunchKernelGGL(sqdist_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, B, S, N, out);
+    DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
+}
+int pn_index_rows(const float *points, const int *idx, int B, int N, int M, int C, float *out, hipStream_t s) {
+    const int64_t n = (int64_t)B * M * C;
+    hipLaunchKernelGGL(index_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, points, idx, B, N, M, C, out);
+    DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 int pn_fps_table(const float *xyz, int N, int nv, int npoint, int *out, int *flags, hipStream_t s, int nobj) {
     hipLaunchKernelGGL(fps_table_kernel, dim3((nv + 3) / 4, nobj), dim3(256), (size_t)3 * N * sizeof(float), s, xyz, N, nv, npoint, out, flags);

@@ -126,6 +126,20 @@ int dgdm_dyn3d_forward(DgdmDynamics *m, const float *x_ctrl_dev, const float *x_
                        const float *t_dev, const float *xyz_dev, const int64_t *start_sa1_host,
                        const int64_t *start_sa2_host, float *logits_dev, int rows, int N, void *stream);
 
+/* The index functions of dynamics/models/pointnet2_utils.py on their own, for arbitrary batches of clouds (the guided path reads
+ * per-object tables built by the same device code instead; these exist so that the reference's names run on the device and can be
+ * compared one to one).  Indices are int32 on the device.
+ *   farthest_point_sample(xyz, npoint)        :71-92   xyz_dev [B][N][3] (N <= 1024); start_host [B] = the torch.randint draw of :83
+ *   query_ball_point(radius, nsample, xyz, new_xyz) :95-115   radius_squared = float32(radius ** 2); out [B][S][nsample], first
+ *                                             in-radius indices in ascending order, padded with the first (N if the ball is empty)
+ *   square_distance(src, dst)                 :27-48   out [B][S][N], the expanded form in the reference's operation order
+ *   index_points(points, idx)                 :51-68   points [B][N][C], idx [B][M] -> out [B][M][C]                                  */
+int dgdm_farthest_point_sample(const float *xyz_dev, const int64_t *start_host, int B, int N, int npoint, int32_t *out_dev, void *stream);
+int dgdm_query_ball_point(float radius_squared, int nsample, const float *xyz_dev, const float *new_xyz_dev, int B, int N, int S,
+                          int32_t *out_dev, void *stream);
+int dgdm_square_distance(const float *src_dev, const float *dst_dev, int B, int S, int N, float *out_dev, void *stream);
+int dgdm_index_points(const float *points_dev, const int32_t *idx_dev, int B, int N, int M, int C, float *out_dev, void *stream);
+
 /* ------------------------------------------------------------------ a4-a6: guidance gradient
  * One DgdmGuidance serves up to max_chains independent chains (object x objective pairs) that
  * share B fingers, the (grid_size, num_pos, ori_range) pose grid and the timestep; each chain

@@ -71,3 +71,41 @@ def test_ball_query_on_reordered_cloud_vs_oracle(dev):
         ref_ids = perm[ref].numpy()                                                # -> point ids; row j = centre point perm[j]
         got = _pad_first(idx["ball2"], idx["ball2_count"])[perm.numpy()]
         assert np.array_equal(got, ref_ids), s1
+
+
+def test_reference_named_index_functions(dev):
+    """dynamics.models.pointnet2_utils with the reference's names and signatures, HIP-backed: bit-exact against the reference's golden
+    index arrays and against the oracle on clouds of another size (N = 300, npoint = 64, radius 0.3, nsample = 16)."""
+    from dynamics.models import pointnet2_utils as pu
+    g = util.load("g4_pointnet.npz")
+    clouds = torch.from_numpy(g["clouds"]).to(dev)
+    st = torch.from_numpy(g["fps_start"].astype(np.int64))
+    orig = torch.randint
+    torch.randint = lambda *a, **k: st.clone()                      # the draw the golden arrays were made with
+    try:
+        fps512, fps128 = pu.farthest_point_sample(clouds, 512), pu.farthest_point_sample(clouds, 128)
+    finally:
+        torch.randint = orig
+    assert fps512.dtype == torch.int64 and np.array_equal(fps512.cpu().numpy(), g["fps512"]) and np.array_equal(fps128.cpu().numpy(), g["fps128"])
+    new_xyz = pu.index_points(clouds, fps128)
+    assert torch.equal(new_xyz.cpu(), torch.from_numpy(g["clouds"])[torch.arange(4)[:, None], torch.from_numpy(g["fps128"]).long()])
+    assert np.array_equal(pu.query_ball_point(0.2, 32, clouds, new_xyz).cpu().numpy(), g["ball_r02_n32"])
+    assert np.array_equal(pu.query_ball_point(0.4, 64, clouds, new_xyz).cpu().numpy(), g["ball_r04_n64"])
+    # other sizes, against the oracle (the CPU restatement of the same functions)
+    rs = np.random.RandomState(3)
+    xyz = torch.from_numpy(rs.uniform(-1, 1, (5, 300, 3)).astype(np.float32))
+    torch.manual_seed(9)
+    fps = pu.farthest_point_sample(xyz.to(dev), 64).cpu()
+    torch.manual_seed(9)
+    assert torch.equal(fps, orc.farthest_point_sample(xyz, 64, torch.randint(0, 300, (5,), dtype=torch.long)))
+    cen = xyz[torch.arange(5)[:, None], fps]
+    assert torch.equal(pu.query_ball_point(0.3, 16, xyz.to(dev), cen.to(dev)).cpu(), orc.query_ball_point(0.3, 16, xyz, cen))
+    # float values of the expanded form: the CPU BLAS's K = 3 dot order is its own affair (fma or not), so a few float32 ulps of |x|^2 ~ 3
+    assert float((pu.square_distance(cen.to(dev), xyz.to(dev)).cpu() - orc.square_distance(cen, xyz)).abs().max()) < 2e-6
+    # an empty ball: every entry is N, as the reference's masked assignment leaves it
+    far = torch.full((5, 1, 3), 9.0)
+    assert torch.equal(pu.query_ball_point(0.3, 16, xyz.to(dev), far.to(dev)).cpu(), orc.query_ball_point(0.3, 16, xyz, far))
+    # sample_and_group: shapes and the relative coordinates of the reference
+    torch.manual_seed(10)
+    nx, npts = pu.sample_and_group(32, 0.5, 8, xyz.to(dev), None)
+    assert nx.shape == (5, 32, 3) and npts.shape == (5, 32, 8, 3) and float(npts.norm(dim=-1).max()) <= 0.5 + 1e-6
