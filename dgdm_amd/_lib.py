@@ -79,6 +79,11 @@ PROTOTYPES = {
     "dgdm_guidance_debug_partials": (C.c_int, [_P, C.c_int, _P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P]),
     "dgdm_prof_read_stage": (C.c_int, [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dgdm_prof_read": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "dgdm_trainer2d_create": (C.c_int, [C.POINTER(_P), C.POINTER(Tensor), C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "dgdm_trainer2d_destroy": (None, [_P]),
+    "dgdm_trainer2d_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_int, _P, C.POINTER(C.c_float), _P]),
+    "dgdm_trainer2d_export": (C.c_int, [_P, C.c_int, C.POINTER(Tensor), C.c_int]),
+    "dgdm_trainer2d_steps": (C.c_int64, [_P]),
 }
 
 _lib = None

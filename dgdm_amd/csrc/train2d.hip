@@ -1,0 +1,766 @@
+// Trainer.step of the 2-D dynamics model (dynamics/trainer.py:53-103 with ProfileForward2DModel, dynamics/profile_forward_2d.py:78-156)
+// on gfx950: forward with BatchNorm1d in TRAINING mode (batch statistics, running statistics updated), MSE loss, backward with
+// weight gradients, torch.optim.Adam (trainer.py:46).  SURVEY.md §8(f) rank 4.
+//
+// All fourteen Linear layers run through one LDS-tiled float32 MFMA GEMM (v_mfma_f32_32x32x2_f32, 128 x 256 tile per 256-thread
+// workgroup, 16-deep contraction chunks):
+//     C[i][j] = sum_r P[i][r] * Q[j][r]
+//   forward      Y  [n][m] = sum_k a[n][k]  Wt[k][m]     i = n (rows),  j = m,  r = k
+//   input grad   G  [n][k] = sum_m dY[n][m] W [m][k]     i = n,         j = k,  r = m
+//   weight grad  dW [k][m] = sum_n a[n][k]  dY[n][m]     i = k,         j = m,  r = n   (split over n, deterministic two-stage sum)
+// The row count of a training batch is large (batch x orientations x positions), the layers are 256 wide: with the float32 MFMA rate
+// the GEMMs are within 3x of HBM-bound, so nothing elementwise gets its own pass over the activations.  What the reference's autograd
+// graph does in separate kernels is folded into the operand loaders and the epilogues:
+//   * BatchNorm + ReLU of the previous layer is applied while its pre-normalisation output Y is loaded as an operand
+//     (a = max(0, sc*Y + sh); Y is the only activation tensor kept per layer),
+//   * the forward epilogue adds the bias and produces per-column partial sums (sum y, sum y^2) for the batch statistics,
+//   * the input-gradient epilogue applies the activation mask of the layer below and produces the two column sums BatchNorm's
+//     backward needs (sum dZ, sum dZ*Y),
+//   * BatchNorm's backward is an affine map per column, dY = alpha*dZ + beta'*Y + gamma', applied while dZ and Y are loaded as the
+//     operand of the next two GEMMs; Linear-bias gradients are column sums taken by the weight-gradient loader.
+// Column statistics are summed per workgroup in float32 and across workgroups in float64, in a fixed order: a step is reproducible
+// bit for bit.
+#include "common.h"
+#include "mfma_chain.h"
+#include "smallnet.h"
+#include <cmath>
+#include <cstring>
+#include <algorithm>
+#include <memory>
+#include <map>
+#include <string>
+
+namespace dgdm {
+namespace {
+
+constexpr int TI = 128, TJ = 256, RC = 16, W = 256;
+enum { XF_PLAIN = 0, XF_ACT = 1, XF_AFFINE2 = 2 };
+enum { EPI_FWD = 0, EPI_BWD = 1, EPI_WGRAD = 2 };
+enum { MASK_NONE = 0, MASK_RELU = 1, MASK_SILU = 2, MASK_RELU_BN = 3 };
+
+// A GEMM operand: T0 (and T1) row-major with leading dimension ld, turned into the operand value on load:
+//   XF_PLAIN    T0
+//   XF_ACT      act(c0[col]*T0 + c2[col])                 (c0 = null: act(T0))
+//   XF_AFFINE2  c0[col]*T0 + c1[col]*T1 + c2[col]
+struct Operand {
+    const float *t0, *t1;
+    int64_t ld;
+    const float *c0, *c1, *c2;
+    int xf, act;
+};
+
+struct GemmArgs {
+    Operand P, Q;
+    int64_t I, R, r_per_split;
+    int J;
+    float *C;
+    int64_t ldc, split_stride;
+    const float *bias;      // EPI_FWD
+    float *stats;           // [i tiles][2][J] partial column sums, or null
+    const float *Yp;        // EPI_BWD: pre-activation output of the layer below, [I][ldy]
+    int64_t ldy;
+    const float *m0, *m2;   // MASK_RELU_BN: z = m0*Yp + m2
+    int mask;
+};
+
+__device__ __forceinline__ float silu(float z) { return z / (1.f + expf(-z)); }
+__device__ __forceinline__ float silu_grad(float z) {
+    const float s = 1.f / (1.f + expf(-z));
+    return s * (1.f + z * (1.f - s));
+}
+__device__ __forceinline__ float bn_pre(float c0, float y, float c2) { return fmaf(c0, y, c2); }   // ONE expression for forward and mask
+
+__device__ __forceinline__ float xf1(int xf, int act, float a, float b, float c0, float c1, float c2) {
+    if (xf == XF_PLAIN) return a;
+    if (xf == XF_ACT) {
+        const float z = bn_pre(c0, a, c2);
+        return act == ACT_RELU ? fmaxf(z, 0.f) : (act == ACT_SILU ? silu(z) : z);
+    }
+    return fmaf(c0, a, fmaf(c1, b, c2));
+}
+__device__ __forceinline__ float4 xf4(int xf, int act, float4 a, float4 b, float4 c0, float4 c1, float4 c2) {
+    return make_float4(xf1(xf, act, a.x, b.x, c0.x, c1.x, c2.x), xf1(xf, act, a.y, b.y, c0.y, c1.y, c2.y),
+                       xf1(xf, act, a.z, b.z, c0.z, c1.z, c2.z), xf1(xf, act, a.w, b.w, c0.w, c1.w, c2.w));
+}
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float4 coef4(const float *c, int64_t col, float dflt) { return c ? ld4(c + col) : make_float4(dflt, dflt, dflt, dflt); }
+
+template <bool PTRANS, int EPI>
+__global__ __launch_bounds__(256, 2) void tgemm_kernel(const GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float sP[RC][TI];
+    __shared__ __attribute__((aligned(16))) float sQ[RC][TJ];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wi = w & 1, wj = w >> 1, n = lane & 31, h = lane >> 5;
+    const int64_t i0 = (int64_t)blockIdx.x * TI;
+    const int j0 = blockIdx.y * TJ;
+    const int64_t rbeg = (int64_t)blockIdx.z * g.r_per_split, rend = min(g.R, rbeg + g.r_per_split);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // ---- loaders.  P transposed source: thread = (tile row px, float4 slots prq, prq + 2 along r); P / Q direct source:
+    // thread = (float4 column, rows prr + 8u / qrr + 4u of the chunk)
+    const int px = tid & 127, prq = tid >> 7, px4 = tid & 31, prr = tid >> 5, qx4 = tid & 63, qrr = tid >> 6;
+    const int64_t prow = i0 + px, pcol = i0 + 4 * px4;
+    const int qcol = j0 + 4 * qx4;
+    const bool pval = PTRANS ? prow < g.I : pcol < g.I, qval = qcol < g.J;
+    const bool p2 = g.P.xf == XF_AFFINE2, q2 = g.Q.xf == XF_AFFINE2;
+    float4 pc0 = zero4, pc1 = zero4, pc2 = zero4, qc0, qc1, qc2;
+    if (!PTRANS) { const int64_t c = pval ? pcol : 0; pc0 = coef4(g.P.c0, c, 1.f); pc1 = coef4(g.P.c1, c, 0.f); pc2 = coef4(g.P.c2, c, 0.f); }
+    { const int c = qval ? qcol : 0; qc0 = coef4(g.Q.c0, c, 1.f); qc1 = coef4(g.Q.c1, c, 0.f); qc2 = coef4(g.Q.c2, c, 0.f); }
+    float4 pa[2], pb[2], qa[4], qb[4];
+    float4 qsum = zero4;
+
+    auto issue = [&](int64_t r) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            pa[u] = pb[u] = zero4;
+            if (PTRANS) {
+                if (pval) {
+                    const int64_t o = prow * g.P.ld + r + 4 * (prq + 2 * u);
+                    pa[u] = ld4(g.P.t0 + o);
+                    if (p2) pb[u] = ld4(g.P.t1 + o);
+                }
+            } else if (pval && r + prr + 8 * u < rend) {
+                const int64_t o = (r + prr + 8 * u) * g.P.ld + pcol;
+                pa[u] = ld4(g.P.t0 + o);
+                if (p2) pb[u] = ld4(g.P.t1 + o);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            qa[u] = qb[u] = zero4;
+            if (qval && r + qrr + 4 * u < rend) {
+                const int64_t o = (r + qrr + 4 * u) * g.Q.ld + qcol;
+                qa[u] = ld4(g.Q.t0 + o);
+                if (q2) qb[u] = ld4(g.Q.t1 + o);
+            }
+        }
+    };
+    auto commit = [&](int64_t r) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (PTRANS) {
+                const int r4 = prq + 2 * u;
+                float4 v = zero4;
+                if (pval) {
+                    const int64_t c = r + 4 * r4;
+                    v = xf4(g.P.xf, g.P.act, pa[u], pb[u], coef4(g.P.c0, c, 1.f), coef4(g.P.c1, c, 0.f), coef4(g.P.c2, c, 0.f));
+                }
+                sP[4 * r4 + 0][px] = v.x; sP[4 * r4 + 1][px] = v.y; sP[4 * r4 + 2][px] = v.z; sP[4 * r4 + 3][px] = v.w;
+            } else {
+                float4 v = zero4;
+                if (pval && r + prr + 8 * u < rend) v = xf4(g.P.xf, g.P.act, pa[u], pb[u], pc0, pc1, pc2);
+                *reinterpret_cast<float4 *>(&sP[prr + 8 * u][4 * px4]) = v;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float4 v = zero4;
+            if (qval && r + qrr + 4 * u < rend) v = xf4(g.Q.xf, g.Q.act, qa[u], qb[u], qc0, qc1, qc2);
+            *reinterpret_cast<float4 *>(&sQ[qrr + 4 * u][4 * qx4]) = v;
+            if (EPI == EPI_WGRAD) { qsum.x += v.x; qsum.y += v.y; qsum.z += v.z; qsum.w += v.w; }
+        }
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[s][u][q] = 0.f;
+
+    if (rbeg < rend) issue(rbeg);
+    for (int64_t r = rbeg; r < rend; r += RC) {
+        __syncthreads();
+        commit(r);
+        __syncthreads();
+        if (r + RC < rend) issue(r + RC);
+#pragma unroll
+        for (int kk = 0; kk < RC / 2; ++kk) {
+            float a[2], b[4];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) a[s] = sP[2 * kk + h][64 * wi + 32 * s + n];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) b[u] = sQ[2 * kk + h][128 * wj + 32 * u + n];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[s][u] = mfma32(a[s], b[u], acc[s][u]);
+        }
+    }
+
+    // ---- epilogue.  acc[s][u][q] of lane (n, h) = C[i0 + 64 wi + 32 s + rho(q, h)][j0 + 128 wj + 32 u + n]
+    if (EPI == EPI_WGRAD) {
+        float *dst = g.C + (int64_t)blockIdx.z * g.split_stride;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int64_t i = i0 + 64 * wi + 32 * s + (q & 3) + 8 * (q >> 2) + 4 * h;
+                if (i < g.I)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) dst[i * g.ldc + j0 + 128 * wj + 32 * u + n] = acc[s][u][q];
+            }
+        if (blockIdx.x == 0) {      // column sums of Q = the Linear-bias gradient, stored as row I of the partial
+            __syncthreads();
+            *reinterpret_cast<float4 *>(&sQ[qrr][4 * qx4]) = qsum;
+            __syncthreads();
+            if (tid < 64) {
+                float4 t = zero4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const float4 v = *reinterpret_cast<const float4 *>(&sQ[k][4 * tid]); t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+                if (j0 + 4 * tid < g.J) *reinterpret_cast<float4 *>(dst + g.I * g.ldc + j0 + 4 * tid) = t;
+            }
+        }
+        return;
+    }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int j = j0 + 128 * wj + 32 * u + n;
+        const bool jv = j < g.J;
+        const int jc = jv ? j : 0;
+        const float bj = EPI == EPI_FWD && g.bias ? g.bias[jc] : 0.f;
+        const float m0 = EPI == EPI_BWD && g.mask == MASK_RELU_BN ? g.m0[jc] : 1.f, m2 = EPI == EPI_BWD && g.mask == MASK_RELU_BN ? g.m2[jc] : 0.f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int64_t i = i0 + 64 * wi + 32 * s + (q & 3) + 8 * (q >> 2) + 4 * h;
+                if (!(jv && i < g.I)) continue;
+                if (EPI == EPI_FWD) {
+                    const float v = acc[s][u][q] + bj;
+                    g.C[i * g.ldc + j] = v;
+                    s1[u] += v;
+                    s2[u] = fmaf(v, v, s2[u]);
+                } else {
+                    float v = acc[s][u][q];
+                    if (g.mask != MASK_NONE) {
+                        const float y = g.Yp[i * g.ldy + j];
+                        if (g.mask == MASK_RELU) v = y > 0.f ? v : 0.f;
+                        else if (g.mask == MASK_SILU) v *= silu_grad(y);
+                        else { v = bn_pre(m0, y, m2) > 0.f ? v : 0.f; s1[u] += v; s2[u] = fmaf(v, y, s2[u]); }
+                    }
+                    g.C[i * g.ldc + j] = v;
+                }
+            }
+    }
+    if (g.stats) {       // per-workgroup column sums: both half-waves, then the two waves stacked along i
+        __syncthreads();
+        float *red = &sP[0][0];     // [wi][2][256]
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float a = s1[u] + __shfl_xor(s1[u], 32), b = s2[u] + __shfl_xor(s2[u], 32);
+            if (h == 0) { red[(wi * 2 + 0) * 256 + 128 * wj + 32 * u + n] = a; red[(wi * 2 + 1) * 256 + 128 * wj + 32 * u + n] = b; }
+        }
+        __syncthreads();
+        if (j0 + tid < g.J) {
+            g.stats[((int64_t)blockIdx.x * 2 + 0) * g.J + j0 + tid] = red[0 * 256 + tid] + red[2 * 256 + tid];
+            g.stats[((int64_t)blockIdx.x * 2 + 1) * g.J + j0 + tid] = red[1 * 256 + tid] + red[3 * 256 + tid];
+        }
+    }
+}
+
+// Batch statistics of one BatchNorm1d layer from the forward partials (float64 across workgroups), the folded coefficients for the
+// next layer's loader, and the running statistics (momentum 0.1, unbiased variance: torch.nn.BatchNorm1d in training mode).
+// grid 8 x block 256: thread (column c = 32 blockIdx + (tid & 31), slice tid >> 5 of the partial tiles)
+// coef rows: 0 sc = gamma*rstd, 1 sh = beta - mean*sc, 2 mean, 3 rstd, 4 alpha, 5 beta', 6 gamma' (backward, bn_bwd_finalize)
+__global__ void bn_fwd_finalize_kernel(const float *__restrict__ part, int T, double N, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                       float eps, float mom, float *__restrict__ rmean, float *__restrict__ rvar, float *__restrict__ coef) {
+    __shared__ double red[2][8][32];
+    const int c = threadIdx.x & 31, sl = threadIdx.x >> 5, j = 32 * blockIdx.x + c;
+    double a = 0.0, b = 0.0;
+    for (int t = sl; t < T; t += 8) { a += (double)part[((int64_t)t * 2 + 0) * W + j]; b += (double)part[((int64_t)t * 2 + 1) * W + j]; }
+    red[0][sl][c] = a; red[1][sl][c] = b;
+    __syncthreads();
+    if (sl) return;
+    a = b = 0.0;
+    for (int k = 0; k < 8; ++k) { a += red[0][k][c]; b += red[1][k][c]; }
+    const double mu = a / N, var = fmax(b / N - mu * mu, 0.0);
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps)), sc = gamma[j] * rstd;
+    coef[0 * W + j] = sc;
+    coef[1 * W + j] = beta[j] - (float)mu * sc;
+    coef[2 * W + j] = (float)mu;
+    coef[3 * W + j] = rstd;
+    rmean[j] = (1.f - mom) * rmean[j] + mom * (float)mu;
+    rvar[j] = (1.f - mom) * rvar[j] + mom * (float)(var * N / (N - 1.0));
+}
+
+// eval mode (Trainer.inference, trainer.py:108): the same two loader coefficients from the running statistics
+__global__ void bn_eval_coef_kernel(const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ rmean,
+                                    const float *__restrict__ rvar, float eps, float *__restrict__ coef) {
+    const int j = threadIdx.x;
+    const float rstd = 1.f / sqrtf(rvar[j] + eps), sc = gamma[j] * rstd;
+    coef[0 * W + j] = sc;
+    coef[1 * W + j] = beta[j] - rmean[j] * sc;
+    coef[2 * W + j] = rmean[j];
+    coef[3 * W + j] = rstd;
+}
+
+// BatchNorm backward per column from the partial sums (sum dZ, sum dZ*Y):  with xhat = (Y - mean)*rstd,
+//   dgamma = sum dZ*xhat, dbeta = sum dZ,  dY = sc*(dZ - mean(dZ) - xhat*mean(dZ*xhat)) = alpha*dZ + beta'*Y + gamma'
+__global__ void bn_bwd_finalize_kernel(const float *__restrict__ part, int T, double N, float *__restrict__ coef, float *__restrict__ dgamma,
+                                       float *__restrict__ dbeta) {
+    __shared__ double red[2][8][32];
+    const int c = threadIdx.x & 31, sl = threadIdx.x >> 5, j = 32 * blockIdx.x + c;
+    double a = 0.0, b = 0.0;
+    for (int t = sl; t < T; t += 8) { a += (double)part[((int64_t)t * 2 + 0) * W + j]; b += (double)part[((int64_t)t * 2 + 1) * W + j]; }
+    red[0][sl][c] = a; red[1][sl][c] = b;
+    __syncthreads();
+    if (sl) return;
+    a = b = 0.0;
+    for (int k = 0; k < 8; ++k) { a += red[0][k][c]; b += red[1][k][c]; }
+    const double sc = coef[0 * W + j], mu = coef[2 * W + j], rstd = coef[3 * W + j];
+    const double sxh = rstd * (b - mu * a);                 // sum dZ*xhat
+    const double c1 = a / N, c2 = sxh / N;
+    const double bp = -sc * c2 * rstd;
+    coef[4 * W + j] = (float)sc;
+    coef[5 * W + j] = (float)bp;
+    coef[6 * W + j] = (float)(-sc * c1 - bp * mu);
+    dgamma[j] = (float)sxh;
+    dbeta[j] = (float)a;
+}
+
+// Output layer + loss + its backward in one pass over Y8 (profile_forward_2d.py:155, trainer.py:96-100):
+//   a = relu(sc*Y8 + sh); pred = a Wout^T + bout; loss = mean (pred - score)^2; dpred = 2 (pred - score) / (3N);
+//   G = dpred Wout, dZ8 = G where a > 0 (+ column partial sums for BatchNorm backward), dWout = dpred^T a, dbout = sum dpred.
+// One wave per row at a time (lane = 4 columns), 64 rows per workgroup.
+constexpr int HEAD_ROWS = 64;
+__global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ Y, const float *__restrict__ coef, const float *__restrict__ Wout,
+                                                   const float *__restrict__ bout, const float *__restrict__ score, int64_t N, float *__restrict__ pred,
+                                                   float *__restrict__ dZ, float *__restrict__ stats /*[T][2][256]*/,
+                                                   float *__restrict__ hpart /*[T][3*256 + 4]*/, int train) {
+    __shared__ __attribute__((aligned(16))) float red[4][5 * 256 + 4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = 4 * lane;
+    const float4 sc = ld4(coef + c), sh = ld4(coef + W + c), w0 = ld4(Wout + c), w1 = ld4(Wout + W + c), w2 = ld4(Wout + 2 * W + c);
+    const float b0 = bout[0], b1 = bout[1], b2 = bout[2];
+    const float inv = (float)(2.0 / (3.0 * (double)N));
+    float4 sdz = make_float4(0, 0, 0, 0), sdzy = sdz, g0 = sdz, g1 = sdz, g2 = sdz;
+    float db0 = 0.f, db1 = 0.f, db2 = 0.f, lsum = 0.f;
+    const int64_t rb = (int64_t)blockIdx.x * HEAD_ROWS;
+    for (int k = w; k < HEAD_ROWS; k += 4) {
+        const int64_t r = rb + k;
+        if (r >= N) break;
+        const float4 y = ld4(Y + r * W + c);
+        const float4 a = make_float4(fmaxf(bn_pre(sc.x, y.x, sh.x), 0.f), fmaxf(bn_pre(sc.y, y.y, sh.y), 0.f), fmaxf(bn_pre(sc.z, y.z, sh.z), 0.f),
+                                     fmaxf(bn_pre(sc.w, y.w, sh.w), 0.f));
+        float p0 = a.x * w0.x + a.y * w0.y + a.z * w0.z + a.w * w0.w, p1 = a.x * w1.x + a.y * w1.y + a.z * w1.z + a.w * w1.w,
+              p2 = a.x * w2.x + a.y * w2.y + a.z * w2.z + a.w * w2.w;
+#pragma unroll
+        for (int m = 32; m; m >>= 1) { p0 += __shfl_xor(p0, m); p1 += __shfl_xor(p1, m); p2 += __shfl_xor(p2, m); }
+        p0 += b0; p1 += b1; p2 += b2;
+        const float e0 = p0 - score[r * 3 + 0], e1 = p1 - score[r * 3 + 1], e2 = p2 - score[r * 3 + 2];
+        if (lane == 0) { pred[r * 3 + 0] = p0; pred[r * 3 + 1] = p1; pred[r * 3 + 2] = p2; lsum += e0 * e0 + e1 * e1 + e2 * e2; }
+        if (!train) continue;
+        const float d0 = e0 * inv, d1 = e1 * inv, d2 = e2 * inv;
+        float4 gz = make_float4(d0 * w0.x + d1 * w1.x + d2 * w2.x, d0 * w0.y + d1 * w1.y + d2 * w2.y, d0 * w0.z + d1 * w1.z + d2 * w2.z,
+                                d0 * w0.w + d1 * w1.w + d2 * w2.w);
+        gz.x = a.x > 0.f ? gz.x : 0.f; gz.y = a.y > 0.f ? gz.y : 0.f; gz.z = a.z > 0.f ? gz.z : 0.f; gz.w = a.w > 0.f ? gz.w : 0.f;
+        *reinterpret_cast<float4 *>(dZ + r * W + c) = gz;
+        sdz.x += gz.x; sdz.y += gz.y; sdz.z += gz.z; sdz.w += gz.w;
+        sdzy.x = fmaf(gz.x, y.x, sdzy.x); sdzy.y = fmaf(gz.y, y.y, sdzy.y); sdzy.z = fmaf(gz.z, y.z, sdzy.z); sdzy.w = fmaf(gz.w, y.w, sdzy.w);
+        g0.x = fmaf(d0, a.x, g0.x); g0.y = fmaf(d0, a.y, g0.y); g0.z = fmaf(d0, a.z, g0.z); g0.w = fmaf(d0, a.w, g0.w);
+        g1.x = fmaf(d1, a.x, g1.x); g1.y = fmaf(d1, a.y, g1.y); g1.z = fmaf(d1, a.z, g1.z); g1.w = fmaf(d1, a.w, g1.w);
+        g2.x = fmaf(d2, a.x, g2.x); g2.y = fmaf(d2, a.y, g2.y); g2.z = fmaf(d2, a.z, g2.z); g2.w = fmaf(d2, a.w, g2.w);
+        db0 += d0; db1 += d1; db2 += d2;
+    }
+    float *mine = red[w];
+    *reinterpret_cast<float4 *>(mine + c) = sdz;
+    *reinterpret_cast<float4 *>(mine + 256 + c) = sdzy;
+    *reinterpret_cast<float4 *>(mine + 512 + c) = g0;
+    *reinterpret_cast<float4 *>(mine + 768 + c) = g1;
+    *reinterpret_cast<float4 *>(mine + 1024 + c) = g2;
+    if (lane == 0) { mine[1280] = db0; mine[1281] = db1; mine[1282] = db2; mine[1283] = lsum; }
+    __syncthreads();
+    const int t = threadIdx.x;
+    auto col = [&](int o) { return red[0][o] + red[1][o] + red[2][o] + red[3][o]; };
+    stats[((int64_t)blockIdx.x * 2 + 0) * W + t] = col(t);
+    stats[((int64_t)blockIdx.x * 2 + 1) * W + t] = col(256 + t);
+    float *hp = hpart + (int64_t)blockIdx.x * (3 * W + 4);
+    hp[t] = col(512 + t); hp[W + t] = col(768 + t); hp[2 * W + t] = col(1024 + t);
+    if (t < 4) hp[3 * W + t] = col(1280 + t);
+}
+
+// sums the head partials: gWout [3][256], gbout [3], loss (mean squared error)
+__global__ void head_finalize_kernel(const float *__restrict__ hpart, int T, double N, float *__restrict__ gW, float *__restrict__ gb,
+                                     float *__restrict__ loss) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 3 * W + 4) return;
+    double a = 0.0;
+    for (int t = 0; t < T; ++t) a += (double)hpart[(int64_t)t * (3 * W + 4) + e];
+    if (e < 3 * W) gW[e] = (float)a;
+    else if (e < 3 * W + 3) gb[e - 3 * W] = (float)a;
+    else *loss = (float)(a / (3.0 * N));
+}
+
+// weight-gradient partials [split][I + 1][256] (row k, column m; row I = bias) -> gW [256][I] (the Linear's own layout), gb [256]
+__global__ void wgrad_reduce_kernel(const float *__restrict__ part, int splits, int64_t stride, int I, float *__restrict__ gW, float *__restrict__ gb) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (I + 1) * W) return;
+    float a = 0.f;
+    for (int s = 0; s < splits; ++s) a += part[(int64_t)s * stride + e];
+    const int k = e / W, m = e - k * W;
+    if (k < I) gW[(int64_t)m * I + k] = a;
+    else gb[m] = a;
+}
+
+// torch.optim.Adam, single-tensor form (lerp for the first moment, bias corrections on the host)
+__global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, int64_t n, float b1, float b2,
+                            float eps, float wd, float step_size, float bc2_sqrt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float gi = g[i];
+    if (wd != 0.f) gi = fmaf(wd, p[i], gi);
+    const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+    const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+}
+
+struct TrDesc { int64_t w, wt; int K; };      // offsets of W [256][K] in the parameter buffer and of Wt [K][256] in the transposed one
+__global__ void transpose_all_kernel(const float *__restrict__ P, float *__restrict__ WT, const TrDesc *__restrict__ d) {
+    const TrDesc t = d[blockIdx.y];
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;        // index into Wt: k * 256 + m
+    if (e >= t.K * W) return;
+    const int k = e / W, m = e - k * W;
+    WT[t.wt + e] = P[t.w + (int64_t)m * t.K + k];
+}
+
+// noisy control points (DDIMScheduler.add_noise per row), zero-padded copies of the inputs, pose embedding into columns 768.. of X0
+__global__ void prep2d_kernel(const float *__restrict__ ctrl, const float *__restrict__ noise, const float *__restrict__ sa, const float *__restrict__ sb,
+                              const float *__restrict__ ori, const float *__restrict__ pos, const float *__restrict__ obj, int64_t N, int L, int Lp,
+                              int OC, int OCp, float *__restrict__ bufC, float *__restrict__ bufO, float *__restrict__ X0) {
+    const int S = Lp + OCp + 32;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N * S) return;
+    const int64_t r = e / S;
+    int s = (int)(e - r * S);
+    if (s < Lp) {
+        bufC[r * Lp + s] = s < L ? (noise ? __fadd_rn(__fmul_rn(sa[r], ctrl[r * L + s]), __fmul_rn(sb[r], noise[r * L + s])) : ctrl[r * L + s]) : 0.f;
+        return;
+    }
+    s -= Lp;
+    if (s < OCp) { bufO[r * OCp + s] = s < OC ? obj[r * OC + s] : 0.f; return; }
+    s -= OCp;
+    // get_embedder(d, 4): [x, sin(2^k x), cos(2^k x)]_k; pose = cat(embed(ori) [9], embed(pos) [18])  (profile_forward_2d.py:10-56, 149-151)
+    float v = 0.f;
+    if (s == 0) v = ori[r];
+    else if (s < 9) { const int k = (s - 1) >> 1; const float a = ori[r] * (float)(1 << k); v = (s - 1) & 1 ? cosf(a) : sinf(a); }
+    else if (s < 11) v = pos[2 * r + (s - 9)];
+    else if (s < 27) { const int q = s - 11, k = q >> 2, which = q & 3; const float a = pos[2 * r + (which & 1)] * (float)(1 << k); v = which & 2 ? cosf(a) : sinf(a); }
+    X0[r * 800 + 768 + s] = v;
+}
+
+std::vector<float> train_tfreqs(int half) {   // timestep_embedding (profile_forward_2d.py:68-71), float32 ops
+    std::vector<float> f(half);
+    const float l = -(float)std::log(10000.0);
+    for (int i = 0; i < half; ++i) f[i] = expf(l * (float)i / (float)half);
+    return f;
+}
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+}  // namespace dgdm
+
+using namespace dgdm;
+
+// Linear layers: 0 gripper_encoder.0, 1 gripper_encoder.2, 2 object_encoder.0, 3 object_encoder.2, 4 time_encoder.0, 5 time_encoder.2,
+// 6..13 linears.{0,3,...,21}; then the eight BatchNorm1d layers linears.{1,4,...,22} and the output layer.
+struct DgdmTrainer2d {
+    struct Lin { std::string name; int K = 0, Kp = 0; size_t w = 0, b = 0, wt = 0; };
+    int L = 0, OC = 0, Lp = 0, OCp = 0;
+    float beta1 = 0.9f, beta2 = 0.95f, eps = 1e-8f, wd = 0.f;
+    int64_t adam_steps = 0, bn_batches = 0;
+    Lin lin[14];
+    size_t bn_g[8], bn_b[8], out_w = 0, out_b = 0, n_params = 0, n_wt = 0;
+    DevBuf P, G, M, V, WT, bn_run /* [8][2][256] running mean, var */, coef /* [8][7][256] */, tfreq, trdesc, loss_dev;
+    DevBuf ws;
+    int64_t ws_rows = 0;
+    // workspace pointers (set by reserve)
+    float *bufC = nullptr, *bufO = nullptr, *bufT = nullptr, *H[3] = {nullptr, nullptr, nullptr}, *X0 = nullptr, *Y[8] = {}, *D[2] = {nullptr, nullptr},
+          *G0 = nullptr, *stats = nullptr, *hpart = nullptr, *wpart = nullptr;
+    int64_t wpart_floats = 0;
+
+    float *p(size_t o) const { return P.as<float>() + o; }
+    float *gr(size_t o) const { return G.as<float>() + o; }
+    float *cf(int l, int row) const { return coef.as<float>() + ((size_t)l * 7 + row) * 256; }
+    int col_of(int l, int c) const;      // internal column c of layer l -> column of the reference's weight, or -1 (padding)
+    int reserve(int64_t N);
+    int gemm(bool ptrans, int epi, GemmArgs &g, hipStream_t s) const;
+    int wgrad(int l, const Operand &a, const Operand &dy, int64_t N, hipStream_t s);
+    int run(const float *ctrl, const float *noise, const float *sa, const float *sb, const float *t, const float *ori, const float *pos,
+            const float *obj, const float *score, int64_t N, float lr, int train, float *pred, float *loss_host, hipStream_t s);
+    int copy_state(int which, DgdmTensor *t, int n, bool to_device);
+};
+
+int DgdmTrainer2d::col_of(int l, int c) const {
+    const Lin &x = lin[l];
+    if (l != 6) return c < x.K ? c : -1;
+    // linears.0 reads cat([object, gripper, pose, time]) (profile_forward_2d.py:154); internally [object | gripper | time | pose | pad]
+    if (c < 512) return c;
+    if (c < 768) return c - 512 + 539;
+    if (c < 795) return c - 768 + 512;
+    return -1;
+}
+
+int DgdmTrainer2d::reserve(int64_t N) {
+    if (N <= ws_rows) return DGDM_OK;
+    const int64_t T = (N + TI - 1) / TI, TH = (N + HEAD_ROWS - 1) / HEAD_ROWS;
+    const int64_t splits_max = 256;
+    wpart_floats = splits_max * (800 + 1) * 256;
+    const int64_t per_row = Lp + OCp + 128 + 3 * 256 + 800 + 8 * 256 + 2 * 256 + 768;
+    const int64_t total = N * per_row + std::max(T, TH) * 2 * 256 + TH * (3 * 256 + 4) + wpart_floats + 1024;
+    int rc = ws.alloc((size_t)total * sizeof(float));
+    if (rc) return rc;
+    float *q = ws.as<float>();
+    auto take = [&](int64_t n) { float *r = q; q += (n + 63) / 64 * 64; return r; };
+    bufC = take(N * Lp); bufO = take(N * OCp); bufT = take(N * 128);
+    for (int k = 0; k < 3; ++k) H[k] = take(N * 256);
+    X0 = take(N * 800);
+    for (int k = 0; k < 8; ++k) Y[k] = take(N * 256);
+    D[0] = take(N * 256); D[1] = take(N * 256);
+    G0 = take(N * 768);
+    stats = take(std::max(T, TH) * 2 * 256);
+    hpart = take(TH * (3 * 256 + 4));
+    wpart = take(wpart_floats);
+    ws_rows = N;
+    DGDM_HIP_CHECK(hipMemset(X0, 0, (size_t)N * 800 * sizeof(float)));       // the padding columns 795..799 stay zero
+    return DGDM_OK;
+}
+
+int DgdmTrainer2d::gemm(bool ptrans, int epi, GemmArgs &g, hipStream_t s) const {
+    const int64_t it = (g.I + TI - 1) / TI;
+    const int jt = (g.J + TJ - 1) / TJ;
+    const int64_t splits = (g.R + g.r_per_split - 1) / g.r_per_split;
+    const dim3 grid((unsigned)it, (unsigned)jt, (unsigned)splits), block(256);
+    if (epi == EPI_FWD) hipLaunchKernelGGL((tgemm_kernel<true, EPI_FWD>), grid, block, 0, s, g);
+    else if (epi == EPI_BWD) hipLaunchKernelGGL((tgemm_kernel<true, EPI_BWD>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((tgemm_kernel<false, EPI_WGRAD>), grid, block, 0, s, g);
+    (void)ptrans;
+    DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
+}
+
+// dW_l [k][m] = sum_n a[n][k] dY[n][m] and db_l = sum_n dY[n]: split over the rows, then one ordered sum
+int DgdmTrainer2d::wgrad(int l, const Operand &a, const Operand &dy, int64_t N, hipStream_t s) {
+    const Lin &x = lin[l];
+    const int it = (x.Kp + TI - 1) / TI;
+    int64_t splits = std::min<int64_t>(std::max<int64_t>(1, (N + 255) / 256), std::max(1, 512 / it));
+    int64_t per = ((N + splits - 1) / splits + RC - 1) / RC * RC;
+    splits = (N + per - 1) / per;
+    GemmArgs g{};
+    g.P = a; g.Q = dy; g.I = x.Kp; g.J = 256; g.R = N; g.r_per_split = per;
+    g.C = wpart; g.ldc = 256; g.split_stride = (int64_t)(x.Kp + 1) * 256;
+    int rc = gemm(false, EPI_WGRAD, g, s);
+    if (rc) return rc;
+    const int n = (x.Kp + 1) * 256;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, wpart, (int)splits, g.split_stride, x.Kp, gr(x.w), gr(x.b));
+    DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
+}
+
+int DgdmTrainer2d::run(const float *ctrl, const float *noise, const float *sa, const float *sb, const float *t, const float *ori, const float *pos,
+                       const float *obj, const float *score, int64_t N, float lr, int train, float *pred, float *loss_host, hipStream_t s) {
+    int rc = reserve(N);
+    if (rc) return rc;
+    const int T = (int)((N + TI - 1) / TI), TH = (int)((N + HEAD_ROWS - 1) / HEAD_ROWS);
+    {
+        const int64_t n = N * (Lp + OCp + 32);
+        hipLaunchKernelGGL(prep2d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ctrl, noise, sa, sb, ori, pos, obj, N, L, Lp, OC, OCp, bufC, bufO, X0);
+        DGDM_HIP_CHECK(hipGetLastError());
+        if ((rc = time_embed(t, 0.f, tfreq.as<float>(), bufT, (int)N, 64, s))) return rc;
+    }
+    auto plain = [](const float *p, int64_t ld) { Operand o{}; o.t0 = p; o.ld = ld; o.xf = XF_PLAIN; return o; };
+    auto act = [](const float *p, int64_t ld, int a, const float *c0, const float *c2) { Operand o{}; o.t0 = p; o.ld = ld; o.xf = XF_ACT; o.act = a; o.c0 = c0; o.c2 = c2; return o; };
+    auto weight_t = [&](int l) { return plain(WT.as<float>() + lin[l].wt, 256); };
+    auto forward = [&](int l, const Operand &in, float *out, int64_t ldo, float *st) {
+        GemmArgs g{};
+        g.P = in; g.Q = weight_t(l); g.I = N; g.J = 256; g.R = lin[l].Kp; g.r_per_split = lin[l].Kp;
+        g.C = out; g.ldc = ldo; g.bias = p(lin[l].b); g.stats = st;
+        return gemm(true, EPI_FWD, g, s);
+    };
+    // encoders (profile_forward_2d.py:147-153); their second layers write straight into the concatenated trunk input X0
+    const float *enc_in[3] = {bufC, bufO, bufT};
+    const int enc_ld[3] = {Lp, OCp, 128}, enc_act[3] = {ACT_RELU, ACT_RELU, ACT_SILU}, enc_col[3] = {256, 0, 512};
+    for (int e = 0; e < 3; ++e) {
+        if ((rc = forward(2 * e, plain(enc_in[e], enc_ld[e]), H[e], 256, nullptr))) return rc;
+        if ((rc = forward(2 * e + 1, act(H[e], 256, enc_act[e], nullptr, nullptr), X0 + enc_col[e], 800, nullptr))) return rc;
+    }
+    // trunk: Linear -> BatchNorm1d (batch statistics) -> ReLU, eight times (profile_forward_2d.py:108-133)
+    float *rm = bn_run.as<float>();
+    if (!train)
+        for (int k = 0; k < 8; ++k) {
+            hipLaunchKernelGGL(bn_eval_coef_kernel, dim3(1), dim3(256), 0, s, p(bn_g[k]), p(bn_b[k]), rm + (size_t)k * 512, rm + (size_t)k * 512 + 256, 1e-5f, cf(k, 0));
+            DGDM_HIP_CHECK(hipGetLastError());
+        }
+    for (int k = 0; k < 8; ++k) {
+        const Operand in = k == 0 ? plain(X0, 800) : act(Y[k - 1], 256, ACT_RELU, cf(k - 1, 0), cf(k - 1, 1));
+        if ((rc = forward(6 + k, in, Y[k], 256, train ? stats : nullptr))) return rc;
+        if (train) {
+            hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(8), dim3(256), 0, s, stats, T, (double)N, p(bn_g[k]), p(bn_b[k]), 1e-5f, 0.1f,
+                               rm + (size_t)k * 512, rm + (size_t)k * 512 + 256, cf(k, 0));
+            DGDM_HIP_CHECK(hipGetLastError());
+        }
+    }
+    hipLaunchKernelGGL(head_kernel, dim3(TH), dim3(256), 0, s, Y[7], cf(7, 0), p(out_w), p(out_b), score, N, pred, D[0], stats, hpart, train);
+    DGDM_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(4), dim3(256), 0, s, hpart, TH, (double)N, gr(out_w), gr(out_b), loss_dev.as<float>());
+    DGDM_HIP_CHECK(hipGetLastError());
+    if (train) {
+        int nstat = TH;      // number of partial tiles `stats` holds for the layer about to be finalised
+        for (int k = 7; k >= 0; --k) {
+            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(8), dim3(256), 0, s, stats, nstat, (double)N, cf(k, 0), gr(bn_g[k]), gr(bn_b[k]));
+            DGDM_HIP_CHECK(hipGetLastError());
+            float *dz = D[(7 - k) & 1], *dnext = D[(8 - k) & 1];
+            Operand dy{};
+            dy.t0 = dz; dy.t1 = Y[k]; dy.ld = 256; dy.xf = XF_AFFINE2; dy.c0 = cf(k, 4); dy.c1 = cf(k, 5); dy.c2 = cf(k, 6);
+            const Operand a = k == 0 ? plain(X0, 800) : act(Y[k - 1], 256, ACT_RELU, cf(k - 1, 0), cf(k - 1, 1));
+            if ((rc = wgrad(6 + k, a, dy, N, s))) return rc;
+            GemmArgs g{};
+            g.P = dy; g.Q = plain(p(lin[6 + k].w), lin[6 + k].Kp); g.I = N; g.R = 256; g.r_per_split = 256;
+            if (k > 0) {
+                g.J = 256; g.C = dnext; g.ldc = 256; g.stats = stats; g.Yp = Y[k - 1]; g.ldy = 256; g.m0 = cf(k - 1, 0); g.m2 = cf(k - 1, 1); g.mask = MASK_RELU_BN;
+            } else {
+                g.J = 768; g.C = G0; g.ldc = 768; g.mask = MASK_NONE;       // the pose columns need no gradient
+            }
+            if ((rc = gemm(true, EPI_BWD, g, s))) return rc;
+            nstat = T;
+        }
+        for (int e = 0; e < 3; ++e) {
+            const Operand gsec = plain(G0 + enc_col[e], 768);
+            if ((rc = wgrad(2 * e + 1, act(H[e], 256, enc_act[e], nullptr, nullptr), gsec, N, s))) return rc;
+            GemmArgs g{};
+            g.P = gsec; g.Q = plain(p(lin[2 * e + 1].w), 256); g.I = N; g.J = 256; g.R = 256; g.r_per_split = 256;
+            g.C = D[0]; g.ldc = 256; g.Yp = H[e]; g.ldy = 256; g.mask = enc_act[e] == ACT_SILU ? MASK_SILU : MASK_RELU;
+            if ((rc = gemm(true, EPI_BWD, g, s))) return rc;
+            if ((rc = wgrad(2 * e, plain(enc_in[e], enc_ld[e]), plain(D[0], 256), N, s))) return rc;
+        }
+        // torch.optim.Adam(lr, betas, weight_decay) over every parameter (trainer.py:46), then the transposed weight copies
+        ++adam_steps;
+        const double bc1 = 1.0 - std::pow((double)beta1, (double)adam_steps), bc2 = 1.0 - std::pow((double)beta2, (double)adam_steps);
+        hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, s, P.as<float>(), G.as<float>(), M.as<float>(), V.as<float>(),
+                           (int64_t)n_params, beta1, beta2, eps, wd, (float)((double)lr / bc1), (float)std::sqrt(bc2));
+        DGDM_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(transpose_all_kernel, dim3((800 * 256 + 255) / 256, 14), dim3(256), 0, s, P.as<float>(), WT.as<float>(), trdesc.as<TrDesc>());
+        DGDM_HIP_CHECK(hipGetLastError());
+        ++bn_batches;
+    }
+    if (loss_host) {
+        DGDM_HIP_CHECK(hipMemcpyAsync(loss_host, loss_dev.p, sizeof(float), hipMemcpyDeviceToHost, s));
+        DGDM_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    return DGDM_OK;
+}
+
+// which: 0 parameters and BatchNorm running statistics, 1 gradients, 2 / 3 Adam's first / second moments
+int DgdmTrainer2d::copy_state(int which, DgdmTensor *t, int n, bool to_device) {
+    DevBuf *src = which == 0 ? &P : which == 1 ? &G : which == 2 ? &M : &V;
+    std::vector<float> host(n_params), run(8 * 512);
+    DGDM_HIP_CHECK(hipDeviceSynchronize());
+    DGDM_HIP_CHECK(hipMemcpy(host.data(), src->p, n_params * sizeof(float), hipMemcpyDeviceToHost));
+    DGDM_HIP_CHECK(hipMemcpy(run.data(), bn_run.p, run.size() * sizeof(float), hipMemcpyDeviceToHost));
+    std::map<std::string, DgdmTensor *> by;
+    for (int i = 0; i < n; ++i) by[t[i].name] = &t[i];
+    auto slot = [&](const std::string &k, int64_t numel, bool required) -> float * {
+        auto it = by.find(k);
+        if (it == by.end()) { if (required) set_error("state_dict key '%s' missing", k.c_str()); return nullptr; }
+        if (it->second->dtype != 0 || it->second->numel != numel) { set_error("state_dict key '%s': expected %lld float32 values", k.c_str(), (long long)numel); return nullptr; }
+        return const_cast<float *>(static_cast<const float *>(it->second->data));
+    };
+    auto xfer = [&](float *user, float *mine, size_t cnt) { if (to_device) memcpy(mine, user, cnt * sizeof(float)); else memcpy(user, mine, cnt * sizeof(float)); };
+    for (int l = 0; l < 14; ++l) {
+        const Lin &x = lin[l];
+        float *wu = slot(x.name + ".weight", (int64_t)256 * x.K, true), *bu = slot(x.name + ".bias", 256, true);
+        if (!wu || !bu) return DGDM_EKEY;
+        for (int m = 0; m < 256; ++m)
+            for (int c = 0; c < x.Kp; ++c) {
+                const int rc = col_of(l, c);
+                if (rc < 0) { if (to_device) host[x.w + (size_t)m * x.Kp + c] = 0.f; continue; }
+                xfer(wu + (size_t)m * x.K + rc, &host[x.w + (size_t)m * x.Kp + c], 1);
+            }
+        xfer(bu, &host[x.b], 256);
+    }
+    for (int k = 0; k < 8; ++k) {
+        const std::string bn = "linears." + std::to_string(3 * k + 1);
+        float *gu = slot(bn + ".weight", 256, true), *bu = slot(bn + ".bias", 256, true);
+        if (!gu || !bu) return DGDM_EKEY;
+        xfer(gu, &host[bn_g[k]], 256); xfer(bu, &host[bn_b[k]], 256);
+        if (which == 0) {
+            float *mu = slot(bn + ".running_mean", 256, true), *vu = slot(bn + ".running_var", 256, true);
+            if (!mu || !vu) return DGDM_EKEY;
+            xfer(mu, &run[(size_t)k * 512], 256); xfer(vu, &run[(size_t)k * 512 + 256], 256);
+        }
+    }
+    float *wu = slot("output.weight", 3 * 256, true), *bu = slot("output.bias", 3, true);
+    if (!wu || !bu) return DGDM_EKEY;
+    xfer(wu, &host[out_w], 768); xfer(bu, &host[out_b], 3);
+    if (to_device) {
+        DGDM_HIP_CHECK(hipMemcpy(src->p, host.data(), n_params * sizeof(float), hipMemcpyHostToDevice));
+        if (which == 0) {
+            DGDM_HIP_CHECK(hipMemcpy(bn_run.p, run.data(), run.size() * sizeof(float), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(transpose_all_kernel, dim3((800 * 256 + 255) / 256, 14), dim3(256), 0, 0, P.as<float>(), WT.as<float>(), trdesc.as<TrDesc>());
+            DGDM_HIP_CHECK(hipGetLastError());
+            DGDM_HIP_CHECK(hipDeviceSynchronize());
+        }
+    }
+    return DGDM_OK;
+}
+
+extern "C" int dgdm_trainer2d_create(DgdmTrainer2d **out, const DgdmTensor *state_dict, int n_tensors, int params_ch, int object_ch, float beta1,
+                                     float beta2, float eps, float weight_decay) {
+    DGDM_REQUIRE(out && state_dict && params_ch > 0 && object_ch > 0, DGDM_EINVAL, "dgdm_trainer2d_create: bad argument");
+    std::unique_ptr<DgdmTrainer2d> m(new DgdmTrainer2d());
+    m->L = params_ch; m->OC = object_ch; m->Lp = round_up(params_ch, RC); m->OCp = round_up(object_ch, RC);
+    m->beta1 = beta1; m->beta2 = beta2; m->eps = eps; m->wd = weight_decay;
+    const char *names[14] = {"gripper_encoder.0", "gripper_encoder.2", "object_encoder.0", "object_encoder.2", "time_encoder.0", "time_encoder.2",
+                             "linears.0", "linears.3", "linears.6", "linears.9", "linears.12", "linears.15", "linears.18", "linears.21"};
+    const int K[14] = {params_ch, 256, object_ch, 256, 128, 256, 795, 256, 256, 256, 256, 256, 256, 256};
+    size_t o = 0, ot = 0;
+    std::vector<TrDesc> td(14);
+    for (int l = 0; l < 14; ++l) {
+        DgdmTrainer2d::Lin &x = m->lin[l];
+        x.name = names[l]; x.K = K[l]; x.Kp = round_up(K[l], RC);
+        x.w = o; o += (size_t)256 * x.Kp; x.b = o; o += 256;
+        x.wt = ot; ot += (size_t)256 * x.Kp;
+        td[l] = TrDesc{(int64_t)x.w, (int64_t)x.wt, x.Kp};
+    }
+    for (int k = 0; k < 8; ++k) { m->bn_g[k] = o; o += 256; m->bn_b[k] = o; o += 256; }
+    m->out_w = o; o += 768; m->out_b = o; o += 64;
+    m->n_params = o; m->n_wt = ot;
+    int rc;
+    for (DevBuf *b : {&m->P, &m->G, &m->M, &m->V}) {
+        if ((rc = b->alloc(o * sizeof(float)))) return rc;
+        DGDM_HIP_CHECK(hipMemset(b->p, 0, o * sizeof(float)));
+    }
+    if ((rc = m->WT.alloc(ot * sizeof(float)))) return rc;
+    if ((rc = m->bn_run.alloc(8 * 512 * sizeof(float)))) return rc;
+    if ((rc = m->coef.alloc(8 * 7 * 256 * sizeof(float)))) return rc;
+    DGDM_HIP_CHECK(hipMemset(m->coef.p, 0, 8 * 7 * 256 * sizeof(float)));
+    if ((rc = m->loss_dev.alloc(64))) return rc;
+    const std::vector<float> f = train_tfreqs(64);
+    if ((rc = m->tfreq.upload(f.data(), f.size() * sizeof(float)))) return rc;
+    if ((rc = m->trdesc.upload(td.data(), td.size() * sizeof(TrDesc)))) return rc;
+    if ((rc = m->copy_state(0, const_cast<DgdmTensor *>(state_dict), n_tensors, true))) return rc;
+    *out = m.release();
+    return DGDM_OK;
+}
+
+extern "C" void dgdm_trainer2d_destroy(DgdmTrainer2d *m) { delete m; }
+
+extern "C" int dgdm_trainer2d_step(DgdmTrainer2d *m, const float *ctrl_dev, const float *noise_dev, const float *sqrt_abar_dev,
+                                   const float *sqrt_1m_abar_dev, const float *t_dev, const float *ori_dev, const float *pos_dev, const float *object_dev,
+                                   const float *score_dev, int64_t rows, float lr, int train, float *pred_dev, float *loss_host, void *stream) {
+    DGDM_REQUIRE(m && ctrl_dev && t_dev && ori_dev && pos_dev && object_dev && score_dev && pred_dev, DGDM_EINVAL, "dgdm_trainer2d_step: null argument");
+    DGDM_REQUIRE(!noise_dev || (sqrt_abar_dev && sqrt_1m_abar_dev), DGDM_EINVAL, "dgdm_trainer2d_step: noise without its two scale vectors");
+    DGDM_REQUIRE(rows >= 2 && rows < ((int64_t)1 << 31) / 800, DGDM_EINVAL,
+                 "dgdm_trainer2d_step: %lld rows (BatchNorm1d in training mode needs at least 2; the workspace index math stops at 2^31/800)", (long long)rows);
+    return m->run(ctrl_dev, noise_dev, sqrt_abar_dev, sqrt_1m_abar_dev, t_dev, ori_dev, pos_dev, object_dev, score_dev, rows, lr, train, pred_dev,
+                  loss_host, (hipStream_t)stream);
+}
+
+extern "C" int dgdm_trainer2d_export(DgdmTrainer2d *m, int which, DgdmTensor *tensors, int n_tensors) {
+    DGDM_REQUIRE(m && tensors && which >= 0 && which <= 3, DGDM_EINVAL, "dgdm_trainer2d_export: bad argument");
+    return m->copy_state(which, tensors, n_tensors, false);
+}
+
+extern "C" int64_t dgdm_trainer2d_steps(const DgdmTrainer2d *m) { return m ? m->bn_batches : -1; }

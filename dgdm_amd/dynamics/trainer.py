@@ -1,0 +1,163 @@
+"""``Trainer`` of the dynamics model with the reference's interface (dynamics/trainer.py:16-146) on the HIP path.
+
+2-D (``ProfileForward2DModel``) only: parameters, gradients and the Adam state live in a ``DgdmTrainer2d`` handle inside
+libdgdm_hip.so and one ``step`` is forward (BatchNorm in training mode) + MSE loss + backward + Adam on the GPU
+(csrc/train2d.hip).  The random draws are the reference's: ``torch.randn`` for the noise, then ``torch.randint`` for the
+timesteps, both from the CPU generator (trainer.py:68-74).  The 3-D model (PointNet++ weight gradients) is not built: asking
+for ``fingers_3d`` raises.  There is no CPU path."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib import check, dptr, lib, stream_ptr
+from ..scheduler import DDIMScheduler
+from .profile_forward_2d import ProfileForward2DModel
+
+
+class _Adam:
+    """What dynamics/main.py reads of ``trainer.optimizer`` (:155): ``param_groups[0]['lr']``."""
+
+    def __init__(self, lr: float, betas: Tuple[float, float], weight_decay: float):
+        self.param_groups = [{"lr": lr, "initial_lr": lr, "betas": betas, "weight_decay": weight_decay, "eps": 1e-8}]
+
+
+class _CosineAnnealingLR:
+    """torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max, eta_min) in closed form (trainer.py:47)."""
+
+    def __init__(self, optimizer: _Adam, T_max: int, eta_min: float):
+        self.optimizer, self.T_max, self.eta_min, self.last_epoch = optimizer, T_max, eta_min, 0
+        self.base_lr = optimizer.param_groups[0]["initial_lr"]
+
+    def step(self) -> None:
+        self.last_epoch += 1
+        self.optimizer.param_groups[0]["lr"] = self.eta_min + (self.base_lr - self.eta_min) * (1 + math.cos(math.pi * self.last_epoch / self.T_max)) / 2
+
+    def get_last_lr(self):
+        return [self.optimizer.param_groups[0]["lr"]]
+
+
+class Trainer(object):
+    def __init__(self, args):
+        self.use_sub_batch = args.use_sub_batch
+        self.sub_batch_size = args.sub_bs
+        self.grid_size = args.grid_size
+        self.learning_rate = args.learning_rate
+        self.weight_decay = args.weight_decay
+        self.num_epochs = args.num_epochs
+        self.ckpt_path = args.checkpoint_path
+        self.fingers_3d = args.fingers_3d
+        if self.fingers_3d:
+            raise NotImplementedError("training the 3-D dynamics model (PointNet++ weight gradients) is not part of the HIP path; "
+                                      "2-D (ProfileForward2DModel) is")
+        if self.use_sub_batch:
+            raise NotImplementedError("--use_sub_batch is the 3-D training configuration (dynamics/train_dynamics_3d.sh)")
+        self.gripperpts_dim = args.ctrlpts_dim
+        self.object_vertices_dim = 2 * args.object_max_num_vertices
+        self.num_timesteps_per_batch = args.num_timesteps_per_batch
+        if self.num_timesteps_per_batch != 1:
+            # trainer.py:68-72 sizes the noise with num_timesteps_per_batch applied twice: only 1 is shape-consistent there
+            raise NotImplementedError("num_timesteps_per_batch must be 1 (the value of dynamics/train_dynamics_2d.sh)")
+        self.num_inference_steps = args.num_inference_steps
+        self.noise_scheduler = DDIMScheduler(num_train_timesteps=args.num_train_timesteps, beta_schedule='squaredcos_cap_v2', clip_sample=True,
+                                             prediction_type='epsilon')
+        self.noise_scheduler.set_timesteps(self.num_inference_steps)
+        self._h = None
+        self.model: Optional[ProfileForward2DModel] = None
+
+    # ------------------------------------------------------------------ model / optimizer (trainer.py:40-51)
+    def create_model(self, state_dict: Optional[Dict[str, torch.Tensor]] = None):
+        self.model = ProfileForward2DModel(output_ch=3, params_ch=self.gripperpts_dim, object_ch=self.object_vertices_dim)
+        if state_dict is None and self.ckpt_path is not None:
+            print('loading checkpoint from', self.ckpt_path)
+            state_dict = torch.load(self.ckpt_path, map_location='cpu')
+        if state_dict is not None:
+            state_dict = {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in state_dict.items()}
+            self.model.load_state_dict(state_dict)
+        self.optimizer = _Adam(self.learning_rate, (0.9, 0.95), self.weight_decay)
+        self.lr_scheduler = _CosineAnnealingLR(self.optimizer, T_max=self.num_epochs, eta_min=1e-2 * self.learning_rate)
+        if not torch.cuda.is_available():
+            raise RuntimeError("dgdm_amd runs on an MI355X through libdgdm_hip.so; no GPU is visible and there is no CPU path")
+        self._packed = _lib.PackedStateDict(self.model.plain_state_dict())
+        h = C.c_void_p()
+        check(lib().dgdm_trainer2d_create(C.byref(h), self._packed.array, self._packed.n, self.gripperpts_dim, self.object_vertices_dim,
+                                          0.9, 0.95, 1e-8, float(self.weight_decay)))
+        self._h = h
+        self._nbt0 = {k: int(v) for k, v in self.model.state_dict().items() if k.endswith('num_batches_tracked')}
+        print('done')
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and lib is not None:
+                lib().dgdm_trainer2d_destroy(self._h)
+        except Exception:        # interpreter shutdown: module globals are already gone
+            pass
+        self._h = None
+
+    # ------------------------------------------------------------------ one batch
+    def _inputs(self, ctrl, score, input_ori, input_pos, object_vertices):
+        dev = torch.device("cuda", torch.cuda.current_device())
+        n = self.num_timesteps_per_batch
+        f = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()       # noqa: E731
+        ctrl_all, obj_all = f(ctrl.repeat(n, 1)), f(object_vertices.repeat(n, 1))
+        ori_all, pos_all, score_all = f(input_ori.repeat(n, 1)), f(input_pos.repeat(n, 1)), f(score.repeat(n, 1))
+        rows = ctrl_all.shape[0]
+        # the reference's draws, in its order, from the CPU generator (trainer.py:68-74)
+        noise = torch.randn((rows * n, self.gripperpts_dim))
+        timesteps = torch.randint(0, self.noise_scheduler.config.num_train_timesteps, (rows,)).long()
+        ac = self.noise_scheduler.alphas_cumprod[timesteps]
+        sa, sb = f(ac ** 0.5), f((1 - ac) ** 0.5)                                       # DDIMScheduler.add_noise (diffusers 0.11.1)
+        t = f(timesteps.float() / self.noise_scheduler.config.num_train_timesteps)       # rescale to [0,1] (:80)
+        return ctrl_all, f(noise), sa, sb, t, ori_all, pos_all, obj_all, score_all, rows
+
+    def _run(self, ctrl, score, input_ori, input_pos, object_vertices, train: bool):
+        if self._h is None:
+            raise RuntimeError("Trainer.create_model() has not been called")
+        c, nz, sa, sb, t, o, p, ob, sc, rows = self._inputs(ctrl, score, input_ori, input_pos, object_vertices)
+        pred = torch.empty((rows, 3), dtype=torch.float32, device=c.device)
+        loss = C.c_float()
+        lr = float(self.optimizer.param_groups[0]["lr"])
+        check(lib().dgdm_trainer2d_step(self._h, dptr(c), dptr(nz), dptr(sa), dptr(sb), dptr(t), dptr(o), dptr(p), dptr(ob), dptr(sc), rows, lr,
+                                        1 if train else 0, dptr(pred), C.byref(loss), stream_ptr()))
+        return float(loss.value), pred
+
+    def step(self, ctrl, score, input_ori=None, input_pos=None, object_vertices=None):
+        """trainer.py:53-103: returns (loss.item(), pred.detach())."""
+        return self._run(ctrl, score, input_ori, input_pos, object_vertices, True)
+
+    def inference(self, ctrl, score, input_ori=None, input_pos=None, object_vertices=None):
+        """trainer.py:108-146 (eval mode, no update): returns (pred, loss)."""
+        loss, pred = self._run(ctrl, score, input_ori, input_pos, object_vertices, False)
+        return pred, loss
+
+    # ------------------------------------------------------------------ state
+    def _export(self, which: int) -> Dict[str, torch.Tensor]:
+        sd = {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()}
+        packed = _lib.PackedStateDict({k: v for k, v in sd.items() if v.dtype == torch.float32})
+        check(lib().dgdm_trainer2d_export(self._h, which, packed.array, packed.n))
+        out = {}
+        for name, arr in zip(packed.names, packed.keep):
+            out[name.decode()] = torch.from_numpy(arr.copy()).reshape(sd[name.decode()].shape)
+        if which == 0:
+            steps = int(lib().dgdm_trainer2d_steps(self._h))
+            for k, v0 in self._nbt0.items():
+                out[k] = torch.tensor(v0 + steps, dtype=torch.long)
+        else:
+            out = {k: v for k, v in out.items() if 'running_' not in k}
+        return out
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        """The trained model's state_dict (host tensors), keys as the reference's bare module gives them."""
+        return self._export(0)
+
+    def gradients(self) -> Dict[str, torch.Tensor]:
+        return self._export(1)
+
+    def save_checkpoint(self, checkpoint_path):
+        """trainer.py:105-106: the DataParallel-wrapped model's state_dict ('module.' prefix)."""
+        torch.save({'module.' + k: v for k, v in self.state_dict().items()}, checkpoint_path)

@@ -291,6 +291,30 @@ int dgdm_debug_pointnet_indices(DgdmDynamics *m, const float *xyz_dev, int N, co
                                 int32_t *fps512_dev, int32_t *fps128_dev, int32_t *fps128_flags_dev, int32_t *ball1_dev,
                                 int32_t *ball2_dev, int32_t *ball2_count_dev, int32_t *crowded_dev, void *stream);
 
+/* ------------------------------------------------------------------ (f) rank 4: training the 2-D dynamics model
+ * Trainer (dynamics/trainer.py:16-106) for ProfileForward2DModel: parameters, gradients and torch.optim.Adam state
+ * (trainer.py:46: betas (0.9, 0.95), weight_decay) live on the device.  state_dict: the model's tensors ("module."-prefix
+ * stripped), BatchNorm running statistics included.                                                                        */
+typedef struct DgdmTrainer2d DgdmTrainer2d;
+int dgdm_trainer2d_create(DgdmTrainer2d **out, const DgdmTensor *state_dict, int n_tensors, int params_ch, int object_ch,
+                          float beta1, float beta2, float eps, float weight_decay);
+void dgdm_trainer2d_destroy(DgdmTrainer2d *m);
+/* Trainer.step (trainer.py:53-103, the branch without sub-batches) on `rows` rows when train != 0: noisy control points
+ * sqrt_abar[r]*ctrl + sqrt_1m_abar[r]*noise (DDIMScheduler.add_noise, :75-79; noise_dev null = ctrl as given), model forward in
+ * training mode (BatchNorm1d batch statistics; running statistics updated), loss = nn.MSELoss()(pred, score), backward, one Adam
+ * update with learning rate lr.  train == 0 is Trainer.inference (:108-146): eval-mode forward (running statistics) and the loss,
+ * nothing is updated.  t_dev [rows] = timesteps / num_train_timesteps (:80).  pred_dev [rows][3]; loss_host (optional) receives
+ * the loss and makes the call synchronous, like loss.item().  Deterministic: same inputs, same bits.                              */
+int dgdm_trainer2d_step(DgdmTrainer2d *m, const float *ctrl_dev, const float *noise_dev, const float *sqrt_abar_dev,
+                        const float *sqrt_1m_abar_dev, const float *t_dev, const float *ori_dev, const float *pos_dev,
+                        const float *object_dev, const float *score_dev, int64_t rows, float lr, int train, float *pred_dev,
+                        float *loss_host, void *stream);
+/* Copies into the host buffers of `tensors` (matched by name; data is written despite the const): which = 0 the state_dict
+ * (parameters + running statistics: Trainer.save_checkpoint, trainer.py:105-106), 1 the gradients of the last step, 2 / 3 Adam's
+ * exp_avg / exp_avg_sq.                                                                                                           */
+int dgdm_trainer2d_export(DgdmTrainer2d *m, int which, DgdmTensor *tensors, int n_tensors);
+int64_t dgdm_trainer2d_steps(const DgdmTrainer2d *m);      /* training steps taken = BatchNorm's num_batches_tracked increment */
+
 #ifdef __cplusplus
 }
 #endif

@@ -610,3 +610,79 @@ def guided_sample_multi_object(s: Setup, noise: torch.Tensor, objects: Sequence[
         eps = eps - (1 - s.sched.alphas_cumprod[t]).sqrt() * g * scale
         x = s.sched.step(eps, t, x)
     return x
+
+
+# =========================================================================== (f) rank 4  Trainer.step of the 2-D dynamics model
+class Trainer2D:
+    """``Trainer`` (dynamics/trainer.py:16-106) for ``ProfileForward2DModel``, restated functionally over a flat state_dict:
+    ``step`` = trainer.py:53-103 without sub-batches (the 2-D configuration, dynamics/train_dynamics_2d.sh), the model in
+    training mode (BatchNorm1d batch statistics, running statistics momentum 0.1 with the unbiased variance), nn.MSELoss,
+    torch.autograd for the gradients, and torch.optim.Adam(lr, betas=(0.9, 0.95), weight_decay) (:46) written out
+    (single-tensor form of torch 2.x: lerp first moment, bias corrections, eps added after the corrected square root)."""
+
+    def __init__(self, sd: SD, num_train_timesteps: int, lr: float, weight_decay: float = 0.0, betas=(0.9, 0.95), eps: float = 1e-8):
+        self.sd = {k: v.clone() for k, v in sd.items()}
+        self.names = [k for k, v in self.sd.items() if v.dtype.is_floating_point and "running_" not in k]
+        self.ddim = DDIM(num_train_timesteps)
+        self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.m = {k: torch.zeros_like(self.sd[k]) for k in self.names}
+        self.v = {k: torch.zeros_like(self.sd[k]) for k in self.names}
+        self.t = 0
+        self.grads: SD = {}
+        self.draws = None
+        self.relu_margin = float("inf")
+
+    def _forward(self, sd: SD, x_ctrl, x_ori, x_pos, timesteps, object_vertices, training: bool) -> torch.Tensor:
+        # profile_forward_2d.py:137-156
+        def relu(z):        # every ReLU input passes here: relu_margin = how far the nearest one is from its kink (see tests)
+            self.relu_margin = min(self.relu_margin, float(z.detach().abs().min()))
+            return F.relu(z)
+        g = _mlp2(sd, "gripper_encoder", x_ctrl, relu)
+        pose = torch.cat([nerf_embed(x_ori), nerf_embed(x_pos)], dim=1)
+        o = _mlp2(sd, "object_encoder", object_vertices, relu)
+        te = _mlp2(sd, "time_encoder", timestep_embedding(timesteps, 128), F.silu)
+        x = torch.cat([o, g, pose, te], dim=1)
+        for i in range(8):
+            x = F.linear(x, sd[f"linears.{3 * i}.weight"], sd[f"linears.{3 * i}.bias"])
+            b = f"linears.{3 * i + 1}"
+            x = F.batch_norm(x, self.sd[b + ".running_mean"], self.sd[b + ".running_var"], sd[b + ".weight"], sd[b + ".bias"],
+                             training=training, momentum=0.1, eps=1e-5)      # in place on the running statistics, as nn.BatchNorm1d
+            x = relu(x)
+        return F.linear(x, sd["output.weight"], sd["output.bias"])
+
+    def _noisy(self, ctrl, forced=None):
+        rows = ctrl.shape[0]
+        if forced is None:
+            noise = torch.randn((rows, ctrl.shape[1]))                                   # trainer.py:71
+            timesteps = torch.randint(0, self.ddim.num_train_timesteps, (rows,)).long()  # :72-76
+        else:
+            noise, timesteps = forced
+        self.draws = (noise, timesteps)
+        return self.ddim.add_noise(ctrl, noise, timesteps), timesteps.float() / self.ddim.num_train_timesteps
+
+    def step(self, ctrl, score, input_ori, input_pos, object_vertices, forced=None):
+        noisy, t = self._noisy(ctrl, forced)
+        leaf = {k: self.sd[k].clone().requires_grad_(True) for k in self.names}
+        pred = self._forward({**self.sd, **leaf}, noisy, input_ori, input_pos, t, object_vertices, True)
+        loss = F.mse_loss(pred, score)
+        grads = torch.autograd.grad(loss, [leaf[k] for k in self.names])
+        self.grads = dict(zip(self.names, grads))
+        self.t += 1
+        b1, b2 = self.betas
+        bc1, bc2 = 1 - b1 ** self.t, 1 - b2 ** self.t
+        for k in self.names:
+            g = self.grads[k] + self.wd * self.sd[k] if self.wd else self.grads[k]
+            self.m[k] = self.m[k] + (g - self.m[k]) * (1 - b1)
+            self.v[k] = self.v[k] * b2 + (1 - b2) * g * g
+            self.sd[k] = self.sd[k] - (self.lr / bc1) * self.m[k] / (self.v[k].sqrt() / math.sqrt(bc2) + self.eps)
+        for k in self.sd:
+            if k.endswith("num_batches_tracked"):
+                self.sd[k] = self.sd[k] + 1
+        return float(loss.detach()), pred.detach()
+
+    def inference(self, ctrl, score, input_ori, input_pos, object_vertices, forced=None):
+        # trainer.py:108-146: eval mode, same draws, no update
+        with torch.no_grad():
+            noisy, t = self._noisy(ctrl, forced)
+            pred = self._forward(self.sd, noisy, input_ori, input_pos, t, object_vertices, False)
+            return pred, float(F.mse_loss(pred, score))

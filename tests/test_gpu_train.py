@@ -1,0 +1,157 @@
+"""Trainer.step / Trainer.inference of the 2-D dynamics model on the GPU (csrc/train2d.hip through dgdm_amd.dynamics.trainer)
+against the reference's own Trainer (tests/golden/g10_train2d.npz) and against the oracle at other sizes."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dgdm_oracle as orc
+from tests import util
+from tests.test_oracle_golden import BN_FED_BIAS, _train_case, check_training
+
+pytestmark = pytest.mark.gpu
+
+
+def _args(wd, L=14, nv=100, T=15, lr=1e-4):
+    return argparse.Namespace(use_sub_batch=False, sub_bs=1024, grid_size=360, learning_rate=lr, weight_decay=wd, num_epochs=100,
+                              checkpoint_path=None, fingers_3d=False, ctrlpts_dim=L, object_max_num_vertices=nv,
+                              num_timesteps_per_batch=1, num_inference_steps=5, num_train_timesteps=T)
+
+
+class _HipTrainer:
+    def __init__(self, sd, T, wd):
+        from dynamics.trainer import Trainer
+        self.t = Trainer(_args(wd, T=T))
+        self.t.create_model(state_dict=sd)
+
+    def lr_step(self):
+        self.t.lr_scheduler.step()
+
+    def step(self, *a):
+        return self.t.step(*a)
+
+    def inference(self, *a):
+        return self.t.inference(*a)
+
+    def gradients(self):
+        return self.t.gradients()
+
+    def state_dict(self):
+        return self.t.state_dict()
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from dgdm_amd import _lib
+    _lib.device_init(0)
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("tag", ["wd0", "wd1"])
+def test_trainer2d_matches_reference(dev, tag):
+    """Three training steps (cosine schedule stepped once) and one eval call: losses, predictions, the gradients of step 1, every
+    parameter after step 3 and the BatchNorm running statistics against the reference's own Trainer on the same draws."""
+    g = util.load("g10_train2d.npz")
+    rec = _train_case(g, tag, _HipTrainer)
+    worst = check_training(g, tag, rec, 2e-5, 5e-5, 4e-6)
+    print(tag, "largest gradient error / tensor rms:", max(worst.values()))
+    # Trainer.inference (eval mode: running statistics) on the weights this run ended with, against the oracle on the same weights
+    n_g, n_p, L, nv, T = [int(v) for v in g["dims"]]
+    data = util.train2d_data(int(g["data_seed"]), n_g, n_p)
+    o = orc.Trainer2D(rec["final"], T, 1e-4)
+    torch.manual_seed(9)
+    po, lo = o.inference(*data)
+    torch.manual_seed(9)
+    ph, lh = rec["trainer"].inference(*data)
+    assert util.rel_l2(ph.cpu(), po) < 2e-5 and abs(lh / lo - 1) < 2e-5
+
+
+def _one_step(rows, L, nv, seed):
+    sd = util.synth.synth_state_dict(util.synth.dyn2d_spec(L, 2 * nv), 50 + seed)
+    rs = np.random.RandomState(seed)
+    data = [torch.from_numpy(rs.uniform(-1, 1, s).astype(np.float32)) for s in ((rows, L), (rows, 3), (rows, 1), (rows, 2), (rows, 2 * nv))]
+    o = orc.Trainer2D(sd, 15, 1e-4)
+    torch.manual_seed(77)
+    lo, po = o.step(*data)
+    return sd, data, o, lo, po
+
+
+def _hip_step(sd, data, L, nv):
+    from dynamics.trainer import Trainer
+    t = Trainer(_args(0.0, L, nv))
+    t.create_model(state_dict=sd)
+    torch.manual_seed(77)
+    lh, ph = t.step(*data)
+    return lh, ph.cpu(), t.gradients(), t.state_dict()
+
+
+def test_trainer2d_ragged_rows_vs_oracle(dev):
+    """Row counts that are no multiple of any tile (130, 200), another control-point and object size (L = 42, 64 vertices), one step
+    each: loss, predictions, every gradient and the running statistics against the oracle on the same draws; the same step twice
+    gives the same bits.  The batch is the first of its seeds whose ReLU inputs all stay 5e-6 from zero in the oracle's run (see
+    make_golden.g10_train2d: a ReLU input that rounds to the other side in another summation order changes a whole BatchNorm
+    column of the backward pass, in the reference as much as here)."""
+    for rows, L, nv in ((130, 42, 64), (200, 14, 100)):
+        for seed in range(200):
+            sd, data, o, lo, po = _one_step(rows, L, nv, seed)
+            if o.relu_margin >= 5e-6:
+                break
+        assert o.relu_margin >= 5e-6
+        outs = [_hip_step(sd, data, L, nv) for _ in range(2)]
+        lh, ph, gh, sh = outs[0]
+        assert abs(lh / lo - 1) < 1e-5 and util.rel_l2(ph, po) < 2e-5
+        for k, ref in o.grads.items():
+            if k in BN_FED_BIAS:
+                continue
+            err = float((gh[k].double() - ref.double()).abs().max() / ref.double().pow(2).mean().sqrt())
+            # (the time encoder sees 15 distinct inputs: its gradients are sums that cancel ten-fold, and carry that much more rounding)
+            assert err < (2e-4 if k.startswith('time_encoder') else 6e-5), (rows, k, err)
+        for k in sh:
+            assert torch.equal(sh[k], outs[1][3][k]), k
+        assert torch.equal(ph, outs[1][1]) and lh == outs[1][0]
+        for k in ("linears.1.running_mean", "linears.22.running_var"):
+            assert float((sh[k] - o.sd[k]).abs().max()) < 1e-5, k
+
+
+def test_trainer2d_many_rows_vs_oracle(dev):
+    """4099 rows (33 row tiles, 17 weight-gradient splits): forward exact to float32 rounding; the gradients within what a handful of
+    ReLU inputs at rounding distance from zero can move them (1e-2 of the tensor norm: a million ReLU inputs per layer, about one of
+    them within 1e-6 of zero; an indexing error at a tile or split edge would show as O(0.1)); the output layer's - the only
+    gradients above every ReLU mask - tight."""
+    sd, data, o, lo, po = _one_step(4099, 14, 100, 1)
+    lh, ph, gh, sh = _hip_step(sd, data, 14, 100)
+    assert abs(lh / lo - 1) < 1e-5 and util.rel_l2(ph, po) < 2e-5
+    for k in ("output.weight", "output.bias"):
+        assert util.rel_l2(gh[k], o.grads[k]) < 2e-5, k
+    for k, ref in o.grads.items():
+        if k not in BN_FED_BIAS:
+            assert util.rel_l2(gh[k], ref) < 1e-2, (k, util.rel_l2(gh[k], ref))
+
+
+def test_trainer2d_checkpoint_round_trip(dev, tmp_path):
+    """save_checkpoint writes the DataParallel key layout the sampling path loads (trainer.py:105-106 -> generator/train.py:90), and the
+    eval-mode forward of the saved weights equals Trainer.inference's predictions."""
+    from dynamics.trainer import Trainer
+    from dynamics.profile_forward_2d import ProfileForward2DModel
+    sd = util.dyn2d_sd(41, 100)
+    data = util.train2d_data(5)
+    t = Trainer(_args(0.0))
+    t.create_model(state_dict=sd)
+    torch.manual_seed(1)
+    for _ in range(2):
+        t.step(*data)
+    path = str(tmp_path / "dyn.pt")
+    t.save_checkpoint(path)
+    ck = torch.load(path)
+    assert all(k.startswith("module.") for k in ck) and int(ck["module.linears.1.num_batches_tracked"]) == 2
+    torch.manual_seed(2)
+    pred, loss = t.inference(*data)
+    torch.manual_seed(2)
+    noise = torch.randn((384, 14))
+    ts = torch.randint(0, 15, (384,)).long()
+    noisy = orc.DDIM(15).add_noise(data[0], noise, ts)
+    m = ProfileForward2DModel(params_ch=14, object_ch=200)
+    m.load_state_dict({k[len("module."):]: v for k, v in ck.items()})
+    out = m.to(dev)(noisy.to(dev), data[2].to(dev), data[3].to(dev), (ts.float() / 15).to(dev), data[4].to(dev))
+    assert util.rel_l2(out.cpu(), pred.cpu()) < 2e-5

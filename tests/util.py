@@ -73,3 +73,25 @@ def oracle_band(fn):
 def within_band(out, refs, tol):
     err = torch.stack([finger_err(out, r) for r in refs]).min(dim=0).values
     return bool((err < tol).all()), err
+
+
+def train2d_data(seed, n_grippers=3, n_poses=128, L=14, nv=100):
+    """A synthetic training batch shaped like dynamics/main.py:132-145 hands it to Trainer.step: every (gripper, object) sample
+    repeated over its pose grid, scores per row.  Inputs only."""
+    rs = np.random.RandomState(seed)
+    rep = lambda a: np.repeat(a, n_poses, axis=0)                                   # noqa: E731
+    ctrl = rep(rs.uniform(-1, 1, (n_grippers, L))).astype(np.float32)
+    obj = rep(rs.uniform(-1, 1, (n_grippers, 2 * nv))).astype(np.float32)
+    ori = rs.uniform(-1, 1, (n_grippers * n_poses, 1)).astype(np.float32)
+    pos = rs.uniform(-1, 1, (n_grippers * n_poses, 2)).astype(np.float32)
+    score = rs.normal(0, 1, (n_grippers * n_poses, 3)).astype(np.float32)
+    return [torch.from_numpy(a) for a in (ctrl, score, ori, pos, obj)]
+
+
+def sample_idx(name, numel, k=96):
+    """Which entries of a parameter tensor the training fixture keeps (all of a small one)."""
+    import zlib
+    if numel <= k:
+        return np.arange(numel)
+    return np.sort(np.random.RandomState(zlib.crc32(name.encode()) & 0x7fffffff).choice(numel, k, replace=False))
+
