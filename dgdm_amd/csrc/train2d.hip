@@ -34,19 +34,16 @@ namespace dgdm {
 namespace {
 
 constexpr int TI = 128, TJ = 256, RC = 16, W = 256;
-enum { XF_PLAIN = 0, XF_ACT = 1, XF_AFFINE2 = 2 };
 enum { EPI_FWD = 0, EPI_BWD = 1, EPI_WGRAD = 2 };
 enum { MASK_NONE = 0, MASK_RELU = 1, MASK_SILU = 2, MASK_RELU_BN = 3 };
 
-// A GEMM operand: T0 (and T1) row-major with leading dimension ld, turned into the operand value on load:
-//   XF_PLAIN    T0
-//   XF_ACT      act(c0[col]*T0 + c2[col])                 (c0 = null: act(T0))
-//   XF_AFFINE2  c0[col]*T0 + c1[col]*T1 + c2[col]
+// A GEMM operand: T0 (and T1) row-major with leading dimension ld, turned into the operand value on load (X_* below) with the
+// per-column coefficient vectors c0, c1, c2.
 struct Operand {
     const float *t0, *t1;
     int64_t ld;
     const float *c0, *c1, *c2;
-    int xf, act;
+    int xf;
 };
 
 struct GemmArgs {
@@ -70,30 +67,44 @@ __device__ __forceinline__ float silu_grad(float z) {
 }
 __device__ __forceinline__ float bn_pre(float c0, float y, float c2) { return fmaf(c0, y, c2); }   // ONE expression for forward and mask
 
-__device__ __forceinline__ float xf1(int xf, int act, float a, float b, float c0, float c1, float c2) {
-    if (xf == XF_PLAIN) return a;
-    if (xf == XF_ACT) {
-        const float z = bn_pre(c0, a, c2);
-        return act == ACT_RELU ? fmaxf(z, 0.f) : (act == ACT_SILU ? silu(z) : z);
-    }
+// Operand transforms are compile-time (straight-line loaders: every global load of a chunk is issued back to back, invalid rows
+// and columns read a clamped address and are zeroed by a select when the value is written to LDS).
+//   PX / QX:  X_PLAIN  T0 | X_RELU  max(0, c0*T0 + c2) | X_SILU  silu(T0) | X_AFF2  c0*T0 + c1*T1 + c2
+enum { X_PLAIN = 0, X_RELU = 1, X_SILU = 2, X_AFF2 = 3 };
+
+template <int X>
+__device__ __forceinline__ float xf1(float a, float b, float c0, float c1, float c2) {
+    if (X == X_PLAIN) return a;
+    if (X == X_RELU) return fmaxf(bn_pre(c0, a, c2), 0.f);
+    if (X == X_SILU) return silu(a);
     return fmaf(c0, a, fmaf(c1, b, c2));
 }
-__device__ __forceinline__ float4 xf4(int xf, int act, float4 a, float4 b, float4 c0, float4 c1, float4 c2) {
-    return make_float4(xf1(xf, act, a.x, b.x, c0.x, c1.x, c2.x), xf1(xf, act, a.y, b.y, c0.y, c1.y, c2.y),
-                       xf1(xf, act, a.z, b.z, c0.z, c1.z, c2.z), xf1(xf, act, a.w, b.w, c0.w, c1.w, c2.w));
+template <int X>
+__device__ __forceinline__ float4 xf4(float4 a, float4 b, float4 c0, float4 c1, float4 c2, bool valid) {
+    float4 v = make_float4(xf1<X>(a.x, b.x, c0.x, c1.x, c2.x), xf1<X>(a.y, b.y, c0.y, c1.y, c2.y), xf1<X>(a.z, b.z, c0.z, c1.z, c2.z),
+                           xf1<X>(a.w, b.w, c0.w, c1.w, c2.w));
+    if (!valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    return v;
 }
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
-__device__ __forceinline__ float4 coef4(const float *c, int64_t col, float dflt) { return c ? ld4(c + col) : make_float4(dflt, dflt, dflt, dflt); }
 
-template <bool PTRANS, int EPI>
+template <bool PTRANS, int EPI, int PX, int QX, int MASK>
 __global__ __launch_bounds__(256, 2) void tgemm_kernel(const GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float sP[RC][TI];
     __shared__ __attribute__((aligned(16))) float sQ[RC][TJ];
+    constexpr bool PC = PX == X_RELU || PX == X_AFF2, QC = QX == X_RELU || QX == X_AFF2;      // operand has per-column coefficients
+    __shared__ __attribute__((aligned(16))) float sC[PTRANS && PC ? 3 : 1][PTRANS && PC ? W : 4];   // P's coefficients (transposed source: R <= 256 columns)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wi = w & 1, wj = w >> 1, n = lane & 31, h = lane >> 5;
     const int64_t i0 = (int64_t)blockIdx.x * TI;
     const int j0 = blockIdx.y * TJ;
     const int64_t rbeg = (int64_t)blockIdx.z * g.r_per_split, rend = min(g.R, rbeg + g.r_per_split);
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (PTRANS && PC) {
+        const bool in = tid < g.R;
+        sC[0][tid] = in ? g.P.c0[tid] : 0.f;
+        sC[2][tid] = in ? g.P.c2[tid] : 0.f;
+        sC[1][tid] = in && PX == X_AFF2 ? g.P.c1[tid] : 0.f;
+    }
 
     // ---- loaders.  P transposed source: thread = (tile row px, float4 slots prq, prq + 2 along r); P / Q direct source:
     // thread = (float4 column, rows prr + 8u / qrr + 4u of the chunk)
@@ -101,37 +112,26 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const GemmArgs g) {
     const int64_t prow = i0 + px, pcol = i0 + 4 * px4;
     const int qcol = j0 + 4 * qx4;
     const bool pval = PTRANS ? prow < g.I : pcol < g.I, qval = qcol < g.J;
-    const bool p2 = g.P.xf == XF_AFFINE2, q2 = g.Q.xf == XF_AFFINE2;
-    float4 pc0 = zero4, pc1 = zero4, pc2 = zero4, qc0, qc1, qc2;
-    if (!PTRANS) { const int64_t c = pval ? pcol : 0; pc0 = coef4(g.P.c0, c, 1.f); pc1 = coef4(g.P.c1, c, 0.f); pc2 = coef4(g.P.c2, c, 0.f); }
-    { const int c = qval ? qcol : 0; qc0 = coef4(g.Q.c0, c, 1.f); qc1 = coef4(g.Q.c1, c, 0.f); qc2 = coef4(g.Q.c2, c, 0.f); }
+    const int64_t pbase = PTRANS ? (pval ? prow : g.I - 1) * g.P.ld : (pval ? pcol : 0);      // clamped: always a readable address
+    const int64_t qbase = qval ? qcol : 0;
+    float4 pc0 = zero4, pc1 = zero4, pc2 = zero4, qc0 = zero4, qc1 = zero4, qc2 = zero4;
+    if (!PTRANS && PC) { const int64_t c = pval ? pcol : 0; pc0 = ld4(g.P.c0 + c); pc2 = ld4(g.P.c2 + c); if (PX == X_AFF2) pc1 = ld4(g.P.c1 + c); }
+    if (QC) { qc0 = ld4(g.Q.c0 + qbase); qc2 = ld4(g.Q.c2 + qbase); if (QX == X_AFF2) qc1 = ld4(g.Q.c1 + qbase); }
     float4 pa[2], pb[2], qa[4], qb[4];
     float4 qsum = zero4;
 
     auto issue = [&](int64_t r) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            pa[u] = pb[u] = zero4;
-            if (PTRANS) {
-                if (pval) {
-                    const int64_t o = prow * g.P.ld + r + 4 * (prq + 2 * u);
-                    pa[u] = ld4(g.P.t0 + o);
-                    if (p2) pb[u] = ld4(g.P.t1 + o);
-                }
-            } else if (pval && r + prr + 8 * u < rend) {
-                const int64_t o = (r + prr + 8 * u) * g.P.ld + pcol;
-                pa[u] = ld4(g.P.t0 + o);
-                if (p2) pb[u] = ld4(g.P.t1 + o);
-            }
+            const int64_t o = PTRANS ? pbase + r + 4 * (prq + 2 * u) : min(r + prr + 8 * u, rend - 1) * g.P.ld + pbase;
+            pa[u] = ld4(g.P.t0 + o);
+            if (PX == X_AFF2) pb[u] = ld4(g.P.t1 + o);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            qa[u] = qb[u] = zero4;
-            if (qval && r + qrr + 4 * u < rend) {
-                const int64_t o = (r + qrr + 4 * u) * g.Q.ld + qcol;
-                qa[u] = ld4(g.Q.t0 + o);
-                if (q2) qb[u] = ld4(g.Q.t1 + o);
-            }
+            const int64_t o = min(r + qrr + 4 * u, rend - 1) * g.Q.ld + qbase;
+            qa[u] = ld4(g.Q.t0 + o);
+            if (QX == X_AFF2) qb[u] = ld4(g.Q.t1 + o);
         }
     };
     auto commit = [&](int64_t r) {
@@ -139,22 +139,16 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const GemmArgs g) {
         for (int u = 0; u < 2; ++u) {
             if (PTRANS) {
                 const int r4 = prq + 2 * u;
-                float4 v = zero4;
-                if (pval) {
-                    const int64_t c = r + 4 * r4;
-                    v = xf4(g.P.xf, g.P.act, pa[u], pb[u], coef4(g.P.c0, c, 1.f), coef4(g.P.c1, c, 0.f), coef4(g.P.c2, c, 0.f));
-                }
+                if (PC) { const int c = (int)r + 4 * r4; pc0 = ld4(&sC[0][c]); pc2 = ld4(&sC[2][c]); if (PX == X_AFF2) pc1 = ld4(&sC[1][c]); }
+                const float4 v = xf4<PX>(pa[u], pb[u], pc0, pc1, pc2, pval);
                 sP[4 * r4 + 0][px] = v.x; sP[4 * r4 + 1][px] = v.y; sP[4 * r4 + 2][px] = v.z; sP[4 * r4 + 3][px] = v.w;
             } else {
-                float4 v = zero4;
-                if (pval && r + prr + 8 * u < rend) v = xf4(g.P.xf, g.P.act, pa[u], pb[u], pc0, pc1, pc2);
-                *reinterpret_cast<float4 *>(&sP[prr + 8 * u][4 * px4]) = v;
+                *reinterpret_cast<float4 *>(&sP[prr + 8 * u][4 * px4]) = xf4<PX>(pa[u], pb[u], pc0, pc1, pc2, pval && r + prr + 8 * u < rend);
             }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            float4 v = zero4;
-            if (qval && r + qrr + 4 * u < rend) v = xf4(g.Q.xf, g.Q.act, qa[u], qb[u], qc0, qc1, qc2);
+            const float4 v = xf4<QX>(qa[u], qb[u], qc0, qc1, qc2, qval && r + qrr + 4 * u < rend);
             *reinterpret_cast<float4 *>(&sQ[qrr + 4 * u][4 * qx4]) = v;
             if (EPI == EPI_WGRAD) { qsum.x += v.x; qsum.y += v.y; qsum.z += v.z; qsum.w += v.w; }
         }
@@ -219,8 +213,8 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const GemmArgs g) {
         const int j = j0 + 128 * wj + 32 * u + n;
         const bool jv = j < g.J;
         const int jc = jv ? j : 0;
-        const float bj = EPI == EPI_FWD && g.bias ? g.bias[jc] : 0.f;
-        const float m0 = EPI == EPI_BWD && g.mask == MASK_RELU_BN ? g.m0[jc] : 1.f, m2 = EPI == EPI_BWD && g.mask == MASK_RELU_BN ? g.m2[jc] : 0.f;
+        const float bj = EPI == EPI_FWD ? g.bias[jc] : 0.f;
+        const float m0 = MASK == MASK_RELU_BN ? g.m0[jc] : 1.f, m2 = MASK == MASK_RELU_BN ? g.m2[jc] : 0.f;
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -234,10 +228,10 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const GemmArgs g) {
                     s2[u] = fmaf(v, v, s2[u]);
                 } else {
                     float v = acc[s][u][q];
-                    if (g.mask != MASK_NONE) {
+                    if (MASK != MASK_NONE) {
                         const float y = g.Yp[i * g.ldy + j];
-                        if (g.mask == MASK_RELU) v = y > 0.f ? v : 0.f;
-                        else if (g.mask == MASK_SILU) v *= silu_grad(y);
+                        if (MASK == MASK_RELU) v = y > 0.f ? v : 0.f;
+                        else if (MASK == MASK_SILU) v *= silu_grad(y);
                         else { v = bn_pre(m0, y, m2) > 0.f ? v : 0.f; s1[u] += v; s2[u] = fmaf(v, y, s2[u]); }
                     }
                     g.C[i * g.ldc + j] = v;
@@ -260,21 +254,31 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const GemmArgs g) {
     }
 }
 
+// column sums of per-workgroup partials in float64: out[s][c] = sum over t = s, s + S, ... of in[t][c]   (fixed order: reproducible)
+constexpr int RED_S = 64;
+__global__ void reduce_partials_kernel(const float *__restrict__ in, int T, int ncol, double *__restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+    if (c >= ncol) return;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int t = s;
+    for (; t + 3 * RED_S < T; t += 4 * RED_S) {
+        a0 += (double)in[(int64_t)t * ncol + c]; a1 += (double)in[(int64_t)(t + RED_S) * ncol + c];
+        a2 += (double)in[(int64_t)(t + 2 * RED_S) * ncol + c]; a3 += (double)in[(int64_t)(t + 3 * RED_S) * ncol + c];
+    }
+    for (; t < T; t += RED_S) a0 += (double)in[(int64_t)t * ncol + c];
+    out[(int64_t)s * ncol + c] = (a0 + a1) + (a2 + a3);
+}
+
 // Batch statistics of one BatchNorm1d layer from the forward partials (float64 across workgroups), the folded coefficients for the
 // next layer's loader, and the running statistics (momentum 0.1, unbiased variance: torch.nn.BatchNorm1d in training mode).
-// grid 8 x block 256: thread (column c = 32 blockIdx + (tid & 31), slice tid >> 5 of the partial tiles)
+// one block of 256 threads (thread = column) over the RED_S float64 partial rows reduce_partials_kernel left
 // coef rows: 0 sc = gamma*rstd, 1 sh = beta - mean*sc, 2 mean, 3 rstd, 4 alpha, 5 beta', 6 gamma' (backward, bn_bwd_finalize)
-__global__ void bn_fwd_finalize_kernel(const float *__restrict__ part, int T, double N, const float *__restrict__ gamma, const float *__restrict__ beta,
-                                       float eps, float mom, float *__restrict__ rmean, float *__restrict__ rvar, float *__restrict__ coef) {
-    __shared__ double red[2][8][32];
-    const int c = threadIdx.x & 31, sl = threadIdx.x >> 5, j = 32 * blockIdx.x + c;
+__global__ void bn_fwd_finalize_kernel(const double *__restrict__ part /*[RED_S / 2][2][256]*/, double N, const float *__restrict__ gamma,
+                                       const float *__restrict__ beta, float eps, float mom, float *__restrict__ rmean, float *__restrict__ rvar,
+                                       float *__restrict__ coef) {
+    const int j = threadIdx.x;
     double a = 0.0, b = 0.0;
-    for (int t = sl; t < T; t += 8) { a += (double)part[((int64_t)t * 2 + 0) * W + j]; b += (double)part[((int64_t)t * 2 + 1) * W + j]; }
-    red[0][sl][c] = a; red[1][sl][c] = b;
-    __syncthreads();
-    if (sl) return;
-    a = b = 0.0;
-    for (int k = 0; k < 8; ++k) { a += red[0][k][c]; b += red[1][k][c]; }
+    for (int k = 0; k < RED_S / 2; ++k) { a += part[(k * 2 + 0) * W + j]; b += part[(k * 2 + 1) * W + j]; }
     const double mu = a / N, var = fmax(b / N - mu * mu, 0.0);
     const float rstd = (float)(1.0 / sqrt(var + (double)eps)), sc = gamma[j] * rstd;
     coef[0 * W + j] = sc;
@@ -298,17 +302,11 @@ __global__ void bn_eval_coef_kernel(const float *__restrict__ gamma, const float
 
 // BatchNorm backward per column from the partial sums (sum dZ, sum dZ*Y):  with xhat = (Y - mean)*rstd,
 //   dgamma = sum dZ*xhat, dbeta = sum dZ,  dY = sc*(dZ - mean(dZ) - xhat*mean(dZ*xhat)) = alpha*dZ + beta'*Y + gamma'
-__global__ void bn_bwd_finalize_kernel(const float *__restrict__ part, int T, double N, float *__restrict__ coef, float *__restrict__ dgamma,
-                                       float *__restrict__ dbeta) {
-    __shared__ double red[2][8][32];
-    const int c = threadIdx.x & 31, sl = threadIdx.x >> 5, j = 32 * blockIdx.x + c;
+__global__ void bn_bwd_finalize_kernel(const double *__restrict__ part /*[RED_S / 2][2][256]*/, double N, float *__restrict__ coef,
+                                       float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    const int j = threadIdx.x;
     double a = 0.0, b = 0.0;
-    for (int t = sl; t < T; t += 8) { a += (double)part[((int64_t)t * 2 + 0) * W + j]; b += (double)part[((int64_t)t * 2 + 1) * W + j]; }
-    red[0][sl][c] = a; red[1][sl][c] = b;
-    __syncthreads();
-    if (sl) return;
-    a = b = 0.0;
-    for (int k = 0; k < 8; ++k) { a += red[0][k][c]; b += red[1][k][c]; }
+    for (int k = 0; k < RED_S / 2; ++k) { a += part[(k * 2 + 0) * W + j]; b += part[(k * 2 + 1) * W + j]; }
     const double sc = coef[0 * W + j], mu = coef[2 * W + j], rstd = coef[3 * W + j];
     const double sxh = rstd * (b - mu * a);                 // sum dZ*xhat
     const double c1 = a / N, c2 = sxh / N;
@@ -381,12 +379,12 @@ __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ Y, 
 }
 
 // sums the head partials: gWout [3][256], gbout [3], loss (mean squared error)
-__global__ void head_finalize_kernel(const float *__restrict__ hpart, int T, double N, float *__restrict__ gW, float *__restrict__ gb,
+__global__ void head_finalize_kernel(const double *__restrict__ part /*[RED_S][3*256 + 4]*/, double N, float *__restrict__ gW, float *__restrict__ gb,
                                      float *__restrict__ loss) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= 3 * W + 4) return;
     double a = 0.0;
-    for (int t = 0; t < T; ++t) a += (double)hpart[(int64_t)t * (3 * W + 4) + e];
+    for (int k = 0; k < RED_S; ++k) a += part[k * (3 * W + 4) + e];
     if (e < 3 * W) gW[e] = (float)a;
     else if (e < 3 * W + 3) gb[e - 3 * W] = (float)a;
     else *loss = (float)(a / (3.0 * N));
@@ -396,8 +394,14 @@ __global__ void head_finalize_kernel(const float *__restrict__ hpart, int T, dou
 __global__ void wgrad_reduce_kernel(const float *__restrict__ part, int splits, int64_t stride, int I, float *__restrict__ gW, float *__restrict__ gb) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (I + 1) * W) return;
-    float a = 0.f;
-    for (int s = 0; s < splits; ++s) a += part[(int64_t)s * stride + e];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int s = 0;
+    for (; s + 3 < splits; s += 4) {
+        a0 += part[(int64_t)s * stride + e]; a1 += part[(int64_t)(s + 1) * stride + e];
+        a2 += part[(int64_t)(s + 2) * stride + e]; a3 += part[(int64_t)(s + 3) * stride + e];
+    }
+    for (; s < splits; ++s) a0 += part[(int64_t)s * stride + e];
+    const float a = (a0 + a1) + (a2 + a3);
     const int k = e / W, m = e - k * W;
     if (k < I) gW[(int64_t)m * I + k] = a;
     else gb[m] = a;
@@ -474,6 +478,7 @@ struct DgdmTrainer2d {
     Lin lin[14];
     size_t bn_g[8], bn_b[8], out_w = 0, out_b = 0, n_params = 0, n_wt = 0;
     DevBuf P, G, M, V, WT, bn_run /* [8][2][256] running mean, var */, coef /* [8][7][256] */, tfreq, trdesc, loss_dev;
+    DevBuf red /* [RED_S][3*256 + 4] float64 */, unit /* [256] ones, [256] zeros: coefficients of a ReLU without BatchNorm */;
     DevBuf ws;
     int64_t ws_rows = 0;
     // workspace pointers (set by reserve)
@@ -487,6 +492,7 @@ struct DgdmTrainer2d {
     int col_of(int l, int c) const;      // internal column c of layer l -> column of the reference's weight, or -1 (padding)
     int reserve(int64_t N);
     int gemm(bool ptrans, int epi, GemmArgs &g, hipStream_t s) const;
+    int reduce(const float *part, int T, int ncol, hipStream_t s) const;
     int wgrad(int l, const Operand &a, const Operand &dy, int64_t N, hipStream_t s);
     int run(const float *ctrl, const float *noise, const float *sa, const float *sb, const float *t, const float *ori, const float *pos,
             const float *obj, const float *score, int64_t N, float lr, int train, float *pred, float *loss_host, hipStream_t s);
@@ -533,10 +539,32 @@ int DgdmTrainer2d::gemm(bool ptrans, int epi, GemmArgs &g, hipStream_t s) const 
     const int jt = (g.J + TJ - 1) / TJ;
     const int64_t splits = (g.R + g.r_per_split - 1) / g.r_per_split;
     const dim3 grid((unsigned)it, (unsigned)jt, (unsigned)splits), block(256);
-    if (epi == EPI_FWD) hipLaunchKernelGGL((tgemm_kernel<true, EPI_FWD>), grid, block, 0, s, g);
-    else if (epi == EPI_BWD) hipLaunchKernelGGL((tgemm_kernel<true, EPI_BWD>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((tgemm_kernel<false, EPI_WGRAD>), grid, block, 0, s, g);
-    (void)ptrans;
+    const int key = epi * 1000 + g.P.xf * 100 + g.Q.xf * 10 + g.mask;
+    DGDM_REQUIRE(!ptrans || g.R <= 256 || g.P.xf == X_PLAIN, DGDM_EINVAL, "train2d gemm: transposed operand with coefficients wider than 256");
+#define DGDM_TG(PT, E, PXV, QXV, MK) hipLaunchKernelGGL((tgemm_kernel<PT, E, PXV, QXV, MK>), grid, block, 0, s, g)
+    switch (key) {
+    case EPI_FWD * 1000 + X_PLAIN * 100: DGDM_TG(true, EPI_FWD, X_PLAIN, X_PLAIN, MASK_NONE); break;
+    case EPI_FWD * 1000 + X_RELU * 100: DGDM_TG(true, EPI_FWD, X_RELU, X_PLAIN, MASK_NONE); break;
+    case EPI_FWD * 1000 + X_SILU * 100: DGDM_TG(true, EPI_FWD, X_SILU, X_PLAIN, MASK_NONE); break;
+    case EPI_BWD * 1000 + X_AFF2 * 100 + MASK_RELU_BN: DGDM_TG(true, EPI_BWD, X_AFF2, X_PLAIN, MASK_RELU_BN); break;
+    case EPI_BWD * 1000 + X_AFF2 * 100 + MASK_NONE: DGDM_TG(true, EPI_BWD, X_AFF2, X_PLAIN, MASK_NONE); break;
+    case EPI_BWD * 1000 + X_PLAIN * 100 + MASK_RELU: DGDM_TG(true, EPI_BWD, X_PLAIN, X_PLAIN, MASK_RELU); break;
+    case EPI_BWD * 1000 + X_PLAIN * 100 + MASK_SILU: DGDM_TG(true, EPI_BWD, X_PLAIN, X_PLAIN, MASK_SILU); break;
+    case EPI_WGRAD * 1000 + X_RELU * 100 + X_AFF2 * 10: DGDM_TG(false, EPI_WGRAD, X_RELU, X_AFF2, MASK_NONE); break;
+    case EPI_WGRAD * 1000 + X_PLAIN * 100 + X_AFF2 * 10: DGDM_TG(false, EPI_WGRAD, X_PLAIN, X_AFF2, MASK_NONE); break;
+    case EPI_WGRAD * 1000 + X_RELU * 100 + X_PLAIN * 10: DGDM_TG(false, EPI_WGRAD, X_RELU, X_PLAIN, MASK_NONE); break;
+    case EPI_WGRAD * 1000 + X_SILU * 100 + X_PLAIN * 10: DGDM_TG(false, EPI_WGRAD, X_SILU, X_PLAIN, MASK_NONE); break;
+    case EPI_WGRAD * 1000 + X_PLAIN * 100 + X_PLAIN * 10: DGDM_TG(false, EPI_WGRAD, X_PLAIN, X_PLAIN, MASK_NONE); break;
+    default: DGDM_REQUIRE(false, DGDM_EINVAL, "train2d gemm: no kernel for epilogue %d, operands %d/%d, mask %d", epi, g.P.xf, g.Q.xf, g.mask);
+    }
+#undef DGDM_TG
+    DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
+}
+
+// column sums of `T` per-workgroup partial rows of `ncol` floats into the RED_S float64 rows the finalize kernels read
+int DgdmTrainer2d::reduce(const float *part, int T, int ncol, hipStream_t s) const {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((ncol + 255) / 256, RED_S), dim3(256), 0, s, part, T, ncol, red.as<double>());
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
 }
@@ -570,8 +598,13 @@ int DgdmTrainer2d::run(const float *ctrl, const float *noise, const float *sa, c
         DGDM_HIP_CHECK(hipGetLastError());
         if ((rc = time_embed(t, 0.f, tfreq.as<float>(), bufT, (int)N, 64, s))) return rc;
     }
-    auto plain = [](const float *p, int64_t ld) { Operand o{}; o.t0 = p; o.ld = ld; o.xf = XF_PLAIN; return o; };
-    auto act = [](const float *p, int64_t ld, int a, const float *c0, const float *c2) { Operand o{}; o.t0 = p; o.ld = ld; o.xf = XF_ACT; o.act = a; o.c0 = c0; o.c2 = c2; return o; };
+    const float *ones = unit.as<float>(), *zeros = unit.as<float>() + 256;
+    auto plain = [](const float *p, int64_t ld) { Operand o{}; o.t0 = p; o.ld = ld; o.xf = X_PLAIN; return o; };
+    auto act = [&](const float *p, int64_t ld, int a, const float *c0, const float *c2) {
+        Operand o{};
+        o.t0 = p; o.ld = ld; o.xf = a == ACT_SILU ? X_SILU : X_RELU; o.c0 = c0 ? c0 : ones; o.c2 = c2 ? c2 : zeros;
+        return o;
+    };
     auto weight_t = [&](int l) { return plain(WT.as<float>() + lin[l].wt, 256); };
     auto forward = [&](int l, const Operand &in, float *out, int64_t ldo, float *st) {
         GemmArgs g{};
@@ -597,23 +630,26 @@ int DgdmTrainer2d::run(const float *ctrl, const float *noise, const float *sa, c
         const Operand in = k == 0 ? plain(X0, 800) : act(Y[k - 1], 256, ACT_RELU, cf(k - 1, 0), cf(k - 1, 1));
         if ((rc = forward(6 + k, in, Y[k], 256, train ? stats : nullptr))) return rc;
         if (train) {
-            hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(8), dim3(256), 0, s, stats, T, (double)N, p(bn_g[k]), p(bn_b[k]), 1e-5f, 0.1f,
+            if ((rc = reduce(stats, 2 * T, 256, s))) return rc;      // partial tile t = rows 2t (sum y), 2t + 1 (sum y^2): even / odd rows stay apart (RED_S is even)
+            hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(1), dim3(256), 0, s, red.as<double>(), (double)N, p(bn_g[k]), p(bn_b[k]), 1e-5f, 0.1f,
                                rm + (size_t)k * 512, rm + (size_t)k * 512 + 256, cf(k, 0));
             DGDM_HIP_CHECK(hipGetLastError());
         }
     }
     hipLaunchKernelGGL(head_kernel, dim3(TH), dim3(256), 0, s, Y[7], cf(7, 0), p(out_w), p(out_b), score, N, pred, D[0], stats, hpart, train);
     DGDM_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(head_finalize_kernel, dim3(4), dim3(256), 0, s, hpart, TH, (double)N, gr(out_w), gr(out_b), loss_dev.as<float>());
+    if ((rc = reduce(hpart, TH, 3 * 256 + 4, s))) return rc;
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(4), dim3(256), 0, s, red.as<double>(), (double)N, gr(out_w), gr(out_b), loss_dev.as<float>());
     DGDM_HIP_CHECK(hipGetLastError());
     if (train) {
         int nstat = TH;      // number of partial tiles `stats` holds for the layer about to be finalised
         for (int k = 7; k >= 0; --k) {
-            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(8), dim3(256), 0, s, stats, nstat, (double)N, cf(k, 0), gr(bn_g[k]), gr(bn_b[k]));
+            if ((rc = reduce(stats, 2 * nstat, 256, s))) return rc;
+            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, s, red.as<double>(), (double)N, cf(k, 0), gr(bn_g[k]), gr(bn_b[k]));
             DGDM_HIP_CHECK(hipGetLastError());
             float *dz = D[(7 - k) & 1], *dnext = D[(8 - k) & 1];
             Operand dy{};
-            dy.t0 = dz; dy.t1 = Y[k]; dy.ld = 256; dy.xf = XF_AFFINE2; dy.c0 = cf(k, 4); dy.c1 = cf(k, 5); dy.c2 = cf(k, 6);
+            dy.t0 = dz; dy.t1 = Y[k]; dy.ld = 256; dy.xf = X_AFF2; dy.c0 = cf(k, 4); dy.c1 = cf(k, 5); dy.c2 = cf(k, 6);
             const Operand a = k == 0 ? plain(X0, 800) : act(Y[k - 1], 256, ACT_RELU, cf(k - 1, 0), cf(k - 1, 1));
             if ((rc = wgrad(6 + k, a, dy, N, s))) return rc;
             GemmArgs g{};
@@ -737,6 +773,12 @@ extern "C" int dgdm_trainer2d_create(DgdmTrainer2d **out, const DgdmTensor *stat
     if ((rc = m->coef.alloc(8 * 7 * 256 * sizeof(float)))) return rc;
     DGDM_HIP_CHECK(hipMemset(m->coef.p, 0, 8 * 7 * 256 * sizeof(float)));
     if ((rc = m->loss_dev.alloc(64))) return rc;
+    if ((rc = m->red.alloc((size_t)RED_S * (3 * 256 + 4) * sizeof(double)))) return rc;
+    {
+        std::vector<float> u(512, 0.f);
+        std::fill(u.begin(), u.begin() + 256, 1.f);
+        if ((rc = m->unit.upload(u.data(), u.size() * sizeof(float)))) return rc;
+    }
     const std::vector<float> f = train_tfreqs(64);
     if ((rc = m->tfreq.upload(f.data(), f.size() * sizeof(float)))) return rc;
     if ((rc = m->trdesc.upload(td.data(), td.size() * sizeof(TrDesc)))) return rc;
