@@ -56,6 +56,7 @@ def parse():
                    help="arithmetic of the dynamics-trunk contractions: f32 (the parity path, default) or bf16 operands with f32 accumulation")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true", help="skip the secondary workload summary")
+    p.add_argument("--train-only", action="store_true", help="print only the Trainer.step leg of the secondary summary (1 GPU)")
     p.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                    help="collective backend for N > 1: nccl (= RCCL, one GPU per rank; the measured configuration) or gloo (launcher / sharding "
                         "test on a box with fewer GPUs than ranks: ranks share the GPUs round-robin and the final gather goes through host memory)")
@@ -379,6 +380,71 @@ def sweep_leg(dev):
             "dtype": "f32", "samples": n, **out}
 
 
+def train_leg(dev, with_cpu=True):
+    """Trainer.step of the 2-D dynamics model (dynamics/trainer.py:53-103, configuration of
+    dynamics/train_dynamics_2d.sh: batch_size 128, ctrlpts_dim 14, 100-vertex objects, T = 15) on one batch of 128 samples x the 9000
+    pose cells of the 2-D grid = 1 152 000 rows.  Timed: the C-ABI step (forward with batch statistics, loss, backward, Adam) on
+    device-resident inputs, HIP events on the launch stream; the reference's CPU-generator draws (16 M normals per step) are host
+    work outside it and reported beside it.  FLOPs = 2 x rows x weights for the forward, twice that for the backward (no input
+    gradient below the three first layers)."""
+    import argparse
+    import ctypes as C
+    from dgdm_amd._lib import check, dptr, lib, stream_ptr
+    from dgdm_amd.dynamics.trainer import Trainer
+    L, nv, T, rows = 14, 100, 15, 128 * 9000
+    args = argparse.Namespace(use_sub_batch=False, sub_bs=1024, grid_size=360, learning_rate=1e-4, weight_decay=0.0, num_epochs=100,
+                              checkpoint_path=None, fingers_3d=False, ctrlpts_dim=L, object_max_num_vertices=nv, num_timesteps_per_batch=1,
+                              num_inference_steps=5, num_train_timesteps=T)
+    sd = synth.synth_state_dict(synth.dyn2d_spec(L, 2 * nv), 41)
+    import contextlib, io
+    tr = Trainer(args)
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr.create_model(state_dict=sd)
+    g = torch.Generator().manual_seed(3)
+    data = [torch.rand(shape, generator=g) * 2 - 1 for shape in ((rows, L), (rows, 3), (rows, 1), (rows, 2), (rows, 2 * nv))]
+    data = [d.to(dev) for d in data]
+    t0 = time.perf_counter()
+    inp = tr._inputs(*data)
+    torch.cuda.synchronize()
+    host_s = time.perf_counter() - t0
+    c, nz, sa, sb, tt, o, p, ob, sc, _ = inp
+    pred = torch.empty((rows, 3), device=dev)
+    loss = C.c_float()
+
+    def step():
+        check(lib().dgdm_trainer2d_step(tr._h, dptr(c), dptr(nz), dptr(sa), dptr(sb), dptr(tt), dptr(o), dptr(p), dptr(ob), dptr(sc), rows, 1e-4, 1,
+                                        dptr(pred), C.byref(loss), stream_ptr()))
+    step()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    n = 3
+    ev[0].record()
+    for _ in range(n):
+        step()
+    ev[1].record()
+    torch.cuda.synchronize()
+    secs = ev[0].elapsed_time(ev[1]) / 1e3 / n
+    K = [L, 256, 2 * nv, 256, 128, 256, 795] + [256] * 7
+    flops = rows * (3 * 2 * 256 * sum(K) - 2 * 256 * (L + 2 * nv + 128 + 27) + 3 * 2 * 3 * 256)
+    out = {"workload": "train2d (Trainer.step, dynamics/train_dynamics_2d.sh: 128 samples x 9000 pose cells = 1152000 rows, L=14, 100-vertex objects, T=15)",
+           "dtype": "f32", "rows_per_s": rows / secs, "ms_per_step": secs * 1e3, "loss": float(loss.value),
+           "host_draws_and_uploads_ms": host_s * 1e3,
+           "roofline": {"bound": "mfma", "achieved": flops / secs / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flops / secs / 157.3e12,
+                        "traffic": None, "flops_per_step": flops, "note": "whole step (39 GEMM launches + reductions + Adam), float32 MFMA peak"}}
+    del tr, data, inp, c, nz, sa, sb, tt, o, p, ob, sc, pred
+    torch.cuda.empty_cache()
+    if with_cpu:
+        from oracle import dgdm_oracle as orc
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))
+        rs = 128 * 36
+        g = torch.Generator().manual_seed(4)
+        small = [torch.rand(shape, generator=g) * 2 - 1 for shape in ((rs, L), (rs, 3), (rs, 1), (rs, 2), (rs, 2 * nv))]
+        ot = orc.Trainer2D(sd, T, 1e-4)
+        t_c, runs = _median3(lambda: ot.step(*small))
+        out["cpu_baseline"] = {"value": rs / t_c, "unit": "rows/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"median of 3 Trainer2D.step (torch CPU autograd) on {rs} rows (128 samples x 36 pose cells)", "runs_s": runs}
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------------- main
 def workload_text(kind, pairs):
     if kind == "3d_ensemble":
@@ -416,6 +482,9 @@ def main():
     _lib.device_init(local)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if a.train_only:
+        print(json.dumps(train_leg(dev, not a.no_cpu_baseline)))
+        return
     pairs = a.pairs or DEFAULT_PAIRS[a.workload]
     wl = Workload(a.workload, pairs, dev, rank, world, a.contraction)
 
@@ -451,7 +520,7 @@ def main():
         del wl
         torch.cuda.empty_cache()
         # the other BASELINE configurations (not the headline: `value` above is what the driver reads)
-        extras = [config0(dev), sweep_leg(dev)]
+        extras = [config0(dev), sweep_leg(dev), train_leg(dev, not a.no_cpu_baseline)]
         for kind, contraction in ((other, "f32"), ("3d", "bf16"), ("2d", "bf16"), ("3d_ensemble", "bf16")):
             w2 = Workload(kind, DEFAULT_PAIRS[kind], dev, rank, world, contraction)
             s2, _ = timed_loop(w2, 2, 1, None)

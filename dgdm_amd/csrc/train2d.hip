@@ -33,7 +33,10 @@
 namespace dgdm {
 namespace {
 
-constexpr int TI = 128, TJ = 256, RC = 16, W = 256;
+#ifndef DGDM_TRAIN_RC
+#define DGDM_TRAIN_RC 16
+#endif
+constexpr int TI = 128, TJ = 256, RC = DGDM_TRAIN_RC, PU = RC / 8, QU = RC / 4, W = 256;      // RC = contraction depth of one LDS chunk
 enum { EPI_FWD = 0, EPI_BWD = 1, EPI_WGRAD = 2 };
 enum { MASK_NONE = 0, MASK_RELU = 1, MASK_SILU = 2, MASK_RELU_BN = 3 };
 
@@ -117,18 +120,18 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const GemmArgs g) {
     float4 pc0 = zero4, pc1 = zero4, pc2 = zero4, qc0 = zero4, qc1 = zero4, qc2 = zero4;
     if (!PTRANS && PC) { const int64_t c = pval ? pcol : 0; pc0 = ld4(g.P.c0 + c); pc2 = ld4(g.P.c2 + c); if (PX == X_AFF2) pc1 = ld4(g.P.c1 + c); }
     if (QC) { qc0 = ld4(g.Q.c0 + qbase); qc2 = ld4(g.Q.c2 + qbase); if (QX == X_AFF2) qc1 = ld4(g.Q.c1 + qbase); }
-    float4 pa[2], pb[2], qa[4], qb[4];
+    float4 pa[PU], pb[PU], qa[QU], qb[QU];
     float4 qsum = zero4;
 
     auto issue = [&](int64_t r) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < PU; ++u) {
             const int64_t o = PTRANS ? pbase + r + 4 * (prq + 2 * u) : min(r + prr + 8 * u, rend - 1) * g.P.ld + pbase;
             pa[u] = ld4(g.P.t0 + o);
             if (PX == X_AFF2) pb[u] = ld4(g.P.t1 + o);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < QU; ++u) {
             const int64_t o = min(r + qrr + 4 * u, rend - 1) * g.Q.ld + qbase;
             qa[u] = ld4(g.Q.t0 + o);
             if (QX == X_AFF2) qb[u] = ld4(g.Q.t1 + o);
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const GemmArgs g) {
     };
     auto commit = [&](int64_t r) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < PU; ++u) {
             if (PTRANS) {
                 const int r4 = prq + 2 * u;
                 if (PC) { const int c = (int)r + 4 * r4; pc0 = ld4(&sC[0][c]); pc2 = ld4(&sC[2][c]); if (PX == X_AFF2) pc1 = ld4(&sC[1][c]); }
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const GemmArgs g) {
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < QU; ++u) {
             const float4 v = xf4<QX>(qa[u], qb[u], qc0, qc1, qc2, qval && r + qrr + 4 * u < rend);
             *reinterpret_cast<float4 *>(&sQ[qrr + 4 * u][4 * qx4]) = v;
             if (EPI == EPI_WGRAD) { qsum.x += v.x; qsum.y += v.y; qsum.z += v.z; qsum.w += v.w; }
@@ -208,35 +211,52 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const GemmArgs g) {
         return;
     }
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    int jc[4];
+    bool jv[4];
+    float bj[4], m0[4], m2[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int j = j0 + 128 * wj + 32 * u + n;
-        const bool jv = j < g.J;
-        const int jc = jv ? j : 0;
-        const float bj = EPI == EPI_FWD ? g.bias[jc] : 0.f;
-        const float m0 = MASK == MASK_RELU_BN ? g.m0[jc] : 1.f, m2 = MASK == MASK_RELU_BN ? g.m2[jc] : 0.f;
+        jv[u] = j < g.J;
+        jc[u] = jv[u] ? j : 0;
+        bj[u] = EPI == EPI_FWD ? g.bias[jc[u]] : 0.f;
+        m0[u] = MASK == MASK_RELU_BN ? g.m0[jc[u]] : 1.f;
+        m2[u] = MASK == MASK_RELU_BN ? g.m2[jc[u]] : 0.f;
+    }
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < 2; ++s) {
+        // one half of the wave's rows at a time: its 64 loads of the layer below are issued together (clamped addresses), then consumed
+        float y[16][4];
+        if (EPI == EPI_BWD && MASK != MASK_NONE) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const int64_t i = i0 + 64 * wi + 32 * s + (q & 3) + 8 * (q >> 2) + 4 * h;
-                if (!(jv && i < g.I)) continue;
+                const int64_t i = min(i0 + 64 * wi + 32 * s + (q & 3) + 8 * (q >> 2) + 4 * h, g.I - 1);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) y[q][u] = g.Yp[i * g.ldy + jc[u]];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int64_t i = i0 + 64 * wi + 32 * s + (q & 3) + 8 * (q >> 2) + 4 * h;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!(jv[u] && i < g.I)) continue;
                 if (EPI == EPI_FWD) {
-                    const float v = acc[s][u][q] + bj;
-                    g.C[i * g.ldc + j] = v;
+                    const float v = acc[s][u][q] + bj[u];
+                    g.C[i * g.ldc + jc[u]] = v;
                     s1[u] += v;
                     s2[u] = fmaf(v, v, s2[u]);
                 } else {
                     float v = acc[s][u][q];
-                    if (MASK != MASK_NONE) {
-                        const float y = g.Yp[i * g.ldy + j];
-                        if (MASK == MASK_RELU) v = y > 0.f ? v : 0.f;
-                        else if (MASK == MASK_SILU) v *= silu_grad(y);
-                        else { v = bn_pre(m0, y, m2) > 0.f ? v : 0.f; s1[u] += v; s2[u] = fmaf(v, y, s2[u]); }
-                    }
-                    g.C[i * g.ldc + j] = v;
+                    if (MASK == MASK_RELU) v = y[q][u] > 0.f ? v : 0.f;
+                    else if (MASK == MASK_SILU) v *= silu_grad(y[q][u]);
+                    else if (MASK == MASK_RELU_BN) { v = bn_pre(m0[u], y[q][u], m2[u]) > 0.f ? v : 0.f; s1[u] += v; s2[u] = fmaf(v, y[q][u], s2[u]); }
+                    g.C[i * g.ldc + jc[u]] = v;
                 }
             }
+        }
+        if (EPI == EPI_BWD && MASK != MASK_NONE) __builtin_amdgcn_sched_barrier(0);
     }
     if (g.stats) {       // per-workgroup column sums: both half-waves, then the two waves stacked along i
         __syncthreads();
