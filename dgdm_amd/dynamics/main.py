@@ -1,0 +1,111 @@
+"""Training driver of the 2-D dynamics model (reference: dynamics/main.py:17-208, ``python dynamics/main.py <flags of
+dynamics/train_dynamics_2d.sh>``): datasets, the epoch loop around ``Trainer.step``, validation with ``Trainer.inference``,
+three-class accuracies, checkpoints (periodic and best), cosine schedule, early stopping.  The compute is ``Trainer`` (HIP);
+this file is host glue.  wandb is optional: without it the same scalars go to ``<save_dir>/log.jsonl``."""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import torch
+from torch.utils.data import DataLoader
+
+from .dataloader import DynamicsDataset
+from .parser import parse
+from .trainer import Trainer
+
+
+def batch_rows(batch):
+    """A DataLoader batch [samples, cells, ...] -> the row tensors Trainer.step takes (main.py:25-35, 2-D branch): every sample's
+    control ordinates and object vertices repeated over its pose cells."""
+    score = batch['scores']
+    cells = score.size(1)
+    ori, pos = batch['input_ori'].reshape(-1, 1), batch['input_pos'].reshape(-1, 2)
+    ctrl = batch['ctrlpts'][..., 1].repeat(1, cells).reshape(ori.shape[0], -1)        # y ordinates only (:33)
+    obj = batch['object_vertices'].repeat(1, cells, 1).reshape(ori.shape[0], -1)
+    return ctrl, score.reshape(-1, 3), ori, pos, obj
+
+
+def class_accuracy(score: torch.Tensor, pred: torch.Tensor, threshold_std) -> list:
+    """Share of rows whose three-way class (below -threshold / between / above threshold) agrees, per output (main.py:37-39)."""
+    t = torch.as_tensor(threshold_std, dtype=torch.float32, device=score.device)
+    cls = lambda v: (v > t).long() - (v < -t).long()                                    # noqa: E731
+    return (cls(score) == cls(pred.to(score.device))).float().mean(dim=0).tolist()
+
+
+class _Log:
+    def __init__(self, args):
+        self.path = os.path.join(args.save_dir, 'log.jsonl')
+        self.wandb = None
+        if getattr(args, 'wandb_id', None):
+            try:
+                import wandb
+                wandb.init(project='dynamics model', config=vars(args), dir=args.save_dir, name=args.wandb_id)
+                self.wandb = wandb
+            except ImportError:
+                pass
+
+    def log(self, scalars):
+        if self.wandb is not None:
+            self.wandb.log(scalars)
+        with open(self.path, 'a') as f:
+            f.write(json.dumps(scalars) + '\n')
+
+
+def validate(args, val_loader, trainer, threshold_std):
+    n, loss_sum, acc_sum = 0, 0.0, [0.0, 0.0, 0.0]
+    for batch in val_loader:
+        ctrl, score, ori, pos, obj = batch_rows(batch)
+        pred, loss = trainer.inference(ctrl, score, ori, pos, obj)
+        acc = class_accuracy(score, pred.cpu(), threshold_std)
+        loss_sum, acc_sum, n = loss_sum + loss, [a + b for a, b in zip(acc_sum, acc)], n + 1
+    n = max(n, 1)
+    return (loss_sum / n, *[a / n for a in acc_sum])
+
+
+def train(args):
+    os.makedirs(args.save_dir, exist_ok=True)
+    kw = dict(object_max_num_vertices=args.object_max_num_vertices, fingers_3d=args.fingers_3d)
+    train_set, val_set = DynamicsDataset(args.data_dir, **kw), DynamicsDataset(args.test_data_dir, **kw)
+    threshold_std = train_set.threshold / train_set.std
+    train_loader = DataLoader(train_set, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers, drop_last=False)
+    val_loader = DataLoader(val_set, batch_size=args.batch_size, shuffle=False, num_workers=args.num_workers, drop_last=False)
+    trainer = Trainer(args)
+    trainer.create_model()
+    if args.mode == 'validate':
+        if args.checkpoint_path is None:
+            raise ValueError('checkpoint path is not specified')
+        return validate(args, val_loader, trainer, threshold_std)
+    log = _Log(args)
+    best, last_best = float('inf'), 0
+    for epoch in range(args.num_epochs):
+        loss_sum, acc_sum = 0.0, [0.0, 0.0, 0.0]
+        for i, batch in enumerate(train_loader):
+            ctrl, score, ori, pos, obj = batch_rows(batch)
+            loss, pred = trainer.step(ctrl, score, ori, pos, obj)
+            acc = class_accuracy(score, pred.cpu(), threshold_std)
+            loss_sum, acc_sum = loss_sum + loss, [a + b for a, b in zip(acc_sum, acc)]
+            log.log({'train/lr': trainer.optimizer.param_groups[0]['lr'], 'train/batch loss': loss, 'train/batch accuracy ori': acc[0],
+                     'train/batch accuracy x': acc[1], 'train/batch accuracy y': acc[2]})
+            if i % args.save_ckpt_step == 0:
+                trainer.save_checkpoint(os.path.join(args.save_dir, '%d_%d.pt' % (epoch, i)))
+        trainer.lr_scheduler.step()
+        nb = max(len(train_loader), 1)
+        print('epoch:', epoch, 'loss:', loss_sum / nb, 'accuracy (ori, x, y):', [a / nb for a in acc_sum])
+        log.log({'train/average loss': loss_sum / nb, 'train/average accuracy ori': acc_sum[0] / nb, 'train/average accuracy x': acc_sum[1] / nb,
+                 'train/average accuracy y': acc_sum[2] / nb})
+        if epoch % args.val_step == 0:
+            v = validate(args, val_loader, trainer, threshold_std)
+            log.log({'val/average loss': v[0], 'val/average accuracy ori': v[1], 'val/average accuracy x': v[2], 'val/average accuracy y': v[3]})
+            if v[0] < best:
+                best, last_best = v[0], epoch
+                trainer.save_checkpoint(os.path.join(args.save_dir, 'best.pt'))
+            elif epoch - last_best >= args.patience:
+                print('early stopping...')
+                break
+    return trainer
+
+
+if __name__ == '__main__':
+    train(parse(sys.argv[1:]))

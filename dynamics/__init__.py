@@ -1,9 +1,9 @@
 """Import-path shim: ``dynamics.*`` of the reference maps onto ``dgdm_amd.dynamics.*``."""
 import sys as _sys
-from dgdm_amd.dynamics import metrics, parser, profile_forward_2d, profile_forward_3d, trainer  # noqa: F401
+from dgdm_amd.dynamics import dataloader, metrics, parser, profile_forward_2d, profile_forward_3d, trainer  # noqa: F401
 from dgdm_amd.dynamics import models  # noqa: F401
 from dgdm_amd.dynamics.models import pointnet2, pointnet2_utils  # noqa: F401
-for _n in ("metrics", "parser", "profile_forward_2d", "profile_forward_3d", "trainer", "models"):
+for _n in ("dataloader", "metrics", "parser", "profile_forward_2d", "profile_forward_3d", "trainer", "models"):
     _sys.modules[__name__ + "." + _n] = getattr(_sys.modules[__name__], _n)
 _sys.modules[__name__ + ".models.pointnet2"] = pointnet2
 _sys.modules[__name__ + ".models.pointnet2_utils"] = pointnet2_utils

@@ -40,7 +40,7 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 from dgdm_amd import synth                      # noqa: E402
 from oracle import dgdm_oracle as orc           # noqa: E402  (only its DDIM restatement is used here)
 from tests.golden.make_golden_names import OBJ16     # noqa: E402
-from tests.util import train2d_data, sample_idx     # noqa: E402
+from tests.util import train2d_data, sample_idx, write_synth_dataset     # noqa: E402
 
 # From here on `generator` / `dynamics` must resolve to the REFERENCE (namespace packages under /root/reference), not to
 # this repository's import-path shims of the same names (regular packages win over namespace packages on sys.path).
@@ -908,12 +908,34 @@ def g10_train2d():
         torch.Tensor.cuda, nn.Module.cuda = saved
     np.savez_compressed(os.path.join(OUT, "g10_train2d.npz"), **out)
 
+
+
+def g11_dataset():
+    """The reference's own DynamicsDataset (dynamics/dataloader.py) on three synthetic 2-D files: every tensor of every item.
+    open3d (imported by dynamics/utils.py for the 3-D branch) is absent: an empty stand-in module for this function."""
+    import shutil
+    sys.modules.setdefault("open3d", types.ModuleType("open3d"))
+    from dynamics.dataloader import DynamicsDataset
+    root = "/tmp/dgdm_golden/ds"
+    shutil.rmtree(root, ignore_errors=True)
+    write_synth_dataset(root, 21)
+    ds = DynamicsDataset(dataset_dir=root, object_mesh_dir=None, fingers_3d=False, gripper_pts_max_x=0.12, gripper_pts_min_x=-0.12,
+                         gripper_pts_max_y=0.015, gripper_pts_min_y=-0.045, gripper_pts_max_z=0.12, gripper_pts_min_z=0.0,
+                         object_max_num_vertices=8, object_pts_max_x=0.05, object_pts_min_x=-0.05, object_pts_max_y=0.05,
+                         object_pts_min_y=-0.05, object_pts_max_z=0.12, object_pts_min_z=0.0)
+    ds.data_files = sorted(ds.data_files)
+    out = {"seed": np.int64(21), "n": np.int64(len(ds)), "threshold_std": ds.threshold / ds.std}
+    for i in range(len(ds)):
+        for k, v in ds[i].items():
+            out[f"{i}/{k}"] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "g11_dataset.npz"), **out)
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     os.makedirs("/tmp/dgdm_golden", exist_ok=True)
     only = sys.argv[1:]
     for name, fn in (("g2", g2_unet), ("g3", g3_dyn2d), ("g4", g4_pointnet), ("g5", g5_dyn3d), ("g6", g6_chains),
-                     ("g7", g7_convergence), ("g8", g8_harness), ("g9_2d", g9_2d), ("g9_3d", g9_3d), ("g9_f64", g9_f64), ("g9_tiles", g9_tiles), ("g10", g10_train2d)):
+                     ("g7", g7_convergence), ("g8", g8_harness), ("g9_2d", g9_2d), ("g9_3d", g9_3d), ("g9_f64", g9_f64), ("g9_tiles", g9_tiles), ("g10", g10_train2d), ("g11", g11_dataset)):
         if only and name not in [a.split(":")[0] for a in only]:
             continue
         sub = [a.split(":", 1)[1].split(",") for a in only if a.startswith(name + ":")]

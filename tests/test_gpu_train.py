@@ -155,3 +155,43 @@ def test_trainer2d_checkpoint_round_trip(dev, tmp_path):
     m.load_state_dict({k[len("module."):]: v for k, v in ck.items()})
     out = m.to(dev)(noisy.to(dev), data[2].to(dev), data[3].to(dev), (ts.float() / 15).to(dev), data[4].to(dev))
     assert util.rel_l2(out.cpu(), pred.cpu()) < 2e-5
+
+
+def test_training_driver_end_to_end(dev, tmp_path):
+    """`python dynamics/main.py <flags of train_dynamics_2d.sh>` on a synthetic dataset in the simulator's file format (scores a smooth
+    function of the inputs so there is something to learn): the validation loss falls, the log and the checkpoints appear, and
+    best.pt - DataParallel key layout - loads into the sampling path's model (generator/train.py:88-90)."""
+    import json
+    import subprocess
+    import sys
+    from dynamics.profile_forward_2d import ProfileForward2DModel
+    rs = np.random.RandomState(0)
+    for split, n in (("train", 12), ("val", 4)):
+        root = tmp_path / split
+        root.mkdir()
+        for i in range(n):
+            cells = 48
+            cy = rs.uniform(-0.045, 0.015, 14)
+            th, pos = rs.uniform(0, 2 * np.pi, cells), rs.uniform(-0.03, 0.03, (cells, 3))
+            d = {"ctrlpts": np.stack([np.linspace(-0.12, 0.12, 14), cy], 1), "obj_theta": th, "obj_pos": pos,
+                 "delta_theta": 0.05 * np.sin(th) * (1 + 10 * cy.mean()), "delta_pos": 0.1 * pos[:, :2] + 0.002 * np.cos(th)[:, None],
+                 "object_vertices": rs.uniform(-0.05, 0.05, (6, 2))}
+            np.savez(root / f"s{i}.npz", d)
+    save = tmp_path / "out"
+    cmd = [sys.executable, "dynamics/main.py", f"--save_dir={save}", "--ctrlpts_dim=14", "--batch_size=4", "--object_max_num_vertices=100",
+           f"--data_dir={tmp_path / 'train'}", f"--test_data_dir={tmp_path / 'val'}", "--learning_rate=1e-3", "--weight_decay=0", "--num_epochs=12",
+           "--val_step=1", "--save_ckpt_step=1000", "--patience=100", "--num_workers=0", "--num_train_timesteps=15", "--num_inference_steps=5",
+           "--num_timesteps_per_batch=1"]
+    r = subprocess.run(cmd, cwd=str(util.GOLDEN + "/../.."), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    logs = [json.loads(l) for l in open(save / "log.jsonl")]
+    val = [l["val/average loss"] for l in logs if "val/average loss" in l]
+    assert len(val) == 12 and min(val[-3:]) < 0.7 * val[0], val
+    assert (save / "best.pt").exists() and (save / "0_0.pt").exists()
+    ck = torch.load(save / "best.pt")
+    m = ProfileForward2DModel(params_ch=14, object_ch=200)
+    missing = m.load_state_dict({k[len("module."):]: v for k, v in ck.items()})
+    assert not missing.missing_keys and not missing.unexpected_keys
+    out = m.to(dev)(torch.zeros(4, 14, device=dev), torch.zeros(4, 1, device=dev), torch.zeros(4, 2, device=dev), torch.zeros(4, device=dev),
+                    torch.zeros(4, 200, device=dev))
+    assert out.shape == (4, 3) and bool(torch.isfinite(out).all())

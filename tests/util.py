@@ -95,3 +95,16 @@ def sample_idx(name, numel, k=96):
         return np.arange(numel)
     return np.sort(np.random.RandomState(zlib.crc32(name.encode()) & 0x7fffffff).choice(numel, k, replace=False))
 
+
+
+def write_synth_dataset(root, seed, n_files=3, cells=12, n_ctrl=14, n_verts=(5, 7, 4)):
+    """Synthetic dynamics-training files in the simulator's format (dynamics/dataloader.py:41-55 reads them): inputs only."""
+    rs = np.random.RandomState(seed)
+    os.makedirs(root, exist_ok=True)
+    for i in range(n_files):
+        d = {"ctrlpts": np.stack([np.linspace(-0.12, 0.12, n_ctrl), rs.uniform(-0.045, 0.015, n_ctrl)], 1),
+             "delta_theta": rs.normal(0, 0.05, cells), "delta_pos": rs.normal(0, 0.003, (cells, 2)),
+             "obj_theta": rs.uniform(0, 2 * np.pi, cells), "obj_pos": rs.uniform(-0.03, 0.03, (cells, 3)),
+             "object_vertices": rs.uniform(-0.05, 0.05, (n_verts[i % len(n_verts)], 2))}
+        np.savez(os.path.join(root, "sample_%02d.npz" % i), d)
+
