@@ -82,6 +82,10 @@ PROTOTYPES = {
     "dgdm_trainer2d_create": (C.c_int, [C.POINTER(_P), C.POINTER(Tensor), C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]),
     "dgdm_trainer2d_destroy": (None, [_P]),
     "dgdm_trainer2d_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_int, _P, C.POINTER(C.c_float), _P]),
+    "dgdm_trainer2d_forward_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, _P, C.POINTER(C.c_float), _P]),
+    "dgdm_trainer2d_gradient_count": (C.c_int64, [_P]),
+    "dgdm_trainer2d_gradients": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
+    "dgdm_trainer2d_apply": (C.c_int, [_P, C.c_float, _P]),
     "dgdm_trainer2d_export": (C.c_int, [_P, C.c_int, C.POINTER(Tensor), C.c_int]),
     "dgdm_trainer2d_steps": (C.c_int64, [_P]),
 }

@@ -346,12 +346,12 @@ constexpr int HEAD_ROWS = 64;
 __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ Y, const float *__restrict__ coef, const float *__restrict__ Wout,
                                                    const float *__restrict__ bout, const float *__restrict__ score, int64_t N, float *__restrict__ pred,
                                                    float *__restrict__ dZ, float *__restrict__ stats /*[T][2][256]*/,
-                                                   float *__restrict__ hpart /*[T][3*256 + 4]*/, int train) {
+                                                   float *__restrict__ hpart /*[T][3*256 + 4]*/, int train, double Ntot) {
     __shared__ __attribute__((aligned(16))) float red[4][5 * 256 + 4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = 4 * lane;
     const float4 sc = ld4(coef + c), sh = ld4(coef + W + c), w0 = ld4(Wout + c), w1 = ld4(Wout + W + c), w2 = ld4(Wout + 2 * W + c);
     const float b0 = bout[0], b1 = bout[1], b2 = bout[2];
-    const float inv = (float)(2.0 / (3.0 * (double)N));
+    const float inv = (float)(2.0 / (3.0 * Ntot));      // d mean((pred - score)^2) / d pred over ALL rows of the batch (every rank's)
     float4 sdz = make_float4(0, 0, 0, 0), sdzy = sdz, g0 = sdz, g1 = sdz, g2 = sdz;
     float db0 = 0.f, db1 = 0.f, db2 = 0.f, lsum = 0.f;
     const int64_t rb = (int64_t)blockIdx.x * HEAD_ROWS;
@@ -405,8 +405,8 @@ __global__ void head_finalize_kernel(const double *__restrict__ part /*[RED_S][3
     if (e >= 3 * W + 4) return;
     double a = 0.0;
     for (int k = 0; k < RED_S; ++k) a += part[k * (3 * W + 4) + e];
-    if (e < 3 * W) gW[e] = (float)a;
-    else if (e < 3 * W + 3) gb[e - 3 * W] = (float)a;
+    if (e < 3 * W) { if (gW) gW[e] = (float)a; }
+    else if (e < 3 * W + 3) { if (gb) gb[e - 3 * W] = (float)a; }
     else *loss = (float)(a / (3.0 * N));
 }
 
@@ -515,7 +515,8 @@ struct DgdmTrainer2d {
     int reduce(const float *part, int T, int ncol, hipStream_t s) const;
     int wgrad(int l, const Operand &a, const Operand &dy, int64_t N, hipStream_t s);
     int run(const float *ctrl, const float *noise, const float *sa, const float *sb, const float *t, const float *ori, const float *pos,
-            const float *obj, const float *score, int64_t N, float lr, int train, float *pred, float *loss_host, hipStream_t s);
+            const float *obj, const float *score, int64_t N, int64_t Ntot, float lr, int train, bool update, float *pred, float *loss_host, hipStream_t s);
+    int adam(float lr, hipStream_t s);
     int copy_state(int which, DgdmTensor *t, int n, bool to_device);
 };
 
@@ -607,8 +608,23 @@ int DgdmTrainer2d::wgrad(int l, const Operand &a, const Operand &dy, int64_t N, 
     return DGDM_OK;
 }
 
+// torch.optim.Adam(lr, betas, weight_decay) over every parameter (trainer.py:46), then the transposed weight copies
+int DgdmTrainer2d::adam(float lr, hipStream_t s) {
+    ++adam_steps;
+    const double bc1 = 1.0 - std::pow((double)beta1, (double)adam_steps), bc2 = 1.0 - std::pow((double)beta2, (double)adam_steps);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, s, P.as<float>(), G.as<float>(), M.as<float>(), V.as<float>(),
+                       (int64_t)n_params, beta1, beta2, eps, wd, (float)((double)lr / bc1), (float)std::sqrt(bc2));
+    DGDM_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(transpose_all_kernel, dim3((800 * 256 + 255) / 256, 14), dim3(256), 0, s, P.as<float>(), WT.as<float>(), trdesc.as<TrDesc>());
+    DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
+}
+
+// N = this call's rows (BatchNorm statistics are taken over them); Ntot = the rows of the whole batch the loss is a mean over
+// (= N for one process; the sum over the ranks for data-parallel training, dgdm_trainer2d_forward_backward)
 int DgdmTrainer2d::run(const float *ctrl, const float *noise, const float *sa, const float *sb, const float *t, const float *ori, const float *pos,
-                       const float *obj, const float *score, int64_t N, float lr, int train, float *pred, float *loss_host, hipStream_t s) {
+                       const float *obj, const float *score, int64_t N, int64_t Ntot, float lr, int train, bool update, float *pred, float *loss_host,
+                       hipStream_t s) {
     int rc = reserve(N);
     if (rc) return rc;
     const int T = (int)((N + TI - 1) / TI), TH = (int)((N + HEAD_ROWS - 1) / HEAD_ROWS);
@@ -656,10 +672,11 @@ int DgdmTrainer2d::run(const float *ctrl, const float *noise, const float *sa, c
             DGDM_HIP_CHECK(hipGetLastError());
         }
     }
-    hipLaunchKernelGGL(head_kernel, dim3(TH), dim3(256), 0, s, Y[7], cf(7, 0), p(out_w), p(out_b), score, N, pred, D[0], stats, hpart, train);
+    hipLaunchKernelGGL(head_kernel, dim3(TH), dim3(256), 0, s, Y[7], cf(7, 0), p(out_w), p(out_b), score, N, pred, D[0], stats, hpart, train, (double)Ntot);
     DGDM_HIP_CHECK(hipGetLastError());
     if ((rc = reduce(hpart, TH, 3 * 256 + 4, s))) return rc;
-    hipLaunchKernelGGL(head_finalize_kernel, dim3(4), dim3(256), 0, s, red.as<double>(), (double)N, gr(out_w), gr(out_b), loss_dev.as<float>());
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(4), dim3(256), 0, s, red.as<double>(), (double)Ntot, train ? gr(out_w) : nullptr, train ? gr(out_b) : nullptr,
+                       loss_dev.as<float>());      // eval mode leaves the gradient buffer alone
     DGDM_HIP_CHECK(hipGetLastError());
     if (train) {
         int nstat = TH;      // number of partial tiles `stats` holds for the layer about to be finalised
@@ -691,14 +708,7 @@ int DgdmTrainer2d::run(const float *ctrl, const float *noise, const float *sa, c
             if ((rc = gemm(true, EPI_BWD, g, s))) return rc;
             if ((rc = wgrad(2 * e, plain(enc_in[e], enc_ld[e]), plain(D[0], 256), N, s))) return rc;
         }
-        // torch.optim.Adam(lr, betas, weight_decay) over every parameter (trainer.py:46), then the transposed weight copies
-        ++adam_steps;
-        const double bc1 = 1.0 - std::pow((double)beta1, (double)adam_steps), bc2 = 1.0 - std::pow((double)beta2, (double)adam_steps);
-        hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, s, P.as<float>(), G.as<float>(), M.as<float>(), V.as<float>(),
-                           (int64_t)n_params, beta1, beta2, eps, wd, (float)((double)lr / bc1), (float)std::sqrt(bc2));
-        DGDM_HIP_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(transpose_all_kernel, dim3((800 * 256 + 255) / 256, 14), dim3(256), 0, s, P.as<float>(), WT.as<float>(), trdesc.as<TrDesc>());
-        DGDM_HIP_CHECK(hipGetLastError());
+        if (update && (rc = adam(lr, s))) return rc;
         ++bn_batches;
     }
     if (loss_host) {
@@ -816,8 +826,34 @@ extern "C" int dgdm_trainer2d_step(DgdmTrainer2d *m, const float *ctrl_dev, cons
     DGDM_REQUIRE(!noise_dev || (sqrt_abar_dev && sqrt_1m_abar_dev), DGDM_EINVAL, "dgdm_trainer2d_step: noise without its two scale vectors");
     DGDM_REQUIRE(rows >= 2 && rows < ((int64_t)1 << 31) / 800, DGDM_EINVAL,
                  "dgdm_trainer2d_step: %lld rows (BatchNorm1d in training mode needs at least 2; the workspace index math stops at 2^31/800)", (long long)rows);
-    return m->run(ctrl_dev, noise_dev, sqrt_abar_dev, sqrt_1m_abar_dev, t_dev, ori_dev, pos_dev, object_dev, score_dev, rows, lr, train, pred_dev,
-                  loss_host, (hipStream_t)stream);
+    return m->run(ctrl_dev, noise_dev, sqrt_abar_dev, sqrt_1m_abar_dev, t_dev, ori_dev, pos_dev, object_dev, score_dev, rows, rows, lr, train, true,
+                  pred_dev, loss_host, (hipStream_t)stream);
+}
+
+extern "C" int dgdm_trainer2d_forward_backward(DgdmTrainer2d *m, const float *ctrl_dev, const float *noise_dev, const float *sqrt_abar_dev,
+                                               const float *sqrt_1m_abar_dev, const float *t_dev, const float *ori_dev, const float *pos_dev,
+                                               const float *object_dev, const float *score_dev, int64_t rows, int64_t total_rows, float *pred_dev,
+                                               float *loss_host, void *stream) {
+    DGDM_REQUIRE(m && ctrl_dev && t_dev && ori_dev && pos_dev && object_dev && score_dev && pred_dev, DGDM_EINVAL, "dgdm_trainer2d_forward_backward: null argument");
+    DGDM_REQUIRE(!noise_dev || (sqrt_abar_dev && sqrt_1m_abar_dev), DGDM_EINVAL, "dgdm_trainer2d_forward_backward: noise without its two scale vectors");
+    DGDM_REQUIRE(rows >= 2 && rows <= total_rows && rows < ((int64_t)1 << 31) / 800, DGDM_EINVAL, "dgdm_trainer2d_forward_backward: %lld of %lld rows",
+                 (long long)rows, (long long)total_rows);
+    return m->run(ctrl_dev, noise_dev, sqrt_abar_dev, sqrt_1m_abar_dev, t_dev, ori_dev, pos_dev, object_dev, score_dev, rows, total_rows, 0.f, 1, false,
+                  pred_dev, loss_host, (hipStream_t)stream);
+}
+
+extern "C" int64_t dgdm_trainer2d_gradient_count(const DgdmTrainer2d *m) { return m ? (int64_t)m->n_params : -1; }
+
+extern "C" int dgdm_trainer2d_gradients(DgdmTrainer2d *m, float *flat_dev, int64_t numel, int to_trainer, void *stream) {
+    DGDM_REQUIRE(m && flat_dev && numel == (int64_t)m->n_params, DGDM_EINVAL, "dgdm_trainer2d_gradients: expected %lld values", m ? (long long)m->n_params : 0LL);
+    DGDM_HIP_CHECK(hipMemcpyAsync(to_trainer ? m->G.p : (void *)flat_dev, to_trainer ? (const void *)flat_dev : m->G.p, (size_t)numel * sizeof(float),
+                                  hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return DGDM_OK;
+}
+
+extern "C" int dgdm_trainer2d_apply(DgdmTrainer2d *m, float lr, void *stream) {
+    DGDM_REQUIRE(m, DGDM_EINVAL, "dgdm_trainer2d_apply: null handle");
+    return m->adam(lr, (hipStream_t)stream);
 }
 
 extern "C" int dgdm_trainer2d_export(DgdmTrainer2d *m, int which, DgdmTensor *tensors, int n_tensors) {

@@ -195,3 +195,28 @@ def guided_multi_object_sharded(unet, spec: GuidanceSpec, sched, mode: str, nois
         if on_step is not None:
             on_step(i, x.reshape(B, L, 1))
     return x.reshape(B, L, 1)
+
+
+def all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
+    """Sum over the ranks (gradients of data-parallel training): RCCL on the device tensor; through host memory under gloo."""
+    if world_rank(group)[0] == 1:
+        return t
+    if t.is_cuda and dist.get_backend(group) != "nccl":
+        h = t.cpu()
+        dist.all_reduce(h, group=group)
+        return h.to(t.device)
+    dist.all_reduce(t, group=group)
+    return t
+
+
+def all_gather_rows(t: torch.Tensor, group=None) -> torch.Tensor:
+    """[n, ...] of equal shape on every rank -> [world, n, ...] on every rank."""
+    world, _ = world_rank(group)
+    if world == 1:
+        return t[None]
+    via_host = t.is_cuda and dist.get_backend(group) != "nccl"
+    src = t.cpu() if via_host else t.contiguous()
+    bufs = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(bufs, src, group=group)
+    out = torch.stack(bufs)
+    return out.to(t.device) if via_host else out

@@ -11,6 +11,8 @@ import sys
 import torch
 from torch.utils.data import DataLoader
 
+from .. import _lib
+from .. import dist as _dist
 from .dataloader import DynamicsDataset
 from .parser import parse
 from .trainer import Trainer
@@ -65,6 +67,11 @@ def validate(args, val_loader, trainer, threshold_std):
 
 
 def train(args):
+    # under a launcher (torchrun --nproc-per-node N): one rank per GPU, data-parallel steps (Trainer._run); every rank loads the same
+    # batches in the same order (the CPU generator is synchronised), rank 0 writes the log and the checkpoints
+    world, rank, local = _dist.init_from_env()
+    if torch.cuda.is_available():
+        _lib.device_init(local)
     os.makedirs(args.save_dir, exist_ok=True)
     kw = dict(object_max_num_vertices=args.object_max_num_vertices, fingers_3d=args.fingers_3d)
     train_set, val_set = DynamicsDataset(args.data_dir, **kw), DynamicsDataset(args.test_data_dir, **kw)
@@ -77,7 +84,8 @@ def train(args):
         if args.checkpoint_path is None:
             raise ValueError('checkpoint path is not specified')
         return validate(args, val_loader, trainer, threshold_std)
-    log = _Log(args)
+    log = _Log(args) if rank == 0 else None
+    save = trainer.save_checkpoint if rank == 0 else (lambda path: None)
     best, last_best = float('inf'), 0
     for epoch in range(args.num_epochs):
         loss_sum, acc_sum = 0.0, [0.0, 0.0, 0.0]
@@ -86,21 +94,21 @@ def train(args):
             loss, pred = trainer.step(ctrl, score, ori, pos, obj)
             acc = class_accuracy(score, pred.cpu(), threshold_std)
             loss_sum, acc_sum = loss_sum + loss, [a + b for a, b in zip(acc_sum, acc)]
-            log.log({'train/lr': trainer.optimizer.param_groups[0]['lr'], 'train/batch loss': loss, 'train/batch accuracy ori': acc[0],
+            rank or log.log({'train/lr': trainer.optimizer.param_groups[0]['lr'], 'train/batch loss': loss, 'train/batch accuracy ori': acc[0],
                      'train/batch accuracy x': acc[1], 'train/batch accuracy y': acc[2]})
             if i % args.save_ckpt_step == 0:
-                trainer.save_checkpoint(os.path.join(args.save_dir, '%d_%d.pt' % (epoch, i)))
+                save(os.path.join(args.save_dir, '%d_%d.pt' % (epoch, i)))
         trainer.lr_scheduler.step()
         nb = max(len(train_loader), 1)
-        print('epoch:', epoch, 'loss:', loss_sum / nb, 'accuracy (ori, x, y):', [a / nb for a in acc_sum])
-        log.log({'train/average loss': loss_sum / nb, 'train/average accuracy ori': acc_sum[0] / nb, 'train/average accuracy x': acc_sum[1] / nb,
+        rank or print('epoch:', epoch, 'loss:', loss_sum / nb, 'accuracy (ori, x, y):', [a / nb for a in acc_sum])
+        rank or log.log({'train/average loss': loss_sum / nb, 'train/average accuracy ori': acc_sum[0] / nb, 'train/average accuracy x': acc_sum[1] / nb,
                  'train/average accuracy y': acc_sum[2] / nb})
         if epoch % args.val_step == 0:
             v = validate(args, val_loader, trainer, threshold_std)
-            log.log({'val/average loss': v[0], 'val/average accuracy ori': v[1], 'val/average accuracy x': v[2], 'val/average accuracy y': v[3]})
+            rank or log.log({'val/average loss': v[0], 'val/average accuracy ori': v[1], 'val/average accuracy x': v[2], 'val/average accuracy y': v[3]})
             if v[0] < best:
                 best, last_best = v[0], epoch
-                trainer.save_checkpoint(os.path.join(args.save_dir, 'best.pt'))
+                save(os.path.join(args.save_dir, 'best.pt'))
             elif epoch - last_best >= args.patience:
                 print('early stopping...')
                 break

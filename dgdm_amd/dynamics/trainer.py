@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from .. import _lib
+from .. import dist as _dist
 from .._lib import check, dptr, lib, stream_ptr
 from ..scheduler import DDIMScheduler
 from .profile_forward_2d import ProfileForward2DModel
@@ -118,13 +119,46 @@ class Trainer(object):
     def _run(self, ctrl, score, input_ori, input_pos, object_vertices, train: bool):
         if self._h is None:
             raise RuntimeError("Trainer.create_model() has not been called")
+        world, rank = _dist.world_rank()
         c, nz, sa, sb, t, o, p, ob, sc, rows = self._inputs(ctrl, score, input_ori, input_pos, object_vertices)
-        pred = torch.empty((rows, 3), dtype=torch.float32, device=c.device)
-        loss = C.c_float()
         lr = float(self.optimizer.param_groups[0]["lr"])
-        check(lib().dgdm_trainer2d_step(self._h, dptr(c), dptr(nz), dptr(sa), dptr(sb), dptr(t), dptr(o), dptr(p), dptr(ob), dptr(sc), rows, lr,
-                                        1 if train else 0, dptr(pred), C.byref(loss), stream_ptr()))
-        return float(loss.value), pred
+        loss = C.c_float()
+        if world == 1:
+            pred = torch.empty((rows, 3), dtype=torch.float32, device=c.device)
+            check(lib().dgdm_trainer2d_step(self._h, dptr(c), dptr(nz), dptr(sa), dptr(sb), dptr(t), dptr(o), dptr(p), dptr(ob), dptr(sc), rows, lr,
+                                            1 if train else 0, dptr(pred), C.byref(loss), stream_ptr()))
+            return float(loss.value), pred
+        # Data parallel, one process per GPU, with nn.DataParallel's semantics (trainer.py:41-43): the batch is cut into `world` chunks
+        # like torch.chunk does for scatter, every replica normalises with ITS chunk's statistics, the loss is the mean over the whole
+        # batch, the replicas' gradients add up (RCCL all-reduce) and every rank takes the same Adam step.  Every rank was handed the
+        # whole batch and drew the whole batch's noise and timesteps from the synchronised CPU generator (dist.init_from_env).
+        cs = -(-rows // world)
+        lo, hi = min(rows, rank * cs), min(rows, (rank + 1) * cs)
+        n = hi - lo
+        if n == 1 and train:
+            raise ValueError("Expected more than 1 value per channel when training (a DataParallel chunk of one row)")
+        cut = lambda v: v[lo:hi].contiguous()                                           # noqa: E731
+        pred = torch.zeros((cs, 3), dtype=torch.float32, device=c.device)
+        share = 0.0
+        if train:
+            flat = torch.zeros(int(lib().dgdm_trainer2d_gradient_count(self._h)), dtype=torch.float32, device=c.device)
+            if n:
+                check(lib().dgdm_trainer2d_forward_backward(self._h, *[dptr(cut(v)) for v in (c, nz, sa, sb, t, o, p, ob, sc)], n, rows, dptr(pred),
+                                                            C.byref(loss), stream_ptr()))
+                check(lib().dgdm_trainer2d_gradients(self._h, dptr(flat), flat.numel(), 0, stream_ptr()))
+                share = float(loss.value)
+            flat = _dist.all_reduce_sum(flat)
+            check(lib().dgdm_trainer2d_gradients(self._h, dptr(flat), flat.numel(), 1, stream_ptr()))
+            check(lib().dgdm_trainer2d_apply(self._h, lr, stream_ptr()))
+        elif n:
+            check(lib().dgdm_trainer2d_step(self._h, *[dptr(cut(v)) for v in (c, nz, sa, sb, t, o, p, ob, sc)], n, lr, 0, dptr(pred), C.byref(loss),
+                                            stream_ptr()))
+            share = float(loss.value) * n / rows
+        tail = torch.zeros((1, 3), dtype=torch.float32, device=c.device)
+        tail[0, 0] = share
+        got = _dist.all_gather_rows(torch.cat([pred, tail]))                            # [world, cs + 1, 3]
+        full = torch.cat([got[r, :max(0, min(rows, (r + 1) * cs) - min(rows, r * cs))] for r in range(world)])
+        return float(got[:, cs, 0].sum()), full
 
     def step(self, ctrl, score, input_ori=None, input_pos=None, object_vertices=None):
         """trainer.py:53-103: returns (loss.item(), pred.detach())."""

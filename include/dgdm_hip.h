@@ -309,6 +309,23 @@ int dgdm_trainer2d_step(DgdmTrainer2d *m, const float *ctrl_dev, const float *no
                         const float *sqrt_1m_abar_dev, const float *t_dev, const float *ori_dev, const float *pos_dev,
                         const float *object_dev, const float *score_dev, int64_t rows, float lr, int train, float *pred_dev,
                         float *loss_host, void *stream);
+/* Data-parallel training, one process per GPU (replaces nn.DataParallel around the model, dynamics/trainer.py:41-43, whose replicas
+ * each normalise with the batch statistics of THEIR chunk and whose gradients add up on the source device):
+ *   dgdm_trainer2d_forward_backward  this rank's `rows` of a batch of `total_rows`: forward in training mode on these rows' statistics,
+ *                                    d loss / d pred = 2 (pred - score) / (3 total_rows), backward; no update.  *loss_host = this rank's
+ *                                    share of the loss (the shares add up to the batch loss).
+ *   dgdm_trainer2d_gradients         the flat gradient buffer (dgdm_trainer2d_gradient_count floats, layout private to the library:
+ *                                    only elementwise reductions are meaningful) device -> flat_dev, or flat_dev -> device (to_trainer);
+ *                                    between the two calls: all-reduce(sum) over RCCL.
+ *   dgdm_trainer2d_apply             one Adam update from the gradient buffer.
+ * dgdm_trainer2d_step == forward_backward(rows, rows) + apply.                                                                      */
+int dgdm_trainer2d_forward_backward(DgdmTrainer2d *m, const float *ctrl_dev, const float *noise_dev, const float *sqrt_abar_dev,
+                                    const float *sqrt_1m_abar_dev, const float *t_dev, const float *ori_dev, const float *pos_dev,
+                                    const float *object_dev, const float *score_dev, int64_t rows, int64_t total_rows, float *pred_dev,
+                                    float *loss_host, void *stream);
+int64_t dgdm_trainer2d_gradient_count(const DgdmTrainer2d *m);
+int dgdm_trainer2d_gradients(DgdmTrainer2d *m, float *flat_dev, int64_t numel, int to_trainer, void *stream);
+int dgdm_trainer2d_apply(DgdmTrainer2d *m, float lr, void *stream);
 /* Copies into the host buffers of `tensors` (matched by name; data is written despite the const): which = 0 the state_dict
  * (parameters + running statistics: Trainer.save_checkpoint, trainer.py:105-106), 1 the gradients of the last step, 2 / 3 Adam's
  * exp_avg / exp_avg_sq.                                                                                                           */

@@ -632,7 +632,8 @@ class Trainer2D:
         self.draws = None
         self.relu_margin = float("inf")
 
-    def _forward(self, sd: SD, x_ctrl, x_ori, x_pos, timesteps, object_vertices, training: bool) -> torch.Tensor:
+    def _forward(self, sd: SD, x_ctrl, x_ori, x_pos, timesteps, object_vertices, training: bool, buffers: Optional[SD] = None) -> torch.Tensor:
+        buffers = self.sd if buffers is None else buffers      # BatchNorm running statistics (updated in place when training)
         # profile_forward_2d.py:137-156
         def relu(z):        # every ReLU input passes here: relu_margin = how far the nearest one is from its kink (see tests)
             self.relu_margin = min(self.relu_margin, float(z.detach().abs().min()))
@@ -645,7 +646,7 @@ class Trainer2D:
         for i in range(8):
             x = F.linear(x, sd[f"linears.{3 * i}.weight"], sd[f"linears.{3 * i}.bias"])
             b = f"linears.{3 * i + 1}"
-            x = F.batch_norm(x, self.sd[b + ".running_mean"], self.sd[b + ".running_var"], sd[b + ".weight"], sd[b + ".bias"],
+            x = F.batch_norm(x, buffers[b + ".running_mean"], buffers[b + ".running_var"], sd[b + ".weight"], sd[b + ".bias"],
                              training=training, momentum=0.1, eps=1e-5)      # in place on the running statistics, as nn.BatchNorm1d
             x = relu(x)
         return F.linear(x, sd["output.weight"], sd["output.bias"])
@@ -660,10 +661,23 @@ class Trainer2D:
         self.draws = (noise, timesteps)
         return self.ddim.add_noise(ctrl, noise, timesteps), timesteps.float() / self.ddim.num_train_timesteps
 
-    def step(self, ctrl, score, input_ori, input_pos, object_vertices, forced=None):
+    def step(self, ctrl, score, input_ori, input_pos, object_vertices, forced=None, replicas: int = 1):
+        """replicas > 1: nn.DataParallel around the model (trainer.py:41-43) as its documentation states it - the inputs are cut with
+        torch.chunk, every replica runs the module on its chunk (BatchNorm batch statistics per chunk; only the first replica's
+        running-statistics updates survive, the others work on copies), the outputs are concatenated for one loss, and autograd adds
+        the replicas' gradients.  No multi-GPU host exists to pin this against the real wrapper: parity unpinned for replicas > 1."""
         noisy, t = self._noisy(ctrl, forced)
         leaf = {k: self.sd[k].clone().requires_grad_(True) for k in self.names}
-        pred = self._forward({**self.sd, **leaf}, noisy, input_ori, input_pos, t, object_vertices, True)
+        if replicas == 1:
+            pred = self._forward({**self.sd, **leaf}, noisy, input_ori, input_pos, t, object_vertices, True)
+        else:
+            outs, first = [], None
+            for part in zip(*[torch.chunk(v, replicas) for v in (noisy, input_ori, input_pos, t, object_vertices)]):
+                bufs = {k: v.clone() for k, v in self.sd.items() if "running_" in k}       # every replica starts from the same buffers
+                outs.append(self._forward({**self.sd, **leaf}, *part, True, buffers=bufs))
+                first = first or bufs
+            self.sd.update(first)
+            pred = torch.cat(outs)
         loss = F.mse_loss(pred, score)
         grads = torch.autograd.grad(loss, [leaf[k] for k in self.names])
         self.grads = dict(zip(self.names, grads))

@@ -161,3 +161,31 @@ def test_multi_object_stream_split():
                 for j in mine:
                     assert np.array_equal(per[j], full[si][j])
             assert torch.equal(torch.get_rng_state(), end)
+
+
+# ------------------------------------------------------------------------------------------------ data-parallel training collectives
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dgdm_amd.dist import all_gather_rows, all_reduce_sum
+    g = all_reduce_sum(torch.arange(6, dtype=torch.float32) * (rank + 1))            # the gradient buffers of Trainer's data-parallel step
+    rows = all_gather_rows(torch.full((3, 2), float(rank)))
+    ok = torch.equal(g, torch.arange(6, dtype=torch.float32) * 3) and rows.shape == (2, 3, 2) and torch.equal(rows[:, 0, 0], torch.tensor([0.0, 1.0]))
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_collectives():
+    """all_reduce_sum / all_gather_rows as Trainer._run uses them (summed gradients, gathered prediction chunks + loss shares)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]

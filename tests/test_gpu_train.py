@@ -1,6 +1,7 @@
 """Trainer.step / Trainer.inference of the 2-D dynamics model on the GPU (csrc/train2d.hip through dgdm_amd.dynamics.trainer)
 against the reference's own Trainer (tests/golden/g10_train2d.npz) and against the oracle at other sizes."""
 import argparse
+import os
 
 import numpy as np
 import pytest
@@ -17,6 +18,13 @@ def _args(wd, L=14, nv=100, T=15, lr=1e-4):
     return argparse.Namespace(use_sub_batch=False, sub_bs=1024, grid_size=360, learning_rate=lr, weight_decay=wd, num_epochs=100,
                               checkpoint_path=None, fingers_3d=False, ctrlpts_dim=L, object_max_num_vertices=nv,
                               num_timesteps_per_batch=1, num_inference_steps=5, num_train_timesteps=T)
+
+
+def dp_data(seed, rows, L=14, nv=100):
+    sd = util.synth.synth_state_dict(util.synth.dyn2d_spec(L, 2 * nv), 50 + seed)
+    rs = np.random.RandomState(seed)
+    data = [torch.from_numpy(rs.uniform(-1, 1, s).astype(np.float32)) for s in ((rows, L), (rows, 3), (rows, 1), (rows, 2), (rows, 2 * nv))]
+    return sd, data
 
 
 class _HipTrainer:
@@ -195,3 +203,43 @@ def test_training_driver_end_to_end(dev, tmp_path):
     out = m.to(dev)(torch.zeros(4, 14, device=dev), torch.zeros(4, 1, device=dev), torch.zeros(4, 2, device=dev), torch.zeros(4, device=dev),
                     torch.zeros(4, 200, device=dev))
     assert out.shape == (4, 3) and bool(torch.isfinite(out).all())
+
+
+def test_trainer2d_data_parallel(dev, tmp_path):
+    """Two ranks (sharing this box's GPU; gloo carries the gradient all-reduce) train data-parallel with nn.DataParallel's semantics
+    (trainer.py:41-43): chunks as torch.chunk cuts them (51 + 50 rows), BatchNorm statistics per chunk, gradients summed, the same Adam
+    step on every rank, running statistics of rank 0.  Against the oracle's statement of those semantics on the same draws, one step
+    tight (a batch whose ReLU inputs stay clear of zero) and a second step + eval call loosely; and the draws do not depend on the
+    rank count (DGDM_TORCH_SEED pins the CPU generator the reference leaves unseeded)."""
+    import subprocess
+    import sys
+    rows = 101
+    for seed in range(300):
+        sd, data = dp_data(seed, rows)
+        o = orc.Trainer2D(sd, 15, 1e-4)
+        torch.manual_seed(4242)
+        lo, po = o.step(*data, replicas=2)
+        if o.relu_margin >= 5e-6:
+            break
+    assert o.relu_margin >= 5e-6
+    g1 = {k: v.clone() for k, v in o.grads.items()}
+    lo2, po2 = o.step(*data, replicas=2)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DGDM_TORCH_SEED="4242", DGDM_DIST_BACKEND="gloo")
+    out = str(tmp_path / "dp.npz")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", os.path.join(root, "tests", "dp_train_worker.py"), str(seed), str(rows), "2", out],
+                       capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    g = np.load(out)
+    assert int(g["world"]) == 2
+    assert abs(float(g["loss0"]) / lo - 1) < 1e-5 and util.rel_l2(g["pred0"], po) < 2e-5
+    # the second step's predictions depend on the first update (every parameter moved by about lr): agreement = the update was the same
+    assert abs(float(g["loss1"]) / lo2 - 1) < 1e-4 and util.rel_l2(g["pred1"], po2) < 1e-3
+    for k, ref in o.grads.items():        # gradients of the LAST step are what the trainer holds; compare loosely (second step), then
+        if k not in BN_FED_BIAS:          # the running statistics, which only rank 0's chunk feeds
+            assert util.rel_l2(g["grad/" + k], ref) < 2e-2, k
+    for k in ("linears.1.running_var", "linears.22.running_var"):
+        assert float(np.abs(g["sd/" + k] - o.sd[k].numpy()).max()) < 1e-4, k
+    assert int(g["sd/linears.1.num_batches_tracked"]) == 2
