@@ -30,6 +30,10 @@ class Objective(C.Structure):
     _fields_ = [("lin", C.c_float * 3), ("quad", C.c_float * 3), ("use_rowcoef", C.c_int32), ("object", C.c_int32)]
 
 
+class TrainGroups(C.Structure):
+    _fields_ = [("t_index_dev", C.c_void_p), ("t_values_dev", C.c_void_p), ("n_t", C.c_int32), ("rows_per_object", C.c_int32)]
+
+
 class GuidanceConfig(C.Structure):
     _fields_ = [("batch", C.c_int32), ("grid_size", C.c_int32), ("num_pos", C.c_int32), ("ori_lo", C.c_float),
                 ("ori_hi", C.c_float), ("max_chains", C.c_int32), ("num_train_timesteps", C.c_int32),
@@ -83,6 +87,7 @@ PROTOTYPES = {
     "dgdm_trainer2d_destroy": (None, [_P]),
     "dgdm_trainer2d_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_int, _P, C.POINTER(C.c_float), _P]),
     "dgdm_trainer2d_forward_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, _P, C.POINTER(C.c_float), _P]),
+    "dgdm_trainer2d_set_groups": (C.c_int, [_P, C.POINTER(TrainGroups)]),
     "dgdm_trainer2d_gradient_count": (C.c_int64, [_P]),
     "dgdm_trainer2d_gradients": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
     "dgdm_trainer2d_apply": (C.c_int, [_P, C.c_float, _P]),

@@ -449,10 +449,58 @@ __global__ void transpose_all_kernel(const float *__restrict__ P, float *__restr
     WT[t.wt + e] = P[t.w + (int64_t)m * t.K + k];
 }
 
+// ---- exact de-duplication of the row-invariant encoders (the same idea as the guided path's tables): the time
+// encoder sees num_train_timesteps distinct inputs and the object encoder one input per sample, whatever the number of rows.
+// dst[n][0..256) (row stride ldd) = src[group(n)][0..256),  group(n) = idx[n] or n / run
+__global__ void expand_groups_kernel(const float *__restrict__ src, const int32_t *__restrict__ idx, int run, float *__restrict__ dst, int64_t ldd, int64_t N) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one float4
+    if (e >= N * 64) return;
+    const int64_t n = e >> 6;
+    const int c = (int)(e & 63) * 4;
+    const int64_t gsrc = idx ? idx[n] : n / run;
+    *reinterpret_cast<float4 *>(dst + n * ldd + c) = ld4(src + gsrc * W + c);
+}
+// gradient of a grouped encoder output: part[block][group][256] = sum over the block's 256 rows with that group index (rows in order,
+// one thread per column: a fixed summation order); groups <= 32 (LDS)
+constexpr int SEG_ROWS = 256, SEG_GROUPS = 32;
+__global__ __launch_bounds__(256) void segsum_index_kernel(const float *__restrict__ G, int64_t ldg, const int32_t *__restrict__ idx, int ngroups, int64_t N,
+                                                           float *__restrict__ part) {
+    __shared__ float acc[SEG_GROUPS][W];
+    const int c = threadIdx.x;
+    for (int k = 0; k < ngroups; ++k) acc[k][c] = 0.f;
+    const int64_t r0 = (int64_t)blockIdx.x * SEG_ROWS, r1 = min(N, r0 + SEG_ROWS);
+    for (int64_t r = r0; r < r1; ++r) acc[idx[r]][c] += G[r * ldg + c];
+    for (int k = 0; k < ngroups; ++k) part[((int64_t)blockIdx.x * ngroups + k) * W + c] = acc[k][c];
+}
+// the same for groups that are runs of `run` consecutive rows: grid (groups, chunks of 256 rows of a run)
+__global__ __launch_bounds__(256) void segsum_run_kernel(const float *__restrict__ G, int64_t ldg, int run, float *__restrict__ part /*[groups][chunks][256]*/) {
+    const int c = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * run + (int64_t)blockIdx.y * SEG_ROWS, r1 = min((int64_t)(blockIdx.x + 1) * run, r0 + SEG_ROWS);
+    float a = 0.f;
+    for (int64_t r = r0; r < r1; ++r) a += G[r * ldg + c];
+    part[((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * W + c] = a;
+}
+// out[g][c] = sum over k < nk of in[(g * nk + k) * stride_k ...]: double accumulation, fixed order
+__global__ void sum_chunks_kernel(const float *__restrict__ in, int nk, float *__restrict__ out, int64_t n /* groups * 256 */) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int64_t g = e / W, c = e % W;
+    double a = 0.0;
+    for (int k = 0; k < nk; ++k) a += (double)in[(g * nk + k) * W + c];
+    out[e] = (float)a;
+}
+__global__ void sum_red_kernel(const double *__restrict__ red, int ncol, float *__restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncol) return;
+    double a = 0.0;
+    for (int k = 0; k < RED_S; ++k) a += red[(int64_t)k * ncol + c];
+    out[c] = (float)a;
+}
+
 // noisy control points (DDIMScheduler.add_noise per row), zero-padded copies of the inputs, pose embedding into columns 768.. of X0
 __global__ void prep2d_kernel(const float *__restrict__ ctrl, const float *__restrict__ noise, const float *__restrict__ sa, const float *__restrict__ sb,
                               const float *__restrict__ ori, const float *__restrict__ pos, const float *__restrict__ obj, int64_t N, int L, int Lp,
-                              int OC, int OCp, float *__restrict__ bufC, float *__restrict__ bufO, float *__restrict__ X0) {
+                              int OC, int OCp, float *__restrict__ bufC, float *__restrict__ bufO, float *__restrict__ X0, int obj_run, int64_t obj_rows) {
     const int S = Lp + OCp + 32;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= N * S) return;
@@ -463,7 +511,7 @@ __global__ void prep2d_kernel(const float *__restrict__ ctrl, const float *__res
         return;
     }
     s -= Lp;
-    if (s < OCp) { bufO[r * OCp + s] = s < OC ? obj[r * OC + s] : 0.f; return; }
+    if (s < OCp) { if (r < obj_rows) bufO[r * OCp + s] = s < OC ? obj[r * obj_run * OC + s] : 0.f; return; }      // grouped: row r = the first row of run r
     s -= OCp;
     // get_embedder(d, 4): [x, sin(2^k x), cos(2^k x)]_k; pose = cat(embed(ori) [9], embed(pos) [18])  (profile_forward_2d.py:10-56, 149-151)
     float v = 0.f;
@@ -499,8 +547,9 @@ struct DgdmTrainer2d {
     size_t bn_g[8], bn_b[8], out_w = 0, out_b = 0, n_params = 0, n_wt = 0;
     DevBuf P, G, M, V, WT, bn_run /* [8][2][256] running mean, var */, coef /* [8][7][256] */, tfreq, trdesc, loss_dev;
     DevBuf red /* [RED_S][3*256 + 4] float64 */, unit /* [256] ones, [256] zeros: coefficients of a ReLU without BatchNorm */;
-    DevBuf ws;
+    DevBuf ws, seg /* grouped encoders: outputs, their gradients, partial sums (grow-only) */;
     int64_t ws_rows = 0;
+    DgdmTrainGroups groups{};      // one-shot hints of dgdm_trainer2d_set_groups
     // workspace pointers (set by reserve)
     float *bufC = nullptr, *bufO = nullptr, *bufT = nullptr, *H[3] = {nullptr, nullptr, nullptr}, *X0 = nullptr, *Y[8] = {}, *D[2] = {nullptr, nullptr},
           *G0 = nullptr, *stats = nullptr, *hpart = nullptr, *wpart = nullptr;
@@ -628,11 +677,27 @@ int DgdmTrainer2d::run(const float *ctrl, const float *noise, const float *sa, c
     int rc = reserve(N);
     if (rc) return rc;
     const int T = (int)((N + TI - 1) / TI), TH = (int)((N + HEAD_ROWS - 1) / HEAD_ROWS);
+    // one-shot grouping hints (dgdm_trainer2d_set_groups): which encoders run on their distinct inputs only
+    const DgdmTrainGroups gh = groups;
+    groups = DgdmTrainGroups{};
+    const bool tgrp = gh.t_index_dev && gh.t_values_dev && gh.n_t > 0 && gh.n_t <= SEG_GROUPS;
+    const bool ogrp = gh.rows_per_object > 1 && N % gh.rows_per_object == 0;
+    const int orun = ogrp ? gh.rows_per_object : 1;
+    const int64_t nobj = N / orun, erows[3] = {N, nobj, tgrp ? gh.n_t : N};
+    const int ochunks = (orun + SEG_ROWS - 1) / SEG_ROWS;
+    const int64_t tblocks = (N + SEG_ROWS - 1) / SEG_ROWS;
+    float *encO = nullptr, *dencO = nullptr, *encT = nullptr, *dencT = nullptr, *segpart = nullptr;
+    if (tgrp || ogrp) {
+        const int64_t part = std::max<int64_t>(tgrp ? tblocks * gh.n_t * 256 : 0, ogrp ? nobj * ochunks * 256 : 0);
+        if ((rc = seg.alloc((size_t)(2 * nobj * 256 + 2 * SEG_GROUPS * 256 + part + 256) * sizeof(float)))) return rc;
+        encO = seg.as<float>(); dencO = encO + nobj * 256; encT = dencO + nobj * 256; dencT = encT + SEG_GROUPS * 256; segpart = dencT + SEG_GROUPS * 256;
+    }
     {
         const int64_t n = N * (Lp + OCp + 32);
-        hipLaunchKernelGGL(prep2d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ctrl, noise, sa, sb, ori, pos, obj, N, L, Lp, OC, OCp, bufC, bufO, X0);
+        hipLaunchKernelGGL(prep2d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ctrl, noise, sa, sb, ori, pos, obj, N, L, Lp, OC, OCp, bufC, bufO, X0,
+                           orun, nobj);
         DGDM_HIP_CHECK(hipGetLastError());
-        if ((rc = time_embed(t, 0.f, tfreq.as<float>(), bufT, (int)N, 64, s))) return rc;
+        if ((rc = time_embed(tgrp ? gh.t_values_dev : t, 0.f, tfreq.as<float>(), bufT, (int)erows[2], 64, s))) return rc;
     }
     const float *ones = unit.as<float>(), *zeros = unit.as<float>() + 256;
     auto plain = [](const float *p, int64_t ld) { Operand o{}; o.t0 = p; o.ld = ld; o.xf = X_PLAIN; return o; };
@@ -642,18 +707,27 @@ int DgdmTrainer2d::run(const float *ctrl, const float *noise, const float *sa, c
         return o;
     };
     auto weight_t = [&](int l) { return plain(WT.as<float>() + lin[l].wt, 256); };
-    auto forward = [&](int l, const Operand &in, float *out, int64_t ldo, float *st) {
+    auto forward = [&](int l, const Operand &in, float *out, int64_t ldo, float *st, int64_t rows) {
         GemmArgs g{};
-        g.P = in; g.Q = weight_t(l); g.I = N; g.J = 256; g.R = lin[l].Kp; g.r_per_split = lin[l].Kp;
+        g.P = in; g.Q = weight_t(l); g.I = rows; g.J = 256; g.R = lin[l].Kp; g.r_per_split = lin[l].Kp;
         g.C = out; g.ldc = ldo; g.bias = p(lin[l].b); g.stats = st;
         return gemm(true, EPI_FWD, g, s);
     };
-    // encoders (profile_forward_2d.py:147-153); their second layers write straight into the concatenated trunk input X0
+    // encoders (profile_forward_2d.py:147-153); their second layers write straight into the concatenated trunk input X0 - or, grouped,
+    // into a [groups][256] table that is then expanded over the rows
     const float *enc_in[3] = {bufC, bufO, bufT};
     const int enc_ld[3] = {Lp, OCp, 128}, enc_act[3] = {ACT_RELU, ACT_RELU, ACT_SILU}, enc_col[3] = {256, 0, 512};
+    float *enc_tab[3] = {nullptr, ogrp ? encO : nullptr, tgrp ? encT : nullptr}, *enc_dtab[3] = {nullptr, dencO, dencT};
     for (int e = 0; e < 3; ++e) {
-        if ((rc = forward(2 * e, plain(enc_in[e], enc_ld[e]), H[e], 256, nullptr))) return rc;
-        if ((rc = forward(2 * e + 1, act(H[e], 256, enc_act[e], nullptr, nullptr), X0 + enc_col[e], 800, nullptr))) return rc;
+        if ((rc = forward(2 * e, plain(enc_in[e], enc_ld[e]), H[e], 256, nullptr, erows[e]))) return rc;
+        if (!enc_tab[e]) {
+            if ((rc = forward(2 * e + 1, act(H[e], 256, enc_act[e], nullptr, nullptr), X0 + enc_col[e], 800, nullptr, N))) return rc;
+            continue;
+        }
+        if ((rc = forward(2 * e + 1, act(H[e], 256, enc_act[e], nullptr, nullptr), enc_tab[e], 256, nullptr, erows[e]))) return rc;
+        hipLaunchKernelGGL(expand_groups_kernel, dim3((unsigned)((N * 64 + 255) / 256)), dim3(256), 0, s, enc_tab[e], e == 2 ? gh.t_index_dev : nullptr, orun,
+                           X0 + enc_col[e], (int64_t)800, N);
+        DGDM_HIP_CHECK(hipGetLastError());
     }
     // trunk: Linear -> BatchNorm1d (batch statistics) -> ReLU, eight times (profile_forward_2d.py:108-133)
     float *rm = bn_run.as<float>();
@@ -664,7 +738,7 @@ int DgdmTrainer2d::run(const float *ctrl, const float *noise, const float *sa, c
         }
     for (int k = 0; k < 8; ++k) {
         const Operand in = k == 0 ? plain(X0, 800) : act(Y[k - 1], 256, ACT_RELU, cf(k - 1, 0), cf(k - 1, 1));
-        if ((rc = forward(6 + k, in, Y[k], 256, train ? stats : nullptr))) return rc;
+        if ((rc = forward(6 + k, in, Y[k], 256, train ? stats : nullptr, N))) return rc;
         if (train) {
             if ((rc = reduce(stats, 2 * T, 256, s))) return rc;      // partial tile t = rows 2t (sum y), 2t + 1 (sum y^2): even / odd rows stay apart (RED_S is even)
             hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(1), dim3(256), 0, s, red.as<double>(), (double)N, p(bn_g[k]), p(bn_b[k]), 1e-5f, 0.1f,
@@ -700,13 +774,27 @@ int DgdmTrainer2d::run(const float *ctrl, const float *noise, const float *sa, c
             nstat = T;
         }
         for (int e = 0; e < 3; ++e) {
-            const Operand gsec = plain(G0 + enc_col[e], 768);
-            if ((rc = wgrad(2 * e + 1, act(H[e], 256, enc_act[e], nullptr, nullptr), gsec, N, s))) return rc;
+            Operand gsec = plain(G0 + enc_col[e], 768);
+            if (enc_tab[e]) {       // gradient of the table: the rows' gradients summed per group, in a fixed order
+                if (e == 2) {
+                    hipLaunchKernelGGL(segsum_index_kernel, dim3((unsigned)tblocks), dim3(256), 0, s, G0 + enc_col[e], (int64_t)768, gh.t_index_dev, gh.n_t, N, segpart);
+                    DGDM_HIP_CHECK(hipGetLastError());
+                    if ((rc = reduce(segpart, (int)tblocks, gh.n_t * 256, s))) return rc;
+                    hipLaunchKernelGGL(sum_red_kernel, dim3((gh.n_t * 256 + 255) / 256), dim3(256), 0, s, red.as<double>(), gh.n_t * 256, enc_dtab[e]);
+                } else {
+                    hipLaunchKernelGGL(segsum_run_kernel, dim3((unsigned)nobj, (unsigned)ochunks), dim3(256), 0, s, G0 + enc_col[e], (int64_t)768, orun, segpart);
+                    DGDM_HIP_CHECK(hipGetLastError());
+                    hipLaunchKernelGGL(sum_chunks_kernel, dim3((unsigned)((nobj * 256 + 255) / 256)), dim3(256), 0, s, segpart, ochunks, enc_dtab[e], nobj * 256);
+                }
+                DGDM_HIP_CHECK(hipGetLastError());
+                gsec = plain(enc_dtab[e], 256);
+            }
+            if ((rc = wgrad(2 * e + 1, act(H[e], 256, enc_act[e], nullptr, nullptr), gsec, erows[e], s))) return rc;
             GemmArgs g{};
-            g.P = gsec; g.Q = plain(p(lin[2 * e + 1].w), 256); g.I = N; g.J = 256; g.R = 256; g.r_per_split = 256;
+            g.P = gsec; g.Q = plain(p(lin[2 * e + 1].w), 256); g.I = erows[e]; g.J = 256; g.R = 256; g.r_per_split = 256;
             g.C = D[0]; g.ldc = 256; g.Yp = H[e]; g.ldy = 256; g.mask = enc_act[e] == ACT_SILU ? MASK_SILU : MASK_RELU;
             if ((rc = gemm(true, EPI_BWD, g, s))) return rc;
-            if ((rc = wgrad(2 * e, plain(enc_in[e], enc_ld[e]), plain(D[0], 256), N, s))) return rc;
+            if ((rc = wgrad(2 * e, plain(enc_in[e], enc_ld[e]), plain(D[0], 256), erows[e], s))) return rc;
         }
         if (update && (rc = adam(lr, s))) return rc;
         ++bn_batches;
@@ -803,7 +891,7 @@ extern "C" int dgdm_trainer2d_create(DgdmTrainer2d **out, const DgdmTensor *stat
     if ((rc = m->coef.alloc(8 * 7 * 256 * sizeof(float)))) return rc;
     DGDM_HIP_CHECK(hipMemset(m->coef.p, 0, 8 * 7 * 256 * sizeof(float)));
     if ((rc = m->loss_dev.alloc(64))) return rc;
-    if ((rc = m->red.alloc((size_t)RED_S * (3 * 256 + 4) * sizeof(double)))) return rc;
+    if ((rc = m->red.alloc((size_t)RED_S * SEG_GROUPS * 256 * sizeof(double)))) return rc;       // also >= RED_S * (3*256 + 4)
     {
         std::vector<float> u(512, 0.f);
         std::fill(u.begin(), u.begin() + 256, 1.f);
@@ -840,6 +928,12 @@ extern "C" int dgdm_trainer2d_forward_backward(DgdmTrainer2d *m, const float *ct
                  (long long)rows, (long long)total_rows);
     return m->run(ctrl_dev, noise_dev, sqrt_abar_dev, sqrt_1m_abar_dev, t_dev, ori_dev, pos_dev, object_dev, score_dev, rows, total_rows, 0.f, 1, false,
                   pred_dev, loss_host, (hipStream_t)stream);
+}
+
+extern "C" int dgdm_trainer2d_set_groups(DgdmTrainer2d *m, const DgdmTrainGroups *g) {
+    DGDM_REQUIRE(m, DGDM_EINVAL, "dgdm_trainer2d_set_groups: null handle");
+    m->groups = g ? *g : DgdmTrainGroups{};
+    return DGDM_OK;
 }
 
 extern "C" int64_t dgdm_trainer2d_gradient_count(const DgdmTrainer2d *m) { return m ? (int64_t)m->n_params : -1; }

@@ -59,7 +59,7 @@ def validate(args, val_loader, trainer, threshold_std):
     n, loss_sum, acc_sum = 0, 0.0, [0.0, 0.0, 0.0]
     for batch in val_loader:
         ctrl, score, ori, pos, obj = batch_rows(batch)
-        pred, loss = trainer.inference(ctrl, score, ori, pos, obj)
+        pred, loss = trainer.inference(ctrl, score, ori, pos, obj, rows_per_sample=batch['scores'].size(1))
         acc = class_accuracy(score, pred.cpu(), threshold_std)
         loss_sum, acc_sum, n = loss_sum + loss, [a + b for a, b in zip(acc_sum, acc)], n + 1
     n = max(n, 1)
@@ -91,7 +91,7 @@ def train(args):
         loss_sum, acc_sum = 0.0, [0.0, 0.0, 0.0]
         for i, batch in enumerate(train_loader):
             ctrl, score, ori, pos, obj = batch_rows(batch)
-            loss, pred = trainer.step(ctrl, score, ori, pos, obj)
+            loss, pred = trainer.step(ctrl, score, ori, pos, obj, rows_per_sample=batch['scores'].size(1))
             acc = class_accuracy(score, pred.cpu(), threshold_std)
             loss_sum, acc_sum = loss_sum + loss, [a + b for a, b in zip(acc_sum, acc)]
             rank or log.log({'train/lr': trainer.optimizer.param_groups[0]['lr'], 'train/batch loss': loss, 'train/batch accuracy ori': acc[0],

@@ -70,6 +70,8 @@ class Trainer(object):
         self.noise_scheduler.set_timesteps(self.num_inference_steps)
         self._h = None
         self.model: Optional[ProfileForward2DModel] = None
+        # exact de-duplication of the time / object encoders over the rows (dgdm_trainer2d_set_groups); False = every row through both
+        self.group_encoders = True
 
     # ------------------------------------------------------------------ model / optimizer (trainer.py:40-51)
     def create_model(self, state_dict: Optional[Dict[str, torch.Tensor]] = None):
@@ -113,10 +115,25 @@ class Trainer(object):
         timesteps = torch.randint(0, self.noise_scheduler.config.num_train_timesteps, (rows,)).long()
         ac = self.noise_scheduler.alphas_cumprod[timesteps]
         sa, sb = f(ac ** 0.5), f((1 - ac) ** 0.5)                                       # DDIMScheduler.add_noise (diffusers 0.11.1)
-        t = f(timesteps.float() / self.noise_scheduler.config.num_train_timesteps)       # rescale to [0,1] (:80)
+        T = self.noise_scheduler.config.num_train_timesteps
+        t = f(timesteps.float() / T)                                                       # rescale to [0,1] (:80)
+        self._t_index = timesteps.to(device=dev, dtype=torch.int32).contiguous() if T <= 32 else None
+        self._t_values = f(torch.arange(T).float() / T) if T <= 32 else None
         return ctrl_all, f(noise), sa, sb, t, ori_all, pos_all, obj_all, score_all, rows
 
-    def _run(self, ctrl, score, input_ori, input_pos, object_vertices, train: bool):
+    def _hint(self, lo: int, hi: int, rows_per_sample: Optional[int]):
+        """Grouping hints for the rows [lo, hi) of the batch the next library call works on."""
+        if not self.group_encoders:
+            return
+        g = _lib.TrainGroups()
+        if self._t_index is not None:
+            self._t_slice = self._t_index[lo:hi].contiguous()
+            g.t_index_dev, g.t_values_dev, g.n_t = dptr(self._t_slice), dptr(self._t_values), int(self._t_values.numel())
+        if rows_per_sample and rows_per_sample > 1 and lo % rows_per_sample == 0 and (hi - lo) % rows_per_sample == 0:
+            g.rows_per_object = int(rows_per_sample)
+        check(lib().dgdm_trainer2d_set_groups(self._h, C.byref(g)))
+
+    def _run(self, ctrl, score, input_ori, input_pos, object_vertices, train: bool, rows_per_sample: Optional[int] = None):
         if self._h is None:
             raise RuntimeError("Trainer.create_model() has not been called")
         world, rank = _dist.world_rank()
@@ -125,6 +142,7 @@ class Trainer(object):
         loss = C.c_float()
         if world == 1:
             pred = torch.empty((rows, 3), dtype=torch.float32, device=c.device)
+            self._hint(0, rows, rows_per_sample)
             check(lib().dgdm_trainer2d_step(self._h, dptr(c), dptr(nz), dptr(sa), dptr(sb), dptr(t), dptr(o), dptr(p), dptr(ob), dptr(sc), rows, lr,
                                             1 if train else 0, dptr(pred), C.byref(loss), stream_ptr()))
             return float(loss.value), pred
@@ -143,6 +161,7 @@ class Trainer(object):
         if train:
             flat = torch.zeros(int(lib().dgdm_trainer2d_gradient_count(self._h)), dtype=torch.float32, device=c.device)
             if n:
+                self._hint(lo, hi, rows_per_sample)
                 check(lib().dgdm_trainer2d_forward_backward(self._h, *[dptr(cut(v)) for v in (c, nz, sa, sb, t, o, p, ob, sc)], n, rows, dptr(pred),
                                                             C.byref(loss), stream_ptr()))
                 check(lib().dgdm_trainer2d_gradients(self._h, dptr(flat), flat.numel(), 0, stream_ptr()))
@@ -151,6 +170,7 @@ class Trainer(object):
             check(lib().dgdm_trainer2d_gradients(self._h, dptr(flat), flat.numel(), 1, stream_ptr()))
             check(lib().dgdm_trainer2d_apply(self._h, lr, stream_ptr()))
         elif n:
+            self._hint(lo, hi, rows_per_sample)
             check(lib().dgdm_trainer2d_step(self._h, *[dptr(cut(v)) for v in (c, nz, sa, sb, t, o, p, ob, sc)], n, lr, 0, dptr(pred), C.byref(loss),
                                             stream_ptr()))
             share = float(loss.value) * n / rows
@@ -160,13 +180,15 @@ class Trainer(object):
         full = torch.cat([got[r, :max(0, min(rows, (r + 1) * cs) - min(rows, r * cs))] for r in range(world)])
         return float(got[:, cs, 0].sum()), full
 
-    def step(self, ctrl, score, input_ori=None, input_pos=None, object_vertices=None):
-        """trainer.py:53-103: returns (loss.item(), pred.detach())."""
-        return self._run(ctrl, score, input_ori, input_pos, object_vertices, True)
+    def step(self, ctrl, score, input_ori=None, input_pos=None, object_vertices=None, rows_per_sample: Optional[int] = None):
+        """trainer.py:53-103: returns (loss.item(), pred.detach()).  rows_per_sample (not in the reference): the caller's promise that
+        `object_vertices` holds runs of that many identical rows - dynamics/main.py builds its batches so - which lets the object
+        encoder run once per sample."""
+        return self._run(ctrl, score, input_ori, input_pos, object_vertices, True, rows_per_sample)
 
-    def inference(self, ctrl, score, input_ori=None, input_pos=None, object_vertices=None):
+    def inference(self, ctrl, score, input_ori=None, input_pos=None, object_vertices=None, rows_per_sample: Optional[int] = None):
         """trainer.py:108-146 (eval mode, no update): returns (pred, loss)."""
-        loss, pred = self._run(ctrl, score, input_ori, input_pos, object_vertices, False)
+        loss, pred = self._run(ctrl, score, input_ori, input_pos, object_vertices, False, rows_per_sample)
         return pred, loss
 
     # ------------------------------------------------------------------ state

@@ -309,6 +309,20 @@ int dgdm_trainer2d_step(DgdmTrainer2d *m, const float *ctrl_dev, const float *no
                         const float *sqrt_1m_abar_dev, const float *t_dev, const float *ori_dev, const float *pos_dev,
                         const float *object_dev, const float *score_dev, int64_t rows, float lr, int train, float *pred_dev,
                         float *loss_host, void *stream);
+/* Optional hints for the NEXT dgdm_trainer2d_step / _forward_backward call only: which encoder inputs repeat over the rows.  The
+ * result is the same function of the inputs (only the float32 summation order of the two encoders' gradients changes); the time and
+ * object encoders then run on their distinct inputs instead of on every row (1.15 M rows -> 15 and 128 at the shipped configuration).
+ *   t_index_dev [rows] + t_values_dev [n_t], n_t <= 32: row r's t is t_values[t_index[r]] (t_dev of the step call is then ignored);
+ *   rows_per_object > 1: object_dev's rows come in runs of that many identical rows (dynamics/main.py:34 builds them so); rows must
+ *                        be a multiple of it, otherwise the hint is ignored.                                                        */
+typedef struct DgdmTrainGroups {
+    const int32_t *t_index_dev;
+    const float   *t_values_dev;
+    int32_t        n_t;
+    int32_t        rows_per_object;
+} DgdmTrainGroups;
+int dgdm_trainer2d_set_groups(DgdmTrainer2d *m, const DgdmTrainGroups *g);
+
 /* Data-parallel training, one process per GPU (replaces nn.DataParallel around the model, dynamics/trainer.py:41-43, whose replicas
  * each normalise with the batch statistics of THEIR chunk and whose gradients add up on the source device):
  *   dgdm_trainer2d_forward_backward  this rank's `rows` of a batch of `total_rows`: forward in training mode on these rows' statistics,

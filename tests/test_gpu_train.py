@@ -243,3 +243,31 @@ def test_trainer2d_data_parallel(dev, tmp_path):
     for k in ("linears.1.running_var", "linears.22.running_var"):
         assert float(np.abs(g["sd/" + k] - o.sd[k].numpy()).max()) < 1e-4, k
     assert int(g["sd/linears.1.num_batches_tracked"]) == 2
+
+
+def test_trainer2d_grouped_encoders(dev):
+    """The time encoder on its 15 distinct inputs and the object encoder once per sample (dgdm_trainer2d_set_groups) give the step
+    every-row evaluation gives: same loss and predictions to float32 rounding, gradients within the summation-order noise (the two
+    encoders' gradients are summed per group first), and the object hint is ignored when the rows are no multiple of the run."""
+    from dynamics.trainer import Trainer
+    n_g, n_p = 5, 40
+    sd = util.dyn2d_sd(41, 100)
+    data = util.train2d_data(9, n_g, n_p)
+    res = []
+    for grouped, rps in ((False, None), (True, None), (True, n_p), (True, 7)):
+        t = Trainer(_args(0.0))
+        t.create_model(state_dict=sd)
+        t.group_encoders = grouped
+        torch.manual_seed(5)
+        loss, pred = t.step(*data, rows_per_sample=rps)
+        torch.manual_seed(6)
+        pi, li = t.inference(*data, rows_per_sample=rps)
+        res.append((loss, pred.cpu(), t.gradients(), pi.cpu(), li))
+    base = res[0]
+    for loss, pred, grads, pi, li in res[1:]:
+        assert abs(loss / base[0] - 1) < 1e-6 and util.rel_l2(pred, base[1]) < 1e-6
+        assert abs(li / base[4] - 1) < 1e-4 and util.rel_l2(pi, base[3]) < 1e-4          # after one Adam step on gradients that differ by rounding
+        for k, ref in base[2].items():
+            if k not in BN_FED_BIAS:
+                assert util.rel_l2(grads[k], ref) < (2e-4 if "encoder" in k else 2e-5), (k, util.rel_l2(grads[k], ref))
+    assert all(torch.equal(res[1][2][k], res[3][2][k]) for k in res[1][2])          # rows_per_sample = 7 does not divide 200 rows: ignored
