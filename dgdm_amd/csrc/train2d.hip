@@ -912,7 +912,7 @@ extern "C" int dgdm_trainer2d_step(DgdmTrainer2d *m, const float *ctrl_dev, cons
                                    const float *score_dev, int64_t rows, float lr, int train, float *pred_dev, float *loss_host, void *stream) {
     DGDM_REQUIRE(m && ctrl_dev && t_dev && ori_dev && pos_dev && object_dev && score_dev && pred_dev, DGDM_EINVAL, "dgdm_trainer2d_step: null argument");
     DGDM_REQUIRE(!noise_dev || (sqrt_abar_dev && sqrt_1m_abar_dev), DGDM_EINVAL, "dgdm_trainer2d_step: noise without its two scale vectors");
-    DGDM_REQUIRE(rows >= 2 && rows < ((int64_t)1 << 31) / 800, DGDM_EINVAL,
+    DGDM_REQUIRE(rows >= (train ? 2 : 1) && rows < ((int64_t)1 << 31) / 800, DGDM_EINVAL,
                  "dgdm_trainer2d_step: %lld rows (BatchNorm1d in training mode needs at least 2; the workspace index math stops at 2^31/800)", (long long)rows);
     return m->run(ctrl_dev, noise_dev, sqrt_abar_dev, sqrt_1m_abar_dev, t_dev, ori_dev, pos_dev, object_dev, score_dev, rows, rows, lr, train, true,
                   pred_dev, loss_host, (hipStream_t)stream);

@@ -163,6 +163,12 @@ def test_trainer2d_checkpoint_round_trip(dev, tmp_path):
     m.load_state_dict({k[len("module."):]: v for k, v in ck.items()})
     out = m.to(dev)(noisy.to(dev), data[2].to(dev), data[3].to(dev), (ts.float() / 15).to(dev), data[4].to(dev))
     assert util.rel_l2(out.cpu(), pred.cpu()) < 2e-5
+    # a single row: fine in eval mode, refused in training mode as nn.BatchNorm1d refuses it
+    one = [d[:1] for d in data]
+    p1, _ = t.inference(*one)
+    assert p1.shape == (1, 3) and bool(torch.isfinite(p1).all())
+    with pytest.raises(Exception):
+        t.step(*one)
 
 
 def test_training_driver_end_to_end(dev, tmp_path):
