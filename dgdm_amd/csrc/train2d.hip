@@ -29,6 +29,7 @@
 #include <memory>
 #include <map>
 #include <string>
+#include <type_traits>
 
 namespace dgdm {
 namespace {
@@ -61,6 +62,7 @@ struct GemmArgs {
     int64_t ldy;
     const float *m0, *m2;   // MASK_RELU_BN: z = m0*Yp + m2
     int mask;
+    int64_t p_bytes, q_bytes, c_bytes, y_bytes;     // extents of the tensors behind P, Q, C, Yp (set by the launcher)
 };
 
 __device__ __forceinline__ float silu(float z) { return z / (1.f + expf(-z)); }
@@ -91,6 +93,32 @@ __device__ __forceinline__ float4 xf4(float4 a, float4 b, float4 c0, float4 c1, 
 }
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
+// Memory access of tgemm_kernel goes through buffer descriptors: the float32 MFMA runs at the vector-ALU rate and does not overlap
+// with other VALU work (scripts/micro/mfma_dep.hip: every filler instruction beside v_mfma_f32_32x32x2_f32 adds its full 4-16
+// cycles), so every 64-bit address computation, bounds compare and select in the loop is time taken from the matrix pipe.  With a
+// descriptor the tile / chunk offset moves the BASE (scalar ALU, a window of the tensor from there to its end), the thread's part
+// is one constant 32-bit VGPR offset, and the hardware's range check returns 0 for (drops stores to) anything past the tensor's end.
+__device__ void llvm_amdgcn_raw_buffer_store_f32(float data, wrsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
+__device__ float llvm_amdgcn_raw_buffer_load_f32(wrsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+constexpr int OOB = (int)0x80000000;       // a voffset no window reaches
+
+// window of the tensor at `base` ([.., bytes)) starting `off` bytes in; base, off, bytes wave-uniform
+__device__ __forceinline__ wrsrc_t window(const float *base, int64_t off, int64_t bytes) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base) + (uint64_t)off;
+    int64_t rem = bytes - off;
+    rem = rem < 0 ? 0 : (rem > 0x7fffffffLL ? 0x7fffffffLL : rem);
+    wrsrc_t rs;
+    rs.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    rs.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)((a >> 32) & 0xffffu));
+    rs.z = __builtin_amdgcn_readfirstlane((int)rem);
+    rs.w = 0x00020000;
+    return rs;
+}
+__device__ __forceinline__ float4 bload4(wrsrc_t rs, int voff) {
+    const v4f32 v = llvm_amdgcn_raw_buffer_load_v4f32(rs, voff, 0, 0);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 template <bool PTRANS, int EPI, int PX, int QX, int MASK>
 __global__ __launch_bounds__(256, 2) void tgemm_kernel(const GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float sP[RC][TI];
@@ -110,50 +138,62 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const GemmArgs g) {
     }
 
     // ---- loaders.  P transposed source: thread = (tile row px, float4 slots prq, prq + 2 along r); P / Q direct source:
-    // thread = (float4 column, rows prr + 8u / qrr + 4u of the chunk)
+    // thread = (float4 column, rows prr + 8u / qrr + 4u of the chunk).  Per-thread byte offsets inside the chunk's window:
     const int px = tid & 127, prq = tid >> 7, px4 = tid & 31, prr = tid >> 5, qx4 = tid & 63, qrr = tid >> 6;
-    const int64_t prow = i0 + px, pcol = i0 + 4 * px4;
-    const int qcol = j0 + 4 * qx4;
-    const bool pval = PTRANS ? prow < g.I : pcol < g.I, qval = qcol < g.J;
-    const int64_t pbase = PTRANS ? (pval ? prow : g.I - 1) * g.P.ld : (pval ? pcol : 0);      // clamped: always a readable address
-    const int64_t qbase = qval ? qcol : 0;
+    const int pld4 = (int)g.P.ld * 4, qld4 = (int)g.Q.ld * 4;
+    const bool pcolv = PTRANS || i0 + 4 * px4 < g.I, qcolv = j0 + 4 * qx4 < g.J;
+    int pvo[PU], qvo[QU];
+#pragma unroll
+    for (int u = 0; u < PU; ++u) pvo[u] = !pcolv ? OOB : (PTRANS ? px * pld4 + 16 * (prq + 2 * u) : (prr + 8 * u) * pld4 + 16 * px4);
+#pragma unroll
+    for (int u = 0; u < QU; ++u) qvo[u] = !qcolv ? OOB : (qrr + 4 * u) * qld4 + 16 * qx4;
     float4 pc0 = zero4, pc1 = zero4, pc2 = zero4, qc0 = zero4, qc1 = zero4, qc2 = zero4;
-    if (!PTRANS && PC) { const int64_t c = pval ? pcol : 0; pc0 = ld4(g.P.c0 + c); pc2 = ld4(g.P.c2 + c); if (PX == X_AFF2) pc1 = ld4(g.P.c1 + c); }
-    if (QC) { qc0 = ld4(g.Q.c0 + qbase); qc2 = ld4(g.Q.c2 + qbase); if (QX == X_AFF2) qc1 = ld4(g.Q.c1 + qbase); }
+    if (!PTRANS && PC) { const int64_t c = pcolv ? i0 + 4 * px4 : 0; pc0 = ld4(g.P.c0 + c); pc2 = ld4(g.P.c2 + c); if (PX == X_AFF2) pc1 = ld4(g.P.c1 + c); }
+    if (QC) { const int c = qcolv ? j0 + 4 * qx4 : 0; qc0 = ld4(g.Q.c0 + c); qc2 = ld4(g.Q.c2 + c); if (QX == X_AFF2) qc1 = ld4(g.Q.c1 + c); }
     float4 pa[PU], pb[PU], qa[QU], qb[QU];
     float4 qsum = zero4;
 
     auto issue = [&](int64_t r) {
+        const int64_t poff = (PTRANS ? i0 * g.P.ld + r : r * g.P.ld + i0) * 4, qoff = (r * g.Q.ld + j0) * 4;
+        const wrsrc_t rp0 = window(g.P.t0, poff, g.p_bytes), rq0 = window(g.Q.t0, qoff, g.q_bytes);
 #pragma unroll
-        for (int u = 0; u < PU; ++u) {
-            const int64_t o = PTRANS ? pbase + r + 4 * (prq + 2 * u) : min(r + prr + 8 * u, rend - 1) * g.P.ld + pbase;
-            pa[u] = ld4(g.P.t0 + o);
-            if (PX == X_AFF2) pb[u] = ld4(g.P.t1 + o);
+        for (int u = 0; u < PU; ++u) pa[u] = bload4(rp0, pvo[u]);
+        if (PX == X_AFF2) {
+            const wrsrc_t rp1 = window(g.P.t1, poff, g.p_bytes);
+#pragma unroll
+            for (int u = 0; u < PU; ++u) pb[u] = bload4(rp1, pvo[u]);
         }
 #pragma unroll
-        for (int u = 0; u < QU; ++u) {
-            const int64_t o = min(r + qrr + 4 * u, rend - 1) * g.Q.ld + qbase;
-            qa[u] = ld4(g.Q.t0 + o);
-            if (QX == X_AFF2) qb[u] = ld4(g.Q.t1 + o);
+        for (int u = 0; u < QU; ++u) qa[u] = bload4(rq0, qvo[u]);
+        if (QX == X_AFF2) {
+            const wrsrc_t rq1 = window(g.Q.t1, qoff, g.q_bytes);
+#pragma unroll
+            for (int u = 0; u < QU; ++u) qb[u] = bload4(rq1, qvo[u]);
         }
     };
-    auto commit = [&](int64_t r) {
+    // Rows past the end of a contraction over rows (weight gradient: the last chunk of the last split) read as 0 but do not TRANSFORM
+    // to 0; `tail` = that chunk: there the Q rows are zeroed by hand.  Elsewhere (forward / input gradient) rows past the tensor's end
+    // only feed output rows that are never stored.
+    const bool bias_sums = EPI == EPI_WGRAD && blockIdx.x == 0;      // only the first i tile of a split takes the column sums of Q
+    auto commit = [&](int64_t r, auto tail_c) {
+        constexpr bool tail = decltype(tail_c)::value;
 #pragma unroll
         for (int u = 0; u < PU; ++u) {
             if (PTRANS) {
                 const int r4 = prq + 2 * u;
                 if (PC) { const int c = (int)r + 4 * r4; pc0 = ld4(&sC[0][c]); pc2 = ld4(&sC[2][c]); if (PX == X_AFF2) pc1 = ld4(&sC[1][c]); }
-                const float4 v = xf4<PX>(pa[u], pb[u], pc0, pc1, pc2, pval);
+                const float4 v = xf4<PX>(pa[u], pb[u], pc0, pc1, pc2, true);
                 sP[4 * r4 + 0][px] = v.x; sP[4 * r4 + 1][px] = v.y; sP[4 * r4 + 2][px] = v.z; sP[4 * r4 + 3][px] = v.w;
             } else {
-                *reinterpret_cast<float4 *>(&sP[prr + 8 * u][4 * px4]) = xf4<PX>(pa[u], pb[u], pc0, pc1, pc2, pval && r + prr + 8 * u < rend);
+                *reinterpret_cast<float4 *>(&sP[prr + 8 * u][4 * px4]) = xf4<PX>(pa[u], pb[u], pc0, pc1, pc2, true);
             }
         }
 #pragma unroll
         for (int u = 0; u < QU; ++u) {
-            const float4 v = xf4<QX>(qa[u], qb[u], qc0, qc1, qc2, qval && r + qrr + 4 * u < rend);
+            float4 v = xf4<QX>(qa[u], qb[u], qc0, qc1, qc2, true);
+            if (EPI == EPI_WGRAD && tail && (QX != X_PLAIN || PX != X_PLAIN) && r + qrr + 4 * u >= rend) v = zero4;
             *reinterpret_cast<float4 *>(&sQ[qrr + 4 * u][4 * qx4]) = v;
-            if (EPI == EPI_WGRAD) { qsum.x += v.x; qsum.y += v.y; qsum.z += v.z; qsum.w += v.w; }
+            if (bias_sums) { qsum.x += v.x; qsum.y += v.y; qsum.z += v.z; qsum.w += v.w; }
         }
     };
 
@@ -168,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const GemmArgs g) {
     if (rbeg < rend) issue(rbeg);
     for (int64_t r = rbeg; r < rend; r += RC) {
         __syncthreads();
-        commit(r);
+        if (r + RC > rend) commit(r, std::true_type{}); else commit(r, std::false_type{});
         __syncthreads();
         if (r + RC < rend) issue(r + RC);
 #pragma unroll
@@ -210,54 +250,65 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const GemmArgs g) {
         }
         return;
     }
+    // forward / input gradient: the wave's 64 x 128 block, one output row (two half-rows of 32 lanes) per descriptor window
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    int jc[4];
-    bool jv[4];
     float bj[4], m0[4], m2[4];
+    const bool colv = j0 + 128 * wj + n + 96 < g.J || g.J % TJ == 0;       // J is a multiple of 256 for every caller; kept general
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const int j = j0 + 128 * wj + 32 * u + n;
-        jv[u] = j < g.J;
-        jc[u] = jv[u] ? j : 0;
-        bj[u] = EPI == EPI_FWD ? g.bias[jc[u]] : 0.f;
-        m0[u] = MASK == MASK_RELU_BN ? g.m0[jc[u]] : 1.f;
-        m2[u] = MASK == MASK_RELU_BN ? g.m2[jc[u]] : 0.f;
+        const int j = min(j0 + 128 * wj + 32 * u + n, g.J - 1);
+        bj[u] = EPI == EPI_FWD ? g.bias[j] : 0.f;
+        m0[u] = MASK == MASK_RELU_BN ? g.m0[j] : 1.f;
+        m2[u] = MASK == MASK_RELU_BN ? g.m2[j] : 0.f;
     }
+    const int ldc4 = (int)g.ldc * 4, ldy4 = (int)g.ldy * 4;
+    const int cvo = colv ? 4 * h * ldc4 + (128 * wj + n) * 4 : OOB, yvo = colv ? 4 * h * ldy4 + (128 * wj + n) * 4 : OOB;
+    // FULL: every row of the tile exists - no per-row predicate on the column statistics (all but the last row tile)
+    auto body = [&](auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        // one half of the wave's rows at a time: its 64 loads of the layer below are issued together (clamped addresses), then consumed
-        float y[16][4];
-        if (EPI == EPI_BWD && MASK != MASK_NONE) {
+        for (int sq = 0; sq < 4; ++sq) {
+            // half of a 32-row group at a time: its 32 loads of the layer below are issued together, then consumed
+            const int s = sq >> 1, qb = (sq & 1) * 8;
+            float y[8][4];
+            if (EPI == EPI_BWD && MASK != MASK_NONE) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int64_t i = min(i0 + 64 * wi + 32 * s + (q & 3) + 8 * (q >> 2) + 4 * h, g.I - 1);
+                for (int q = 0; q < 8; ++q) {
+                    const int64_t row = i0 + 64 * wi + 32 * s + ((qb + q) & 3) + 8 * ((qb + q) >> 2);       // + 4h in the lane's offset
+                    const wrsrc_t ry = window(g.Yp, (row * g.ldy + j0) * 4, g.y_bytes);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) y[q][u] = g.Yp[i * g.ldy + jc[u]];
+                    for (int u = 0; u < 4; ++u) y[q][u] = llvm_amdgcn_raw_buffer_load_f32(ry, yvo + 128 * u, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-        }
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int64_t i = i0 + 64 * wi + 32 * s + (q & 3) + 8 * (q >> 2) + 4 * h;
+            for (int q = 0; q < 8; ++q) {
+                const int64_t row = i0 + 64 * wi + 32 * s + ((qb + q) & 3) + 8 * ((qb + q) >> 2);
+                const wrsrc_t rc = window(g.C, (row * g.ldc + j0) * 4, g.c_bytes);
+                const bool rowv = FULL || row + 4 * h < g.I;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (!(jv[u] && i < g.I)) continue;
-                if (EPI == EPI_FWD) {
-                    const float v = acc[s][u][q] + bj[u];
-                    g.C[i * g.ldc + jc[u]] = v;
-                    s1[u] += v;
-                    s2[u] = fmaf(v, v, s2[u]);
-                } else {
-                    float v = acc[s][u][q];
-                    if (MASK == MASK_RELU) v = y[q][u] > 0.f ? v : 0.f;
-                    else if (MASK == MASK_SILU) v *= silu_grad(y[q][u]);
-                    else if (MASK == MASK_RELU_BN) { v = bn_pre(m0[u], y[q][u], m2[u]) > 0.f ? v : 0.f; s1[u] += v; s2[u] = fmaf(v, y[q][u], s2[u]); }
-                    g.C[i * g.ldc + jc[u]] = v;
+                for (int u = 0; u < 4; ++u) {
+                    const float a = s == 0 ? acc[0][u][qb + q] : acc[1][u][qb + q];
+                    float v;
+                    if (EPI == EPI_FWD) {
+                        v = a + bj[u];
+                        if (rowv) { s1[u] += v; s2[u] = fmaf(v, v, s2[u]); }
+                    } else {
+                        v = a;
+                        if (MASK == MASK_RELU) v = y[q][u] > 0.f ? v : 0.f;
+                        else if (MASK == MASK_SILU) v *= silu_grad(y[q][u]);
+                        else if (MASK == MASK_RELU_BN) {
+                            v = bn_pre(m0[u], y[q][u], m2[u]) > 0.f ? v : 0.f;
+                            if (rowv) { s1[u] += v; s2[u] = fmaf(v, y[q][u], s2[u]); }
+                        }
+                    }
+                    llvm_amdgcn_raw_buffer_store_f32(v, rc, cvo + 128 * u, 0, 0);
                 }
             }
+            if (EPI == EPI_BWD && MASK != MASK_NONE) __builtin_amdgcn_sched_barrier(0);
         }
-        if (EPI == EPI_BWD && MASK != MASK_NONE) __builtin_amdgcn_sched_barrier(0);
-    }
+    };
+    if (i0 + TI <= g.I) body(std::true_type{}); else body(std::false_type{});
     if (g.stats) {       // per-workgroup column sums: both half-waves, then the two waves stacked along i
         __syncthreads();
         float *red = &sP[0][0];     // [wi][2][256]
@@ -609,6 +660,12 @@ int DgdmTrainer2d::gemm(bool ptrans, int epi, GemmArgs &g, hipStream_t s) const 
     const int jt = (g.J + TJ - 1) / TJ;
     const int64_t splits = (g.R + g.r_per_split - 1) / g.r_per_split;
     const dim3 grid((unsigned)it, (unsigned)jt, (unsigned)splits), block(256);
+    // bytes from each tensor's first element to the end of its last row's used columns: what the kernel's descriptor windows end at
+    g.p_bytes = (ptrans ? (g.I - 1) * g.P.ld + g.R : (g.R - 1) * g.P.ld + g.I) * 4;
+    g.q_bytes = ((g.R - 1) * g.Q.ld + g.J) * 4;
+    g.c_bytes = epi == EPI_WGRAD ? 0 : ((g.I - 1) * g.ldc + g.J) * 4;
+    g.y_bytes = g.Yp ? ((g.I - 1) * g.ldy + g.J) * 4 : 0;
+    DGDM_REQUIRE(g.P.ld * 4 * 136 < 0x7fffffffLL && g.Q.ld * 4 * 36 < 0x7fffffffLL && g.ldc * 4 * 136 < 0x7fffffffLL, DGDM_EINVAL, "train2d gemm: row pitch too large");
     const int key = epi * 1000 + g.P.xf * 100 + g.Q.xf * 10 + g.mask;
     DGDM_REQUIRE(!ptrans || g.R <= 256 || g.P.xf == X_PLAIN, DGDM_EINVAL, "train2d gemm: transposed operand with coefficients wider than 256");
 #define DGDM_TG(PT, E, PXV, QXV, MK) hipLaunchKernelGGL((tgemm_kernel<PT, E, PXV, QXV, MK>), grid, block, 0, s, g)
