@@ -56,8 +56,6 @@ class Trainer(object):
         if self.fingers_3d:
             raise NotImplementedError("training the 3-D dynamics model (PointNet++ weight gradients) is not part of the HIP path; "
                                       "2-D (ProfileForward2DModel) is")
-        if self.use_sub_batch:
-            raise NotImplementedError("--use_sub_batch is the 3-D training configuration (dynamics/train_dynamics_3d.sh)")
         self.gripperpts_dim = args.ctrlpts_dim
         self.object_vertices_dim = 2 * args.object_max_num_vertices
         self.num_timesteps_per_batch = args.num_timesteps_per_batch
@@ -103,16 +101,20 @@ class Trainer(object):
         self._h = None
 
     # ------------------------------------------------------------------ one batch
-    def _inputs(self, ctrl, score, input_ori, input_pos, object_vertices):
+    def _draw(self, rows: int):
+        """The reference's draws, in its order, from the CPU generator (trainer.py:68-74)."""
+        noise = torch.randn((rows * self.num_timesteps_per_batch, self.gripperpts_dim))
+        timesteps = torch.randint(0, self.noise_scheduler.config.num_train_timesteps, (rows,)).long()
+        return noise, timesteps
+
+    def _inputs(self, ctrl, score, input_ori, input_pos, object_vertices, drawn=None):
         dev = torch.device("cuda", torch.cuda.current_device())
         n = self.num_timesteps_per_batch
         f = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()       # noqa: E731
         ctrl_all, obj_all = f(ctrl.repeat(n, 1)), f(object_vertices.repeat(n, 1))
         ori_all, pos_all, score_all = f(input_ori.repeat(n, 1)), f(input_pos.repeat(n, 1)), f(score.repeat(n, 1))
         rows = ctrl_all.shape[0]
-        # the reference's draws, in its order, from the CPU generator (trainer.py:68-74)
-        noise = torch.randn((rows * n, self.gripperpts_dim))
-        timesteps = torch.randint(0, self.noise_scheduler.config.num_train_timesteps, (rows,)).long()
+        noise, timesteps = drawn if drawn is not None else self._draw(rows)
         ac = self.noise_scheduler.alphas_cumprod[timesteps]
         sa, sb = f(ac ** 0.5), f((1 - ac) ** 0.5)                                       # DDIMScheduler.add_noise (diffusers 0.11.1)
         T = self.noise_scheduler.config.num_train_timesteps
@@ -133,11 +135,11 @@ class Trainer(object):
             g.rows_per_object = int(rows_per_sample)
         check(lib().dgdm_trainer2d_set_groups(self._h, C.byref(g)))
 
-    def _run(self, ctrl, score, input_ori, input_pos, object_vertices, train: bool, rows_per_sample: Optional[int] = None):
+    def _run(self, ctrl, score, input_ori, input_pos, object_vertices, train: bool, rows_per_sample: Optional[int] = None, drawn=None):
         if self._h is None:
             raise RuntimeError("Trainer.create_model() has not been called")
         world, rank = _dist.world_rank()
-        c, nz, sa, sb, t, o, p, ob, sc, rows = self._inputs(ctrl, score, input_ori, input_pos, object_vertices)
+        c, nz, sa, sb, t, o, p, ob, sc, rows = self._inputs(ctrl, score, input_ori, input_pos, object_vertices, drawn)
         lr = float(self.optimizer.param_groups[0]["lr"])
         loss = C.c_float()
         if world == 1:
@@ -184,7 +186,18 @@ class Trainer(object):
         """trainer.py:53-103: returns (loss.item(), pred.detach()).  rows_per_sample (not in the reference): the caller's promise that
         `object_vertices` holds runs of that many identical rows - dynamics/main.py builds its batches so - which lets the object
         encoder run once per sample."""
-        return self._run(ctrl, score, input_ori, input_pos, object_vertices, True, rows_per_sample)
+        if not self.use_sub_batch:
+            return self._run(ctrl, score, input_ori, input_pos, object_vertices, True, rows_per_sample)
+        # --use_sub_batch (trainer.py:81-94): the draws once for the whole batch, then one optimizer step per slice of sub_bs rows;
+        # returns the mean of the slices' losses (as the reference weighs them) and all predictions
+        losses, preds, n = [], [], ctrl.shape[0]
+        noise, timesteps = self._draw(n)
+        for i in range(0, n, self.sub_batch_size):
+            sl = slice(i, i + self.sub_batch_size)
+            loss, pred = self._run(ctrl[sl], score[sl], input_ori[sl], input_pos[sl], object_vertices[sl], True, None, (noise[sl], timesteps[sl]))
+            losses.append(loss)
+            preds.append(pred)
+        return sum(losses) / (n / self.sub_batch_size), torch.cat(preds, dim=0)
 
     def inference(self, ctrl, score, input_ori=None, input_pos=None, object_vertices=None, rows_per_sample: Optional[int] = None):
         """trainer.py:108-146 (eval mode, no update): returns (pred, loss)."""

@@ -277,3 +277,28 @@ def test_trainer2d_grouped_encoders(dev):
             if k not in BN_FED_BIAS:
                 assert util.rel_l2(grads[k], ref) < (2e-4 if "encoder" in k else 2e-5), (k, util.rel_l2(grads[k], ref))
     assert all(torch.equal(res[1][2][k], res[3][2][k]) for k in res[1][2])          # rows_per_sample = 7 does not divide 200 rows: ignored
+
+
+def test_trainer2d_sub_batches(dev):
+    """--use_sub_batch (trainer.py:81-94): the draws once for the whole batch, one optimizer step per slice; equals stepping a plain
+    trainer slice by slice with the same draws, and returns the reference's loss average."""
+    from dynamics.trainer import Trainer
+    sd = util.dyn2d_sd(41, 100)
+    data = util.train2d_data(9, 3, 40)           # 120 rows, slices of 50, 50, 20
+    a = _args(0.0)
+    a.use_sub_batch, a.sub_bs = True, 50
+    t = Trainer(a)
+    t.create_model(state_dict=sd)
+    torch.manual_seed(3)
+    loss, pred = t.step(*data)
+    ref = Trainer(_args(0.0))
+    ref.create_model(state_dict=sd)
+    torch.manual_seed(3)
+    noise, ts = ref._draw(120)
+    losses, preds = [], []
+    for i in range(0, 120, 50):
+        l, p = ref._run(*[d[i:i + 50] for d in (data[0], data[1], data[2], data[3], data[4])], True, None, (noise[i:i + 50], ts[i:i + 50]))
+        losses.append(l)
+        preds.append(p)
+    assert torch.equal(pred, torch.cat(preds)) and abs(loss - sum(losses) / (120 / 50)) < 1e-7
+    assert all(torch.equal(v, ref.state_dict()[k]) for k, v in t.state_dict().items())
