@@ -20,4 +20,18 @@ struct Blob {
     const float4 *at4(size_t off) const { return reinterpret_cast<const float4 *>(dev.as<float>() + off); }
 };
 
+// The float64 weights of the stages that run in double precision (see Folded64): same idea, offsets in doubles.
+struct Blob64 {
+    std::vector<double> host;
+    DevBuf dev;
+    size_t add(const std::vector<double> &v) {
+        size_t off = (host.size() + 31) & ~size_t(31);
+        host.resize(off + v.size());
+        for (size_t i = 0; i < v.size(); ++i) host[off + i] = v[i];
+        return off;
+    }
+    int upload() { host.resize((host.size() + 31) & ~size_t(31)); return dev.upload(host.data(), host.size() * sizeof(double)); }
+    const double *at(size_t off) const { return dev.as<double>() + off; }
+};
+
 }  // namespace dgdm

@@ -74,6 +74,19 @@ struct Folded {
 };
 int fold_linear(const StateDict &sd, const std::string &lin, const std::string &bn /* "" = none */, int out, int in,
                 Folded *dst);
+// The same fold kept in double precision (nothing rounded to float32): weights of the stages that run in float64 because they are
+// evaluated once per object / per finger instead of once per replicated row
+struct Folded64 {
+    int out = 0, in = 0;
+    std::vector<double> w;  // [out][in]
+    std::vector<double> b;  // [out]
+};
+int fold_linear64(const StateDict &sd, const std::string &lin, const std::string &bn /* "" = none */, int out, int in, Folded64 *dst);
+std::vector<double> transpose64(const double *src, int rows, int cols);   // -> [cols][rows]
+// A-operand image of W [M][K] (row-major doubles, M a multiple of 32, K of 4) for v_mfma_f64_16x16x4_f64 (pointnet64.hip):
+//   entry e = ks * (M/32) + mp, lane (m = l & 15, kq = l >> 4), slot j in {0, 1}  =  W[f(2 mp + j, m)][kq * (K/4) + ks],
+//   f(mt, m) = 16 mt + 4 (m & 3) + (m >> 2)   (so that lane group rb of the C/D layout holds four CONSECUTIVE features)
+std::vector<double> pack_mfma64(const double *src, int M, int K);
 
 // ---- MFMA-chain weight image (see mfma_chain.h).  src is [M][K] row-major, M,K multiples of 32.
 //   img[((op*KB + o)*4 + q)*64 + lane][0..3] = src[32 op + (lane&31)][32 o + 8 q + 4 (lane>>5) + 0..3]

@@ -49,7 +49,7 @@ struct DgdmGuidance {
     int64_t R = 0, Rs = 0;                       // rows per chain: cond_fn grid, orientation sweep
     DevBuf ptab, ptab_sweep;                     // [C][W1], [G][W1]
     DevBuf ptab_t, ptab_sweep_t;                 // the same tables tiled for the trunk kernels (smallnet.h tile_table)
-    DevBuf objpart;                              // 2-D: [max_objects][W1]
+    DevBuf objpart;                              // 2-D: [max_objects][W1] doubles
     std::vector<std::unique_ptr<ObjectTables>> tables;   // 3-D
     bool bf16 = false;                           // contractions of the trunk on bf16 MFMA (dgdm_guidance_set_contraction_dtype)
     static constexpr int NBUILD = 3;             // objects whose tables are built concurrently (own stream + temporaries each)
@@ -57,7 +57,9 @@ struct DgdmGuidance {
     DevBuf tmpF1[NBUILD], tmpU[NBUILD], tmpY[NBUILD], tmpL2[NBUILD], tmpOff[NBUILD], tmpPairs[NBUILD], tmpRank[NBUILD], vlist;      // 3-D table-build temporaries
     hipStream_t bstream[NBUILD] = {nullptr, nullptr, nullptr}, fstream = nullptr;    // fstream: sa2's FPS table, beside the builds
     hipEvent_t bev[NBUILD] = {nullptr, nullptr, nullptr}, bstart = nullptr, fstart = nullptr, fdone = nullptr;
-    DevBuf V, genc, atab, chainbias, timepart, ttmp, partial, objdev, objidx, xobj, xobj16, starts, order, xchains, todo, groupoff;
+    // V, genc, chainbias, timepart: float64 (smallnet.h linear64: per-finger / per-chain quantities are evaluated in double precision,
+    // so the A table carries one float32 rounding); ttmp64: scratch of the time encoder
+    DevBuf V, genc, atab, chainbias, timepart, ttmp, ttmp64, partial, objdev, objidx, xobj, xobj16, starts, order, xchains, todo, groupoff;
     DevBuf loopx[2], loopeps, loopgrad, loopxrep, loopts;      // workspace of dgdm_guided_chains_run
     DevBuf xidx, xidxchains, xtabptrs;       // embedding-table path: row index per reference row, per-chain lookup info, per-chain table base pointers
     bool xtab_enabled = true;       // test hook: modes 1-3 read materialised rows (per-step gather kernels) instead of the embedding table
@@ -100,7 +102,7 @@ int DgdmGuidance::build_pose_table(const std::vector<float> &ori, const std::vec
     if ((rc = d_emb.alloc(sizeof(float) * 27 * n))) return rc;
     if ((rc = dst->alloc(sizeof(float) * (size_t)W1 * n))) return rc;
     if ((rc = pose_embed(d_ori.as<float>(), d_pos.as<float>(), d_emb.as<float>(), n, s))) return rc;
-    if ((rc = linear(d_emb.as<float>(), 27, m->blob.at(m->off.w1p_wt), nullptr, nullptr, 1, dst->as<float>(), W1, n, 27, W1, ACT_NONE, false, s))) return rc;
+    if ((rc = linear64(d_emb.as<float>(), nullptr, 27, m->blob64.at(m->off64.w1p_wt), nullptr, nullptr, 1, nullptr, dst->as<float>(), W1, n, 27, W1, ACT_NONE, s))) return rc;
     if ((rc = dst_tiled->alloc(sizeof(float) * (size_t)W1 * ((n + 31) / 32) * 32))) return rc;
     if ((rc = tile_table(dst->as<float>(), n, W1, dst_tiled->as<float>(), s))) return rc;
     DGDM_HIP_CHECK(hipStreamSynchronize(s));     // temporaries die here
@@ -140,13 +142,14 @@ extern "C" int dgdm_guidance_create(DgdmGuidance **out, DgdmDynamics *model, con
     if ((rc = g->build_pose_table(lo, pos0, &g->ptab_sweep, &g->ptab_sweep_t, nullptr))) return rc;
     const int W1 = model->W1, nc = cfg->max_chains;
     const size_t rows = (size_t)nc * g->B;
-    if ((rc = g->V.alloc(rows * 256 * 4)) || (rc = g->genc.alloc(rows * 256 * 4)) || (rc = g->atab.alloc(rows * W1 * 4)) ||
-        (rc = g->chainbias.alloc((size_t)nc * W1 * 4)) || (rc = g->timepart.alloc((size_t)W1 * 4)) || (rc = g->ttmp.alloc(768 * 4)) ||
+    if ((rc = g->V.alloc(rows * 256 * 8)) || (rc = g->genc.alloc(rows * 256 * 8)) || (rc = g->atab.alloc(rows * W1 * 4)) ||
+        (rc = g->chainbias.alloc((size_t)nc * W1 * 8)) || (rc = g->timepart.alloc((size_t)W1 * 8)) || (rc = g->ttmp.alloc(768 * 4)) ||
+        (rc = g->ttmp64.alloc(512 * 8)) ||
         (rc = g->partial.alloc(rows * g->tiles_per_b * W1 * 4)) || (rc = g->objdev.alloc(sizeof(TrunkObjective) * nc)) ||
         (rc = g->objidx.alloc(sizeof(int) * nc)))
         return rc;
     if (model->kind == 2) {
-        if ((rc = g->objpart.alloc((size_t)std::max(1, cfg->max_objects) * W1 * 4))) return rc;
+        if ((rc = g->objpart.alloc((size_t)std::max(1, cfg->max_objects) * W1 * 8))) return rc;
     } else {
         if ((rc = g->xobj.alloc((size_t)nc * g->R * 256 * 4)) || (rc = g->starts.alloc((size_t)nc * g->R * 2 * sizeof(int))) ||
             (rc = g->order.alloc((size_t)nc * g->R * sizeof(int))) || (rc = g->xchains.alloc(sizeof(XobjChain) * nc)) ||
@@ -213,25 +216,35 @@ int DgdmGuidance::build_object(int oi, int slot, hipStream_t s) {
     if (bf16 && ((rc = t.Z16.alloc((size_t)N * N * 128 * 4)) || (rc = t.M0_16.alloc((size_t)N * 128 * 4)))) return rc;
     uint32_t *z16 = bf16 ? t.Z16.as<uint32_t>() : nullptr;
     DevBuf &tF1 = tmpF1[slot], &tU = tmpU[slot], &tY = tmpY[slot], &tL2 = tmpL2[slot];
-    if ((rc = tF1.alloc((size_t)N * 128 * 4)) || (rc = tU.alloc((size_t)N * 128 * 4)) || (rc = tY.alloc((size_t)N * N * 256 * 4)) ||
+    if ((rc = tF1.alloc((size_t)N * 128 * 8)) || (rc = tU.alloc((size_t)N * 128 * 8)) || (rc = tY.alloc((size_t)N * N * 256 * 4)) ||
         (rc = tL2.alloc((size_t)N * N * 256 * 4)))
         return rc;
     const float *xyz = t.xyz;                                                                                  // T1: set_objects, batched
-    if ((rc = pn_sa1(xyz, N, w, tF1.as<float>(), s))) return rc;                                               // T2
-    if ((rc = linear(tF1.as<float>(), 128, w.sa2_wf_t, w.sa2_b0, nullptr, 1, tU.as<float>(), 128, N, 128, 128, ACT_NONE, false, s))) return rc;  // T3
     DevBuf &tOff = tmpOff[slot], &tPairs = tmpPairs[slot], &tRank = tmpRank[slot];
     if ((rc = tOff.alloc((size_t)(N + 1) * sizeof(int))) || (rc = tPairs.alloc((size_t)N * N * sizeof(int))) || (rc = tRank.alloc((size_t)N * N * sizeof(short))))
         return rc;
     if ((rc = pn_crowd(xyz, N, w, t.crowded.as<int>(), t.clist.as<int>(), t.clist.as<int>() + N, tOff.as<int>(), tPairs.as<int>(), tRank.as<short>(), s,
                        pool_ncr.as<int>() + oi))) return rc;
-    // bf16 mode: the sa3 contraction (T6) runs on the bf16 matrix pipe and rounds its input, so T4 writes and T5 reduces bf16
-    // rows (the temporaries tY / tL2 are simply used at half size); float32 mode: everything float32
-    if ((rc = pn_pairs(xyz, N, tU.as<float>(), w, tPairs.as<int>(), tOff.as<int>(), tY.as<float>(), bf16 ? tY.as<uint32_t>() : nullptr, s))) return rc;   // T4
-    if ((rc = pn_l2(xyz, N, w, t.fps1, vlist.as<int>(), N, tY.as<float>(), tL2.as<float>(), t.clist.as<int>(), t.clist.as<int>() + N,
-                    tOff.as<int>(), tRank.as<short>(), bf16, s, l2_gather_mode ? 0 : 1))) return rc;                       // T5
     if (bf16) {
+        // bf16 mode: the sa3 contraction (T6) runs on the bf16 matrix pipe and rounds its input, so T4 writes and T5 reduces bf16
+        // rows (the temporaries tY / tL2 are simply used at half size); the stages in front of it stay float32
+        if ((rc = pn_sa1(xyz, N, w, tF1.as<float>(), s))) return rc;                                               // T2
+        if ((rc = linear(tF1.as<float>(), 128, w.sa2_wf_t, w.sa2_b0, nullptr, 1, tU.as<float>(), 128, N, 128, 128, ACT_NONE, false, s))) return rc;  // T3
+        if ((rc = pn_pairs(xyz, N, tU.as<float>(), w, tPairs.as<int>(), tOff.as<int>(), tY.as<float>(), tY.as<uint32_t>(), s))) return rc;   // T4
+        if ((rc = pn_l2(xyz, N, w, t.fps1, vlist.as<int>(), N, tY.as<float>(), tL2.as<float>(), t.clist.as<int>(), t.clist.as<int>() + N,
+                        tOff.as<int>(), tRank.as<short>(), true, s, l2_gather_mode ? 0 : 1))) return rc;                   // T5
         if ((rc = pn_z16(xyz, N, N, w, tL2.as<uint32_t>(), t.Z.as<float>(), z16, t.clist.as<int>(), t.clist.as<int>() + N, s))) return rc;          // T6
-    } else if ((rc = pn_z(xyz, N, N, w, tL2.as<float>(), t.Z.as<float>(), z16, t.clist.as<int>(), t.clist.as<int>() + N, s))) return rc;
+    } else {
+        // float32 mode (the parity path): every contraction of the build accumulates in float64 and each table entry is rounded once
+        // (pointnet64.hip); the max stages (T5, T7) are exact as they are
+        const PnWeights64 w64 = m->pn64();
+        if ((rc = pn_sa1_64(xyz, N, w.r1sq, w64, tF1.as<double>(), s))) return rc;                                 // T2
+        if ((rc = linear64(nullptr, tF1.as<double>(), 128, w64.sa2_wf_t, w64.sa2_b0, nullptr, 1, tU.as<double>(), nullptr, 128, N, 128, 128, ACT_NONE, s))) return rc;  // T3
+        if ((rc = pn_pairs64(xyz, N, tU.as<double>(), w64, tPairs.as<int>(), tOff.as<int>(), tY.as<float>(), s))) return rc;                 // T4
+        if ((rc = pn_l2(xyz, N, w, t.fps1, vlist.as<int>(), N, tY.as<float>(), tL2.as<float>(), t.clist.as<int>(), t.clist.as<int>() + N,
+                        tOff.as<int>(), tRank.as<short>(), false, s, l2_gather_mode ? 0 : 1))) return rc;                  // T5
+        if ((rc = pn_z64(xyz, N, N, w64, tL2.as<float>(), t.Z.as<float>(), t.clist.as<int>(), t.clist.as<int>() + N, s))) return rc;                // T6
+    }
     DGDM_HIP_CHECK(hipStreamWaitEvent(s, fdone, 0));          // fps2 (sa2's FPS table) is built beside the other stages, on its own stream
     if ((rc = pn_m0(t.fps2, t.crowded.as<int>(), N, t.Z.as<float>(), t.M0.as<float>(), t.cl2.as<int>(), t.cnt2.as<int>(), z16,
                     bf16 ? t.M0_16.as<uint32_t>() : nullptr, t.clist.as<int>(), t.clist.as<int>() + N, t.cl2s.as<int>(), s))) return rc;          // T7
@@ -267,8 +280,8 @@ extern "C" int dgdm_guidance_set_objects(DgdmGuidance *g, const float *objects_d
     prof_begin(s, DGDM_STAGE_TABLES);
     if (g->m->kind == 2) {
         DevBuf tmp;
-        if ((rc = tmp.alloc((size_t)n_objects * 512 * 4))) return rc;
-        if ((rc = g->m->object_part_2d(objects_dev, tmp.as<float>(), g->objpart.as<float>(), n_objects, false, s))) return rc;
+        if ((rc = tmp.alloc((size_t)n_objects * 512 * 8))) return rc;
+        if ((rc = g->m->object_part_2d64(objects_dev, tmp.as<double>(), g->objpart.as<double>(), n_objects, s))) return rc;
         prof_end(s, DGDM_STAGE_TABLES, 0.0);
         DGDM_HIP_CHECK(hipStreamSynchronize(s));
     } else {
@@ -342,16 +355,18 @@ extern "C" int dgdm_guidance_set_objects(DgdmGuidance *g, const float *objects_d
 int DgdmGuidance::common_pre(const float *x_dev, float t_scaled, const int *objidx_host, int n_chains, hipStream_t s) {
     const int rows = n_chains * B, W1 = m->W1;
     int rc;
-    if ((rc = m->gripper_forward(x_dev, m->L, V.as<float>(), genc.as<float>(), rows, s))) return rc;
-    if ((rc = m->time_part(nullptr, t_scaled, ttmp.as<float>(), timepart.as<float>(), 1, s))) return rc;
+    if ((rc = m->gripper_forward64(x_dev, m->L, V.as<double>(), genc.as<double>(), rows, s))) return rc;
+    if ((rc = m->time_part64(t_scaled, ttmp.as<float>(), ttmp64.as<double>(), timepart.as<double>(), s))) return rc;
     if (m->kind == 2) {
         for (int i = 0; i < n_chains; ++i)
             DGDM_REQUIRE(objidx_host[i] >= 0 && objidx_host[i] < n_objects, DGDM_EINVAL, "chain %d refers to object %d of %d", i, objidx_host[i], n_objects);
         DGDM_HIP_CHECK(hipMemcpyAsync(objidx.p, objidx_host, sizeof(int) * n_chains, hipMemcpyHostToDevice, s));   // pageable: staged before return
-        if ((rc = gather_add(objpart.as<float>(), objidx.as<int>(), timepart.as<float>(), chainbias.as<float>(), n_chains, W1, s))) return rc;
-        return linear(genc.as<float>(), 256, m->blob.at(m->off.w1c_wt), nullptr, chainbias.as<float>(), B, atab.as<float>(), W1, rows, 256, W1, ACT_NONE, false, s);
+        if ((rc = gather_add64(objpart.as<double>(), objidx.as<int>(), timepart.as<double>(), chainbias.as<double>(), n_chains, W1, s))) return rc;
+        return linear64(nullptr, genc.as<double>(), 256, m->blob64.at(m->off64.w1c_wt), nullptr, chainbias.as<double>(), B, nullptr, atab.as<float>(), W1, rows, 256, W1,
+                        ACT_NONE, s);
     }
-    return linear(genc.as<float>(), 256, m->blob.at(m->off.w1c_wt), timepart.as<float>(), nullptr, 1, atab.as<float>(), W1, rows, 256, W1, ACT_NONE, false, s);
+    return linear64(nullptr, genc.as<double>(), 256, m->blob64.at(m->off64.w1c_wt), timepart.as<double>(), nullptr, 1, nullptr, atab.as<float>(), W1, rows, 256, W1,
+                    ACT_NONE, s);
 }
 
 // Reference draw order per chain: for each sub-batch i, sa1's torch.randint(rows_i) then sa2's  ->  device [chain][row][2]
@@ -549,8 +564,8 @@ static int guidance_grad(DgdmGuidance *g, int kind, const float *x_dev, int time
     }
 #endif
     prof_begin(s, DGDM_STAGE_GUIDE_MISC);
-    rc = dyn_post(g->m->W1, g->partial.as<float>(), g->tiles_per_b, g->m->blob.at(g->m->off.w1c_w), g->m->blob.at(g->m->off.g2_w),
-                  g->m->blob.at(g->m->off.g0_w), g->V.as<float>(), grad_dev, n_chains * g->B, g->m->L, s);
+    rc = dyn_post64(g->m->W1, g->partial.as<float>(), g->tiles_per_b, g->m->blob64.at(g->m->off64.w1c_w), g->m->blob64.at(g->m->off64.g2_w),
+                    g->m->blob64.at(g->m->off64.g0_w), g->V.as<double>(), grad_dev, n_chains * g->B, g->m->L, s);
     prof_end(s, DGDM_STAGE_GUIDE_MISC, 0.0);
     return rc;
 }
@@ -692,7 +707,8 @@ int pointnet_rows(DgdmDynamics *m, const float *xyz_dev /*[rows][3][N]*/, const 
     const PnWeights w = m->pn();
     DevBuf xyz, fps1, F1, U, Y, L2, Z, vlist, slotmap, starts, chains, out, crowded, clist, poff, pairs, prank;
     int rc;
-    if ((rc = xyz.alloc((size_t)N * 12)) || (rc = fps1.alloc((size_t)N * 512 * 4)) || (rc = F1.alloc((size_t)N * 512)) || (rc = U.alloc((size_t)N * 512)) ||
+    const PnWeights64 w64 = m->pn64();
+    if ((rc = xyz.alloc((size_t)N * 12)) || (rc = fps1.alloc((size_t)N * 512 * 4)) || (rc = F1.alloc((size_t)N * 128 * 8)) || (rc = U.alloc((size_t)N * 128 * 8)) ||
         (rc = Y.alloc((size_t)N * N * 1024)) || (rc = chains.alloc(sizeof(XobjChain))) || (rc = crowded.alloc((size_t)N * 4)) ||
         (rc = clist.alloc((size_t)(N + 1) * 4)) || (rc = poff.alloc((size_t)(N + 1) * 4)) || (rc = pairs.alloc((size_t)N * N * 4)) ||
         (rc = prank.alloc((size_t)N * N * 2)))
@@ -716,13 +732,13 @@ int pointnet_rows(DgdmDynamics *m, const float *xyz_dev /*[rows][3][N]*/, const 
             return rc;
         const float *x = xyz.as<float>();
         if ((rc = pn_fps_table(x, N, N, 512, fps1.as<int>(), nullptr, s))) return rc;
-        if ((rc = pn_sa1(x, N, w, F1.as<float>(), s))) return rc;
-        if ((rc = linear(F1.as<float>(), 128, w.sa2_wf_t, w.sa2_b0, nullptr, 1, U.as<float>(), 128, N, 128, 128, ACT_NONE, false, s))) return rc;
+        if ((rc = pn_sa1_64(x, N, w.r1sq, w64, F1.as<double>(), s))) return rc;
+        if ((rc = linear64(nullptr, F1.as<double>(), 128, w64.sa2_wf_t, w64.sa2_b0, nullptr, 1, U.as<double>(), nullptr, 128, N, 128, 128, ACT_NONE, s))) return rc;
         if ((rc = pn_crowd(x, N, w, crowded.as<int>(), clist.as<int>(), clist.as<int>() + N, poff.as<int>(), pairs.as<int>(), prank.as<short>(), s))) return rc;
-        if ((rc = pn_pairs(x, N, U.as<float>(), w, pairs.as<int>(), poff.as<int>(), Y.as<float>(), nullptr, s))) return rc;
+        if ((rc = pn_pairs64(x, N, U.as<double>(), w64, pairs.as<int>(), poff.as<int>(), Y.as<float>(), s))) return rc;
         if ((rc = pn_l2(x, N, w, fps1.as<int>(), vlist.as<int>(), nv, Y.as<float>(), L2.as<float>(), clist.as<int>(), clist.as<int>() + N,
                         poff.as<int>(), prank.as<short>(), false, s))) return rc;
-        if ((rc = pn_z(x, N, nv, w, L2.as<float>(), Z.as<float>(), nullptr, clist.as<int>(), clist.as<int>() + N, s))) return rc;
+        if ((rc = pn_z64(x, N, nv, w64, L2.as<float>(), Z.as<float>(), clist.as<int>(), clist.as<int>() + N, s))) return rc;
         XobjChain ch{};
         ch.xyz = x; ch.fps1 = fps1.as<int>(); ch.slot_of_start = slotmap.as<int>(); ch.Z = Z.as<float>(); ch.fps2 = nullptr; ch.flags = nullptr; ch.crowded = crowded.as<int>(); ch.N = N;
         DGDM_HIP_CHECK(hipMemcpyAsync(chains.p, &ch, sizeof ch, hipMemcpyHostToDevice, s));

@@ -53,6 +53,47 @@ int fold_linear(const StateDict &sd, const std::string &lin, const std::string &
     return DGDM_OK;
 }
 
+int fold_linear64(const StateDict &sd, const std::string &lin, const std::string &bn, int out, int in, Folded64 *dst) {
+    const float *w = sd.f32(lin + ".weight", (int64_t)out * in);
+    const float *b = sd.f32(lin + ".bias", out);
+    if (!w || !b) return DGDM_EKEY;
+    dst->out = out; dst->in = in;
+    dst->w.resize((size_t)out * in);
+    dst->b.resize(out);
+    const float *g = nullptr, *be = nullptr, *mu = nullptr, *var = nullptr;
+    if (!bn.empty()) {
+        g = sd.f32(bn + ".weight", out); be = sd.f32(bn + ".bias", out);
+        mu = sd.f32(bn + ".running_mean", out); var = sd.f32(bn + ".running_var", out);
+        if (!g || !be || !mu || !var) return DGDM_EKEY;
+    }
+    for (int o = 0; o < out; ++o) {
+        const double s = g ? (double)g[o] / std::sqrt((double)var[o] + 1e-5) : 1.0;      // eps of nn.BatchNorm{1,2}d
+        for (int i = 0; i < in; ++i) dst->w[(size_t)o * in + i] = s * (double)w[(size_t)o * in + i];
+        dst->b[o] = g ? s * ((double)b[o] - (double)mu[o]) + (double)be[o] : (double)b[o];
+    }
+    return DGDM_OK;
+}
+
+std::vector<double> transpose64(const double *src, int rows, int cols) {
+    std::vector<double> t((size_t)rows * cols);
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) t[(size_t)c * rows + r] = src[(size_t)r * cols + c];
+    return t;
+}
+
+std::vector<double> pack_mfma64(const double *src, int M, int K) {
+    const int MP = M / 32, KS = K / 4;
+    std::vector<double> img((size_t)M * K);
+    for (int ks = 0; ks < KS; ++ks)
+        for (int mp = 0; mp < MP; ++mp)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 2; ++j) {
+                    const int m = lane & 15, kq = lane >> 4, f = 16 * (2 * mp + j) + 4 * (m & 3) + (m >> 2);
+                    img[(((size_t)ks * MP + mp) * 64 + lane) * 2 + j] = src[(size_t)f * K + kq * KS + ks];
+                }
+    return img;
+}
+
 std::vector<float> pack_chain(const float *src, int M, int K) {
     const int MB = M / 32, KB = K / 32;
     std::vector<float> img((size_t)M * K);

@@ -28,12 +28,20 @@ struct DynOff {   // offsets (floats) into the blob
     size_t te0_wt, te0_b, te2_wt, te2_b, oe0_wt, oe0_b, oe2_wt, oe2_b, tfreq;
     size_t sa1_w0t, sa1_b0, sa1_w1, sa1_b1, sa2_wf_t, sa2_b0, sa2_vx, sa2_w1_img, sa2_b1, sa3_w_img, sa3_wx, sa3_b;
 };
+struct DynOff64 {   // offsets (doubles) into blob64: the unrounded folds of the stages that run in float64 (smallnet.h, pointnet64)
+    size_t g0_wt, g0_b, g0_w, g2_wt, g2_b, g2_w;
+    size_t w1c_wt, w1c_w, w1p_wt, w1t_wt, b1, w1o_wt;
+    size_t te0_wt, te0_b, te2_wt, te2_b, oe0_wt, oe0_b, oe2_wt, oe2_b;
+    size_t sa1_w0t, sa1_b0, sa1_w1, sa1_b1, sa2_wf_t, sa2_b0, sa2_vx, sa2_w1_img, sa2_b1, sa3_w_img, sa3_wx, sa3_b;
+};
 }  // namespace dgdm
 
 struct DgdmDynamics {
     int kind = 0, L = 0, object_ch = 0, W1 = 256, n_mid = 7, thalf = 64;
     dgdm::Blob blob;
     dgdm::DynOff off{};
+    dgdm::Blob64 blob64;
+    dgdm::DynOff64 off64{};
     dgdm::DevBuf ws;        // grow-only workspace of the plain forward entry points
     dgdm::DevBuf ws2;
     dgdm::DevBuf w16;       // bf16 weight streams of the trunk (trunk_bf16.hip): forward then backward
@@ -45,4 +53,11 @@ struct DgdmDynamics {
     int gripper_forward(const float *x, int ldx, float *V, float *genc, int rows, hipStream_t s) const;
     int time_part(const float *t_dev, float t_scalar, float *tmp, float *out, int rows, hipStream_t s) const;
     int object_part_2d(const float *obj, float *tmp, float *out, int n, bool accumulate, hipStream_t s) const;
+    // the guided path's versions in float64 (smallnet.h linear64): hidden layer V64 and encoding genc64 [rows][256] doubles
+    int gripper_forward64(const float *x, int ldx, double *V64, double *genc64, int rows, hipStream_t s) const;
+    // out64[1][W1] = W1'[:, time part] * time_feature(t) + b1'   (tmp: 768 floats, tmp64: 512 doubles)
+    int time_part64(float t_scalar, float *tmp, double *tmp64, double *out64, hipStream_t s) const;
+    // out64[n][W1] = W1'[:, object part] * object_encoder(obj)   (tmp64: n * 512 doubles)
+    int object_part_2d64(const float *obj, double *tmp64, double *out64, int n, hipStream_t s) const;
+    dgdm::PnWeights64 pn64() const;
 };

@@ -224,6 +224,13 @@ std::vector<float> cols(const std::vector<float> &w, int rows, int ncols, int c0
     return o;
 }
 
+std::vector<double> cols64(const std::vector<double> &w, int rows, int ncols, int c0, int n) {
+    std::vector<double> o((size_t)rows * n);
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < n; ++c) o[(size_t)r * n + c] = w[(size_t)r * ncols + c0 + c];
+    return o;
+}
+
 std::vector<float> tfreqs(int half) {
     // timestep_embedding (profile_forward_2d.py:68-71): exp(-log(10000) * arange(half, f32) / half), float32 ops
     std::vector<float> f(half);
@@ -358,6 +365,49 @@ extern "C" int dgdm_dynamics_create(DgdmDynamics **out, int kind, const DgdmTens
     o.wfwd = bl.add(fwd); o.fwd_floats = fwd.size();
     o.wbwd = bl.add(bwd); o.bwd_floats = bwd.size();
     if ((rc = bl.upload())) return rc;
+    {   // float64 folds (unrounded) of everything outside the per-row trunk: encoders, first-layer tables, PointNet++ table build
+        Blob64 &b6 = m->blob64;
+        DynOff64 &q = m->off64;
+        Folded64 h0, h2, k1;
+        if ((rc = fold_linear64(sd, "gripper_encoder.0", "", W, params_ch, &h0))) return rc;
+        if ((rc = fold_linear64(sd, "gripper_encoder.2", "", W, W, &h2))) return rc;
+        if ((rc = fold_linear64(sd, "linears.0", "linears.1", W1, IN1, &k1))) return rc;
+        q.g0_wt = b6.add(transpose64(h0.w.data(), W, params_ch)); q.g0_b = b6.add(h0.b); q.g0_w = b6.add(h0.w);
+        q.g2_wt = b6.add(transpose64(h2.w.data(), W, W)); q.g2_b = b6.add(h2.b); q.g2_w = b6.add(h2.w);
+        const std::vector<double> v1o = cols64(k1.w, W1, IN1, 0, W), v1c = cols64(k1.w, W1, IN1, W, W), v1p = cols64(k1.w, W1, IN1, 2 * W, 27),
+                                  v1t = cols64(k1.w, W1, IN1, 2 * W + 27, W);
+        q.w1c_wt = b6.add(transpose64(v1c.data(), W1, W)); q.w1c_w = b6.add(v1c);
+        q.w1p_wt = b6.add(transpose64(v1p.data(), W1, 27));
+        q.w1t_wt = b6.add(transpose64(v1t.data(), W1, W));
+        q.b1 = b6.add(k1.b);
+        if (kind == 2) {
+            q.w1o_wt = b6.add(transpose64(v1o.data(), W1, W));
+            Folded64 t0, t2, e0, e2;
+            if ((rc = fold_linear64(sd, "time_encoder.0", "", W, W / 2, &t0))) return rc;
+            if ((rc = fold_linear64(sd, "time_encoder.2", "", W, W, &t2))) return rc;
+            if ((rc = fold_linear64(sd, "object_encoder.0", "", W, object_ch, &e0))) return rc;
+            if ((rc = fold_linear64(sd, "object_encoder.2", "", W, W, &e2))) return rc;
+            q.te0_wt = b6.add(transpose64(t0.w.data(), W, W / 2)); q.te0_b = b6.add(t0.b);
+            q.te2_wt = b6.add(transpose64(t2.w.data(), W, W)); q.te2_b = b6.add(t2.b);
+            q.oe0_wt = b6.add(transpose64(e0.w.data(), W, object_ch)); q.oe0_b = b6.add(e0.b);
+            q.oe2_wt = b6.add(transpose64(e2.w.data(), W, W)); q.oe2_b = b6.add(e2.b);
+        } else {
+            Folded64 a0, a1, b0, b1, c0;
+            if ((rc = fold_linear64(sd, "object_encoder.sa1.mlp_convs.0", "object_encoder.sa1.mlp_bns.0", 64, 3, &a0))) return rc;
+            if ((rc = fold_linear64(sd, "object_encoder.sa1.mlp_convs.1", "object_encoder.sa1.mlp_bns.1", 128, 64, &a1))) return rc;
+            if ((rc = fold_linear64(sd, "object_encoder.sa2.mlp_convs.0", "object_encoder.sa2.mlp_bns.0", 128, 131, &b0))) return rc;
+            if ((rc = fold_linear64(sd, "object_encoder.sa2.mlp_convs.1", "object_encoder.sa2.mlp_bns.1", 256, 128, &b1))) return rc;
+            if ((rc = fold_linear64(sd, "object_encoder.sa3.mlp_convs.0", "object_encoder.sa3.mlp_bns.0", 256, 259, &c0))) return rc;
+            q.sa1_w0t = b6.add(transpose64(a0.w.data(), 64, 3)); q.sa1_b0 = b6.add(a0.b);
+            q.sa1_w1 = b6.add(a1.w); q.sa1_b1 = b6.add(a1.b);
+            q.sa2_wf_t = b6.add(transpose64(cols64(b0.w, 128, 131, 3, 128).data(), 128, 128)); q.sa2_b0 = b6.add(b0.b);
+            q.sa2_vx = b6.add(transpose64(cols64(b0.w, 128, 131, 0, 3).data(), 128, 3));
+            q.sa2_w1_img = b6.add(pack_mfma64(b1.w.data(), 256, 128)); q.sa2_b1 = b6.add(b1.b);
+            q.sa3_w_img = b6.add(pack_mfma64(cols64(c0.w, 256, 259, 3, 256).data(), 256, 256));
+            q.sa3_wx = b6.add(transpose64(cols64(c0.w, 256, 259, 0, 3).data(), 256, 3)); q.sa3_b = b6.add(c0.b);
+        }
+        if ((rc = b6.upload())) return rc;
+    }
     *out = m.release();
     return DGDM_OK;
 }
@@ -390,6 +440,41 @@ PnWeights DgdmDynamics::pn() const {
     w.sa3_w_img16 = reinterpret_cast<const float4 *>(static_cast<const char *>(w16.p) + sa3_16_offset);
     w.sa3_wx = blob.at(off.sa3_wx); w.sa3_b = blob.at(off.sa3_b);
     return w;
+}
+
+PnWeights64 DgdmDynamics::pn64() const {
+    PnWeights64 w{};
+    w.sa1_w0t = blob64.at(off64.sa1_w0t); w.sa1_b0 = blob64.at(off64.sa1_b0); w.sa1_w1 = blob64.at(off64.sa1_w1); w.sa1_b1 = blob64.at(off64.sa1_b1);
+    w.sa2_wf_t = blob64.at(off64.sa2_wf_t); w.sa2_b0 = blob64.at(off64.sa2_b0); w.sa2_vx = blob64.at(off64.sa2_vx);
+    w.sa2_w1_img = blob64.at(off64.sa2_w1_img); w.sa2_b1 = blob64.at(off64.sa2_b1);
+    w.sa3_w_img = blob64.at(off64.sa3_w_img); w.sa3_wx = blob64.at(off64.sa3_wx); w.sa3_b = blob64.at(off64.sa3_b);
+    return w;
+}
+
+int DgdmDynamics::gripper_forward64(const float *x, int ldx, double *V64, double *genc64, int rows, hipStream_t s) const {
+    int rc;
+    if ((rc = linear64(x, nullptr, ldx, blob64.at(off64.g0_wt), blob64.at(off64.g0_b), nullptr, 1, V64, nullptr, 256, rows, L, 256, ACT_RELU, s))) return rc;
+    return linear64(nullptr, V64, 256, blob64.at(off64.g2_wt), blob64.at(off64.g2_b), nullptr, 1, genc64, nullptr, 256, rows, 256, 256, ACT_NONE, s);
+}
+
+int DgdmDynamics::time_part64(float t_scalar, float *tmp /*768 floats*/, double *tmp64 /*512*/, double *out64, hipStream_t s) const {
+    int rc;
+    // the sinusoidal features are float32 values in the reference (profile_forward_2d.py:58-76 on a float32 tensor): same kernel as before
+    if ((rc = time_embed(nullptr, t_scalar, blob.at(off.tfreq), tmp, 1, thalf, s))) return rc;
+    if (kind == 2) {       // time_encoder: Linear -> SiLU -> Linear (profile_forward_2d.py:92-96,153); the 3-D model feeds the raw embedding (_3d.py:83)
+        if ((rc = linear64(tmp, nullptr, 2 * thalf, blob64.at(off64.te0_wt), blob64.at(off64.te0_b), nullptr, 1, tmp64, nullptr, 256, 1, 2 * thalf, 256, ACT_SILU, s))) return rc;
+        if ((rc = linear64(nullptr, tmp64, 256, blob64.at(off64.te2_wt), blob64.at(off64.te2_b), nullptr, 1, tmp64 + 256, nullptr, 256, 1, 256, 256, ACT_NONE, s))) return rc;
+        return linear64(nullptr, tmp64 + 256, 256, blob64.at(off64.w1t_wt), blob64.at(off64.b1), nullptr, 1, out64, nullptr, W1, 1, 256, W1, ACT_NONE, s);
+    }
+    return linear64(tmp, nullptr, 256, blob64.at(off64.w1t_wt), blob64.at(off64.b1), nullptr, 1, out64, nullptr, W1, 1, 256, W1, ACT_NONE, s);
+}
+
+int DgdmDynamics::object_part_2d64(const float *obj, double *tmp64 /*n*512*/, double *out64, int n, hipStream_t s) const {
+    int rc;
+    double *h = tmp64, *e = tmp64 + (size_t)n * 256;
+    if ((rc = linear64(obj, nullptr, object_ch, blob64.at(off64.oe0_wt), blob64.at(off64.oe0_b), nullptr, 1, h, nullptr, 256, n, object_ch, 256, ACT_RELU, s))) return rc;
+    if ((rc = linear64(nullptr, h, 256, blob64.at(off64.oe2_wt), blob64.at(off64.oe2_b), nullptr, 1, e, nullptr, 256, n, 256, 256, ACT_NONE, s))) return rc;
+    return linear64(nullptr, e, 256, blob64.at(off64.w1o_wt), nullptr, nullptr, 1, out64, nullptr, W1, n, 256, W1, ACT_NONE, s);
 }
 
 // gripper encoder forward on `rows` fingers: V = relu(g0 x + b), GENC = g2 V + b   (profile_forward_2d.py:103-107,148)

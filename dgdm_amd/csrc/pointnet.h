@@ -21,6 +21,14 @@ struct PnWeights {
     const float *sa3_b;           // [256]
 };
 
+// The same weights unrounded (float64 folds) for the float64 table build (pointnet64.hip)
+struct PnWeights64 {
+    const double *sa1_w0t, *sa1_b0, *sa1_w1, *sa1_b1;     // [3][64], [64], [128][64], [128]
+    const double *sa2_wf_t, *sa2_b0, *sa2_vx;             // [128][128] (kn), [128], [3][128]
+    const double *sa2_w1_img, *sa2_b1;                    // pack_mfma64 image of sa2.mlp_convs.1 [256 x 128], [256]
+    const double *sa3_w_img, *sa3_wx, *sa3_b;             // pack_mfma64 image of sa3.mlp_convs.0[:, 3:] [256 x 256], [3][256], [256]
+};
+
 struct XobjChain {
     const float *xyz;             // [N][3]
     const int   *fps1;            // [N][512]
@@ -99,6 +107,11 @@ int pn_z16(const float *xyz, int N, int nv, const PnWeights &w, const uint32_t *
 // Z16 (optional): the same rows again in bf16 operand order
 int pn_z(const float *xyz, int N, int nv, const PnWeights &w, const float *L2, float *Z, uint32_t *Z16, const int *clist, const int *ncr,
          hipStream_t s);
+// ---- float64 table build (pointnet64.hip): same inputs, same float32 outputs (each rounded ONCE from a float64 accumulation)
+// F1_64 [N][128] doubles (sa1 features); U is then linear64(F1_64) -> U64 [N][128] doubles
+int pn_sa1_64(const float *xyz, int N, float r1sq, const PnWeights64 &w, double *F1_64, hipStream_t s);
+int pn_pairs64(const float *xyz, int N, const double *U64, const PnWeights64 &w, const int *pairs, const int *off, float *Y, hipStream_t s);
+int pn_z64(const float *xyz, int N, int nv, const PnWeights64 &w, const float *L2, float *Z, const int *clist, const int *ncr, hipStream_t s);
 int pn_m0(const int *fps2, const int *crowded, int N, const float *Z0, float *M0, int *cl2, int *cnt2, const uint32_t *Z0_16, uint32_t *M0_16,
           const int *clist, const int *ncr, int *cl2s, hipStream_t s);
 // lanes per row for an object with `ncr` crowded centres (0 = the group kernel cannot hold its slab: use the per-row kernels)

@@ -24,6 +24,7 @@
 #include "mfma_chain.h"
 #include <type_traits>
 #include "pointnet.h"
+#include "pointnet_dev.h"
 
 // No implicit a*b+c -> fma contraction in this file: the scheduler update, FPS and ball-query distances must round
 // like the reference's separate float32 ops (HIP's __fmul_rn/__fadd_rn are plain * and + and would be contracted).
@@ -31,16 +32,6 @@
 #pragma clang fp contract(off)
 
 namespace dgdm {
-
-__device__ __forceinline__ float sq3(float x, float y, float z) {
-    return __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
-}
-
-// square_distance(src = centre, dst = candidate) in the reference's expanded form
-__device__ __forceinline__ float sqdist_expanded(float cx, float cy, float cz, float cn, float px, float py, float pz, float pn) {
-    const float dot = fmaf(cz, pz, fmaf(cy, py, __fmul_rn(cx, px)));
-    return __fadd_rn(__fadd_rn(__fmul_rn(-2.f, dot), cn), pn);
-}
 
 // wave-wide argmax, first index wins ties (torch.max semantics, pointnet2_utils.py:91); every lane receives the result.
 // Two DPP reductions (v_max_f32 / v_min_u32 with data-parallel-primitive operands: no LDS crossbar traffic, unlike __shfl_xor,
@@ -135,28 +126,6 @@ __global__ __launch_bounds__(256) void fps_table_kernel(const float *__restrict_
         if (N <= 512) fps_wave<8, false>(lx, ly, lz, N, v, npoint, out + (size_t)v * npoint, lane);
         else fps_wave<16, false>(lx, ly, lz, N, v, npoint, out + (size_t)v * npoint, lane);
     }
-}
-
-// query_ball_point (pointnet2_utils.py:95-115) for one centre by one wave: the first 32 in-radius indices in index order,
-// padded with the first one (:112-114), into nbr[0..32) (LDS).  Shared by sa1_kernel and the index test hook.
-__device__ __forceinline__ void ball_first32(const float *__restrict__ xyz, int N, int p, float cx, float cy, float cz, float cn, float r2,
-                                             int *nbr, int lane) {
-    int cnt = 0;
-    for (int base = 0; base < N && cnt < 32; base += 64) {
-        const int k = base + lane;
-        bool in = false;
-        if (k < N) {
-            const float x = xyz[3 * k], y = xyz[3 * k + 1], z = xyz[3 * k + 2];
-            in = !(sqdist_expanded(cx, cy, cz, cn, x, y, z, sq3(x, y, z)) > r2);
-        }
-        const unsigned long long m = __ballot(in);
-        const int rank = cnt + __popcll(m & ((1ull << lane) - 1ull));
-        if (in && rank < 32) nbr[rank] = k;
-        cnt += __popcll(m);
-    }
-    cnt = min(cnt, 32);
-    __builtin_amdgcn_wave_barrier();
-    if (lane >= cnt && lane < 32) nbr[lane] = (cnt > 0) ? nbr[0] : p;   // pad with the first (:112-114)
 }
 
 // ------------------------------------------------------------------------------------------------ T2

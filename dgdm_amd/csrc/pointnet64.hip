@@ -1,0 +1,196 @@
+// The per-object stages of the PointNet++ table pipeline (pointnet.hip: T2 sa1 features, T4 sa2's pair MLP, T6 sa3's layer) with
+// float64 accumulation.  These stages run once per OBJECT, not once per replicated row, so double precision costs a few per cent of a
+// denoise step - and it takes the object embedding from 1.7e-6 (k-ordered float32 chains, BatchNorm folded into rounded weights) to
+// the float32 rounding of an exact result (~1e-7; torch's own float32 embedding is 3e-7 from exact), which is what decides how many
+// ReLU pre-activations of the trunk land on the wrong side of zero (scripts/exp_ties.py).
+//
+// Same dataflow, same index decisions (float32 distances in the reference's operation order), same float32 tables out: every
+// table entry is ONE rounding of a float64 accumulation over float32 inputs, with the BatchNorm fold kept in float64 (Folded64).
+// The two contractions that matter (sa2 128 -> 256 on every in-radius pair, sa3 256 -> 256 on every (variant, crowded centre)) run
+// on v_mfma_f64_16x16x4_f64: one wave = 16 rows x all 256 output features, weights as the A operand from a pre-arranged image
+// (pack_mfma64) through the same buffer-load ring as the float32 chain kernels, activations as the B operand from registers.
+//   A: lane (m = l & 15, kq = l >> 4) supplies W[f(mt, m)][kq * K/4 + ks]     B: lane (n = l & 15, kq) supplies in[row n][kq * K/4 + ks]
+//   C/D: lane (n, rb = l >> 4), register i = output feature f(mt, rb + 4 i) = 16 mt + 4 rb + i of row n  (four consecutive features)
+#include "common.h"
+#include <algorithm>
+#include "mfma_chain.h"
+#include "pointnet.h"
+#include "pointnet_dev.h"
+
+#pragma clang fp contract(off)      // as in pointnet.hip (the float32 index decisions); the float64 arithmetic below uses explicit fma()
+
+namespace dgdm {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// acc[16 M-tiles] += W * in over K = 4 * KS.  in_d(ks): the lane's B value of K-step ks (feature kq * KS + ks of its row).
+template <int KS, class In>
+__device__ __forceinline__ void mfma64_layer(const double *__restrict__ img, f64x4 (&acc)[16], In &&in_d, int lane) {
+    constexpr int TOTAL = KS * 8;                                   // entries (ks, M-tile pair): 64 lanes x 2 doubles = 1 KiB each
+    struct D2 { double lo, hi; };
+    stream_weights<TOTAL>(weight_rsrc(reinterpret_cast<const float4 *>(img), TOTAL * 1024), lane * 16, 0, [&](int e, const float4 a) {
+        const int ks = e / 8, mp = e % 8;
+        const D2 w = __builtin_bit_cast(D2, a);
+        const double b = in_d(ks);
+        acc[2 * mp] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.lo, b, acc[2 * mp], 0, 0, 0);
+        acc[2 * mp + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.hi, b, acc[2 * mp + 1], 0, 0, 0);
+    });
+}
+
+// ------------------------------------------------------------------------------------------------ T2
+// sa1 feature of every point as a centre (pointnet.hip sa1_kernel) -> F1 [N][128] doubles
+__global__ __launch_bounds__(128) void sa1_64_kernel(const float *__restrict__ xyz, int N, float r2, const double *__restrict__ w0t /*[3][64]*/,
+                                                     const double *__restrict__ b0, const double *__restrict__ w1 /*[128][64]*/,
+                                                     const double *__restrict__ b1, double *__restrict__ F1 /*[N][128]*/) {
+    __shared__ int nbr[32];
+    __shared__ double h1[32][64];
+    const int t = threadIdx.x, lane = t & 63;
+    double wrow[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) wrow[k] = w1[t * 64 + k];
+    const double bias1 = b1[t];
+    for (int p = blockIdx.x; p < N; p += gridDim.x) {
+        const float cx = xyz[3 * p], cy = xyz[3 * p + 1], cz = xyz[3 * p + 2];
+        if (t < 64) ball_first32(xyz, N, p, cx, cy, cz, sq3(cx, cy, cz), r2, nbr, lane);      // wave 0; float32 distances (index decision)
+        __syncthreads();
+        for (int i = t; i < 32 * 64; i += 128) {          // layer 0 on the relative coordinates (exact differences of float32 values)
+            const int s = i >> 6, c = i & 63, k = nbr[s];
+            const double dx = (double)xyz[3 * k] - (double)cx, dy = (double)xyz[3 * k + 1] - (double)cy, dz = (double)xyz[3 * k + 2] - (double)cz;
+            h1[s][c] = fmax(fma(w0t[128 + c], dz, fma(w0t[64 + c], dy, fma(w0t[c], dx, b0[c]))), 0.0);
+        }
+        __syncthreads();
+        double best = 0.0;                                 // ReLU outputs are >= 0 and the group is never empty
+        for (int s = 0; s < 32; ++s) {
+            double acc = bias1;
+#pragma unroll
+            for (int k = 0; k < 64; ++k) acc = fma(wrow[k], h1[s][k], acc);
+            best = fmax(best, acc);
+        }
+        F1[(size_t)p * 128 + t] = best;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ T4
+// Y[pair][256] = float32( ReLU(W2b' ReLU(U[k] + Vx (xyz_k - xyz_c)) + b2b') ) for every in-radius ordered pair (pointnet.hip pair_kernel)
+__global__ __launch_bounds__(256) void pair64_kernel(const float *__restrict__ xyz, int N, const double *__restrict__ U /*[N][128]*/,
+                                                     const double *__restrict__ vx /*[3][128]*/, const double *__restrict__ img,
+                                                     const double *__restrict__ bias, const int *__restrict__ pairs,
+                                                     const int *__restrict__ off /*[N+1]*/, float *__restrict__ Y) {
+    const int lane = threadIdx.x & 63, n = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int total = off[N];
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile * 16 >= total) return;
+    const int p = min(tile * 16 + n, total - 1);
+    const int ck = pairs[p], c = ck >> 16, k = ck & 0xffff;
+    const double dx = (double)xyz[3 * k] - (double)xyz[3 * c], dy = (double)xyz[3 * k + 1] - (double)xyz[3 * c + 1],
+                 dz = (double)xyz[3 * k + 2] - (double)xyz[3 * c + 2];
+    double in[32];
+    const double *urow = U + (size_t)k * 128 + kq * 32, *v = vx + kq * 32;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) in[j] = fmax(fma(v[256 + j], dz, fma(v[128 + j], dy, fma(v[j], dx, urow[j]))), 0.0);
+    f64x4 acc[16];
+#pragma unroll
+    for (int mt = 0; mt < 16; ++mt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[mt][i] = bias[16 * mt + 4 * kq + i];
+    }
+    mfma64_layer<32>(img, acc, [&](int ks) { return in[ks]; }, lane);
+    if (tile * 16 + n < total) {
+        float *dst = Y + (size_t)p * 256 + 4 * kq;
+#pragma unroll
+        for (int mt = 0; mt < 16; ++mt)
+            *reinterpret_cast<float4 *>(dst + 16 * mt) = make_float4(fmaxf((float)acc[mt][0], 0.f), fmaxf((float)acc[mt][1], 0.f),
+                                                                      fmaxf((float)acc[mt][2], 0.f), fmaxf((float)acc[mt][3], 0.f));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ T6
+// Z[row][256] = float32( ReLU(W3'[:,3:] L2[row] + W3'[:,0:3] xyz_c + b3') ),  rows / modes as pointnet.hip z_kernel
+__global__ __launch_bounds__(256) void z64_kernel(const float *__restrict__ xyz, int N, int nv, const float *__restrict__ L2,
+                                                  const double *__restrict__ img, const double *__restrict__ w3x /*[3][256]*/,
+                                                  const double *__restrict__ bias, float *__restrict__ Z, int mode,
+                                                  const int *__restrict__ clist, const int *__restrict__ ncr) {
+    const int lane = threadIdx.x & 63, n = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    const int ncrv = mode ? *ncr : N;
+    const int64_t items = mode ? (int64_t)(nv - 1) * ncrv : N;
+    if (tile * 16 >= items) return;
+    const int64_t item = min(tile * 16 + n, items - 1);
+    const int c = mode ? clist[item % ncrv] : (int)item;
+    const int64_t row = mode ? (1 + item / ncrv) * N + c : c;
+    const double x = xyz[3 * c], y = xyz[3 * c + 1], z = xyz[3 * c + 2];
+    const float4 *src = reinterpret_cast<const float4 *>(L2 + (size_t)row * 256 + kq * 64);
+    f64x4 acc[16];
+#pragma unroll
+    for (int mt = 0; mt < 16; ++mt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = 16 * mt + 4 * kq + i;
+            acc[mt][i] = fma(w3x[512 + f], z, fma(w3x[256 + f], y, fma(w3x[f], x, bias[f])));
+        }
+    }
+    // K = 256 in four chunks of 16 K-steps (a rolled loop: 1024 MFMAs in one basic block is more than hipcc unrolls); the lane's 16
+    // inputs of the next chunk are loaded while the current one runs, the weight ring is carried across the chunks
+    struct D2 { double lo, hi; };
+    const wrsrc_t rs = weight_rsrc(reinterpret_cast<const float4 *>(img), 512 * 1024);
+    float4 ring[CONT_DEPTH];
+    ring_fill(rs, lane * 16, 0, ring);
+    float4 cur[4], nxt[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cur[j] = src[j];
+#pragma nounroll
+    for (int ch = 0; ch < 4; ++ch) {
+        const int cn = min(ch + 1, 3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nxt[j] = src[4 * cn + j];
+        float in[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { in[4 * j] = cur[j].x; in[4 * j + 1] = cur[j].y; in[4 * j + 2] = cur[j].z; in[4 * j + 3] = cur[j].w; }
+        stream_cont<128>(rs, lane * 16, ch * 128 * 1024, ring, [&](int e, const float4 a) {
+            const int ks = e / 8, mp = e % 8;
+            const D2 w = __builtin_bit_cast(D2, a);
+            const double b = (double)in[ks];
+            acc[2 * mp] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.lo, b, acc[2 * mp], 0, 0, 0);
+            acc[2 * mp + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.hi, b, acc[2 * mp + 1], 0, 0, 0);
+        });
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+    }
+    if (tile * 16 + n < items) {
+        float *dst = Z + (size_t)row * 256 + 4 * kq;       // rows of one tile are distinct (item -> row is injective)
+#pragma unroll
+        for (int mt = 0; mt < 16; ++mt)
+            *reinterpret_cast<float4 *>(dst + 16 * mt) = make_float4(fmaxf((float)acc[mt][0], 0.f), fmaxf((float)acc[mt][1], 0.f),
+                                                                      fmaxf((float)acc[mt][2], 0.f), fmaxf((float)acc[mt][3], 0.f));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+int pn_sa1_64(const float *xyz, int N, float r1sq, const PnWeights64 &w, double *F1_64, hipStream_t s) {
+    hipLaunchKernelGGL(sa1_64_kernel, dim3(std::min(N, 1024)), dim3(128), 0, s, xyz, N, r1sq, w.sa1_w0t, w.sa1_b0, w.sa1_w1, w.sa1_b1, F1_64);
+    DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
+}
+
+int pn_pairs64(const float *xyz, int N, const double *U64, const PnWeights64 &w, const int *pairs, const int *off, float *Y, hipStream_t s) {
+    const int tiles = N * ((N + 15) / 16);     // worst case (every point inside every ball); surplus workgroups leave at once
+    hipLaunchKernelGGL(pair64_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, xyz, N, U64, w.sa2_vx, w.sa2_w1_img, w.sa2_b1, pairs, off, Y);
+    DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
+}
+
+int pn_z64(const float *xyz, int N, int nv, const PnWeights64 &w, const float *L2, float *Z, const int *clist, const int *ncr, hipStream_t s) {
+    const int64_t t0 = (N + 15) / 16;
+    hipLaunchKernelGGL(z64_kernel, dim3((unsigned)((t0 + 3) / 4)), dim3(256), 0, s, xyz, N, nv, L2, w.sa3_w_img, w.sa3_wx, w.sa3_b, Z, 0, clist, ncr);
+    if (nv > 1) {      // sized for the worst case (every centre crowded); surplus workgroups leave at once
+        const int64_t t1 = ((int64_t)(nv - 1) * N + 15) / 16;
+        hipLaunchKernelGGL(z64_kernel, dim3((unsigned)((t1 + 3) / 4)), dim3(256), 0, s, xyz, N, nv, L2, w.sa3_w_img, w.sa3_wx, w.sa3_b, Z, 1, clist, ncr);
+    }
+    DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
+}
+
+}  // namespace dgdm

@@ -18,4 +18,18 @@ int gather_add(const float *a, const int *idx, const float *b, float *out, int g
 int dyn_post(int W1, const float *partial, int tiles_per_b, const float *w1c, const float *g2w, const float *g0w, const float *V,
              float *grad, int rows, int L, hipStream_t s);
 
+
+// ---- the same small stages in float64.  Everything that is evaluated once per finger, per pose cell or per object
+// instead of once per replicated row costs nothing in double precision, and what it feeds - the first trunk layer's tables - then
+// carries one float32 rounding instead of the error of a 256..795-term float32 dot product.
+// Y = act(X * WT + bias + rowbias[row / rb_div]): X float32 (Xf) or float64 (Xd) rows, WT [K][N] / bias / rowbias float64; the result
+// as float64 (Yd) and/or rounded once to float32 (Yf); either may be null.
+int linear64(const float *Xf, const double *Xd, int ldx, const double *WT, const double *bias, const double *rowbias, int rb_div,
+             double *Yd, float *Yf, int ldy, int rows, int K, int N, int act, hipStream_t s);
+// out[g][n] = a[idx[g]][n] + b[n]  (float64)
+int gather_add64(const double *a, const int *idx, const double *b, double *out, int groups, int N, hipStream_t s);
+// dyn_post with float64 sums (tile partials are float32 inputs); V64 = the float64 hidden layer of the gripper encoder
+int dyn_post64(int W1, const float *partial, int tiles_per_b, const double *w1c, const double *g2w, const double *g0w, const double *V64,
+               float *grad, int rows, int L, hipStream_t s);
+
 }  // namespace dgdm

@@ -220,6 +220,128 @@ int dyn_post(int W1, const float *partial, int tiles_per_b, const float *w1c, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// Float64 versions of the per-finger / per-cell / per-object stages (smallnet.h).  Sizes are KBs..MBs: a thread per output column,
+// RB rows per workgroup, X staged in LDS as doubles.
+template <int ACT, int RB>
+__global__ __launch_bounds__(256) void linear64_kernel(const float *__restrict__ Xf, const double *__restrict__ Xd, int ldx,
+                                                       const double *__restrict__ WT, const double *__restrict__ bias,
+                                                       const double *__restrict__ rowbias, int rb_div, double *__restrict__ Yd,
+                                                       float *__restrict__ Yf, int ldy, int rows, int K, int N) {
+    constexpr int KC = 64;
+    __shared__ double xs[RB][KC];
+    const int r0 = blockIdx.x * RB;
+    const int n = blockIdx.y * 256 + threadIdx.x;
+    const int nn = min(n, N - 1);
+    double acc[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) acc[r] = 0.0;
+    for (int k0 = 0; k0 < K; k0 += KC) {
+        const int kc = min(KC, K - k0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < RB * KC; i += 256) {
+            const int r = i / KC, k = i - r * KC;
+            double v = 0.0;
+            if (r0 + r < rows && k < kc) v = Xd ? Xd[(size_t)(r0 + r) * ldx + k0 + k] : (double)Xf[(size_t)(r0 + r) * ldx + k0 + k];
+            xs[r][k] = v;
+        }
+        __syncthreads();
+        const double *wp = WT + (size_t)k0 * N + nn;
+        for (int k = 0; k < kc; ++k) {
+            const double w = wp[(size_t)k * N];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) acc[r] = fma(xs[r][k], w, acc[r]);
+        }
+    }
+    if (n >= N) return;
+    const double bn = bias ? bias[n] : 0.0;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        if (r0 + r >= rows) break;
+        double v = acc[r] + bn;
+        if (rowbias) v += rowbias[(size_t)((r0 + r) / rb_div) * N + n];
+        if (ACT == ACT_RELU) v = fmax(v, 0.0);
+        if (ACT == ACT_SILU) v = v / (1.0 + exp(-v));
+        if (Yd) Yd[(size_t)(r0 + r) * ldy + n] = v;
+        if (Yf) Yf[(size_t)(r0 + r) * ldy + n] = (float)v;
+    }
+}
+
+int linear64(const float *Xf, const double *Xd, int ldx, const double *WT, const double *bias, const double *rowbias, int rb_div,
+             double *Yd, float *Yf, int ldy, int rows, int K, int N, int act, hipStream_t s) {
+    if (rows <= 0) return DGDM_OK;
+    constexpr int RB = 8;
+    dim3 grid((rows + RB - 1) / RB, (N + 255) / 256);
+    if (act == ACT_NONE)
+        hipLaunchKernelGGL((linear64_kernel<ACT_NONE, RB>), grid, dim3(256), 0, s, Xf, Xd, ldx, WT, bias, rowbias, rb_div, Yd, Yf, ldy, rows, K, N);
+    else if (act == ACT_RELU)
+        hipLaunchKernelGGL((linear64_kernel<ACT_RELU, RB>), grid, dim3(256), 0, s, Xf, Xd, ldx, WT, bias, rowbias, rb_div, Yd, Yf, ldy, rows, K, N);
+    else
+        hipLaunchKernelGGL((linear64_kernel<ACT_SILU, RB>), grid, dim3(256), 0, s, Xf, Xd, ldx, WT, bias, rowbias, rb_div, Yd, Yf, ldy, rows, K, N);
+    DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
+}
+
+__global__ void gather_add64_kernel(const double *__restrict__ a, const int *__restrict__ idx, const double *__restrict__ b,
+                                    double *__restrict__ out, int groups, int N) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= groups * N) return;
+    const int g = i / N, n = i - g * N;
+    out[i] = a[(size_t)idx[g] * N + n] + b[n];
+}
+
+int gather_add64(const double *a, const int *idx, const double *b, double *out, int groups, int N, hipStream_t s) {
+    if (groups <= 0) return DGDM_OK;
+    hipLaunchKernelGGL(gather_add64_kernel, dim3((groups * N + 255) / 256), dim3(256), 0, s, a, idx, b, out, groups, N);
+    DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
+}
+
+template <int W1>
+__global__ __launch_bounds__(256) void dyn_post64_kernel(const float *__restrict__ partial, int tiles_per_b,
+                                                         const double *__restrict__ w1c /*[W1][256]*/,
+                                                         const double *__restrict__ g2w /*[256][256]*/,
+                                                         const double *__restrict__ g0w /*[256][L]*/,
+                                                         const double *__restrict__ V /*[rows][256] relu(g0 x + b)*/,
+                                                         float *__restrict__ grad /*[rows][L]*/, int L) {
+    __shared__ double da[W1];
+    __shared__ double v1[256];
+    __shared__ double v2[256];
+    const int row = blockIdx.x, t = threadIdx.x;
+    for (int f = t; f < W1; f += 256) {
+        const float *src = partial + (size_t)row * tiles_per_b * W1 + f;
+        double acc = 0.0;
+        for (int ct = 0; ct < tiles_per_b; ++ct) acc += (double)src[(size_t)ct * W1];
+        da[f] = acc;
+    }
+    __syncthreads();
+    double acc = 0.0;
+    for (int f = 0; f < W1; ++f) acc = fma(w1c[(size_t)f * 256 + t], da[f], acc);
+    v1[t] = acc;
+    __syncthreads();
+    acc = 0.0;
+    for (int f = 0; f < 256; ++f) acc = fma(g2w[(size_t)f * 256 + t], v1[f], acc);
+    v2[t] = V[(size_t)row * 256 + t] > 0.0 ? acc : 0.0;
+    __syncthreads();
+    if (t < L) {
+        acc = 0.0;
+        for (int f = 0; f < 256; ++f) acc = fma(g0w[(size_t)f * L + t], v2[f], acc);
+        grad[(size_t)row * L + t] = (float)acc;
+    }
+}
+
+int dyn_post64(int W1, const float *partial, int tiles_per_b, const double *w1c, const double *g2w, const double *g0w, const double *V64,
+               float *grad, int rows, int L, hipStream_t s) {
+    if (rows <= 0) return DGDM_OK;
+    DGDM_REQUIRE(L <= 256, DGDM_EINVAL, "params_ch %d > 256 not supported", L);
+    if (W1 == 256)
+        hipLaunchKernelGGL(dyn_post64_kernel<256>, dim3(rows), dim3(256), 0, s, partial, tiles_per_b, w1c, g2w, g0w, V64, grad, L);
+    else
+        hipLaunchKernelGGL(dyn_post64_kernel<512>, dim3(rows), dim3(256), 0, s, partial, tiles_per_b, w1c, g2w, g0w, V64, grad, L);
+    DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // a13/a14: guidance combine + DDIM(eta=0, clip) step, elementwise (see dgdm_hip.h)
 __global__ void ddim_step_kernel(const float *__restrict__ x, const float *__restrict__ eps, const float *__restrict__ grad,
                                  int n_grad, float *__restrict__ out, int64_t n, float sa, float sb, float sap, float sbp,
