@@ -7,9 +7,9 @@ benchmark is one batch of `--pairs` independent (object x objective) pairs per G
 B = 32 fingers: PointNet++ object tables, then S = 5 x [eps-net, cond_fn over R = 32*45*25 = 36 000 replicated rows with
 sub_bs = 512 FPS-start partition, guidance combine, DDIM step].  Every pair has its own synthetic 512-point object, so
 nothing is shared between pairs; the tables are rebuilt inside the timed region for every pair.  The FPS start
-indices (the torch.randint draws of pointnet2_utils.py:83) are the path's random input: they are drawn on the host before the
-clock starts and handed over as host int64 buffers (the boundary's contract), so the timed region contains their conversion and
-host->device copy but not the Mersenne-Twister draw.  Every pair has a global index (step, rank, slot) -> its object, objective and its own start
+indices (the torch.randint draws of pointnet2_utils.py:83) are the path's random input: they are drawn INSIDE the timed region, as the
+product path draws them - a worker thread makes step k+1's draws (the library's replay of torch's CPU generator, one stream per pair)
+while the GPU runs step k - and handed over as host int64 buffers (the boundary's contract).  Every pair has a global index (step, rank, slot) -> its object, objective and its own start
 stream are functions of that index only, so the work of a pair does not depend on how many ranks share the batch.
 `--workload 2d` runs BASELINE configs[1] (B = 64, G = 360, P = 5, R = 576 000 rows per pair, 100-vertex contours).
 
@@ -130,13 +130,23 @@ class Workload:
         mk = synth.synth_object_3d if self.kind == "3d" else synth.synth_object_2d
         return torch.stack([mk(g * self.n_obj + j, self.N) for g in self.pair_ids(step) for j in range(self.n_obj)]).to(self.dev)
 
-    def draw(self, step):
+    def draw_buffer(self):
+        """A reusable host buffer for one step's FPS start draws (3-D), in the layout the library takes; None for 2-D."""
+        if self.kind != "3d":
+            return None
+        shape = (self.S, self.n_obj, self.pairs, self.guid.starts_per_call) if self.ensemble else (self.S, self.pairs, self.guid.starts_per_call)
+        return np.zeros(shape, dtype=np.int64)          # zeros: the pages are touched here, not inside the timed region
+
+    def draw(self, step, out=None, pool=None):
+        """The FPS start draws of this step's pairs (pointnet2_utils.py:83): every pair consumes its own generator stream - the stream
+        of torch.Generator().manual_seed(f(STREAM_SEED, global pair index)), replayed by the library (sampler.TorchRng) - chain after
+        chain as the reference's loops do; independent streams are drawn side by side on `pool`."""
         if self.kind != "3d":
             return None
         streams = [sampler.pair_stream(self.N, self.sub, STREAM_SEED, g) for g in self.pair_ids(step)]
         if self.ensemble:
-            return sampler.draw_ensemble_starts(self.guid, self.pairs, self.n_obj, self.S, streams)
-        return sampler.draw_chain_starts(self.guid, self.chains(step), self.S, streams=streams)
+            return sampler.draw_ensemble_starts(self.guid, self.pairs, self.n_obj, self.S, streams, out=out, pool=pool)
+        return sampler.draw_chain_starts(self.guid, self.chains(step), self.S, streams=streams, out=out, pool=pool)
 
     def run(self, step, objs, predrawn):
         self.guid.set_objects(objs)                      # 3-D: builds the PointNet++ tables of every pair (timed)
@@ -148,21 +158,28 @@ class Workload:
 
 
 def timed_loop(wl, steps, warmup, dist):
-    """Returns (seconds for `steps` steps, last output).  The synthetic inputs of every step - objects (uploaded) and the FPS
-    start draws (host int64 arrays, as the reference's torch.randint hands them over) - exist before the clock starts, like a
-    dataset would; when they would not fit in host memory (> 6 GB of draws) the inputs of step k+1 are prepared while step k runs."""
+    """Returns (seconds for `steps` steps, last output, mean host seconds per step spent drawing).
+
+    The synthetic objects of every step exist on the device before the clock starts, like a dataset would.  The FPS start draws - the
+    path's random input, torch.randint on the CPU generator in the reference (pointnet2_utils.py:83) - are made INSIDE the timed region,
+    the way the product path makes them (sampler.StartPlan): a worker thread draws step k+1 while the GPU runs step k.  The first
+    timed step's draws start after the clock does (not during the last warm-up step), so all K steps' draws are on the clock and the
+    pipeline fill is paid once."""
+    from concurrent.futures import ThreadPoolExecutor
     total = warmup + steps
-    prepared = {}
+    objs = {k: wl.objects(k) for k in range(total)}
+    bufs = [wl.draw_buffer(), wl.draw_buffer()]
+    pool = ThreadPoolExecutor(max_workers=max(1, min(8, (os.cpu_count() or 8) // max(1, wl.world))))
+    drawer = ThreadPoolExecutor(max_workers=1)
+    draw_s = {}
 
-    def prepare(k):
-        prepared[k] = (wl.objects(k), wl.draw(k))
+    def draw(k):
+        t = time.perf_counter()
+        r = wl.draw(k, out=bufs[k % 2], pool=pool)
+        draw_s[k] = time.perf_counter() - t
+        return r
 
-    per_step = 8 * 2 * wl.rows * wl.pairs * wl.n_obj * wl.S if wl.kind == "3d" else 0
-    ahead = per_step * total <= 6 * 2 ** 30
-    for k in range(total if ahead else 1):
-        prepare(k)
-    out = None
-    t0 = None
+    out, t0, fut = None, None, None
     for k in range(total):
         if k == warmup:
             torch.cuda.synchronize()
@@ -170,22 +187,23 @@ def timed_loop(wl, steps, warmup, dist):
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-        th = None
-        if not ahead and k + 1 < total:
-            th = threading.Thread(target=prepare, args=(k + 1,))
-            th.start()
-        objs, pre = prepared.pop(k)
-        out = wl.run(k, objs, pre)
+        if fut is None:
+            fut = drawer.submit(draw, k)
+        pre = fut.result()
+        fut = drawer.submit(draw, k + 1) if (k + 1 < total and k + 1 != warmup) else None
+        out = wl.run(k, objs.pop(k), pre)
         if dist is not None and dist.get_world_size() > 1:
             # the path's only collective: final samples; RCCL on device tensors, or host tensors for the gloo test mode
             out = gather_pairs(out, wl.pairs * dist.get_world_size())
-        if th is not None:
-            th.join()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    return time.perf_counter() - t0, out
+    secs = time.perf_counter() - t0
+    drawer.shutdown()
+    pool.shutdown()
+    timed = [draw_s[k] for k in range(warmup, total) if k in draw_s]
+    return secs, out, (sum(timed) / len(timed) if timed else 0.0)
 
 
 # ---------------------------------------------------------------------------------------------------------------- roofline
@@ -494,7 +512,7 @@ def main():
     wl = Workload(a.workload, pairs, dev, rank, world, a.contraction)
 
     engine.prof_enable(False)
-    secs, _ = timed_loop(wl, a.steps, a.warmup, dist)
+    secs, _, draw_secs = timed_loop(wl, a.steps, a.warmup, dist)
     if dist is not None:
         tmax = torch.tensor([secs], device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -513,6 +531,9 @@ def main():
                    "denoise_steps": wl.S, "rows_per_cond_fn": wl.rows, "cond_fn_per_chain_step": wl.n_obj},
         "ms_per_denoise_step": secs / a.steps / wl.S * 1e3,
         "ms_per_denoise_step_per_pair": secs / a.steps / wl.S / pairs * 1e3,
+        "host_draw_ms_per_step": draw_secs * 1e3,
+        "host_draw_note": "FPS start draws (the reference's torch.randint on the CPU generator, pointnet2_utils.py:83) of one step: made inside the "
+                          "timed region by a worker thread while the GPU runs the previous step; the first timed step's draws are not overlapped",
     }
     if roof:
         line["roofline"] = roof
@@ -528,10 +549,11 @@ def main():
         extras = [config0(dev), sweep_leg(dev), train_leg(dev, not a.no_cpu_baseline)]
         for kind, contraction in ((other, "f32"), ("3d", "bf16"), ("2d", "bf16"), ("3d_ensemble", "bf16")):
             w2 = Workload(kind, DEFAULT_PAIRS[kind], dev, rank, world, contraction)
-            s2, _ = timed_loop(w2, 2, 1, None)
-            e = {"workload": kind, "dtype": contraction, "samples_per_s": w2.B * w2.pairs * 2 / s2, "ms_per_step": s2 / 2 * 1e3,
-                 "ms_per_denoise_step_per_pair": s2 / 2 / w2.S / w2.pairs * 1e3, "cond_fn_per_chain_step": w2.n_obj}
-            r2, sh2 = stage_profile(w2, s2 / 2, contraction)
+            ns = 4
+            s2, _, d2 = timed_loop(w2, ns, 1, None)
+            e = {"workload": kind, "dtype": contraction, "samples_per_s": w2.B * w2.pairs * ns / s2, "ms_per_step": s2 / ns * 1e3,
+                 "ms_per_denoise_step_per_pair": s2 / ns / w2.S / w2.pairs * 1e3, "cond_fn_per_chain_step": w2.n_obj, "host_draw_ms_per_step": d2 * 1e3}
+            r2, sh2 = stage_profile(w2, s2 / ns, contraction)
             if r2:
                 e["roofline"], e["stage_share"] = r2, sh2
             if contraction == "f32" and not a.no_cpu_baseline:

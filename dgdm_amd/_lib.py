@@ -41,7 +41,7 @@ class GuidanceConfig(C.Structure):
 
 
 _P = C.c_void_p
-# name -> (restype, argtypes); mirrors include/dgdm_hip.h line by line (tests/test_abi.py checks the symbol list)
+# name -> (restype, argtypes); mirrors include/dgdm_hip.h line by line (tests/test_host_logic.py::test_abi_exports_every_declared_symbol checks the symbol list)
 PROTOTYPES = {
     "dgdm_version": (C.c_int, []),
     "dgdm_last_error": (C.c_char_p, []),
@@ -77,6 +77,9 @@ PROTOTYPES = {
                                          C.POINTER(C.c_float), C.c_int, _P, _P]),
     "dgdm_guidance_orientation_sweep": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P]),
     "dgdm_convergence_rowcoef": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, _P]),
+    "dgdm_torch_rng_seed": (C.c_int, [_P, C.c_int64, C.c_uint64]),
+    "dgdm_torch_rng_randint": (C.c_int, [_P, C.c_int64, C.c_uint32, C.c_int64, _P]),
+    "dgdm_torch_rng_fps_starts": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int64]),
     "dgdm_prof_enable": (C.c_int, [C.c_int]),
     "dgdm_guidance_debug_fps_path": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int32)]),
     "dgdm_debug_pointnet_indices": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),

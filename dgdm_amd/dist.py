@@ -25,8 +25,10 @@ def shard_range(n_items: int, rank: int, world: int) -> range:
 
 def gather_pairs(local: torch.Tensor, n_items: int, group=None) -> torch.Tensor:
     """all_gather of per-rank results [n_local, ...] (block partition of `n_items`) -> [n_items, ...] on every rank."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized():
         return local
+    # an initialised group of ONE rank still goes through the collective (RCCL on the device tensor): that is how the 1-GPU box
+    # exercises this branch (tests/test_gpu_dist.py)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     most = max(len(shard_range(n_items, r, world)) for r in range(world))
     # RCCL ("nccl") gathers device tensors in place; under gloo (CPU tests, or ranks sharing a GPU) the payload goes through host memory
@@ -79,7 +81,7 @@ def sync_start_stream_seed(group=None) -> int:
     DGDM_TORCH_SEED pins it - for one process as well - otherwise rank 0's own (random) initial seed is broadcast."""
     env = os.environ.get("DGDM_TORCH_SEED")
     seed = int(env) if env else int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():
         t = torch.tensor([seed], dtype=torch.int64)
         if dist.get_backend(group) == "nccl":
             t = t.cuda()
@@ -199,7 +201,7 @@ def guided_multi_object_sharded(unet, spec: GuidanceSpec, sched, mode: str, nois
 
 def all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
     """Sum over the ranks (gradients of data-parallel training): RCCL on the device tensor; through host memory under gloo."""
-    if world_rank(group)[0] == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return t
     if t.is_cuda and dist.get_backend(group) != "nccl":
         h = t.cpu()
@@ -212,7 +214,7 @@ def all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
 def all_gather_rows(t: torch.Tensor, group=None) -> torch.Tensor:
     """[n, ...] of equal shape on every rank -> [world, n, ...] on every rank."""
     world, _ = world_rank(group)
-    if world == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return t[None]
     via_host = t.is_cuda and dist.get_backend(group) != "nccl"
     src = t.cpu() if via_host else t.contiguous()

@@ -349,14 +349,49 @@ class Diffusion(nn.Module):
                 else:
                     tables.skipped("no simulator callable was given to Diffusion(simulator=...): the objective tables of "
                                    "generator/diffusion.py:304-336, 592-619, 697-709 need simulator roll-outs (dynamics/sim_test_mj*.py)")
-            for opt_obj in OBJECTIVE_SWEEP:
-                rng = [-1.0, 1.0]
-                if sim_unguided is not None:
-                    if not imgs:
-                        imgs = [None] * B
-                    artefacts.unguided_table(self, tables, sim_unguided, imgs, len(self._object_ids()), B, opt_obj, rng, self.mode == 'point_3d')
-                if opt_obj != 'convergence':
-                    out[f"multi/{opt_obj}"] = self.guided_sample_multi_object(batch_idx, B, noise, self.save_dir, opt_obj=opt_obj, ori_range=rng)
-                out[f"guided/{opt_obj}"] = self.guided_sample(batch_idx, B, noise, self.save_dir, opt_obj=opt_obj, ori_range=rng,
-                                                              unguided_sample=unguided)
+            with self._draw_ahead(B):
+                self._objective_sweep(out, batch_idx, B, noise, unguided, sim_unguided, tables, imgs)
         return out
+
+    def _draw_ahead(self, B: int):
+        """The FPS start draws of the whole objective sweep, made ahead of the launches on a worker thread (sampler.StartPlan): they
+        depend on nothing the GPU computes, only on the order in which the loops below consume the generator - per objective the
+        multi-object chain (per step object after object, :641-643), then the per-object chains (centre sweep, then the steps, :561-576);
+        under a process group every rank walks the whole stream and skips what belongs to other ranks (dgdm_amd/dist.py)."""
+        import contextlib
+        if self.mode != 'point_3d' or self.object_vertices is None:
+            return contextlib.nullcontext()
+        objs = torch.as_tensor(self.object_vertices)
+        n, N, S = objs.shape[0], objs.shape[1], len(self.noise_scheduler.timesteps)
+        rows, sweep_rows = B * self.grid_size * self.num_pos ** 2, B * self.grid_size
+        world, rank = ddist.world_rank()
+        plots = bool(self.save_dir) and self.render_plots and rank == 0
+        jobs = []
+        for opt_obj in OBJECTIVE_SWEEP:
+            if opt_obj != 'convergence':
+                if world > 1:
+                    mine = ddist.shard_range(n, rank, world)
+                    jobs += [(rows, 1, j in mine) for _ in range(S) for j in range(n)]
+                elif plots:
+                    jobs += [(rows, n, True)] * S
+                else:
+                    jobs.append((rows, S * n, True))
+            mine = ddist.shard_range(n, rank, world)
+            for c in range(n):
+                if opt_obj == 'convergence':
+                    jobs.append((sweep_rows, 1, c in mine))
+                jobs.append((rows, S, c in mine))
+        return sampler.StartPlan(N, self.sub_batch_size, jobs)
+
+    def _objective_sweep(self, out, batch_idx, B, noise, unguided, sim_unguided, tables, imgs):
+        """The 12-objective sweep of generator/diffusion.py:307-339: per objective the multi-object chain, then the per-object chains."""
+        for opt_obj in OBJECTIVE_SWEEP:
+            rng = [-1.0, 1.0]
+            if sim_unguided is not None:
+                if not imgs:
+                    imgs = [None] * B
+                artefacts.unguided_table(self, tables, sim_unguided, imgs, len(self._object_ids()), B, opt_obj, rng, self.mode == 'point_3d')
+            if opt_obj != 'convergence':
+                out[f"multi/{opt_obj}"] = self.guided_sample_multi_object(batch_idx, B, noise, self.save_dir, opt_obj=opt_obj, ori_range=rng)
+            out[f"guided/{opt_obj}"] = self.guided_sample(batch_idx, B, noise, self.save_dir, opt_obj=opt_obj, ori_range=rng,
+                                                          unguided_sample=unguided)

@@ -14,7 +14,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from . import engine
+from . import _lib, engine
 from .engine import Guidance, Unet1d, make_objective
 from .scheduler import DDIMScheduler
 
@@ -30,60 +30,209 @@ def classifier_scale(mode: str, opt_obj: str, multi: bool = False) -> float:
     return 0.001
 
 
+class TorchRng:
+    """torch's CPU generator replayed by the library on the generator's own state blob (csrc/torch_rng.hip): the same numbers as
+    ``torch.randint`` bit for bit, ~3x faster, callable from worker threads (ctypes releases the GIL) and able to SKIP draws.
+
+    ``generator``: a ``torch.Generator``, or None for torch's global CPU generator - every operation then loads the generator's
+    state, advances it and stores it back, so torch and this class can be used on the same generator alternately.
+    ``seed``: a detached stream instead - the stream of ``torch.Generator().manual_seed(seed)`` without a torch object."""
+
+    BYTES = 5056
+
+    def __init__(self, generator: Optional[torch.Generator] = None, seed: Optional[int] = None, state: Optional[np.ndarray] = None):
+        self._gen, self._detached = generator, seed is not None or state is not None
+        self._blob = np.zeros(self.BYTES, dtype=np.uint8) if state is None else np.array(state, dtype=np.uint8, copy=True)
+        if seed is not None:
+            _lib.check(_lib.lib().dgdm_torch_rng_seed(self._blob.ctypes.data, self.BYTES, int(seed) & 0xFFFFFFFFFFFFFFFF))
+
+    def _load(self):
+        if not self._detached:
+            st = torch.get_rng_state() if self._gen is None else self._gen.get_state()
+            self._blob = st.numpy().copy()
+
+    def _store(self):
+        if not self._detached:
+            st = torch.from_numpy(self._blob.copy())
+            torch.set_rng_state(st) if self._gen is None else self._gen.set_state(st)
+
+    def detached_copy(self) -> "TorchRng":
+        """A detached stream that starts where the generator stands now (for drawing ahead on a worker thread)."""
+        self._load()
+        return TorchRng(state=self._blob)
+
+    def adopt(self, other: "TorchRng") -> None:
+        """Puts the generator where the detached stream `other` stands."""
+        self._blob = other._blob.copy()
+        self._store()
+
+    def randint(self, high: int, n: int, skip: bool = False) -> Optional[np.ndarray]:
+        self._load()
+        out = None if skip else np.empty(n, dtype=np.int64)
+        _lib.check(_lib.lib().dgdm_torch_rng_randint(self._blob.ctypes.data, self.BYTES, int(high), int(n), None if skip else out.ctypes.data))
+        self._store()
+        return out
+
+    def fps_starts(self, num_points: int, sub_batch_size: int, rows: int, n_calls: int = 1, skip: bool = False,
+                   out: Optional[np.ndarray] = None) -> Optional[np.ndarray]:
+        """The draws of `n_calls` consecutive classifier calls over `rows` rows -> (n_calls, 2 * rows) int64 in the layout
+        dgdm_dyn3d_guidance_grad takes, or None when skipped.  out: an int64 view of that shape to fill (rows contiguous; the
+        calls may be strided - e.g. one chain's column of a [step][chain][2 * rows] array)."""
+        self._load()
+        stride = 0
+        if skip:
+            out = None
+        elif out is None:
+            out = np.empty((n_calls, 2 * rows), dtype=np.int64)
+        else:
+            assert out.dtype == np.int64 and out.shape == (n_calls, 2 * rows) and (n_calls == 0 or out.strides[1] == 8) and out.strides[0] % 8 == 0
+            stride = out.strides[0] // 8 if n_calls > 1 else 0
+        _lib.check(_lib.lib().dgdm_torch_rng_fps_starts(self._blob.ctypes.data, self.BYTES, int(num_points), max(1, int(sub_batch_size)), int(rows),
+                                                       int(n_calls), None if out is None else out.ctypes.data, stride))
+        self._store()
+        return out
+
+
+_ACTIVE_PLAN: Optional["StartPlan"] = None
+
+
+class StartPlan:
+    """Draws ahead.  The FPS start draws of a sweep do not depend on anything the GPU computes, only on the ORDER in which the
+    reference's loops consume the generator; given that order as a list of jobs ``(rows, n_calls, keep)`` a worker thread makes the
+    draws while the GPU runs the chains of earlier jobs.  Used as a context manager around code that draws from the GLOBAL generator
+    through ``StartStream``: inside it those streams take their numbers from the plan (jobs must be asked for in plan order; a
+    request that does not match cancels the plan and the stream continues synchronously from the right state).  On exit the global
+    generator stands where the consumed jobs leave it - exactly as if every draw had been a ``torch.randint``."""
+
+    def __init__(self, num_points: int, sub_batch_size: int, jobs: Sequence[Tuple[int, int, bool]], depth: int = 4):
+        import queue
+        import threading
+        self.N, self.sub, self.jobs = int(num_points), int(sub_batch_size), [(int(r), int(n), bool(k)) for r, n, k in jobs]
+        self._q: "queue.Queue" = queue.Queue(maxsize=max(1, depth))
+        self._stop = threading.Event()
+        self._thread: Optional[threading.Thread] = None
+        self._pos = 0
+        self._rng_after: Optional[TorchRng] = None      # stream position after the last consumed job
+        self.draw_seconds = 0.0
+
+    def _work(self, rng: TorchRng):
+        import time
+        for rows, n, keep in self.jobs:
+            if self._stop.is_set():
+                return
+            t0 = time.perf_counter()
+            arr = rng.fps_starts(self.N, self.sub, rows, n, skip=not keep)
+            self.draw_seconds += time.perf_counter() - t0
+            item = (arr, TorchRng(state=rng._blob))
+            while not self._stop.is_set():
+                try:
+                    self._q.put(item, timeout=0.05)
+                    break
+                except Exception:           # queue.Full
+                    continue
+
+    def __enter__(self):
+        import threading
+        global _ACTIVE_PLAN
+        assert _ACTIVE_PLAN is None, "StartPlan contexts do not nest"
+        self._base = TorchRng()                              # the global generator
+        self._rng_after = self._base.detached_copy()
+        self._thread = threading.Thread(target=self._work, args=(self._base.detached_copy(),), daemon=True)
+        self._thread.start()
+        _ACTIVE_PLAN = self
+        return self
+
+    def _close(self):
+        global _ACTIVE_PLAN
+        if _ACTIVE_PLAN is self:
+            _ACTIVE_PLAN = None
+            self._stop.set()
+            while self._thread is not None and self._thread.is_alive():
+                try:
+                    self._q.get_nowait()
+                except Exception:
+                    pass
+                self._thread.join(timeout=0.01)
+            self._base.adopt(self._rng_after)
+
+    def __exit__(self, *exc):
+        self._close()
+        return False
+
+    def take(self, num_points: int, sub: int, rows: int, n_calls: int, keep: bool):
+        """The next job's draws if it is the job asked for; otherwise cancels the plan (returns False)."""
+        if self._pos < len(self.jobs) and (self.N, self.sub) == (int(num_points), int(sub)) and self.jobs[self._pos] == (int(rows), int(n_calls), bool(keep)):
+            arr, after = self._q.get()
+            self._pos += 1
+            self._rng_after = after
+            return True, arr
+        self._close()
+        return False, None
+
+
 class StartStream:
     """FPS start indices in the reference's draw order.
 
     One classifier call on ``rows`` rows with sub-batch size ``sub`` draws, per sub-batch, ``torch.randint(0, N, (n,))``
     for sa1 and ``torch.randint(0, 512, (n,))`` for sa2 from the global CPU generator
-    (pointnet2_utils.py:83 reached via generator/diffusion.py:495-498 and :524-526).
+    (pointnet2_utils.py:83 reached via generator/diffusion.py:495-498 and :524-526).  The numbers are made by the library's
+    replay of that generator (``TorchRng``: identical to ``torch.randint``, tests/test_host_logic.py) on the generator's own state.
 
-    ``generator``: a private ``torch.Generator`` instead of the global one (per-pair streams, ``pair_stream``)."""
+    ``generator``: a private ``torch.Generator`` instead of the global one; ``seed``: a detached stream (``pair_stream``);
+    ``forced``: recorded draws (golden fixtures)."""
 
     def __init__(self, num_points: int, sub_batch_size: int, forced: Optional[Sequence[torch.Tensor]] = None,
-                 generator: Optional[torch.Generator] = None):
+                 generator: Optional[torch.Generator] = None, seed: Optional[int] = None):
         self.N, self.sub = int(num_points), int(sub_batch_size)
         self._forced = list(forced) if forced is not None else None
-        self._gen = generator
+        self._rng = None if forced is not None else TorchRng(generator, seed)
+        self._plannable = forced is None and generator is None and seed is None
 
-    def _randint(self, high: int, n: int) -> torch.Tensor:
-        if self._gen is not None:
-            return torch.randint(0, high, (n,), dtype=torch.long, generator=self._gen)
-        return torch.randint(0, high, (n,), dtype=torch.long)
-
-    def _draw(self, high: int, n: int) -> np.ndarray:
-        if self._forced is not None:
-            s = self._forced.pop(0)
-            assert s.shape == (n,), (s.shape, n)
-            return s.numpy().astype(np.int64)
-        return self._randint(high, n).numpy()
-
-    def call(self, rows: int) -> np.ndarray:
-        """The 2*rows indices one classifier call over `rows` rows consumes, in draw order:
-        [sub-batch 0: sa1 x n0, sa2 x n0 | sub-batch 1: ...] - the layout dgdm_dyn3d_guidance_grad takes."""
-        if self._forced is None and self.N == 512:
-            # same range for both layers: consecutive randint calls on the CPU generator concatenate
-            # (tests/test_host_logic.py::test_start_stream_matches_reference_draws), so one call does it
-            return self._randint(512, 2 * rows).numpy()
+    def _forced_call(self, rows: int) -> np.ndarray:
         out = np.empty(2 * rows, dtype=np.int64)
         for r0 in range(0, rows, self.sub):
             n = min(self.sub, rows - r0)
-            out[2 * r0:2 * r0 + n] = self._draw(self.N, n)
-            out[2 * r0 + n:2 * r0 + 2 * n] = self._draw(512, n)
+            for k, off in ((0, 2 * r0), (1, 2 * r0 + n)):
+                s = self._forced.pop(0)
+                assert s.shape == (n,), (s.shape, n)
+                out[off:off + n] = s.numpy()
         return out
 
-    def skip(self, rows: int) -> None:
-        """Consume the draws of one classifier call without keeping them (a rank replaying the global stream past chains
-        that belong to other ranks, dgdm_amd/dist.py)."""
-        self.call(rows)
+    def calls(self, rows: int, n_calls: int, keep: bool = True, out: Optional[np.ndarray] = None) -> Optional[np.ndarray]:
+        """The indices `n_calls` consecutive classifier calls over `rows` rows consume -> (n_calls, 2 * rows) int64, each row
+        [sub-batch 0: sa1 x n0, sa2 x n0 | sub-batch 1: ...] - the layout dgdm_dyn3d_guidance_grad takes.  keep=False: the draws
+        are consumed without being materialised (a rank replaying the stream past chains that belong to other ranks).
+        out: where to put them (see TorchRng.fps_starts)."""
+        arr = None
+        if self._forced is not None:
+            arr = np.stack([self._forced_call(rows) for _ in range(n_calls)]) if n_calls else np.empty((0, 2 * rows), np.int64)
+            if not keep:
+                return None
+        elif self._plannable and _ACTIVE_PLAN is not None:
+            ok, arr = _ACTIVE_PLAN.take(self.N, self.sub, rows, n_calls, keep)
+            if ok and not keep:
+                return None
+            arr = arr if ok else None
+        if arr is None:
+            return self._rng.fps_starts(self.N, self.sub, rows, n_calls, skip=not keep, out=out)
+        if out is not None:
+            out[...] = arr
+            return out
+        return arr
+
+    def call(self, rows: int) -> np.ndarray:
+        """One classifier call: 2*rows indices in draw order."""
+        return self.calls(rows, 1)[0]
+
+    def skip(self, rows: int, n_calls: int = 1) -> None:
+        self.calls(rows, n_calls, keep=False)
 
 
 def pair_stream(num_points: int, sub_batch_size: int, seed: int, pair_index: int) -> StartStream:
     """A start stream of its own for pair `pair_index` (seed-derived), for workloads that have no reference draw order to keep
     (bench.py's synthetic pair batches): the draws of a pair depend on (seed, pair index) only, not on the rank that runs it or on
-    how many ranks there are."""
-    g = torch.Generator()
-    g.manual_seed((int(seed) * 1_000_003 + int(pair_index)) & 0x7FFFFFFFFFFFFFFF)
-    return StartStream(num_points, sub_batch_size, generator=g)
+    how many ranks there are.  The stream of ``torch.Generator().manual_seed(...)`` with that seed."""
+    return StartStream(num_points, sub_batch_size, seed=(int(seed) * 1_000_003 + int(pair_index)) & 0x7FFFFFFFFFFFFFFF)
 
 
 def unguided_sample(unet: Unet1d, sched: DDIMScheduler, x: torch.Tensor, on_step=None) -> torch.Tensor:
@@ -123,7 +272,8 @@ def convergence_centers(guid: Guidance, mode: str, unguided: torch.Tensor, objec
 
 
 def draw_chain_starts(guid: Guidance, chains: Sequence[Tuple[int, str]], n_steps: int, starts: Optional[StartStream] = None,
-                      keep: Optional[range] = None, streams: Optional[Sequence[StartStream]] = None):
+                      keep: Optional[range] = None, streams: Optional[Sequence[StartStream]] = None, out: Optional[np.ndarray] = None,
+                      pool=None):
     """FPS starts of a batch of 3-D chains in the order the reference's sequential loops consume the generator:
     chain after chain (generator/diffusion.py:561); inside a chain the centre sweep (:563) and then every step's cond_fn (:574).
 
@@ -136,26 +286,28 @@ def draw_chain_starts(guid: Guidance, chains: Sequence[Tuple[int, str]], n_steps
     if streams is None:
         starts = starts or StartStream(guid.cfg.num_object_points, guid.cfg.sub_batch_size)
     sweep: List[Optional[np.ndarray]] = [None] * len(keep)
-    step = np.zeros((n_steps, len(keep), guid.starts_per_call), dtype=np.int64)
-    for c, (_, o) in enumerate(chains):
-        mine = c in keep
-        if streams is not None:
-            if not mine:
-                continue
-            st = streams[c]
-        else:
-            st = starts
+    step = out if out is not None else np.empty((n_steps, len(keep), guid.starts_per_call), dtype=np.int64)
+    assert step.shape == (n_steps, len(keep), guid.starts_per_call) and step.dtype == np.int64 and step.flags.c_contiguous
+    def one(c, o, st, mine):
         k = c - keep.start
         if o == 'convergence':
+            sw = st.calls(guid.sweep_rows, 1, keep=mine)
             if mine:
-                sweep[k] = st.call(guid.sweep_rows)
-            else:
-                st.skip(guid.sweep_rows)
-        for si in range(n_steps):
-            if mine:
-                step[si, k] = st.call(guid.rows)
-            else:
-                st.skip(guid.rows)
+                sweep[k] = sw[0]
+        st.calls(guid.rows, n_steps, keep=mine, out=step[:, k] if mine else None)
+
+    if streams is not None:
+        # independent streams: the chains' draws can be made side by side (`pool`: a concurrent.futures executor; the library call
+        # releases the interpreter lock)
+        jobs = [(c, o, streams[c], True) for c, (_, o) in enumerate(chains) if c in keep]
+        if pool is not None and len(jobs) > 1:
+            list(pool.map(lambda j: one(*j), jobs))
+        else:
+            for j in jobs:
+                one(*j)
+    else:
+        for c, (_, o) in enumerate(chains):
+            one(c, o, starts, c in keep)
     return sweep, step
 
 
@@ -228,7 +380,7 @@ def guided_multi_object(unet: Unet1d, guid: Guidance, sched: DDIMScheduler, mode
     scale = classifier_scale(mode, opt_obj, multi=True)
     if on_step is None:       # one library call for the whole loop; per step the reference draws object after object (:641-643)
         S = len(sched.timesteps)
-        st = np.stack([np.concatenate([starts.call(guid.rows) for _ in object_indices]) for _ in range(S)]) if is3d else None
+        st = starts.calls(guid.rows, S * n_obj).reshape(S, -1) if is3d else None      # per step object after object (:641-643): one run of draws
         out = engine.guided_chains_run(unet, guid, noise.reshape(B, L), 1, n_obj, objectives, None, st, [int(t) for t in sched.timesteps],
                                        [sched.coefficients(int(t)) for t in sched.timesteps], [scale])
         return out.reshape(B, L, 1)
@@ -237,7 +389,7 @@ def guided_multi_object(unet: Unet1d, guid: Guidance, sched: DDIMScheduler, mode
         t = int(t)
         ts = torch.full((B,), t, dtype=torch.int32, device=dev)
         eps = unet.forward(x.reshape(B, L, 1), ts).reshape(B, L)
-        st = np.concatenate([starts.call(guid.rows) for _ in object_indices]) if is3d else None      # object after object (:641-643)
+        st = starts.calls(guid.rows, n_obj).reshape(-1) if is3d else None      # object after object (:641-643)
         g = guid.grad(x.reshape(1, B, L).expand(n_obj, -1, -1).contiguous(), t, objectives, None, st)
         x = engine.ddim_guided_step(x, eps, g, n_obj, sched.coefficients(t), scale)
         if on_step is not None:                              # the harness's per-step plots (generator/diffusion.py:648-674)
@@ -245,16 +397,24 @@ def guided_multi_object(unet: Unet1d, guid: Guidance, sched: DDIMScheduler, mode
     return x.reshape(B, L, 1)
 
 
-def draw_ensemble_starts(guid: Guidance, n_groups: int, n_obj: int, n_steps: int, streams: Optional[Sequence[StartStream]] = None):
+def draw_ensemble_starts(guid: Guidance, n_groups: int, n_obj: int, n_steps: int, streams: Optional[Sequence[StartStream]] = None,
+                         out: Optional[np.ndarray] = None, pool=None):
     """FPS starts of ``n_groups`` independent multi-object chains: every group has its own generator stream and consumes it as
     ``guided_sample_multi_object`` does - step after step, inside a step object after object (generator/diffusion.py:641-643).
     Returned as (n_steps, n_obj, n_groups, starts_per_call): the launch order of ``guided_multi_object_groups``."""
     streams = streams or [StartStream(guid.cfg.num_object_points, guid.cfg.sub_batch_size) for _ in range(n_groups)]
-    out = np.zeros((n_steps, n_obj, n_groups, guid.starts_per_call), dtype=np.int64)
-    for k in range(n_groups):
-        for si in range(n_steps):
-            for j in range(n_obj):
-                out[si, j, k] = streams[k].call(guid.rows)
+    out = out if out is not None else np.empty((n_steps, n_obj, n_groups, guid.starts_per_call), dtype=np.int64)
+    assert out.shape == (n_steps, n_obj, n_groups, guid.starts_per_call) and out.dtype == np.int64 and out.flags.c_contiguous
+
+    def one(k):
+        for si in range(n_steps):               # a group's stream is consumed step after step, object after object
+            streams[k].calls(guid.rows, n_obj, out=out[si, :, k])
+
+    if pool is not None and n_groups > 1:
+        list(pool.map(one, range(n_groups)))
+    else:
+        for k in range(n_groups):
+            one(k)
     return out
 
 

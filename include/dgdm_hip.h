@@ -217,6 +217,21 @@ int dgdm_guidance_orientation_sweep(DgdmGuidance *g, const float *x_dev, const i
 int dgdm_convergence_rowcoef(const int64_t *centers_host, int n_centers, int grid_size, int num_pos,
                              int64_t total_rows, int64_t sub_batch_size /* 0 = no sub-batching */, float *rowcoef_host);
 
+/* ------------------------------------------------------------------ the path's random input: FPS start draws
+ * farthest_point_sample draws its start index with torch.randint(0, N, (rows,)) on torch's CPU default generator
+ * (dynamics/models/pointnet2_utils.py:83), twice per classifier call and sub-batch.  These host functions replay that generator
+ * (at::mt19937; randint = output % range) on its own state blob - `state` is what torch.get_rng_state() / Generator.get_state()
+ * returns (5056 bytes) - and advance the blob exactly as the torch calls would, so that the draws can be made (or skipped) from a
+ * worker thread ahead of the launches and the blob handed back with torch.set_rng_state().                                    */
+int dgdm_torch_rng_seed(uint8_t *state, int64_t state_bytes, uint64_t seed);             /* torch.Generator().manual_seed(seed)        */
+int dgdm_torch_rng_randint(uint8_t *state, int64_t state_bytes, uint32_t high, int64_t n,
+                           int64_t *out_host /* NULL: the n draws are skipped */);      /* torch.randint(0, high, (n,))               */
+/* The draws of n_calls consecutive classifier calls over `rows` rows each (diffusion.py:495-498): per call and sub-batch of n rows,
+ * sa1's n draws in [0, num_points) then sa2's n draws in [0, 512) - the starts_host layout of dgdm_dyn3d_guidance_grad.          */
+int dgdm_torch_rng_fps_starts(uint8_t *state, int64_t state_bytes, int num_points, int64_t sub_batch_size, int64_t rows,
+                              int64_t n_calls, int64_t *out_host /* NULL: skipped */,
+                              int64_t out_call_stride /* elements between the outputs of consecutive calls; 0 = 2*rows */);
+
 /* ------------------------------------------------------------------ (f) next: finger-geometry decode
  * What the reference does on the host, gripper by gripper, between the sampler and the simulator.  Both maps are linear in
  * the control values, so the library applies one constant matrix (built in double precision) to the whole batch on the device.

@@ -164,8 +164,12 @@ def test_ensemble_groups_equal_single_chains(dev):
             super().__init__(512, sub)
             self.seq = list(seq)
 
-        def call(self, rows):
-            return self.seq.pop(0).numpy()
+        def calls(self, rows, n_calls, keep=True, out=None):
+            arr = np.stack([self.seq.pop(0).numpy() for _ in range(n_calls)])
+            if out is not None:
+                out[...] = arr
+                return out
+            return arr
 
     both = sampler.guided_multi_object_groups(net, g3, s, 'point_3d', noise, groups, objs, streams=[Fixed(draws[0]), Fixed(draws[1])])
     for k in range(2):
@@ -222,3 +226,40 @@ def test_diffusion_class_bf16_switch(dev):
     assert float((outs["bf16"] - outs["f32"]).abs().max()) < 0.2 and not torch.equal(outs["bf16"], outs["f32"])
     with pytest.raises(ValueError):
         Diffusion(noise_pred_net=net, noise_scheduler=DDIMScheduler(num_train_timesteps=15), num_inference_steps=5, contraction_dtype="fp8")
+
+
+def test_config4_full_size_ensemble(dev):
+    """BASELINE configs[4] at its per-GPU size: 8 chains x 4 objects (a 4x guidance ensemble: four dynamics gradients per chain and
+    denoise step), B = 32 fingers, G = 45, P = 5 -> 32 gradient chains x 36 000 rows per launch, bf16 contractions.
+    (i) the grouped launch == the eight chains run one by one with guided_multi_object, bit for bit; (ii) the bf16 guidance gradient
+    of every one of the 32 (chain, object) pairs is within 8e-2 of the float32 path's on the same inputs."""
+    from dgdm_amd.scheduler import DDIMScheduler
+    B, G, P, L, N, sub, T, S, K, n_obj = 32, 45, 5, 42, 512, 512, 15, 5, 8, 4
+    s = DDIMScheduler(num_train_timesteps=T)
+    s.set_timesteps(S)
+    net = engine.Unet1d(util.unet_sd(11), contraction_dtype="bf16")
+    dyn = engine.Dynamics(3, util.dyn3d_sd(33), L)
+    objs = torch.stack([synth.synth_object_3d(4000 + i, N) for i in range(K * n_obj)]).to(dev)
+    g16 = engine.Guidance(dyn, B, G, P, (-1.0, 1.0), K * n_obj, T, N, sub, max_objects=K * n_obj, contraction_dtype="bf16")
+    g16.set_objects(objs)
+    noise = synth.synth_noise(0, B, L).to(dev)
+    groups = [list(range(n_obj * k, n_obj * (k + 1))) for k in range(K)]
+    names = [o for o in synth.OBJECTIVES_12 if o != 'convergence'][:K]
+    mk = lambda k: sampler.pair_stream(N, sub, 77, k)      # noqa: E731
+    pre = sampler.draw_ensemble_starts(g16, K, n_obj, S, [mk(k) for k in range(K)])
+    both = sampler.guided_multi_object_groups(net, g16, s, 'point_3d', noise, groups, names, predrawn=pre)
+    assert both.shape == (K, B, L, 1) and bool(torch.isfinite(both).all()) and float(both.abs().max()) <= 1.0 + 1e-6
+    for k in range(K):
+        one = sampler.guided_multi_object(net, g16, s, 'point_3d', noise, groups[k], names[k], starts=mk(k))
+        assert torch.equal(both[k], one), k
+    # one full-size cond_fn launch (32 gradient chains) in both arithmetics
+    g32 = engine.Guidance(dyn, B, G, P, (-1.0, 1.0), K * n_obj, T, N, sub, max_objects=K * n_obj)
+    g32.set_objects(objs)
+    x = noise.reshape(1, B, L).expand(K * n_obj, -1, -1).contiguous()
+    objectives = [engine.make_objective(names[k], groups[k][j]) for j in range(n_obj) for k in range(K)]
+    st = np.ascontiguousarray(pre[0]).reshape(-1)
+    a = g32.grad(x, int(s.timesteps[0]), objectives, None, st).cpu()
+    b = g16.grad(x, int(s.timesteps[0]), objectives, None, st).cpu()
+    rel = [util.rel_l2(b[i], a[i]) for i in range(K * n_obj)]
+    print(f"configs[4] full size: bf16 vs float32 gradient, relative L2 over the 32 (chain, object) launches: max {max(rel):.2e} median {float(np.median(rel)):.2e}")
+    assert max(rel) < 8e-2, rel

@@ -88,6 +88,78 @@ def test_start_stream_matches_reference_draws():
     assert np.array_equal(a, torch.cat(log.log).numpy())
 
 
+def test_torch_rng_replay_is_bit_exact(lib):
+    """The library's replay of torch's CPU generator (csrc/torch_rng.hip) against torch itself: seeding, randint with power-of-two
+    and other ranges across state refreshes, skipping, and the state blob it hands back."""
+    for seed in (0, 1234, 2 ** 40 + 7):
+        g = torch.Generator()
+        g.manual_seed(seed)
+        r = sampler.TorchRng(seed=seed)
+        for high, n in ((512, 5), (512, 700), (300, 1000), (1000, 3), (512, 100000), (7, 1300), (512, 0)):
+            assert np.array_equal(torch.randint(0, high, (n,), generator=g).numpy(), r.randint(high, n)), (seed, high, n)
+        torch.randint(0, 512, (12345,), generator=g)
+        assert r.randint(512, 12345, skip=True) is None
+        assert np.array_equal(torch.randint(0, 99, (50,), generator=g).numpy(), r.randint(99, 50))
+        assert np.array_equal(g.get_state().numpy(), r._blob)                      # torch could take over from here
+    # attached to the global generator: torch and the replay alternate on one stream
+    torch.manual_seed(42)
+    a = [torch.randint(0, 512, (n,)).numpy() for n in (100, 1000, 10)]
+    torch.manual_seed(42)
+    r = sampler.TorchRng()
+    b = [r.randint(512, 100), torch.randint(0, 512, (1000,)).numpy(), r.randint(512, 10)]
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    # a private torch.Generator
+    g1, g2 = torch.Generator().manual_seed(9), torch.Generator().manual_seed(9)
+    st = sampler.StartStream(300, 64, generator=g2)
+    want = []
+    for r0 in range(0, 150, 64):
+        n = min(64, 150 - r0)
+        want += [torch.randint(0, 300, (n,), generator=g1), torch.randint(0, 512, (n,), generator=g1)]
+    assert np.array_equal(st.call(150), torch.cat(want).numpy())
+    assert torch.equal(g1.get_state(), g2.get_state())
+    # strided destination: one chain's column of a [step][chain][2 * rows] array
+    out = np.full((3, 4, 2 * 40), -1, dtype=np.int64)
+    sampler.StartStream(512, 16, seed=5).calls(40, 3, out=out[:, 2])
+    assert np.array_equal(out[:, 2], sampler.StartStream(512, 16, seed=5).calls(40, 3)) and (out[:, [0, 1, 3]] == -1).all()
+
+
+def test_start_plan_draws_ahead_like_torch():
+    """sampler.StartPlan: the draws of a list of jobs made ahead on a worker thread == the same StartStream calls made one after the
+    other on torch's global generator, kept or skipped; the generator ends where torch.randint would have left it; a request that is
+    not the planned one cancels the plan and continues synchronously from the right place."""
+    jobs = [(24, 3, True), (10, 1, False), (24, 5, True), (7, 2, True)]
+
+    def run(plan):
+        torch.manual_seed(77)
+        st = sampler.StartStream(512, 7)
+        got = []
+        if plan:
+            with sampler.StartPlan(512, 7, jobs):
+                got = [st.calls(r, n, keep=k) for r, n, k in jobs]
+        else:
+            got = [st.calls(r, n, keep=k) for r, n, k in jobs]
+        return got, torch.randint(0, 1000, (5,))
+
+    (a, ta), (b, tb) = run(False), run(True)
+    assert all((x is None and y is None) or np.array_equal(x, y) for x, y in zip(a, b)) and torch.equal(ta, tb)
+    # against torch.randint itself (N = 512: a call is one flat run of 2 * rows draws)
+    torch.manual_seed(77)
+    for (r, n, k), got in zip(jobs, b):
+        want = torch.randint(0, 512, (2 * r * n,)).numpy().reshape(n, 2 * r)
+        assert got is None if not k else np.array_equal(got, want)
+    # deviation from the plan
+    torch.manual_seed(3)
+    ref = [sampler.StartStream(512, 7).calls(24, 3), sampler.StartStream(512, 7).calls(5, 1), torch.randint(0, 9, (4,))]
+    torch.manual_seed(3)
+    with sampler.StartPlan(512, 7, jobs):
+        st = sampler.StartStream(512, 7)
+        x = st.calls(24, 3)
+        y = st.calls(5, 1)                   # not the planned (10, 1, skip): the plan is dropped, the stream goes on from after job 0
+    z = torch.randint(0, 9, (4,))
+    assert np.array_equal(x, ref[0]) and np.array_equal(y, ref[1]) and torch.equal(z, ref[2])
+    assert sampler._ACTIVE_PLAN is None
+
+
 def test_scheduler_tables_match_oracle():
     from dgdm_amd.scheduler import DDIMScheduler
     for T, S in ((15, 5), (1000, 100), (1000, 1000)):
