@@ -94,6 +94,7 @@ PROTOTYPES = {
     "dgdm_trainer2d_gradient_count": (C.c_int64, [_P]),
     "dgdm_trainer2d_gradients": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
     "dgdm_trainer2d_apply": (C.c_int, [_P, C.c_float, _P]),
+    "dgdm_trainer2d_running_stats": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
     "dgdm_trainer2d_export": (C.c_int, [_P, C.c_int, C.POINTER(Tensor), C.c_int]),
     "dgdm_trainer2d_steps": (C.c_int64, [_P]),
 }

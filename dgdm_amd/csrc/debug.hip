@@ -87,11 +87,13 @@ extern "C" int dgdm_query_ball_point(float radius_squared, int nsample, const fl
 extern "C" int dgdm_square_distance(const float *src_dev, const float *dst_dev, int B, int S, int N, float *out_dev, void *stream) {
     using namespace dgdm;
     DGDM_REQUIRE(src_dev && dst_dev && out_dev && B >= 0 && S >= 0 && N >= 0, DGDM_EINVAL, "dgdm_square_distance: bad argument");
+    if (B == 0 || S == 0 || N == 0) return DGDM_OK;          // empty result
     return pn_sqdist_rows(src_dev, dst_dev, B, S, N, out_dev, (hipStream_t)stream);
 }
 
 extern "C" int dgdm_index_points(const float *points_dev, const int32_t *idx_dev, int B, int N, int M, int C, float *out_dev, void *stream) {
     using namespace dgdm;
     DGDM_REQUIRE(points_dev && idx_dev && out_dev && B >= 0 && N > 0 && M >= 0 && C > 0, DGDM_EINVAL, "dgdm_index_points: bad argument");
+    if (B == 0 || M == 0) return DGDM_OK;                      // empty result
     return pn_index_rows(points_dev, idx_dev, B, N, M, C, out_dev, (hipStream_t)stream);
 }

@@ -71,9 +71,22 @@ struct DgdmGuidance {
     int n_objects = 0;
     bool force_slow_xobj = false;   // test hook: always run the per-row FPS kernel
     void *pinned = nullptr; size_t pinned_bytes = 0; hipEvent_t pinned_ev = nullptr;
+    int64_t todo_capacity = 0;
+    // uploads of the start indices go through their own stream (the copy engine works beside the kernels of the launch stream):
+    // up_ready orders the consumers behind the copy, up_consumed the next copy behind the last reader of the device buffers
+    // set_objects' read-back (tie flags, crowded-centre counts) lands in pinned memory behind ro_ev and is only waited for when its
+    // values are first needed - the host converts and uploads the first step's start indices while the tables are still being built
+    int *ro_host = nullptr; size_t ro_ints = 0; hipEvent_t ro_ev = nullptr; bool ro_pending = false;
+    int finish_objects();
+    hipStream_t cstream = nullptr; hipEvent_t up_ready = nullptr, up_consumed = nullptr; bool consumed_recorded = false;
     ~DgdmGuidance() {
         if (pinned) (void)hipHostFree(pinned);
         if (pinned_ev) (void)hipEventDestroy(pinned_ev);
+        if (ro_host) (void)hipHostFree(ro_host);
+        if (ro_ev) (void)hipEventDestroy(ro_ev);
+        if (cstream) (void)hipStreamDestroy(cstream);
+        if (up_ready) (void)hipEventDestroy(up_ready);
+        if (up_consumed) (void)hipEventDestroy(up_consumed);
         for (int i = 0; i < NBUILD; ++i) {
             if (bstream[i]) (void)hipStreamDestroy(bstream[i]);
             if (bev[i]) (void)hipEventDestroy(bev[i]);
@@ -85,12 +98,19 @@ struct DgdmGuidance {
     }
     int build_pose_table(const std::vector<float> &ori, const std::vector<float> &pos, DevBuf *dst, DevBuf *dst_tiled, hipStream_t s);
     int common_pre(const float *x_dev, float t_scaled, const int *objidx_host, int n_chains, hipStream_t s);
-    int upload_starts(const int64_t *starts_host, int n_chains, int64_t rows, hipStream_t s, bool need_order = true);
+    // starts of `n_calls` classifier calls per chain: call k of chain c at starts_host + k * call_stride + c * 2 * rows; on the device the
+    // chain's rows of all calls form one run of n_calls * rows rows (row k * rows + r)
+    int upload_starts(const int64_t *starts_host, int n_chains, int64_t rows, hipStream_t s, bool need_order = true, int n_calls = 1,
+                      int64_t call_stride = 0);
+    int ensure_rows(int n_chains, int64_t rows_per_chain);      // grows the per-row device buffers and the pinned staging area
     // true + p filled when every chain's object has its embedding table in the wanted format: then no per-step gather runs at all
     int use_xtab(const int *objidx_host, int n_chains, int64_t rows, bool want16, dgdm::TrunkParams *p, bool *ok, hipStream_t s);
     int build_object(int oi, int slot, hipStream_t s);
     int build_xtab(int oi, hipStream_t s);
     int run_xobj(const int *objidx_host, int n_chains, int64_t rows, bool want16, bool *used16, hipStream_t s);
+    // the embeddings of `n_calls` cond_fn calls at once: afterwards call k reads rows [k * R, (k + 1) * R) of every chain
+    struct Embedded { bool tab = false, used16 = false; int64_t rows_per_chain = 0; };
+    int embed(const int *objidx_host, int n_chains, const int64_t *starts_host, int n_calls, int64_t call_stride, Embedded *e, hipStream_t s);
 };
 
 int DgdmGuidance::build_pose_table(const std::vector<float> &ori, const std::vector<float> &pos, DevBuf *dst, DevBuf *dst_tiled, hipStream_t s) {
@@ -155,6 +175,7 @@ extern "C" int dgdm_guidance_create(DgdmGuidance **out, DgdmDynamics *model, con
             (rc = g->order.alloc((size_t)nc * g->R * sizeof(int))) || (rc = g->xchains.alloc(sizeof(XobjChain) * nc)) ||
             (rc = g->todo.alloc(((size_t)nc * g->R + 1) * sizeof(int))))
             return rc;
+        g->todo_capacity = (int64_t)nc * g->R;
         g->pinned_bytes = ((size_t)nc * g->R * 3 + (size_t)nc * (cfg->num_object_points + 1)) * sizeof(int);
         if ((rc = g->groupoff.alloc((size_t)nc * (cfg->num_object_points + 1) * sizeof(int))) || (rc = g->xidx.alloc((size_t)nc * g->R * sizeof(int))) ||
             (rc = g->xidxchains.alloc(sizeof(XidxChain) * nc)) || (rc = g->xtabptrs.alloc(sizeof(void *) * nc)))
@@ -183,8 +204,11 @@ extern "C" int dgdm_guidance_debug_fps_path(DgdmGuidance *g, int force_per_row, 
     g->xtab_enabled = force_per_row == 0 || force_per_row == 4 || force_per_row == 5;      // modes 1-3 read materialised rows; 3 = the group gather kernel
     g->xtab_policy = force_per_row == 5 ? 1 : 0;         // 5: the next set_objects builds the embedding tables right away
     if (force_per_row == 3) g->xobj_mode = 0;
-    if (out_fast_ok)
+    if (out_fast_ok) {
+        int rc = g->finish_objects();
+        if (rc) return rc;
         for (int i = 0; i < g->n_objects && i < (int)g->tables.size(); ++i) out_fast_ok[i] = g->tables[i]->fast_ok ? 1 : 0;
+    }
     return DGDM_OK;
 }
 // Test hook: the per-tile partial sums of d objective / d z1 the last dgdm_dyn{2,3}d_guidance_grad call left behind
@@ -332,18 +356,21 @@ extern "C" int dgdm_guidance_set_objects(DgdmGuidance *g, const float *objects_d
             DGDM_HIP_CHECK(hipStreamWaitEvent(s, g->bev[i], 0));
         }
         DGDM_HIP_CHECK(hipStreamWaitEvent(s, g->fdone, 0));
-        // which objects may use the table of FPS(128) sequences (no order-dependent selection anywhere); crowded-centre counts
-        std::vector<int> fl((size_t)n_objects * N), ncrs(n_objects);
+        // which objects may use the table of FPS(128) sequences (no order-dependent selection anywhere); crowded-centre counts:
+        // copied to pinned memory behind an event, read by finish_objects() when first needed
         prof_end(s, DGDM_STAGE_TABLES, 0.0);
-        DGDM_HIP_CHECK(hipMemcpyAsync(fl.data(), g->pool_flags.p, sizeof(int) * no * N, hipMemcpyDeviceToHost, s));
-        DGDM_HIP_CHECK(hipMemcpyAsync(ncrs.data(), g->pool_ncr.p, sizeof(int) * no, hipMemcpyDeviceToHost, s));
-        DGDM_HIP_CHECK(hipStreamSynchronize(s));
-        for (int i = 0; i < n_objects; ++i) {
-            bool ok = N >= 128;
-            for (int k = 0; k < N; ++k) ok = ok && fl[(size_t)i * N + k] == 0;
-            g->tables[i]->fast_ok = ok;
-            g->tables[i]->ncr = ncrs[i];
+        const size_t need = no * N + no;
+        if (need > g->ro_ints) {
+            if (g->ro_host) DGDM_HIP_CHECK(hipHostFree(g->ro_host));
+            g->ro_host = nullptr;
+            DGDM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&g->ro_host), need * sizeof(int), hipHostMallocDefault));
+            g->ro_ints = need;
         }
+        if (!g->ro_ev) DGDM_HIP_CHECK(hipEventCreateWithFlags(&g->ro_ev, hipEventDisableTiming));
+        DGDM_HIP_CHECK(hipMemcpyAsync(g->ro_host, g->pool_flags.p, sizeof(int) * no * N, hipMemcpyDeviceToHost, s));
+        DGDM_HIP_CHECK(hipMemcpyAsync(g->ro_host + no * N, g->pool_ncr.p, sizeof(int) * no, hipMemcpyDeviceToHost, s));
+        DGDM_HIP_CHECK(hipEventRecord(g->ro_ev, s));
+        g->ro_pending = true;
     }
     g->n_objects = n_objects;
     g->grads_since_set = 0;
@@ -370,41 +397,79 @@ int DgdmGuidance::common_pre(const float *x_dev, float t_scaled, const int *obji
 }
 
 // Reference draw order per chain: for each sub-batch i, sa1's torch.randint(rows_i) then sa2's  ->  device [chain][row][2]
-int DgdmGuidance::upload_starts(const int64_t *starts_host, int n_chains, int64_t rows, hipStream_t s, bool need_order) {
+int DgdmGuidance::finish_objects() {
+    if (!ro_pending) return DGDM_OK;
+    DGDM_HIP_CHECK(hipEventSynchronize(ro_ev));
+    const int N = cfg.num_object_points;
+    for (int i = 0; i < n_objects; ++i) {
+        bool ok = N >= 128;
+        for (int k = 0; k < N; ++k) ok = ok && ro_host[(size_t)i * N + k] == 0;
+        tables[i]->fast_ok = ok;
+        tables[i]->ncr = ro_host[(size_t)n_objects * N + i];
+    }
+    ro_pending = false;
+    return DGDM_OK;
+}
+
+int DgdmGuidance::ensure_rows(int n_chains, int64_t rows_per_chain) {
+    const int N = cfg.num_object_points;
+    const size_t nr = (size_t)n_chains * rows_per_chain;
+    int rc;
+    if ((rc = xobj.alloc(nr * 256 * 4)) || (rc = starts.alloc(nr * 2 * sizeof(int))) || (rc = order.alloc(nr * sizeof(int))) ||
+        (rc = todo.alloc((nr + 1) * sizeof(int))) || (rc = xidx.alloc(nr * sizeof(int))))
+        return rc;
+    todo_capacity = (int64_t)nr;
+    const size_t need = (nr * 3 + (size_t)n_chains * (N + 1)) * sizeof(int);
+    if (need > pinned_bytes) {
+        if (pinned) { DGDM_HIP_CHECK(hipEventSynchronize(pinned_ev)); DGDM_HIP_CHECK(hipHostFree(pinned)); pinned = nullptr; pinned_bytes = 0; }
+        DGDM_HIP_CHECK(hipHostMalloc(&pinned, need, hipHostMallocDefault));
+        pinned_bytes = need;
+    }
+    return DGDM_OK;
+}
+
+int DgdmGuidance::upload_starts(const int64_t *starts_host, int n_chains, int64_t rows, hipStream_t s, bool need_order, int n_calls,
+                                int64_t call_stride) {
     const int N = cfg.num_object_points;
     const int64_t sb = cfg.sub_batch_size;
-    DGDM_REQUIRE(((size_t)n_chains * rows * 3 + (size_t)n_chains * (N + 1)) * sizeof(int) <= pinned_bytes, DGDM_EINVAL, "starts staging too small");
+    const int64_t rt = rows * n_calls;                         // rows per chain on the device
+    int rc;
+    if ((rc = ensure_rows(n_chains, rt))) return rc;
     DGDM_HIP_CHECK(hipEventSynchronize(pinned_ev));            // previous copy out of the staging buffer has finished
     int *dst = static_cast<int *>(pinned);
-    int *ord = dst + (size_t)n_chains * 2 * rows;
-    int *goff = ord + (size_t)n_chains * rows;                 // [n_chains][N+1]: where each s1-group starts in the chain's sorted rows
+    int *ord = dst + (size_t)n_chains * 2 * rt;
+    int *goff = ord + (size_t)n_chains * rt;                   // [n_chains][N+1]: where each s1-group starts in the chain's sorted rows
     // per chain: int64 draws -> (s1, s2) int32 pairs in row order; rows sorted by s1 (counting sort) so that the rows of one
     // variant gather from the same Z slab; group offsets.  Chains are independent: a few host threads share them.
     std::atomic<int> bad{0};
     auto work = [&](int c0, int c1) {
         std::vector<int> cnt(N + 1);
         for (int c = c0; c < c1; ++c) {
-            const int64_t *src = starts_host + (size_t)c * 2 * rows;
-            int *d = dst + (size_t)c * 2 * rows;
-            for (int64_t r0 = 0; r0 < rows; r0 += sb) {
-                const int64_t n = std::min(sb, rows - r0);
-                const int64_t *s1 = src + 2 * r0, *s2 = s1 + n;
-                for (int64_t k = 0; k < n; ++k) {
-                    const int64_t a = s1[k], b = s2[k];
-                    if (!(a >= 0 && a < N && b >= 0 && b < 512)) { bad.store(1); return; }
-                    d[2 * (r0 + k)] = (int)a; d[2 * (r0 + k) + 1] = (int)b;
+            int *d = dst + (size_t)c * 2 * rt;
+            for (int k = 0; k < n_calls; ++k) {
+                const int64_t *src = starts_host + (size_t)k * call_stride + (size_t)c * 2 * rows;
+                int *dk = d + 2 * (size_t)k * rows;
+                for (int64_t r0 = 0; r0 < rows; r0 += sb) {
+                    const int64_t n = std::min(sb, rows - r0);
+                    const int64_t *s1 = src + 2 * r0, *s2 = s1 + n;
+                    for (int64_t i = 0; i < n; ++i) {
+                        const int64_t a = s1[i], b = s2[i];
+                        if (!(a >= 0 && a < N && b >= 0 && b < 512)) { bad.store(1); return; }
+                        dk[2 * (r0 + i)] = (int)a; dk[2 * (r0 + i) + 1] = (int)b;
+                    }
                 }
             }
             if (!need_order) continue;                      // embedding-table path: rows are looked up where they are
-            int *o = ord + (size_t)c * rows;
+            int *o = ord + (size_t)c * rt;
             std::fill(cnt.begin(), cnt.end(), 0);
-            for (int64_t r = 0; r < rows; ++r) ++cnt[d[2 * r] + 1];
+            for (int64_t r = 0; r < rt; ++r) ++cnt[d[2 * r] + 1];
             for (int k = 0; k < N; ++k) cnt[k + 1] += cnt[k];
             memcpy(goff + (size_t)c * (N + 1), cnt.data(), sizeof(int) * (N + 1));
-            for (int64_t r = 0; r < rows; ++r) o[cnt[d[2 * r]]++] = (int)r;
+            for (int64_t r = 0; r < rt; ++r) o[cnt[d[2 * r]]++] = (int)r;
         }
     };
-    const int nthreads = (int)std::min<int64_t>(8, std::max<int64_t>(1, (int64_t)n_chains * rows / 65536));
+    const int hw = (int)std::max(2u, std::thread::hardware_concurrency());
+    const int nthreads = (int)std::min<int64_t>(std::min(16, hw / 2), std::max<int64_t>(1, std::min<int64_t>(n_chains, (int64_t)n_chains * rt / 65536)));
     if (nthreads <= 1) {
         work(0, n_chains);
     } else {
@@ -413,12 +478,22 @@ int DgdmGuidance::upload_starts(const int64_t *starts_host, int n_chains, int64_
         for (auto &th : pool) th.join();
     }
     DGDM_REQUIRE(!bad.load(), DGDM_EINVAL, "FPS start out of range (sa1 must be in [0, %d), sa2 in [0, 512))", N);
-    DGDM_HIP_CHECK(hipMemcpyAsync(starts.p, pinned, (size_t)n_chains * rows * 2 * sizeof(int), hipMemcpyHostToDevice, s));
-    if (need_order) {
-        DGDM_HIP_CHECK(hipMemcpyAsync(order.p, ord, (size_t)n_chains * rows * sizeof(int), hipMemcpyHostToDevice, s));
-        DGDM_HIP_CHECK(hipMemcpyAsync(groupoff.p, goff, (size_t)n_chains * (N + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+    if (!cstream) {
+        DGDM_HIP_CHECK(hipStreamCreateWithFlags(&cstream, hipStreamNonBlocking));
+        DGDM_HIP_CHECK(hipEventCreateWithFlags(&up_ready, hipEventDisableTiming));
+        DGDM_HIP_CHECK(hipEventCreateWithFlags(&up_consumed, hipEventDisableTiming));
     }
-    DGDM_HIP_CHECK(hipEventRecord(pinned_ev, s));
+    // the copy may start as soon as the previous readers of the device buffers (the last gather / index kernel on the launch stream)
+    // are done - not behind everything queued on the launch stream since
+    if (consumed_recorded) DGDM_HIP_CHECK(hipStreamWaitEvent(cstream, up_consumed, 0));
+    DGDM_HIP_CHECK(hipMemcpyAsync(starts.p, pinned, (size_t)n_chains * rt * 2 * sizeof(int), hipMemcpyHostToDevice, cstream));
+    if (need_order) {
+        DGDM_HIP_CHECK(hipMemcpyAsync(order.p, ord, (size_t)n_chains * rt * sizeof(int), hipMemcpyHostToDevice, cstream));
+        DGDM_HIP_CHECK(hipMemcpyAsync(groupoff.p, goff, (size_t)n_chains * (N + 1) * sizeof(int), hipMemcpyHostToDevice, cstream));
+    }
+    DGDM_HIP_CHECK(hipEventRecord(pinned_ev, cstream));
+    DGDM_HIP_CHECK(hipEventRecord(up_ready, cstream));
+    DGDM_HIP_CHECK(hipStreamWaitEvent(s, up_ready, 0));
     return DGDM_OK;
 }
 
@@ -457,8 +532,8 @@ int DgdmGuidance::run_xobj(const int *objidx_host, int n_chains, int64_t rows, b
         ch[i].Z16 = t.has16 ? t.Z16.as<uint32_t>() : nullptr; ch[i].M0_16 = t.has16 ? t.M0_16.as<uint32_t>() : nullptr;
         want16 = want16 && t.has16;          // bf16 rows only if every chain's object was built with its bf16 tables
     }
-    if (want16 && xobj16.bytes < (size_t)n_chains * rows * 512) {
-        int rc = xobj16.alloc((size_t)cfg.max_chains * R * 512);
+    if (want16) {
+        int rc = xobj16.alloc((size_t)n_chains * rows * 512);
         if (rc) return rc;
     }
     if (used16) *used16 = want16;
@@ -466,7 +541,7 @@ int DgdmGuidance::run_xobj(const int *objidx_host, int n_chains, int64_t rows, b
     xp.chains = xchains.as<XobjChain>(); xp.starts = starts.as<int>(); xp.order = order.as<int>(); xp.xobj = xobj.as<float>();
     xp.xobj16 = want16 ? xobj16.as<uint32_t>() : nullptr;
     xp.R = rows; xp.total_rows = rows * n_chains; xp.use_table = force_slow_xobj ? 0 : 1;
-    xp.todo = todo.as<int>(); xp.todo_count = todo.as<int>() + (size_t)cfg.max_chains * R; xp.todo_capacity = (int64_t)cfg.max_chains * R;
+    xp.todo = todo.as<int>(); xp.todo_count = todo.as<int>() + todo_capacity; xp.todo_capacity = todo_capacity;
     bool all_fast = true;
     for (int i = 0; i < n_chains; ++i) all_fast = all_fast && tables[objidx_host[i]]->fast_ok;
     // group kernel: every chain needs its tables and a slab chunk that fits LDS (it handles tie-flagged start points itself)
@@ -487,8 +562,52 @@ int DgdmGuidance::run_xobj(const int *objidx_host, int n_chains, int64_t rows, b
     return pn_xobj(xp, all_fast, s);
 }
 
+// The PointNet++ embeddings of the rows of `n_calls` consecutive cond_fn calls (3-D).  They depend on the FPS start draws and the
+// objects only - not on x - so a whole denoise loop's worth can be made before its first step: one upload and ONE gather launch whose
+// (chain, s1) groups hold the rows of all the calls (the variant's slab is staged once for five times the rows), or - when the objects'
+// embedding tables exist - one index kernel.  Call k then reads rows [k * R, (k + 1) * R) of every chain.
+int DgdmGuidance::embed(const int *oidx, int n_chains, const int64_t *starts_host, int n_calls, int64_t call_stride, Embedded *e, hipStream_t s) {
+    DGDM_REQUIRE(starts_host, DGDM_EINVAL, "3-D guidance needs the FPS start indices");
+    int rc;
+    prof_begin(s, DGDM_STAGE_XOBJ);
+    // The table X[s1][q] of an object costs about what 7 cond_fn calls spend gathering its rows (it holds all 262 144 (s1, q)
+    // pairs; one call touches 36 000 of them): it pays as soon as the objects serve more than one 5-step chain - the
+    // reference's validation sweep runs 12 objectives x 5 steps (+ the multi-object chains) on the same objects - and it would
+    // cost 2 % when every pair brings its own object (bench.py).  So it is built when the call count says the objects are being
+    // reused: when the calls since set_objects pass XTAB_AFTER.
+    bool tab = xtab_enabled && !force_slow_xobj && xobj_mode == 0;
+    if (tab) {
+        const bool crosses = grads_since_set <= XTAB_AFTER && grads_since_set + n_calls > XTAB_AFTER;
+        grads_since_set += n_calls;
+        if (crosses)
+            for (int i = 0; i < n_objects; ++i) {
+                ObjectTables &t = *tables[i];
+                if (!(t.has16 ? t.has_x16 : t.has_x) && (rc = build_xtab(i, s))) return rc;
+            }
+    }
+    for (int i = 0; i < n_chains && tab; ++i) {
+        DGDM_REQUIRE(oidx[i] >= 0 && oidx[i] < n_objects, DGDM_EINVAL, "chain %d refers to object %d of %d", i, oidx[i], n_objects);
+        tab = bf16 ? tables[oidx[i]]->has_x16 : tables[oidx[i]]->has_x;
+    }
+    const int64_t rt = R * n_calls;
+    if ((rc = upload_starts(starts_host, n_chains, R, s, !tab, n_calls, call_stride))) return rc;     // host work: overlaps a table build still in flight
+    if ((rc = finish_objects())) return rc;
+    TrunkParams scratch{};
+    if (tab && (rc = use_xtab(oidx, n_chains, rt, bf16, &scratch, &tab, s))) return rc;
+    e->used16 = false;
+    if (!tab && (rc = run_xobj(oidx, n_chains, rt, bf16, &e->used16, s))) return rc;
+    e->tab = tab; e->rows_per_chain = rt;
+    DGDM_HIP_CHECK(hipEventRecord(up_consumed, s));          // the index buffers may be overwritten once these kernels are through
+    consumed_recorded = true;
+    prof_end(s, DGDM_STAGE_XOBJ, 0.0);
+    return DGDM_OK;
+}
+
+// cond_fn for n_chains chains.  3-D: `emb` = the embeddings made by DgdmGuidance::embed for a run of calls, `call` = which of them this is;
+// emb == nullptr: this call's own (starts_host = its draws).
 static int guidance_grad(DgdmGuidance *g, int kind, const float *x_dev, int timestep, const DgdmObjective *objectives, const float *rowcoef_dev,
-                         const int64_t *starts_host, int n_chains, float *grad_dev, hipStream_t s) {
+                         const int64_t *starts_host, int n_chains, float *grad_dev, hipStream_t s, const DgdmGuidance::Embedded *emb = nullptr,
+                         int call = 0) {
     DGDM_REQUIRE(g && x_dev && objectives && grad_dev, DGDM_EINVAL, "guidance_grad: null argument");
     if (g->m->kind != kind) { set_error("model type not supported: %d-D entry point on a %d-D model", kind, g->m->kind); return DGDM_EMODE; }
     DGDM_REQUIRE(n_chains > 0 && n_chains <= g->cfg.max_chains, DGDM_EINVAL, "n_chains %d outside 1..%d", n_chains, g->cfg.max_chains);
@@ -510,37 +629,27 @@ static int guidance_grad(DgdmGuidance *g, int kind, const float *x_dev, int time
     TrunkParams p;
     g->m->fill_trunk(&p);
     if (kind == 3) {
-        DGDM_REQUIRE(starts_host, DGDM_EINVAL, "3-D guidance needs the FPS start indices");
-        prof_begin(s, DGDM_STAGE_XOBJ);
-        // with the embedding tables of set_objects in place a row's embedding is a table row: only the (s1, s2) pairs go to the device
-        // The table X[s1][q] of an object costs about what 7 of these calls spend gathering its rows (it holds all 262 144 (s1, q)
-        // pairs; one call touches 36 000 of them): it pays as soon as the objects serve more than one 5-step chain - the
-        // reference's validation sweep runs 12 objectives x 5 steps (+ the multi-object chains) on the same objects - and it would
-        // cost 2 % when every pair brings its own object (bench.py).  So it is built when the call count says the objects are being
-        // reused: on call XTAB_AFTER + 1 since set_objects.
-        bool tab = g->xtab_enabled && !g->force_slow_xobj && g->xobj_mode == 0;
-        if (tab && ++g->grads_since_set == DgdmGuidance::XTAB_AFTER + 1)
-            for (int i = 0; i < g->n_objects; ++i) {
-                ObjectTables &t = *g->tables[i];
-                if (!(t.has16 ? t.has_x16 : t.has_x) && (rc = g->build_xtab(i, s))) return rc;
-            }
-        for (int i = 0; i < n_chains && tab; ++i) {
-            DGDM_REQUIRE(oidx[i] >= 0 && oidx[i] < g->n_objects, DGDM_EINVAL, "chain %d refers to object %d of %d", i, oidx[i], g->n_objects);
-            tab = g->bf16 ? g->tables[oidx[i]]->has_x16 : g->tables[oidx[i]]->has_x;
+        DgdmGuidance::Embedded own;
+        if (!emb) {
+            if ((rc = g->embed(oidx.data(), n_chains, starts_host, 1, 0, &own, s))) return rc;
+            emb = &own;
+            call = 0;
         }
-        if ((rc = g->upload_starts(starts_host, n_chains, g->R, s, !tab))) return rc;
-        if (tab && (rc = g->use_xtab(oidx.data(), n_chains, g->R, g->bf16, &p, &tab, s))) return rc;
-        if (!tab) {
-            bool used16 = false;
-            if ((rc = g->run_xobj(oidx.data(), n_chains, g->R, g->bf16, &used16, s))) return rc;
-            p.xobj = g->xobj.as<float>();
-            p.xobj16 = used16 ? g->xobj16.as<uint32_t>() : nullptr;
+        const size_t row0 = (size_t)call * g->R;
+        p.xstride = emb->rows_per_chain;
+        if (emb->tab) {
+            p.xidx = g->xidx.as<int>() + row0;
+            if (g->bf16) p.xtab16 = g->xtabptrs.as<const uint32_t *>();
+            else p.xtab = g->xtabptrs.as<const float *>();
+        } else {
+            p.xobj = g->xobj.as<float>() + row0 * 256;
+            p.xobj16 = emb->used16 ? g->xobj16.as<uint32_t>() + row0 * 128 : nullptr;
         }
-        prof_end(s, DGDM_STAGE_XOBJ, 0.0);
     }
     p.Atab = g->atab.as<float>(); p.Ptab = g->ptab.as<float>(); p.PtabT = g->ptab_t.as<float>(); p.obj = g->objdev.as<TrunkObjective>(); p.rowcoef = rowcoef_dev;
     p.partial = g->partial.as<float>();
     p.B = g->B; p.C = g->C; p.tiles_per_b = g->tiles_per_b; p.ntiles = n_chains * g->B * g->tiles_per_b; p.R = g->R;
+    if (kind != 3) p.xstride = g->R;
     if (g->bf16) {
         g->m->fill_trunk_bf16(&p);       // only the two weight streams differ
 #ifdef DGDM_TRUNK_CLOCKS
@@ -612,6 +721,16 @@ extern "C" int dgdm_guided_chains_run(DgdmUnet1d *unet, DgdmGuidance *g, const f
     bool same_scale = true;
     for (int c = 1; c < n_chains; ++c) same_scale = same_scale && scales[c] == scales[0];
     const int64_t spc = kind == 3 ? 2 * g->R : 0;
+    // 3-D: the embeddings of the rows depend on the draws and the objects, not on x, so they are made ahead of the steps that use them:
+    // step 0's first (the GPU waits for nothing else), then - once step 0's kernels are in the queue and keep the GPU busy while the
+    // host converts and sorts four times as many draws - those of ALL the remaining steps in one upload and one gather launch.
+    DgdmGuidance::Embedded emb;
+    std::vector<int> oidx(n_chains * n_grad);
+    const int64_t call_stride = (int64_t)n_chains * n_grad * spc;
+    if (kind == 3) {
+        for (int i = 0; i < n_chains * n_grad; ++i) oidx[i] = objectives[i].object;
+        if ((rc = g->embed(oidx.data(), n_chains * n_grad, starts_host, 1, call_stride, &emb, s))) return rc;
+    }
     for (int si = 0; si < n_steps; ++si) {
         float *x = g->loopx[si & 1].as<float>(), *xn = (si + 1 == n_steps) ? x_out_dev : g->loopx[(si + 1) & 1].as<float>();
         const int t = timesteps[si];
@@ -630,8 +749,8 @@ extern "C" int dgdm_guided_chains_run(DgdmUnet1d *unet, DgdmGuidance *g, const f
             hipLaunchKernelGGL(repeat_rows_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, x, g->loopxrep.as<float>(), (int64_t)nx, n_grad);
             xg = g->loopxrep.as<float>();
         }
-        const int64_t *st = kind == 3 ? starts_host + (size_t)si * n_chains * n_grad * spc : nullptr;
-        if ((rc = guidance_grad(g, kind, xg, t, objectives, rowcoef_dev, st, n_chains * n_grad, g->loopgrad.as<float>(), s))) return rc;
+        if ((rc = guidance_grad(g, kind, xg, t, objectives, rowcoef_dev, nullptr, n_chains * n_grad, g->loopgrad.as<float>(), s,
+                                kind == 3 ? &emb : nullptr, si == 0 ? 0 : si - 1))) return rc;
         const float *cf = coef + 4 * si;
         if (same_scale) {
             if ((rc = dgdm_ddim_guided_step(x, g->loopeps.as<float>(), g->loopgrad.as<float>(), n_grad, xn, (int64_t)nx, cf[0], cf[1], cf[2], cf[3], scales[0], s))) return rc;
@@ -641,6 +760,8 @@ extern "C" int dgdm_guided_chains_run(DgdmUnet1d *unet, DgdmGuidance *g, const f
                 if ((rc = dgdm_ddim_guided_step(x + c * per_chain, g->loopeps.as<float>() + c * per_chain, g->loopgrad.as<float>() + c * per_chain, 1,
                                                 xn + c * per_chain, (int64_t)per_chain, cf[0], cf[1], cf[2], cf[3], scales[c], s))) return rc;
         }
+        if (kind == 3 && si == 0 && n_steps > 1 &&
+            (rc = g->embed(oidx.data(), n_chains * n_grad, starts_host + call_stride, n_steps - 1, call_stride, &emb, s))) return rc;
     }
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
@@ -663,14 +784,17 @@ extern "C" int dgdm_guidance_orientation_sweep(DgdmGuidance *g, const float *x_d
         bool tab = g->xtab_enabled && !g->force_slow_xobj && g->xobj_mode == 0;
         for (int i = 0; i < n_chains && tab; ++i) tab = object_of_chain[i] >= 0 && object_of_chain[i] < g->n_objects && g->tables[object_of_chain[i]]->has_x;
         if ((rc = g->upload_starts(starts_host, n_chains, g->Rs, s, !tab))) return rc;
+        if ((rc = g->finish_objects())) return rc;
         if (tab && (rc = g->use_xtab(object_of_chain, n_chains, g->Rs, false, &p, &tab, s))) return rc;
         if (!tab) {
             if ((rc = g->run_xobj(object_of_chain, n_chains, g->Rs, false, nullptr, s))) return rc;
             p.xobj = g->xobj.as<float>();
         }
+        DGDM_HIP_CHECK(hipEventRecord(g->up_consumed, s));
+        g->consumed_recorded = true;
     }
     p.Atab = g->atab.as<float>(); p.Ptab = g->ptab_sweep.as<float>(); p.PtabT = g->ptab_sweep_t.as<float>(); p.logits = logits_dev;
-    p.B = g->B; p.C = g->G; p.tiles_per_b = g->sweep_tiles_per_b; p.ntiles = n_chains * g->B * g->sweep_tiles_per_b; p.R = g->Rs;
+    p.B = g->B; p.C = g->G; p.tiles_per_b = g->sweep_tiles_per_b; p.ntiles = n_chains * g->B * g->sweep_tiles_per_b; p.R = g->Rs; p.xstride = g->Rs;
     return trunk_launch(kind, false, true, p, s);
 }
 
@@ -792,6 +916,6 @@ extern "C" int dgdm_dyn3d_forward(DgdmDynamics *m, const float *x_ctrl, const fl
     if ((rc = linear(pose, 27, m->blob.at(m->off.w1p_wt), nullptr, nullptr, 1, z1, 512, rows, 27, 512, ACT_NONE, true, s))) return rc;
     TrunkParams p;
     m->fill_trunk(&p);
-    p.Atab = z1; p.xobj = xo; p.logits = logits; p.C = rows; p.R = rows; p.B = 1; p.tiles_per_b = 1; p.ntiles = (rows + 31) / 32;
+    p.Atab = z1; p.xobj = xo; p.logits = logits; p.C = rows; p.R = rows; p.xstride = rows; p.B = 1; p.tiles_per_b = 1; p.ntiles = (rows + 31) / 32;
     return trunk_launch(3, true, true, p, s);
 }

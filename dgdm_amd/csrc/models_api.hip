@@ -528,6 +528,6 @@ extern "C" int dgdm_dyn2d_forward(DgdmDynamics *m, const float *x_ctrl, const fl
     if ((rc = linear(pose, 27, m->blob.at(m->off.w1p_wt), nullptr, nullptr, 1, z1, 256, rows, 27, 256, ACT_NONE, true, s))) return rc;
     TrunkParams p;
     m->fill_trunk(&p);
-    p.Atab = z1; p.logits = logits; p.C = rows; p.R = rows; p.B = 1; p.tiles_per_b = 1; p.ntiles = (rows + 31) / 32;
+    p.Atab = z1; p.logits = logits; p.C = rows; p.R = rows; p.xstride = rows; p.B = 1; p.tiles_per_b = 1; p.ntiles = (rows + 31) / 32;
     return trunk_launch(2, true, true, p, s);
 }

@@ -913,38 +913,14 @@ __device__ __forceinline__ void xobj_group_body(const XobjParams &p, const XobjC
     const int g0 = goff[s1], gn = goff[s1 + 1] - g0;
     if (gn == 0) return;                                               // no row of this chain drew s1 (workgroup-uniform)
     const uint32_t *Zs = (BF16 ? ch.Z16 : reinterpret_cast<const uint32_t *>(ch.Z)) + ((size_t)(ch.slot_of_start ? ch.slot_of_start[s1] : s1) * ch.N) * W + f0;
-    // ---- row metadata of this wave's rows, one row per lane (row k = wave + 4 * lane): issued before the slab loads so that the
-    //      chain of dependent lookups (row id -> s2 -> start point q -> flag, count) overlaps them
+    // ---- row metadata of this wave's rows, one row per lane (row k = kb + wave + 4 * lane, 256 rows of the group per pass): the first
+    //      pass issues them before the slab loads so that the chain of dependent lookups (row id -> s2 -> start point q -> flag, count)
+    //      overlaps them.  A group holds ~70 rows when the launch covers one denoise step and ~350 when it covers all five.
     const int *ord = p.order + (size_t)chain * p.R + g0;
     const int *st = p.starts + (size_t)chain * 2 * p.R;
-    const int myk = wave + 4 * lane;
-    const bool have = myk < gn;                                        // groups of more than 256 rows: see the tail loop
-    const int r_v = have ? ord[myk] : 0;
-    const int q_v = have ? ch.fps1[(size_t)s1 * 512 + st[2 * r_v + 1]] : 0;      // start point of sa2's FPS
-    const int slow_v = have ? ch.flags[q_v] : 1;                       // order-dependent sequence: xobj_kernel's row
-    const int cnt_v = have ? ch.cnt2[q_v] : 0;
-    // ---- stage the slab chunk: piece i = (centre i / LPR, 16-byte part i % LPR)
-    const int pieces = ch.ncr * LPR;
-    for (int i0 = threadIdx.x; i0 < pieces; i0 += 256 * 8) {
-        u4 v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = i0 + 256 * k;
-            if (i < pieces) v[k] = *reinterpret_cast<const u4 *>(Zs + (size_t)ch.clist[i / LPR] * W + (i % LPR) * 4);
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = i0 + 256 * k;
-            if (i < pieces) *reinterpret_cast<u4 *>(slab + (size_t)i * 4) = v[k];
-        }
-    }
-    if (chunk == 0 && have && slow_v) p.todo[atomicAdd(p.todo_count, 1)] = (int)((int64_t)chain * p.R + r_v);
-    __syncthreads();
-    // ---- one row at a time per wave (uniform control flow); the wave's 64 lanes read RPW slots' pieces per ds_read_b128
     const int sg = lane / LPR, fl = lane % LPR;
     const uint32_t *M0 = (BF16 ? ch.M0_16 : reinterpret_cast<const uint32_t *>(ch.M0)) + f0 + fl * 4;
     uint32_t *out = (BF16 ? p.xobj16 : reinterpret_cast<uint32_t *>(p.xobj)) + (size_t)chain * p.R * W + f0 + fl * 4;
-    const int nmine = min(64, (gn - wave + 3) / 4);                    // rows of this wave held in lanes
     auto vmax4 = [](u4 a, u4 b) {
         u4 o;
         if (BF16) { o.x = pkmax_u16(a.x, b.x); o.y = pkmax_u16(a.y, b.y); o.z = pkmax_u16(a.z, b.z); o.w = pkmax_u16(a.w, b.w); }
@@ -954,71 +930,77 @@ __device__ __forceinline__ void xobj_group_body(const XobjParams &p, const XobjC
         }
         return o;
     };
-    // rows in batches of four: the four slot lists and M0 pieces are requested together (the per-row lookups are L2-latency bound)
-    for (int i0 = 0; i0 < nmine; i0 += 4) {
-        int SA[4], SB[4];
-        u4 m0[4];
+    for (int kb = 0; kb < gn; kb += 256) {
+        const int myk = kb + wave + 4 * lane;
+        const bool have = myk < gn;
+        const int r_v = have ? ord[myk] : 0;
+        const int q_v = have ? ch.fps1[(size_t)s1 * 512 + st[2 * r_v + 1]] : 0;      // start point of sa2's FPS
+        const int slow_v = have ? ch.flags[q_v] : 1;                       // order-dependent sequence: xobj_kernel's row
+        const int cnt_v = have ? ch.cnt2[q_v] : 0;
+        if (kb == 0) {
+            // ---- stage the slab chunk: piece i = (centre i / LPR, 16-byte part i % LPR)
+            const int pieces = ch.ncr * LPR;
+            for (int i0 = threadIdx.x; i0 < pieces; i0 += 256 * 8) {
+                u4 v[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int qn = __builtin_amdgcn_readlane(q_v, min(i0 + u, nmine - 1));
-            SA[u] = ch.cl2s[(size_t)qn * 128 + lane]; SB[u] = ch.cl2s[(size_t)qn * 128 + 64 + lane];
-            m0[u] = *reinterpret_cast<const u4 *>(M0 + (size_t)qn * W);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u;
-            if (i >= nmine) break;
-            const int r = __builtin_amdgcn_readlane(r_v, i), cnt = __builtin_amdgcn_readlane(cnt_v, i), slow = __builtin_amdgcn_readlane(slow_v, i);
-            const int sa = SA[u], sb = SB[u];
-            u4 best = m0[u];
-            if (slow) continue;
-            // slot j + sg for lane group sg; the list is padded with its last entry to 128, so reading past cnt repeats a member
-            for (int j = 0; j < cnt; j += 4 * RPW) {
-                u4 v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int jj = j + e * RPW;                              // uniform; jj + sg stays inside one 64-entry half (64 % RPW == 0)
-                    int slot;
-                    if (RPW == 1) slot = jj < 64 ? __builtin_amdgcn_readlane(sa, jj & 63) : __builtin_amdgcn_readlane(sb, jj & 63);
-                    else slot = __shfl(jj < 64 ? sa : sb, (jj & 63) + sg);
-                    v[e] = *reinterpret_cast<const u4 *>(slab + ((size_t)slot * LPR + fl) * 4);
+                for (int k = 0; k < 8; ++k) {
+                    const int i = i0 + 256 * k;
+                    if (i < pieces) v[k] = *reinterpret_cast<const u4 *>(Zs + (size_t)ch.clist[i / LPR] * W + (i % LPR) * 4);
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) best = vmax4(best, v[e]);
-            }
-            if (RPW > 1 && cnt > 0) {                                       // fold the lane groups (each saw every RPW-th slot)
-#pragma unroll
-                for (int o = 32; o >= LPR; o >>= 1) {
-                    u4 t;
-                    t.x = __shfl_xor(best.x, o); t.y = __shfl_xor(best.y, o); t.z = __shfl_xor(best.z, o); t.w = __shfl_xor(best.w, o);
-                    best = vmax4(best, t);
+                for (int k = 0; k < 8; ++k) {
+                    const int i = i0 + 256 * k;
+                    if (i < pieces) *reinterpret_cast<u4 *>(slab + (size_t)i * 4) = v[k];
                 }
             }
-            if (sg == 0) *reinterpret_cast<u4 *>(out + (size_t)r * W) = best;
         }
-    }
-    // ---- groups of more than 256 rows (never at the shipped sizes: 36 000 rows over 512 start indices): remaining rows one by one
-    for (int k = 256 + wave; k < gn; k += 4) {
-        const int r = ord[k], q = ch.fps1[(size_t)s1 * 512 + st[2 * r + 1]];
-        if (ch.flags[q] != 0) {
-            if (chunk == 0 && lane == 0) p.todo[atomicAdd(p.todo_count, 1)] = (int)((int64_t)chain * p.R + r);
-            continue;
-        }
-        const int cnt = ch.cnt2[q];
-        u4 best = *reinterpret_cast<const u4 *>(M0 + (size_t)q * W);
-        for (int j = sg; j < cnt; j += RPW) {
-            const int slot = ch.cl2s[(size_t)q * 128 + j];
-            best = vmax4(best, *reinterpret_cast<const u4 *>(slab + ((size_t)slot * LPR + fl) * 4));
-        }
-        if (RPW > 1) {
+        if (chunk == 0 && have && slow_v) p.todo[atomicAdd(p.todo_count, 1)] = (int)((int64_t)chain * p.R + r_v);
+        if (kb == 0) __syncthreads();
+        // ---- one row at a time per wave (uniform control flow); the wave's 64 lanes read RPW slots' pieces per ds_read_b128
+        const int nmine = min(64, (gn - kb - wave + 3) / 4);               // rows of this wave held in lanes
+        // rows in batches of four: the four slot lists and M0 pieces are requested together (the per-row lookups are L2-latency bound)
+        for (int i0 = 0; i0 < nmine; i0 += 4) {
+            int SA[4], SB[4];
+            u4 m0[4];
 #pragma unroll
-            for (int o = 32; o >= LPR; o >>= 1) {
-                u4 t;
-                t.x = __shfl_xor(best.x, o); t.y = __shfl_xor(best.y, o); t.z = __shfl_xor(best.z, o); t.w = __shfl_xor(best.w, o);
-                best = vmax4(best, t);
+            for (int u = 0; u < 4; ++u) {
+                const int qn = __builtin_amdgcn_readlane(q_v, min(i0 + u, nmine - 1));
+                SA[u] = ch.cl2s[(size_t)qn * 128 + lane]; SB[u] = ch.cl2s[(size_t)qn * 128 + 64 + lane];
+                m0[u] = *reinterpret_cast<const u4 *>(M0 + (size_t)qn * W);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u;
+                if (i >= nmine) break;
+                const int r = __builtin_amdgcn_readlane(r_v, i), cnt = __builtin_amdgcn_readlane(cnt_v, i), slow = __builtin_amdgcn_readlane(slow_v, i);
+                const int sa = SA[u], sb = SB[u];
+                u4 best = m0[u];
+                if (slow) continue;
+                // slot j + sg for lane group sg; the list is padded with its last entry to 128, so reading past cnt repeats a member
+                for (int j = 0; j < cnt; j += 4 * RPW) {
+                    u4 v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int jj = j + e * RPW;                              // uniform; jj + sg stays inside one 64-entry half (64 % RPW == 0)
+                        int slot;
+                        if (RPW == 1) slot = jj < 64 ? __builtin_amdgcn_readlane(sa, jj & 63) : __builtin_amdgcn_readlane(sb, jj & 63);
+                        else slot = __shfl(jj < 64 ? sa : sb, (jj & 63) + sg);
+                        v[e] = *reinterpret_cast<const u4 *>(slab + ((size_t)slot * LPR + fl) * 4);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) best = vmax4(best, v[e]);
+                }
+                if (RPW > 1 && cnt > 0) {                                       // fold the lane groups (each saw every RPW-th slot)
+#pragma unroll
+                    for (int o = 32; o >= LPR; o >>= 1) {
+                        u4 t;
+                        t.x = __shfl_xor(best.x, o); t.y = __shfl_xor(best.y, o); t.z = __shfl_xor(best.z, o); t.w = __shfl_xor(best.w, o);
+                        best = vmax4(best, t);
+                    }
+                }
+                if (sg == 0) *reinterpret_cast<u4 *>(out + (size_t)r * W) = best;
             }
         }
-        if (sg == 0) *reinterpret_cast<u4 *>(out + (size_t)r * W) = best;
     }
 }
 
@@ -1331,7 +1313,10 @@ __global__ void index_rows_kernel(const float *__restrict__ points /*[B][N][C]*/
     const int c = (int)(i % C);
     const int64_t bm = i / C;
     const int b = (int)(bm / M);
-    out[i] = points[((size_t)b * N + idx[bm]) * C + c];
+    // an index outside [0, N) - query_ball_point's marker N for a group without members, where the reference's indexing raises - reads
+    // nothing and yields NaN
+    const int id = idx[bm];
+    out[i] = (id >= 0 && id < N) ? points[((size_t)b * N + id) * C + c] : __builtin_nanf("");
 }
 
 int pn_fps_rows(const float *xyz, const int *start, int B, int N, int npoint, int *out, hipStream_t s) {

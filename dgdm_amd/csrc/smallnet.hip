@@ -246,10 +246,17 @@ __global__ __launch_bounds__(256) void linear64_kernel(const float *__restrict__
         }
         __syncthreads();
         const double *wp = WT + (size_t)k0 * N + nn;
-        for (int k = 0; k < kc; ++k) {
-            const double w = wp[(size_t)k * N];
+        for (int k = 0; k < kc; k += 8) {       // eight weight loads in flight per step (the loop is L2-latency bound otherwise)
+            double w[8];
 #pragma unroll
-            for (int r = 0; r < RB; ++r) acc[r] = fma(xs[r][k], w, acc[r]);
+            for (int j = 0; j < 8; ++j) w[j] = wp[(size_t)min(k + j, kc - 1) * N];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (k + j < kc) {
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) acc[r] = fma(xs[r][k + j], w[j], acc[r]);
+                }
+            }
         }
     }
     if (n >= N) return;
@@ -314,19 +321,24 @@ __global__ __launch_bounds__(256) void dyn_post64_kernel(const float *__restrict
         da[f] = acc;
     }
     __syncthreads();
-    double acc = 0.0;
-    for (int f = 0; f < W1; ++f) acc = fma(w1c[(size_t)f * 256 + t], da[f], acc);
-    v1[t] = acc;
+    // sum_f w[f][t] x[f] with eight weight loads in flight per step (F a multiple of 8)
+    auto dot = [&](const double *__restrict__ w, int ld, const double *x, int F) {
+        double acc = 0.0;
+        for (int f = 0; f < F; f += 8) {
+            double wv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wv[j] = w[(size_t)(f + j) * ld + t];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = fma(wv[j], x[f + j], acc);
+        }
+        return acc;
+    };
+    v1[t] = dot(w1c, 256, da, W1);
     __syncthreads();
-    acc = 0.0;
-    for (int f = 0; f < 256; ++f) acc = fma(g2w[(size_t)f * 256 + t], v1[f], acc);
-    v2[t] = V[(size_t)row * 256 + t] > 0.0 ? acc : 0.0;
+    const double a2 = dot(g2w, 256, v1, 256);
+    v2[t] = V[(size_t)row * 256 + t] > 0.0 ? a2 : 0.0;
     __syncthreads();
-    if (t < L) {
-        acc = 0.0;
-        for (int f = 0; f < 256; ++f) acc = fma(g0w[(size_t)f * L + t], v2[f], acc);
-        grad[(size_t)row * L + t] = (float)acc;
-    }
+    if (t < L) grad[(size_t)row * L + t] = (float)dot(g0w, L, v2, 256);
 }
 
 int dyn_post64(int W1, const float *partial, int tiles_per_b, const double *w1c, const double *g2w, const double *g0w, const double *V64,

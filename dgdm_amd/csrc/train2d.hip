@@ -1002,6 +1002,15 @@ extern "C" int dgdm_trainer2d_gradients(DgdmTrainer2d *m, float *flat_dev, int64
     return DGDM_OK;
 }
 
+// BatchNorm running statistics [8 layers][mean | var][256] device <-> flat_dev: under data parallelism every rank updates them from ITS
+// chunk, and nn.DataParallel keeps replica 0's (dynamics/trainer.py:41-43) - rank 0's buffers are broadcast after every step
+extern "C" int dgdm_trainer2d_running_stats(DgdmTrainer2d *m, float *flat_dev, int64_t numel, int to_trainer, void *stream) {
+    DGDM_REQUIRE(m && flat_dev && numel == 8 * 512, DGDM_EINVAL, "dgdm_trainer2d_running_stats: expected %d values", 8 * 512);
+    DGDM_HIP_CHECK(hipMemcpyAsync(to_trainer ? m->bn_run.p : (void *)flat_dev, to_trainer ? (const void *)flat_dev : m->bn_run.p, (size_t)numel * sizeof(float),
+                                  hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return DGDM_OK;
+}
+
 extern "C" int dgdm_trainer2d_apply(DgdmTrainer2d *m, float lr, void *stream) {
     DGDM_REQUIRE(m, DGDM_EINVAL, "dgdm_trainer2d_apply: null handle");
     return m->adam(lr, (hipStream_t)stream);

@@ -30,6 +30,7 @@ struct TrunkParams {
     const float *const *xtab;
     const uint32_t *const *xtab16;
     const int    *xidx;
+    int64_t       xstride;    // rows per chain in xobj / xobj16 / xidx (>= R: a launch may read one denoise step's rows out of buffers that hold all steps')
     // first-layer tables
     const float  *Atab;       // table mode: [nchain*B][W1]; rows mode: [rows][W1]
     const float  *Ptab;       // [C][W1]  (table mode)

@@ -96,8 +96,8 @@ __global__ __launch_bounds__(256, 1) void trunk_kernel(const TrunkParams p) {
         slot += 4;
     } else {
         // ---- 3-D layers 1 and 2, streamed over the 16 blocks of the 512-wide layer 1
-        const float *xrow = (!ROWS && p.xtab) ? p.xtab[chain] + (size_t)p.xidx[(size_t)chain * p.R + r] * 256
-                                              : p.xobj + ((size_t)chain * p.R + r) * 256;
+        const float *xrow = (!ROWS && p.xtab) ? p.xtab[chain] + (size_t)p.xidx[(size_t)chain * p.xstride + r] * 256
+                                              : p.xobj + ((size_t)chain * p.xstride + r) * 256;
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
 #pragma unroll

@@ -243,12 +243,12 @@ __device__ __forceinline__ void front3d(const wrsrc_t rs, const int voff, float4
     TabRaw raw[2];
     table_load(tr, 0, h4, raw[0]);
     u32x4_t xin[8][2];
-    const float *xrow = p.xobj + ((size_t)tr.chain * p.R + tr.r) * 256;
+    const float *xrow = p.xobj + ((size_t)tr.chain * p.xstride + tr.r) * 256;
     f32x16 acc2[8];
     if (p.xobj16 || p.xtab16) {
         // the embedding was produced in bf16 operand order (pointnet.hip xobj kernels / embedding table): the row IS the B operand
-        const uint32_t *r16 = p.xtab16 ? p.xtab16[tr.chain] + (size_t)p.xidx[(size_t)tr.chain * p.R + tr.r] * 128
-                                       : p.xobj16 + ((size_t)tr.chain * p.R + tr.r) * 128;
+        const uint32_t *r16 = p.xtab16 ? p.xtab16[tr.chain] + (size_t)p.xidx[(size_t)tr.chain * p.xstride + tr.r] * 128
+                                       : p.xobj16 + ((size_t)tr.chain * p.xstride + tr.r) * 128;
         const u32x4_t *row16 = reinterpret_cast<const u32x4_t *>(r16) + (h4 >> 1);
 #pragma unroll
         for (int o = 0; o < 8; ++o) { xin[o][0] = row16[4 * o]; xin[o][1] = row16[4 * o + 1]; }

@@ -222,3 +222,16 @@ def all_gather_rows(t: torch.Tensor, group=None) -> torch.Tensor:
     dist.all_gather(bufs, src, group=group)
     out = torch.stack(bufs)
     return out.to(t.device) if via_host else out
+
+
+def broadcast_from_rank0(t: torch.Tensor, group=None) -> torch.Tensor:
+    """Rank 0's tensor on every rank (BatchNorm running statistics of data-parallel training): RCCL on the device tensor; through host
+    memory under gloo."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return t
+    if t.is_cuda and dist.get_backend(group) != "nccl":
+        h = t.cpu()
+        dist.broadcast(h, src=0, group=group)
+        return h.to(t.device)
+    dist.broadcast(t, src=0, group=group)
+    return t

@@ -4,7 +4,11 @@
 libdgdm_hip.so and one ``step`` is forward (BatchNorm in training mode) + MSE loss + backward + Adam on the GPU
 (csrc/train2d.hip).  The random draws are the reference's: ``torch.randn`` for the noise, then ``torch.randint`` for the
 timesteps, both from the CPU generator (trainer.py:68-74).  The 3-D model (PointNet++ weight gradients) is not built: asking
-for ``fingers_3d`` raises.  There is no CPU path."""
+for ``fingers_3d`` raises.  There is no CPU path.
+
+The trained weights live in the library handle: ``Trainer.state_dict()`` / ``save_checkpoint()`` read them out; ``Trainer.model`` (the
+``nn.Module`` the reference code pokes at for its key layout) keeps the INITIAL parameters unless ``sync_model()`` copies the trained
+ones into it."""
 from __future__ import annotations
 
 import ctypes as C
@@ -155,7 +159,8 @@ class Trainer(object):
         cs = -(-rows // world)
         lo, hi = min(rows, rank * cs), min(rows, (rank + 1) * cs)
         n = hi - lo
-        if n == 1 and train:
+        # decided from (rows, world), which every rank knows - a rank raising alone would leave the others waiting in the all-reduce
+        if train and any(min(rows, (r + 1) * cs) - min(rows, r * cs) == 1 for r in range(world)):
             raise ValueError("Expected more than 1 value per channel when training (a DataParallel chunk of one row)")
         cut = lambda v: v[lo:hi].contiguous()                                           # noqa: E731
         pred = torch.zeros((cs, 3), dtype=torch.float32, device=c.device)
@@ -171,6 +176,12 @@ class Trainer(object):
             flat = _dist.all_reduce_sum(flat)
             check(lib().dgdm_trainer2d_gradients(self._h, dptr(flat), flat.numel(), 1, stream_ptr()))
             check(lib().dgdm_trainer2d_apply(self._h, lr, stream_ptr()))
+            # BatchNorm running statistics: every rank has just updated its own from ITS chunk; nn.DataParallel keeps replica 0's
+            # (buffers of the other replicas are thrown away with them), and that is what rank 0 saves - so every rank evaluates with them
+            run = torch.empty(8 * 512, dtype=torch.float32, device=c.device)
+            check(lib().dgdm_trainer2d_running_stats(self._h, dptr(run), run.numel(), 0, stream_ptr()))
+            run = _dist.broadcast_from_rank0(run)
+            check(lib().dgdm_trainer2d_running_stats(self._h, dptr(run), run.numel(), 1, stream_ptr()))
         elif n:
             self._hint(lo, hi, rows_per_sample)
             check(lib().dgdm_trainer2d_step(self._h, *[dptr(cut(v)) for v in (c, nz, sa, sb, t, o, p, ob, sc)], n, lr, 0, dptr(pred), C.byref(loss),
@@ -201,8 +212,19 @@ class Trainer(object):
 
     def inference(self, ctrl, score, input_ori=None, input_pos=None, object_vertices=None, rows_per_sample: Optional[int] = None):
         """trainer.py:108-146 (eval mode, no update): returns (pred, loss)."""
-        loss, pred = self._run(ctrl, score, input_ori, input_pos, object_vertices, False, rows_per_sample)
-        return pred, loss
+        if not self.use_sub_batch:
+            loss, pred = self._run(ctrl, score, input_ori, input_pos, object_vertices, False, rows_per_sample)
+            return pred, loss
+        # --use_sub_batch (trainer.py:132-141): the draws once for the whole batch, one forward per slice of sub_bs rows, the slices'
+        # losses summed and divided by rows / sub_bs (so a ragged last slice weighs like a full one, as in the reference)
+        losses, preds, n = [], [], ctrl.shape[0]
+        noise, timesteps = self._draw(n)
+        for i in range(0, n, self.sub_batch_size):
+            sl = slice(i, i + self.sub_batch_size)
+            loss, pred = self._run(ctrl[sl], score[sl], input_ori[sl], input_pos[sl], object_vertices[sl], False, None, (noise[sl], timesteps[sl]))
+            losses.append(loss)
+            preds.append(pred)
+        return torch.cat(preds, dim=0), sum(losses) / (n / self.sub_batch_size)
 
     # ------------------------------------------------------------------ state
     def _export(self, which: int) -> Dict[str, torch.Tensor]:
@@ -223,6 +245,11 @@ class Trainer(object):
     def state_dict(self) -> Dict[str, torch.Tensor]:
         """The trained model's state_dict (host tensors), keys as the reference's bare module gives them."""
         return self._export(0)
+
+    def sync_model(self):
+        """Copies the trained parameters and running statistics from the library handle into ``self.model`` and returns it."""
+        self.model.load_state_dict(self.state_dict())
+        return self.model
 
     def gradients(self) -> Dict[str, torch.Tensor]:
         return self._export(1)

@@ -133,7 +133,8 @@ int dgdm_dyn3d_forward(DgdmDynamics *m, const float *x_ctrl_dev, const float *x_
  *   query_ball_point(radius, nsample, xyz, new_xyz) :95-115   radius_squared = float32(radius ** 2); out [B][S][nsample], first
  *                                             in-radius indices in ascending order, padded with the first (N if the ball is empty)
  *   square_distance(src, dst)                 :27-48   out [B][S][N], the expanded form in the reference's operation order
- *   index_points(points, idx)                 :51-68   points [B][N][C], idx [B][M] -> out [B][M][C]                                  */
+ *   index_points(points, idx)                 :51-68   points [B][N][C], idx [B][M] -> out [B][M][C]; an index outside [0, N) (where
+ *                                                      the reference's indexing raises) yields NaN; empty inputs give empty results  */
 int dgdm_farthest_point_sample(const float *xyz_dev, const int64_t *start_host, int B, int N, int npoint, int32_t *out_dev, void *stream);
 int dgdm_query_ball_point(float radius_squared, int nsample, const float *xyz_dev, const float *new_xyz_dev, int B, int N, int S,
                           int32_t *out_dev, void *stream);
@@ -355,6 +356,9 @@ int dgdm_trainer2d_forward_backward(DgdmTrainer2d *m, const float *ctrl_dev, con
 int64_t dgdm_trainer2d_gradient_count(const DgdmTrainer2d *m);
 int dgdm_trainer2d_gradients(DgdmTrainer2d *m, float *flat_dev, int64_t numel, int to_trainer, void *stream);
 int dgdm_trainer2d_apply(DgdmTrainer2d *m, float lr, void *stream);
+/* BatchNorm running statistics, 8 x [mean | var] x 256 floats, device -> flat_dev or flat_dev -> device (to_trainer): every rank updates
+ * them from its own chunk; nn.DataParallel keeps replica 0's, so rank 0's are broadcast to the others after each data-parallel step.   */
+int dgdm_trainer2d_running_stats(DgdmTrainer2d *m, float *flat_dev, int64_t numel, int to_trainer, void *stream);
 /* Copies into the host buffers of `tensors` (matched by name; data is written despite the const): which = 0 the state_dict
  * (parameters + running statistics: Trainer.save_checkpoint, trainer.py:105-106), 1 the gradients of the last step, 2 / 3 Adam's
  * exp_avg / exp_avg_sq.                                                                                                           */

@@ -145,27 +145,46 @@ def _load3d(part):
     return np.load(f) if os.path.exists(f) else None
 
 
-TIE_GRAD, TIE_END = 5e-4, 5e-3          # what a few ReLU ties can do to a 3-D gradient (C = 1125) / to the end point of a 5-step chain
+TIE_GRAD = 5e-4          # what a ReLU tie can do to one 3-D gradient (C = 1125 cells per finger); calls without one agree to ~5e-7
+FLOOR_CLEAN = 3e-5       # below this the reference's own end point does not move: the chain holds no ReLU within rounding of zero
 
 
-@pytest.mark.parametrize("part", ["rotate", "convergence", "multi", "rotate_raw"])
+def reference_floor(part):
+    """How far the REFERENCE's own end point moves under perturbations of the size of its float32 rounding (tests/golden/make_golden.py):
+    ``thread``: the same chain with 4 instead of 8 CPU threads (g9_3d_<part>_alt: some kernels sum in another order - often no change
+    at all); ``eps``: its eps-net output perturbed by 1e-6 relative, the eps-net's own distance from a float64 evaluation
+    (g9_3d_<part>_eps, two seeds).  Returns (max of what exists or None, dict)."""
+    alt, eps = _load3d(part + "_alt"), _load3d(part + "_eps")
+    fl = {}
+    if alt is not None:
+        fl["thread"] = float(alt["floor"])
+    if eps is not None:
+        fl["eps"] = float(eps["eps_floor"])
+    return (max(fl.values()) if fl else None), fl
+
+
+@pytest.mark.parametrize("part", ["rotate", "convergence", "multi", "rotate_raw", "convergence_b", "shift_left_b", "ccw_down"])
 def test_fullgrid_3d(dev, part):
-    """3-D chains at C = 1125 cells per finger.  Here a float32 gradient is exact to ~1e-6 except where a ReLU pre-activation is
-    so close to zero that float32 and exact arithmetic disagree about its sign ("tie"): 1-3 such units per cond_fn call in EITHER
-    implementation (test_fullgrid_3d_tiles localises them), each moving a finger's gradient by 5e-5 .. 1.5e-4 and, when it happens
-    in an early step, the end point by ~1e-3.  The reference parts from itself in the same way between 8 and 4 CPU threads
-    (1.3e-4 on 'rotate', whose first tie falls in step 1; bit-identical on 'convergence').  So: per-step gradients must agree to
-    tie level (5e-4) - calls without a tie agree to 5e-7, but with a linear objective, where every row weighs the same, most calls
-    have one; that the bulk agrees to rounding is test_fullgrid_3d_tiles' job - and end points to tie level (5e-3); the north-star
-    1e-4 is asserted where the reference's own spread shows a tie-free chain (0 < floor < 3e-5)."""
+    """3-D chains at C = 1125 cells per finger against the reference's own free-running ``Diffusion.guided_sample*``.
+
+    Here a float32 gradient is exact to ~5e-7 except where a ReLU pre-activation is so close to zero that rounding decides its sign
+    ("tie"); one such unit moves a finger's gradient by 5e-5 .. 2e-4 and the end point of the chain by about as much.  Which side a
+    tie falls on depends on every rounding before it - summation order, the eps-net's last bits through x - so a chain that contains
+    one is not reproducible to 1e-4 by ANY second float32 implementation, the reference on another thread count included
+    (scripts/exp_ties.py, scripts/exp_attrib.py).  Whether a chain contains one is measured on the reference itself
+    (``reference_floor``).  Asserted:
+      * every recorded cond_fn call, replayed on the reference's trajectory: gradient within tie level (5e-4) of the reference's;
+      * first-step gradient against float64: HIP at most 1.5 x as far as the reference is (where the fixture has one);
+      * end point: ``< 1e-4`` (north_star) wherever the reference's own floor is below 3e-5 - zero included;
+        otherwise within 2 x that floor."""
     g = _load3d(part)
     if g is None:
         pytest.skip(f"tests/golden/g9_3d_{part}.npz has not been generated")
-    alt = _load3d(part + "_alt")
-    floor = float(alt["floor"]) if alt is not None else None
+    floor, floors = reference_floor(part)
     B, G, P, L, T, S, N = [int(v) for v in g["dims"]]
     assert (G, P, N) == (45, 5, 512)
     o, gain = str(g["opt_obj"]), float(g["gain"])
+    oi = int(g["obj"]) if "obj" in g.files else 0
     net = engine.Unet1d(util.unet_sd(g["unet_seed"]))
     dyn = engine.Dynamics(3, synth.scale_output(util.dyn3d_sd(g["dyn3d_seed"]), gain), L)
     objs = torch.from_numpy(g["objs"])
@@ -180,35 +199,36 @@ def test_fullgrid_3d(dev, part):
     errs, grads = [], []
     noise64, g64, _ = grad_noise(f"3d/{part}", g["trace_grad"])
     chaotic = gain == 1.0                    # raw He-init weights: x runs to 1e4 and the recorded trajectory itself is ill-conditioned
-    if part == "multi":
+    if part.startswith("multi"):
         out = sampler.guided_multi_object(net, gd, s, 'point_3d', noise, [0, 1], o, starts=forced()).cpu()
         st = forced()
         step = np.stack([np.stack([st.call(gd.rows), st.call(gd.rows)]) for _ in range(S)])
-        _teacher_forced(net, gd, s, 'point_3d', g, "trace", [(0, o)], ref, step, dev, scale=sampler.SCALE_3D, multi_obj=[0, 1], errs=errs, rel=1.0, grads=grads)
+        _teacher_forced(net, gd, s, 'point_3d', g, "trace", [(0, o)], ref, step, dev, scale=sampler.SCALE_3D, multi_obj=[0, 1], errs=errs,
+                        rel=1.0 if chaotic else TIE_GRAD, grads=grads)
     else:
-        out = sampler.guided_chains(net, gd, s, 'point_3d', noise, [(0, o)], unguided=ug, starts=forced())[0].cpu()
-        sweep, step = sampler.draw_chain_starts(gd, [(0, o)], S, forced())
+        out = sampler.guided_chains(net, gd, s, 'point_3d', noise, [(oi, o)], unguided=ug, starts=forced())[0].cpu()
+        sweep, step = sampler.draw_chain_starts(gd, [(oi, o)], S, forced())
         rc = None
         if o == 'convergence':
-            centers = sampler.convergence_centers(gd, 'point_3d', ug, [0], sweep[0])
+            centers = sampler.convergence_centers(gd, 'point_3d', ug, [oi], sweep[0])
             rc = torch.from_numpy(gd.rowcoef(centers[0])).to(dev).reshape(1, -1)
-        _teacher_forced(net, gd, s, 'point_3d', g, "trace", [(0, o)], ref, step, dev, scale=sampler.classifier_scale('point_3d', o), rowcoef=rc,
-                        errs=errs, rel=1.0, grads=grads)
+        _teacher_forced(net, gd, s, 'point_3d', g, "trace", [(oi, o)], ref, step, dev, scale=sampler.classifier_scale('point_3d', o), rowcoef=rc,
+                        errs=errs, rel=1.0 if chaotic else TIE_GRAD, grads=grads)
     hip64 = util.rel_l2(torch.stack(grads[:g64.shape[0]]), g64) if g64 is not None else None
     err = finger_l2(out, ref)
-    _report({f"3d/{part}": dict(opt_obj=o, gain=gain, reference_thread_floor=floor, hip_vs_reference=err, step_grad_rel=[float(e) for e in errs],
-                                grad0_reference_vs_f64=noise64, grad0_hip_vs_f64=hip64)})
-    print(f"3d {part:12s} gain {gain:.4g} | end point: HIP vs reference {err:.2e}, reference thread floor {floor} | per-call gradient HIP vs reference "
-          f"{[float('%.1e' % e) for e in errs]}; first step vs float64: reference {noise64} HIP {hip64}")
+    tol = None if floor is None else (NORTH_STAR if floor < FLOOR_CLEAN else max(NORTH_STAR, 2.0 * floor))
+    _report({f"3d/{part}": dict(opt_obj=o, gain=gain, object=oi, reference_floors=floors, end_point_tolerance=tol, hip_vs_reference=err,
+                                step_grad_rel=[float(e) for e in errs], grad0_reference_vs_f64=noise64, grad0_hip_vs_f64=hip64)})
+    print(f"3d {part:14s} gain {gain:.4g} | end point: HIP vs reference {err:.2e} (tolerance {tol}), the reference's own floors {floors} | per-call "
+          f"gradient HIP vs reference {[float('%.1e' % e) for e in errs]}; first step vs float64: reference {noise64} HIP {hip64}")
     if chaotic:
         assert np.median(errs) < TIE_GRAD          # the chain itself is chaotic: only the recorded steps are compared, at tie level
         return
     assert max(errs) < TIE_GRAD, (part, errs)
     if hip64 is not None:
-        assert hip64 < TIE_GRAD, (part, hip64, noise64)
-    assert err < TIE_END, (part, err)
-    if floor is not None and 0 < floor < 3e-5:
-        assert err < NORTH_STAR, (part, err, floor)
+        assert hip64 <= max(2e-6, 1.5 * noise64), (part, hip64, noise64)
+    assert tol is not None, f"no reference floor recorded for {part} (make_golden.py g9_3d:{part}_alt / g9_3d_eps:{part})"
+    assert err < tol, (part, err, floors)
 
 
 @pytest.mark.parametrize("part", ["rotate", "convergence", "multi"])
@@ -260,6 +280,6 @@ def test_fullgrid_3d_tiles(dev, part):
                                       hip_outlier_tiles=n_hip, ref_outlier_tiles=n_ref, hip_max=float(e_hip.max()), ref_max=float(e_ref.max()))})
     print(f"3d tiles {part:12s} {e_hip.size} tiles | HIP vs float64: median {np.median(e_hip):.1e}, tiles >= {clean:g}: {n_hip} (max {e_hip.max():.1e}) | "
           f"reference float32 vs float64: median {np.median(e_ref):.1e}, tiles >= {clean:g}: {n_ref} (max {e_ref.max():.1e})")
-    assert np.median(e_hip) < 3e-6                                       # rounding-level agreement on the bulk
-    assert n_hip <= max(6, 3 * n_ref + 3), (n_hip, n_ref)                # ReLU ties are rare and not more frequent than in the reference
+    assert np.median(e_hip) <= max(3e-7, 1.2 * np.median(e_ref))         # the bulk is at least as close to exact as the reference's float32
+    assert n_hip <= n_ref + 1, (n_hip, n_ref)                            # ties are not more frequent than in the reference (+1: a count of events)
     assert e_hip.max() < 0.5                                             # an outlier is at most about one row's contribution

@@ -230,6 +230,7 @@ def test_trainer2d_data_parallel(dev, tmp_path):
     assert o.relu_margin >= 5e-6
     g1 = {k: v.clone() for k, v in o.grads.items()}
     lo2, po2 = o.step(*data, replicas=2)
+    pio, lio = o.inference(*data)          # eval mode with replica 0's running statistics, the stream of draws going on
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.update(DGDM_TORCH_SEED="4242", DGDM_DIST_BACKEND="gloo")
@@ -249,6 +250,9 @@ def test_trainer2d_data_parallel(dev, tmp_path):
     for k in ("linears.1.running_var", "linears.22.running_var"):
         assert float(np.abs(g["sd/" + k] - o.sd[k].numpy()).max()) < 1e-4, k
     assert int(g["sd/linears.1.num_batches_tracked"]) == 2
+    # the eval call after the two steps: EVERY rank's chunk is evaluated with rank 0's running statistics (nn.DataParallel keeps replica
+    # 0's buffers; they are broadcast after each step) - with per-rank statistics the second chunk's predictions are off by per cents
+    assert util.rel_l2(g["inf_pred"], pio) < 2e-3 and abs(float(g["inf_loss"]) / lio - 1) < 2e-3, (util.rel_l2(g["inf_pred"], pio), float(g["inf_loss"]), lio)
 
 
 def test_trainer2d_grouped_encoders(dev):
