@@ -447,9 +447,19 @@ def train_leg(dev, with_cpu=True):
     K = [L, 256, 795] + [256] * 7
     flops = rows * (3 * 2 * 256 * sum(K) - 2 * 256 * (L + 27) + 3 * 2 * 3 * 256)
     as_written = rows * (3 * 2 * 256 * sum([L, 256, 2 * nv, 256, 128, 256, 795] + [256] * 7) - 2 * 256 * (L + 2 * nv + 128 + 27) + 3 * 2 * 3 * 256)
+    # the whole Trainer.step as dynamics/main.py calls it: the reference's CPU-generator draws (made one step ahead by a worker thread),
+    # their upload, and the GPU step - wall clock over a few steps
+    tr.step(*data, rows_per_sample=9000)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nw = 4
+    for _ in range(nw):
+        tr.step(*data, rows_per_sample=9000)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / nw
     out = {"workload": "train2d (Trainer.step, dynamics/train_dynamics_2d.sh: 128 samples x 9000 pose cells = 1152000 rows, L=14, 100-vertex objects, T=15)",
            "dtype": "f32", "rows_per_s": rows / secs, "ms_per_step": secs * 1e3, "loss": float(loss.value),
-           "host_draws_and_uploads_ms": host_s * 1e3,
+           "host_draws_and_uploads_ms": host_s * 1e3, "wall_ms_per_step_python_api": wall * 1e3, "rows_per_s_python_api": rows / wall,
            "roofline": {"bound": "mfma", "achieved": flops / secs / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flops / secs / 157.3e12,
                         "traffic": None, "flops_per_step": flops, "as_written_flops_per_step": as_written,
                         "note": "whole step (GEMM launches + reductions + Adam), float32 MFMA peak; FLOPs = executed (time / object encoders de-duplicated)"}}

@@ -112,7 +112,7 @@ extern "C" int dgdm_unet1d_create(DgdmUnet1d **out, const DgdmTensor *tensors, i
     DGDM_REQUIRE(kernel_size == 5, DGDM_EINVAL, "kernel_size %d unsupported (reference uses 5)", kernel_size);
     const int d0 = down_dims[0], d1 = down_dims[1];
     DGDM_REQUIRE(d0 % n_groups == 0 && d1 % n_groups == 0 && dsed % 2 == 0 && dsed >= 4, DGDM_EINVAL, "bad U-Net dims");
-    DGDM_REQUIRE(d0 % 32 == 0 && d1 % 32 == 0, DGDM_EINVAL, "U-Net widths must be multiples of 32 for the MFMA tiling (got %d, %d)", d0, d1);
+    DGDM_REQUIRE(d0 % 128 == 0 && d1 % 128 == 0, DGDM_EINVAL, "U-Net widths must be multiples of 128 for the MFMA tiling and its chunked accumulation (got %d, %d)", d0, d1);
     StateDict sd(tensors, n_tensors);
     std::unique_ptr<DgdmUnet1d> m(new DgdmUnet1d());
     Blob &bl = m->blob;

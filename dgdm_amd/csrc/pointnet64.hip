@@ -23,19 +23,27 @@ namespace dgdm {
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-// acc[16 M-tiles] += W * in over K = 4 * KS.  in_d(ks): the lane's B value of K-step ks (feature kq * KS + ks of its row).
-template <int KS, class In>
-__device__ __forceinline__ void mfma64_layer(const double *__restrict__ img, f64x4 (&acc)[16], In &&in_d, int lane) {
-    constexpr int TOTAL = KS * 8;                                   // entries (ks, M-tile pair): 64 lanes x 2 doubles = 1 KiB each
-    struct D2 { double lo, hi; };
-    stream_weights<TOTAL>(weight_rsrc(reinterpret_cast<const float4 *>(img), TOTAL * 1024), lane * 16, 0, [&](int e, const float4 a) {
-        const int ks = e / 8, mp = e % 8;
-        const D2 w = __builtin_bit_cast(D2, a);
-        const double b = in_d(ks);
-        acc[2 * mp] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.lo, b, acc[2 * mp], 0, 0, 0);
-        acc[2 * mp + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.hi, b, acc[2 * mp + 1], 0, 0, 0);
-    });
+// Weight ring of depth D (D divides TOTAL) carried across calls, as mfma_chain.h stream_cont with a chosen depth: two waves per SIMD
+// hide the L2 latency for each other, so 8 entries in flight per wave suffice and the kernels fit 256 registers.
+template <int D>
+__device__ __forceinline__ void ring64_fill(wrsrc_t rs, int voff, int base_off, float4 (&ring)[D]) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) ring[i] = wload(rs, voff, base_off + i * 1024);
 }
+
+template <int TOTAL, int D, class Body>
+__device__ __forceinline__ void ring64_stream(wrsrc_t rs, int voff, int base_off, float4 (&ring)[D], Body &&body) {
+    static_assert(TOTAL % D == 0, "pass length must be a multiple of the ring depth");
+#pragma unroll
+    for (int i = 0; i < TOTAL; ++i) {
+        const float4 a = ring[i % D];
+        ring[i % D] = wload(rs, voff, base_off + (i + D) * 1024);
+        body(i, a);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+constexpr int RING64 = 8;
 
 // ------------------------------------------------------------------------------------------------ T2
 // sa1 feature of every point as a centre (pointnet.hip sa1_kernel) -> F1 [N][128] doubles
@@ -73,7 +81,7 @@ __global__ __launch_bounds__(128) void sa1_64_kernel(const float *__restrict__ x
 
 // ------------------------------------------------------------------------------------------------ T4
 // Y[pair][256] = float32( ReLU(W2b' ReLU(U[k] + Vx (xyz_k - xyz_c)) + b2b') ) for every in-radius ordered pair (pointnet.hip pair_kernel)
-__global__ __launch_bounds__(256) void pair64_kernel(const float *__restrict__ xyz, int N, const double *__restrict__ U /*[N][128]*/,
+__global__ __launch_bounds__(256, 2) void pair64_kernel(const float *__restrict__ xyz, int N, const double *__restrict__ U /*[N][128]*/,
                                                      const double *__restrict__ vx /*[3][128]*/, const double *__restrict__ img,
                                                      const double *__restrict__ bias, const int *__restrict__ pairs,
                                                      const int *__restrict__ off /*[N+1]*/, float *__restrict__ Y) {
@@ -86,17 +94,35 @@ __global__ __launch_bounds__(256) void pair64_kernel(const float *__restrict__ x
     const int ck = pairs[p], c = ck >> 16, k = ck & 0xffff;
     const double dx = (double)xyz[3 * k] - (double)xyz[3 * c], dy = (double)xyz[3 * k + 1] - (double)xyz[3 * c + 1],
                  dz = (double)xyz[3 * k + 2] - (double)xyz[3 * c + 2];
-    double in[32];
     const double *urow = U + (size_t)k * 128 + kq * 32, *v = vx + kq * 32;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) in[j] = fmax(fma(v[256 + j], dz, fma(v[128 + j], dy, fma(v[j], dx, urow[j]))), 0.0);
     f64x4 acc[16];
 #pragma unroll
     for (int mt = 0; mt < 16; ++mt) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[mt][i] = bias[16 * mt + 4 * kq + i];
     }
-    mfma64_layer<32>(img, acc, [&](int ks) { return in[ks]; }, lane);
+    // K = 128 in two chunks of 16 K-steps (a rolled loop): the lane's 16 inputs of a chunk are made just before it runs, the weight
+    // ring is carried across - keeps the kernel inside 256 registers, i.e. two waves per SIMD
+    struct D2 { double lo, hi; };
+    const wrsrc_t rs = weight_rsrc(reinterpret_cast<const float4 *>(img), 256 * 1024);
+    float4 ring[RING64];
+    ring64_fill<RING64>(rs, lane * 16, 0, ring);
+#pragma nounroll
+    for (int ch = 0; ch < 2; ++ch) {
+        double in[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int f = 16 * ch + j;
+            in[j] = fmax(fma(v[256 + f], dz, fma(v[128 + f], dy, fma(v[f], dx, urow[f]))), 0.0);
+        }
+        ring64_stream<128, RING64>(rs, lane * 16, ch * 128 * 1024, ring, [&](int e, const float4 a) {
+            const int ks = e / 8, mp = e % 8;
+            const D2 w = __builtin_bit_cast(D2, a);
+            const double b = in[ks];
+            acc[2 * mp] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.lo, b, acc[2 * mp], 0, 0, 0);
+            acc[2 * mp + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.hi, b, acc[2 * mp + 1], 0, 0, 0);
+        });
+    }
     if (tile * 16 + n < total) {
         float *dst = Y + (size_t)p * 256 + 4 * kq;
 #pragma unroll
@@ -108,7 +134,7 @@ __global__ __launch_bounds__(256) void pair64_kernel(const float *__restrict__ x
 
 // ------------------------------------------------------------------------------------------------ T6
 // Z[row][256] = float32( ReLU(W3'[:,3:] L2[row] + W3'[:,0:3] xyz_c + b3') ),  rows / modes as pointnet.hip z_kernel
-__global__ __launch_bounds__(256) void z64_kernel(const float *__restrict__ xyz, int N, int nv, const float *__restrict__ L2,
+__global__ __launch_bounds__(256, 2) void z64_kernel(const float *__restrict__ xyz, int N, int nv, const float *__restrict__ L2,
                                                   const double *__restrict__ img, const double *__restrict__ w3x /*[3][256]*/,
                                                   const double *__restrict__ bias, float *__restrict__ Z, int mode,
                                                   const int *__restrict__ clist, const int *__restrict__ ncr) {
@@ -136,8 +162,8 @@ __global__ __launch_bounds__(256) void z64_kernel(const float *__restrict__ xyz,
     // inputs of the next chunk are loaded while the current one runs, the weight ring is carried across the chunks
     struct D2 { double lo, hi; };
     const wrsrc_t rs = weight_rsrc(reinterpret_cast<const float4 *>(img), 512 * 1024);
-    float4 ring[CONT_DEPTH];
-    ring_fill(rs, lane * 16, 0, ring);
+    float4 ring[RING64];
+    ring64_fill<RING64>(rs, lane * 16, 0, ring);
     float4 cur[4], nxt[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) cur[j] = src[j];
@@ -149,7 +175,7 @@ __global__ __launch_bounds__(256) void z64_kernel(const float *__restrict__ xyz,
         float in[16];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { in[4 * j] = cur[j].x; in[4 * j + 1] = cur[j].y; in[4 * j + 2] = cur[j].z; in[4 * j + 3] = cur[j].w; }
-        stream_cont<128>(rs, lane * 16, ch * 128 * 1024, ring, [&](int e, const float4 a) {
+        ring64_stream<128, RING64>(rs, lane * 16, ch * 128 * 1024, ring, [&](int e, const float4 a) {
             const int ks = e / 8, mp = e % 8;
             const D2 w = __builtin_bit_cast(D2, a);
             const double b = (double)in[ks];

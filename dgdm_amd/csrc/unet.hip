@@ -86,11 +86,11 @@ template <int NT, int MT, int MODE>
 __device__ void conv_mfma(const ConvArgs a, const lds_f *in, int CPi, lds_f *out, int CPo, int Lout) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     const int j = lane & 15, q = lane >> 4;
-    const int groups = a.cin >> 4, mtiles = a.cout >> 4;
+    const int groups = __builtin_amdgcn_readfirstlane(a.cin >> 4), mtiles = __builtin_amdgcn_readfirstlane(a.cout >> 4);
     int base[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) base[nt] = (min(nt * 16 + j, Lout - 1) * a.istride + 2) * CPi + 4 * q;
-    const int iters = a.ntaps * groups;
+    const int iters = __builtin_amdgcn_readfirstlane(a.ntaps * groups);
     for (int mp = wave; mp * MT < mtiles; mp += nwave) {
         int mt[MT];
         glb_f4 *w[MT];
@@ -110,36 +110,37 @@ __device__ void conv_mfma(const ConvArgs a, const lds_f *in, int CPi, lds_f *out
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) { acc[m][nt] = (f32x4)(0.f); tot[m][nt] = (f32x4)(0.f); }
         }
-        int t = 0, g = 0;
-        for (int it = 0; it < iters; ++it) {
-            if (it != 0 && (it & (CHUNK - 1)) == 0) {
+        for (int it0 = 0; it0 < iters; it0 += CHUNK) {          // a chunk = CHUNK groups of one tap (groups is a multiple of CHUNK: launcher)
+            const int t = it0 / groups, g0 = it0 - t * groups;
+            const int tapoff = (a.ioff0 + t * a.iostep) * CPi + g0 * 16;
+            for (int jc = 0; jc < CHUNK; ++jc) {
+                const int it = it0 + jc;
+                float av[MT][4];
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
+                for (int m = 0; m < MT; ++m) {
+                    av[m][0] = nxt[m][0]; av[m][1] = nxt[m][1]; av[m][2] = nxt[m][2]; av[m][3] = nxt[m][3];
+                    nxt[m] = nxt2[m];
+                }
+                // hipcc otherwise proves nxt == w[it] and turns the two-deep prefetch back into load-then-use; an opaque index keeps it
+                int pre = min(it + 2, iters - 1);
+                asm volatile("" : "+v"(pre));
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) { tot[m][nt] += acc[m][nt]; acc[m][nt] = (f32x4)(0.f); }
+                for (int m = 0; m < MT; ++m) nxt2[m] = w[m][(size_t)pre * 64];
+                const int off = tapoff + jc * 16;
+                f32x4 bv[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv[nt] = *(const lds_f4 *)(in + base[nt] + off);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) acc[m][nt] = mfma16(av[m][c], bv[nt][c], acc[m][nt]);
             }
-            float av[MT][4];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                av[m][0] = nxt[m][0]; av[m][1] = nxt[m][1]; av[m][2] = nxt[m][2]; av[m][3] = nxt[m][3];
-                nxt[m] = nxt2[m];
-            }
-            // hipcc otherwise proves nxt == w[it] and turns the two-deep prefetch back into load-then-use; an opaque index keeps it
-            int pre = min(it + 2, iters - 1);
-            asm volatile("" : "+v"(pre));
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) nxt2[m] = w[m][(size_t)pre * 64];
-            const int off = (a.ioff0 + t * a.iostep) * CPi + g * 16;
-            f32x4 bv[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[nt] = *(const lds_f4 *)(in + base[nt] + off);
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) acc[m][nt] = mfma16(av[m][c], bv[nt][c], acc[m][nt]);
-            if (++g == groups) { g = 0; ++t; }
+                for (int nt = 0; nt < NT; ++nt) { tot[m][nt] += acc[m][nt]; acc[m][nt] = (f32x4)(0.f); }
         }
         // D layout: column (position) = lane & 15, rows (channels) = 4*(lane >> 4) + r
 #pragma unroll
@@ -151,7 +152,7 @@ __device__ void conv_mfma(const ConvArgs a, const lds_f *in, int CPi, lds_f *out
                 const int l = nt * 16 + j;
                 if (l < Lout) {
                     lds_f4 *p = (lds_f4 *)(out + ((l * a.ostride + a.ooff) + 2) * CPo + 4 * q + mt[m] * 16);
-                    const f32x4 sum = tot[m][nt] + acc[m][nt];
+                    const f32x4 sum = tot[m][nt];
                     f32x4 v = {sum[0] + b4.x, sum[1] + b4.y, sum[2] + b4.z, sum[3] + b4.w};
                     if (MODE == 1) v += *p;
                     *p = v;
@@ -180,11 +181,11 @@ template <int NT, int MT, int MODE>
 __device__ void conv_mfma_bf16(const ConvArgs a, const lds_f *in, int CPi, lds_f *out, int CPo, int Lout) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     const int j = lane & 15, q = lane >> 4;
-    const int groups = a.cin >> 5, mtiles = a.cout >> 4;
+    const int groups = __builtin_amdgcn_readfirstlane(a.cin >> 5), mtiles = __builtin_amdgcn_readfirstlane(a.cout >> 4);
     int base[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) base[nt] = (min(nt * 16 + j, Lout - 1) * a.istride + 2) * CPi + 4 * q;
-    const int iters = a.ntaps * groups;
+    const int iters = __builtin_amdgcn_readfirstlane(a.ntaps * groups);
     for (int mp = wave; mp * MT < mtiles; mp += nwave) {
         int mt[MT];
         glb_f4 *w[MT];
@@ -199,31 +200,36 @@ __device__ void conv_mfma_bf16(const ConvArgs a, const lds_f *in, int CPi, lds_f
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[m][nt] = (f32x4)(0.f);
         }
-        int t = 0, g = 0;
-        for (int it = 0; it < iters; ++it) {
-            bf16x8_u av[MT];
+        constexpr int UNR = 4;                                   // groups (32 channels each) is a multiple of 4: the weight-fragment rotation unrolls away
+        for (int it0 = 0; it0 < iters; it0 += UNR) {
+            const int t = it0 / groups, g0 = it0 - t * groups;
+            const int tapoff = (a.ioff0 + t * a.iostep) * CPi + g0 * 32;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                av[m] = __builtin_bit_cast(bf16x8_u, nxt[m]);
-                nxt[m] = nxt2[m];
+            for (int jc = 0; jc < UNR; ++jc) {
+                const int it = it0 + jc;
+                bf16x8_u av[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    av[m] = __builtin_bit_cast(bf16x8_u, nxt[m]);
+                    nxt[m] = nxt2[m];
+                }
+                int pre = min(it + 2, iters - 1);
+                asm volatile("" : "+v"(pre));
+#pragma unroll
+                for (int m = 0; m < MT; ++m) nxt2[m] = w[m][(size_t)pre * 64];
+                const int off = tapoff + jc * 32;
+                bf16x8_u bv[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const f32x4 lo = *(const lds_f4 *)(in + base[nt] + off), hi = *(const lds_f4 *)(in + base[nt] + off + 16);
+                    const u32x4_u pk = {pack2_bf16(lo[0], lo[1]), pack2_bf16(lo[2], lo[3]), pack2_bf16(hi[0], hi[1]), pack2_bf16(hi[2], hi[3])};
+                    bv[nt] = __builtin_bit_cast(bf16x8_u, pk);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[m], bv[nt], acc[m][nt], 0, 0, 0);
             }
-            int pre = min(it + 2, iters - 1);
-            asm volatile("" : "+v"(pre));
-#pragma unroll
-            for (int m = 0; m < MT; ++m) nxt2[m] = w[m][(size_t)pre * 64];
-            const int off = (a.ioff0 + t * a.iostep) * CPi + g * 32;
-            bf16x8_u bv[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const f32x4 lo = *(const lds_f4 *)(in + base[nt] + off), hi = *(const lds_f4 *)(in + base[nt] + off + 16);
-                const u32x4_u pk = {pack2_bf16(lo[0], lo[1]), pack2_bf16(lo[2], lo[3]), pack2_bf16(hi[0], hi[1]), pack2_bf16(hi[2], hi[3])};
-                bv[nt] = __builtin_bit_cast(bf16x8_u, pk);
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[m], bv[nt], acc[m][nt], 0, 0, 0);
-            if (++g == groups) { g = 0; ++t; }
         }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {

@@ -74,6 +74,9 @@ class Trainer(object):
         self.model: Optional[ProfileForward2DModel] = None
         # exact de-duplication of the time / object encoders over the rows (dgdm_trainer2d_set_groups); False = every row through both
         self.group_encoders = True
+        # the next step's CPU-generator draws are made by a worker thread while the GPU runs this step (see _draw)
+        self.draw_ahead = True
+        self._ahead = None
 
     # ------------------------------------------------------------------ model / optimizer (trainer.py:40-51)
     def create_model(self, state_dict: Optional[Dict[str, torch.Tensor]] = None):
@@ -106,15 +109,50 @@ class Trainer(object):
 
     # ------------------------------------------------------------------ one batch
     def _draw(self, rows: int):
-        """The reference's draws, in its order, from the CPU generator (trainer.py:68-74)."""
-        noise = torch.randn((rows * self.num_timesteps_per_batch, self.gripperpts_dim))
-        timesteps = torch.randint(0, self.noise_scheduler.config.num_train_timesteps, (rows,)).long()
-        return noise, timesteps
+        """The reference's draws, in its order, from the CPU generator (trainer.py:68-74): ``torch.randn`` for the noise, then
+        ``torch.randint`` for the timesteps.  16 M normals per 1.15 M-row step take as long on one host core as the GPU step itself,
+        and they depend on nothing but the generator: after every step a worker thread draws the NEXT step's numbers (same row
+        count) from a private generator that starts at the global generator's state; the next call adopts them - and moves the
+        global generator to where those draws leave it - if the global state is still the one the worker started from (nobody else
+        drew in between, e.g. a DataLoader reshuffle) and the row count matches; otherwise they are thrown away and drawn here."""
+        ahead, self._ahead = getattr(self, "_ahead", None), None
+        out = None
+        if ahead is not None:
+            th, box = ahead
+            th.join()
+            if box.get("rows") == rows and "state_after" in box and torch.equal(torch.get_rng_state(), box["state_before"]):
+                torch.set_rng_state(box["state_after"])
+                out = (box["noise"], box["timesteps"])
+        if out is None:
+            noise = torch.randn((rows * self.num_timesteps_per_batch, self.gripperpts_dim))
+            timesteps = torch.randint(0, self.noise_scheduler.config.num_train_timesteps, (rows,)).long()
+            out = (noise, timesteps)
+        if self.draw_ahead:
+            self._start_draw_ahead(rows)
+        return out
+
+    def _start_draw_ahead(self, rows: int):
+        import threading
+        box = {"rows": rows, "state_before": torch.get_rng_state()}
+        T, n, dim = self.noise_scheduler.config.num_train_timesteps, self.num_timesteps_per_batch, self.gripperpts_dim
+
+        def work():
+            g = torch.Generator()
+            g.set_state(box["state_before"])
+            pin = torch.cuda.is_available()
+            noise = torch.empty((rows * n, dim), pin_memory=pin)
+            torch.randn((rows * n, dim), generator=g, out=noise)
+            box["noise"] = noise
+            box["timesteps"] = torch.randint(0, T, (rows,), generator=g).long()
+            box["state_after"] = g.get_state()
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        self._ahead = (th, box)
 
     def _inputs(self, ctrl, score, input_ori, input_pos, object_vertices, drawn=None):
         dev = torch.device("cuda", torch.cuda.current_device())
         n = self.num_timesteps_per_batch
-        f = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()       # noqa: E731
+        f = lambda t: t.detach().to(device=dev, dtype=torch.float32, non_blocking=t.is_pinned()).contiguous()       # noqa: E731
         ctrl_all, obj_all = f(ctrl.repeat(n, 1)), f(object_vertices.repeat(n, 1))
         ori_all, pos_all, score_all = f(input_ori.repeat(n, 1)), f(input_pos.repeat(n, 1)), f(score.repeat(n, 1))
         rows = ctrl_all.shape[0]
