@@ -52,6 +52,7 @@ struct DgdmGuidance {
     DevBuf objpart;                              // 2-D: [max_objects][W1] doubles
     std::vector<std::unique_ptr<ObjectTables>> tables;   // 3-D
     bool bf16 = false;                           // contractions of the trunk on bf16 MFMA (dgdm_guidance_set_contraction_dtype)
+    bool f32_mfma = false;                       // float32 mode on the k-ordered float32 MFMA chain (trunk.hip) instead of the split form
     static constexpr int NBUILD = 3;             // objects whose tables are built concurrently (own stream + temporaries each)
     DevBuf pool_xyz, pool_fps1, pool_fps2, pool_flags, pool_ncr;   // [n_objects] x per-object FPS tables (ObjectTables point into these), crowded-centre counts
     DevBuf tmpF1[NBUILD], tmpU[NBUILD], tmpY[NBUILD], tmpL2[NBUILD], tmpOff[NBUILD], tmpPairs[NBUILD], tmpRank[NBUILD], vlist;      // 3-D table-build temporaries
@@ -191,8 +192,10 @@ extern "C" void dgdm_guidance_destroy(DgdmGuidance *g) { delete g; }
 
 extern "C" int dgdm_guidance_set_contraction_dtype(DgdmGuidance *g, int dtype) {
     DGDM_REQUIRE(g, DGDM_EINVAL, "dgdm_guidance_set_contraction_dtype: null handle");
-    DGDM_REQUIRE(dtype == DGDM_DTYPE_F32 || dtype == DGDM_DTYPE_BF16, DGDM_EINVAL, "contraction dtype %d unsupported (0 = f32, 1 = bf16)", dtype);
+    DGDM_REQUIRE(dtype == DGDM_DTYPE_F32 || dtype == DGDM_DTYPE_BF16 || dtype == DGDM_DTYPE_F32_MFMA, DGDM_EINVAL,
+                 "contraction dtype %d unsupported (0 = f32, 1 = bf16, 2 = f32 on the float32 MFMA)", dtype);
     g->bf16 = dtype == DGDM_DTYPE_BF16;
+    g->f32_mfma = dtype == DGDM_DTYPE_F32_MFMA;
     return DGDM_OK;
 }
 
@@ -658,7 +661,12 @@ static int guidance_grad(DgdmGuidance *g, int kind, const float *x_dev, int time
         p.clk = dclk;
 #endif
         if ((rc = trunk_bf16_launch(kind, p, s))) return rc;
-    } else if ((rc = trunk_launch(kind, false, false, p, s))) return rc;
+    } else if (g->f32_mfma) {
+        if ((rc = trunk_launch(kind, false, false, p, s))) return rc;
+    } else {
+        g->m->fill_trunk_split(&p);      // only the two weight streams differ
+        if ((rc = trunk_split_launch(kind, p, s))) return rc;
+    }
 #ifdef DGDM_TRUNK_CLOCKS
     if (g->bf16) {      // mean cycles per phase over all waves (experiment build)
         const size_t nw = (size_t)(p.ntiles + 1) / 2;

@@ -231,6 +231,39 @@ std::vector<double> cols64(const std::vector<double> &w, int rows, int ncols, in
     return o;
 }
 
+// ---- split-float32 weight streams (csrc/trunk_split.hip): a float32 matrix as three bf16 pieces, w = h + m + l exactly
+struct Split3 {
+    std::vector<float> p[3];
+    int K = 0;
+    Split3(const float *src, int M, int K_) : K(K_) {
+        auto bf = [](float x) { const uint32_t u = (uint32_t)f32_to_bf16(x) << 16; float y; memcpy(&y, &u, 4); return y; };
+        for (auto &v : p) v.resize((size_t)M * K_);
+        for (size_t i = 0; i < (size_t)M * K_; ++i) {
+            const float h = bf(src[i]), m = bf(src[i] - h), l = bf(src[i] - h - m);
+            p[0][i] = h; p[1][i] = m; p[2][i] = l;
+        }
+    }
+    // the three 1 KiB entries [h m l] of (output block op, input block ib, K-step s): lane (i, hh), slot j = P[32 op + i][32 ib + rho(8 s + j, hh)]
+    void emit(std::vector<uint16_t> &dst, int op, int ib, int s) const {
+        for (int q = 0; q < 3; ++q)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int i = lane & 31, hh = lane >> 5;
+                for (int j = 0; j < 8; ++j) {
+                    const int rr = 8 * s + j, f = (rr & 3) + 8 * (rr >> 2) + 4 * hh;
+                    dst.push_back(f32_to_bf16(p[q][(size_t)(32 * op + i) * K + 32 * ib + f]));      // exact: the piece is a bf16 value
+                }
+            }
+    }
+};
+
+// 256 -> 256 layer: 4 block pairs x 16 K-steps x [A.h A.m A.l B.h B.m B.l]
+void split_layer_stream(std::vector<uint16_t> &dst, const float *w /*[256][256]*/) {
+    const Split3 sp(w, 256, 256);
+    for (int pp = 0; pp < 4; ++pp)
+        for (int ks = 0; ks < 16; ++ks)
+            for (int blk = 2 * pp; blk < 2 * pp + 2; ++blk) sp.emit(dst, blk, ks / 2, ks % 2);
+}
+
 std::vector<float> tfreqs(int half) {
     // timestep_embedding (profile_forward_2d.py:68-71): exp(-log(10000) * arange(half, f32) / half), float32 ops
     std::vector<float> f(half);
@@ -359,6 +392,42 @@ extern "C" int dgdm_dynamics_create(DgdmDynamics **out, int kind, const DgdmTens
         fwd16.insert(fwd16.end(), sa3_img16.begin(), sa3_img16.end());
         if ((rc = m->w16.upload(fwd16.data(), fwd16.size() * 2))) return rc;
     }
+    {   // split-float32 streams (trunk_split.hip), in consumption order
+        std::vector<uint16_t> fs, bs;
+        if (kind == 3) {
+            Folded l2;
+            if ((rc = fold_linear(sd, "linears.3", "linears.4", W, W1, &l2))) return rc;
+            const std::vector<float> w1o3 = cols(l1.w, W1, IN1, 0, W);
+            const Split3 s1(w1o3.data(), W1, W), s2(l2.w.data(), W, W1);
+            for (int kb = 0; kb < 16; ++kb) {
+                for (int ks = 0; ks < 16; ++ks) s1.emit(fs, kb, ks / 2, ks % 2);                    // layer-1 block kb: 16 K-steps x [h m l]
+                for (int pp = 0; pp < 4; ++pp)                                                      // layer 2, input block kb
+                    for (int sx = 0; sx < 2; ++sx)
+                        for (int blk = 2 * pp; blk < 2 * pp + 2; ++blk) s2.emit(fs, blk, kb, sx);
+            }
+        }
+        std::vector<std::vector<uint16_t>> back;
+        for (int i = 0; i < m->n_mid; ++i) {
+            const int li = 3 * (first_mid + i);
+            Folded f;
+            if ((rc = fold_linear(sd, "linears." + std::to_string(li), "linears." + std::to_string(li + 1), W, W, &f))) return rc;
+            split_layer_stream(fs, f.w.data());
+            back.emplace_back();
+            split_layer_stream(back.back(), transpose(f.w.data(), W, W).data());
+        }
+        for (int i = m->n_mid - 1; i >= 0; --i) bs.insert(bs.end(), back[i].begin(), back[i].end());               // last layer first
+        if (kind == 3) {
+            Folded l2;
+            if ((rc = fold_linear(sd, "linears.3", "linears.4", W, W1, &l2))) return rc;
+            const std::vector<float> w2t = transpose(l2.w.data(), W, W1);                                          // [512][256]
+            const Split3 st(w2t.data(), W1, W);
+            for (int kb = 0; kb < 16; ++kb)
+                for (int ks = 0; ks < 16; ++ks) st.emit(bs, kb, ks / 2, ks % 2);
+        }
+        m->fwds_bytes = fs.size() * 2; m->bwds_bytes = bs.size() * 2;
+        fs.insert(fs.end(), bs.begin(), bs.end());
+        if ((rc = m->wsplit.upload(fs.data(), fs.size() * 2))) return rc;
+    }
     std::vector<float> bwd;
     for (int i = m->n_mid - 1; i >= 0; --i) bwd.insert(bwd.end(), bwd_imgs[i].begin(), bwd_imgs[i].end());     // last layer first
     bwd.insert(bwd.end(), bwd_tail.begin(), bwd_tail.end());
@@ -427,6 +496,11 @@ void DgdmDynamics::fill_trunk(TrunkParams *p) const {
 void DgdmDynamics::fill_trunk_bf16(TrunkParams *p) const {     // after fill_trunk: swaps the two weight streams only
     p->Wfwd = reinterpret_cast<const float4 *>(static_cast<const char *>(w16.p)); p->fwd_bytes = (unsigned)fwd16_bytes;
     p->Wbwd = reinterpret_cast<const float4 *>(static_cast<const char *>(w16.p) + fwd16_bytes); p->bwd_bytes = (unsigned)bwd16_bytes;
+}
+
+void DgdmDynamics::fill_trunk_split(TrunkParams *p) const {    // after fill_trunk: swaps the two weight streams only
+    p->Wfwd = reinterpret_cast<const float4 *>(static_cast<const char *>(wsplit.p)); p->fwd_bytes = (unsigned)fwds_bytes;
+    p->Wbwd = reinterpret_cast<const float4 *>(static_cast<const char *>(wsplit.p) + fwds_bytes); p->bwd_bytes = (unsigned)bwds_bytes;
 }
 
 PnWeights DgdmDynamics::pn() const {

@@ -49,6 +49,10 @@ struct TrunkParams {
 // kind: 2 | 3.  rows_mode: first-layer pre-activations given per row (general forward API).
 int trunk_launch(int kind, bool rows_mode, bool fwd_only, const TrunkParams &p, hipStream_t s);
 
+// float32 contractions on the bf16 matrix pipe, operands split exactly into three bf16 pieces (trunk_split.hip): table mode, forward +
+// backward.  p.Wfwd / p.Wbwd point at the split streams (DgdmDynamics::fill_trunk_split).
+int trunk_split_launch(int kind, const TrunkParams &p, hipStream_t s);
+
 // bf16-contraction variant (trunk_bf16.hip): table mode, forward + backward only.  p.Wfwd / p.Wbwd point at the bf16 streams
 // (DgdmDynamics::fill_trunk_bf16); everything else in TrunkParams means the same.
 int trunk_bf16_launch(int kind, const TrunkParams &p, hipStream_t s);

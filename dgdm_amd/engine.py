@@ -135,10 +135,13 @@ class Guidance:
         self.set_contraction_dtype(contraction_dtype)
 
     def set_contraction_dtype(self, dtype: str) -> None:
-        """'f32' (exact float32 MFMA, default) or 'bf16' (bf16 operands, float32 accumulate) for the trunk of cond_fn."""
-        if dtype not in ("f32", "bf16"):
+        """Arithmetic of the trunk of cond_fn: 'f32' (default: float32 operands split exactly into three bf16 pieces, six bf16 MFMAs per
+        product, float32 accumulation - float32-grade, csrc/trunk_split.hip), 'f32_mfma' (the k-ordered float32 MFMA chain,
+        csrc/trunk.hip) or 'bf16' (operands ROUNDED to bf16, float32 accumulation)."""
+        codes = {"f32": 0, "bf16": 1, "f32_mfma": 2}
+        if dtype not in codes:
             raise ValueError(f"contraction dtype {dtype!r} not supported")
-        check(lib().dgdm_guidance_set_contraction_dtype(self._h, 1 if dtype == "bf16" else 0))
+        check(lib().dgdm_guidance_set_contraction_dtype(self._h, codes[dtype]))
         self.contraction_dtype = dtype
 
     def __del__(self):

@@ -135,9 +135,18 @@ def test_dyn2d_cond_fn_oracle_multichain(dev):
     rc = np.zeros((len(chains), gd.rows), np.float32)
     rc[4] = gd.rowcoef(centers)
     gr = gd.grad(xs.reshape(len(chains), B, L).to(dev), 6, [engine.make_objective(o, oi) for oi, o in chains], torch.from_numpy(rc).to(dev)).cpu()
+    ties = 0
     for c, (oi, o) in enumerate(chains):
         ref = orc.cond_fn(s, xs[c], torch.full((B,), 6, dtype=torch.int64), o, objs[oi], (-1.0, 1.0), centers if o == 'convergence' else None)
-        assert util.rel_l2(gr[c].reshape(B, L, 1), ref) < REL, (c, o)
+        # rounding level - except that ONE ReLU whose pre-activation is within rounding of zero may fall on the other side than in torch's
+        # arithmetic and move ONE finger's gradient by ~1e-4 of the chain's (tests/test_gpu_fullgrid.py); a wrong kernel moves them all
+        err = util.finger_err(gr[c].reshape(B, L, 1), ref).sort().values
+        norm = float(ref.double().norm())
+        if float(err.norm()) / norm < REL:
+            continue
+        ties += 1
+        assert float(err[:-1].norm()) / norm < REL and float(err[-1]) / norm < 1e-3, (c, o, err / norm)
+    assert ties <= 1, ties
 
 
 # ------------------------------------------------------------------------------------------------ a9-a12 (3-D)
