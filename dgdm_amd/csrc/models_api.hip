@@ -256,11 +256,11 @@ struct Split3 {
     }
 };
 
-// 256 -> 256 layer: 4 block pairs x 16 K-steps x [A.h A.m A.l B.h B.m B.l]
+// 256 -> 256 layer (trunk_split.hip stream_layer): 16 K-steps x 4 output-block pairs x [A.h A.m A.l B.h B.m B.l]
 void split_layer_stream(std::vector<uint16_t> &dst, const float *w /*[256][256]*/) {
     const Split3 sp(w, 256, 256);
-    for (int pp = 0; pp < 4; ++pp)
-        for (int ks = 0; ks < 16; ++ks)
+    for (int ks = 0; ks < 16; ++ks)
+        for (int pp = 0; pp < 4; ++pp)
             for (int blk = 2 * pp; blk < 2 * pp + 2; ++blk) sp.emit(dst, blk, ks / 2, ks % 2);
 }
 

@@ -60,7 +60,10 @@ __device__ __forceinline__ void split_all(const f32x16 (&Y)[8], Act3 &X) {
     for (int o = 0; o < 8; ++o) split_block(Y[o], X.v[0][o], X.v[1][o], X.v[2][o]);
 }
 
-constexpr int SRD = 12;      // ring depth in entries: two (pair, K-step) groups ahead
+#ifndef DGDM_SPLIT_RING
+#define DGDM_SPLIT_RING 12
+#endif
+constexpr int SRD = DGDM_SPLIT_RING;      // ring depth in entries: two (pair, K-step) groups ahead
 
 struct SplitRing {
     float4 e[SRD];
@@ -88,34 +91,78 @@ __device__ __forceinline__ void sring_fill(wrsrc_t rs, int voff, int base, Split
         accB = smfma(w[3], xh, accB);              \
     } while (0)
 
-// Y[8] = W X (+ bias): 256 -> 256, 4 block pairs x 16 K-steps x 6 entries at byte offset woff of the stream; ring carried.
-template <bool BIAS>
-__device__ __forceinline__ void split_layer(const wrsrc_t rs, const int voff, const int woff, SplitRing &ring, const float *__restrict__ bias,
-                                            const Act3 &X, f32x16 (&Y)[8], const int h4) {
+// One 256 -> 256 layer, input-streaming form.  The layer's INPUT arrives as the previous layer's float32 accumulators Yp (pre-activation
+// in the forward pass, unmasked gradient in the backward pass); its epilogue - ReLU + sign bits (forward) or the ReLU mask (backward),
+// then the exact three-way bf16 split - is done block by block JUST IN TIME: the K loop runs over the input blocks, all eight output
+// blocks accumulate at once (Y, 128 registers), and while block b's two K-steps (96 MFMAs) run, the eight register pairs of block b+1
+// are converted, one per group of twelve MFMAs, so the VALU work hides in the shadow of the matrix pipe.  Only block 0's conversion
+// is exposed.  Stream order: (K-step, block pair) x [A.h A.m A.l B.h B.m B.l]; 6 entries per twelve MFMAs, ring carried.
+//   FWD : sign bits of Yp's blocks go to smask[slot_in + pair] (the dword layout of relu_mask);  !FWD: they are read from there.
+template <bool FWD, bool BIAS>
+__device__ __forceinline__ void stream_layer(const wrsrc_t rs, const int voff, const int woff, SplitRing &ring, const float *__restrict__ bias,
+                                             const f32x16 (&Yp)[8], f32x16 (&Y)[8], uint32_t (*smask)[256], const int slot_in, const int tid,
+                                             const int h4) {
 #pragma unroll
-    for (int pp = 0; pp < 4; ++pp) {
+    for (int o = 0; o < 8; ++o) {
         if (BIAS) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 a = feat4(bias, 2 * pp, q, h4), b = feat4(bias, 2 * pp + 1, q, h4);
-                Y[2 * pp][4 * q + 0] = a.x; Y[2 * pp][4 * q + 1] = a.y; Y[2 * pp][4 * q + 2] = a.z; Y[2 * pp][4 * q + 3] = a.w;
-                Y[2 * pp + 1][4 * q + 0] = b.x; Y[2 * pp + 1][4 * q + 1] = b.y; Y[2 * pp + 1][4 * q + 2] = b.z; Y[2 * pp + 1][4 * q + 3] = b.w;
+                const float4 a = feat4(bias, o, q, h4);
+                Y[o][4 * q + 0] = a.x; Y[o][4 * q + 1] = a.y; Y[o][4 * q + 2] = a.z; Y[o][4 * q + 3] = a.w;
             }
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { Y[2 * pp][r] = 0.f; Y[2 * pp + 1][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) Y[o][r] = 0.f;
         }
+    }
+    su32x4_t P[2][3][2];                           // [block parity][piece][K-step]: the B operands of the current and the next input block
+    uint32_t mk = FWD ? 0u : smask[slot_in][tid];
+    // one register pair (2d, 2d+1) of input block blk: epilogue + split into P[blk & 1]
+    auto item = [&](const f32x16 &y, const int blk, const int d) {
+        float lo = y[2 * d], hi = y[2 * d + 1];
+        const int sh = 2 * d + 16 * (blk & 1);
+        if (FWD) {
+            mk |= (lo > 0.f ? 1u : 0u) << sh;
+            mk |= (hi > 0.f ? 1u : 0u) << (sh + 1);
+            // one v_max each (fmaxf would first canonicalise its operand: a second v_max per element)
+            asm("v_max_f32 %0, 0, %1" : "=v"(lo) : "v"(lo));
+            asm("v_max_f32 %0, 0, %1" : "=v"(hi) : "v"(hi));
+        } else {
+            lo = ((mk >> sh) & 1u) ? lo : 0.f;
+            hi = ((mk >> (sh + 1)) & 1u) ? hi : 0.f;
+        }
+        uint32_t a, b, c;
+        split_pair(lo, hi, a, b, c);
+        P[blk & 1][0][d / 4][d % 4] = a; P[blk & 1][1][d / 4][d % 4] = b; P[blk & 1][2][d / 4][d % 4] = c;
+    };
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            const int E = (pp * 16 + ks) * 6;
-            float4 w[6];
+    for (int d = 0; d < 8; ++d) item(Yp[0], 0, d);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                w[j] = ring.e[(E + j) % SRD];
-                ring.e[(E + j) % SRD] = wload(rs, voff, woff + (E + j + SRD) * 1024);
+    for (int b = 0; b < 8; ++b) {
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                const int E = (((b * 2 + sx) * 4) + pp) * 6;
+                float4 w[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    w[j] = ring.e[(E + j) % SRD];
+#ifdef DGDM_SPLIT_SAMEW      // experiment: every load hits the same 12 KiB (wrong results; shows what the weight stream's latency costs)
+                    ring.e[(E + j) % SRD] = wload(rs, voff, ((E + j) % SRD) * 1024);
+#else
+                    ring.e[(E + j) % SRD] = wload(rs, voff, woff + (E + j + SRD) * 1024);
+#endif
+                }
+                if (b < 7) {                       // the next input block's pair q, in the shadow of this group's MFMAs
+                    const int q = sx * 4 + pp, nb = b + 1;
+                    if (q == 0 && (nb & 1) == 0) mk = FWD ? 0u : smask[slot_in + nb / 2][tid];
+                    item(Yp[nb], nb, q);
+                    if (FWD && q == 7 && (nb & 1) == 1) smask[slot_in + nb / 2][tid] = mk;
+                }
+                SPLIT_STEP(Y[2 * pp], Y[2 * pp + 1], w, P[b & 1][0][sx], P[b & 1][1][sx], P[b & 1][2][sx]);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            SPLIT_STEP(Y[2 * pp], Y[2 * pp + 1], w, X.v[0][ks / 2][ks % 2], X.v[1][ks / 2][ks % 2], X.v[2][ks / 2][ks % 2]);
-            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -261,21 +308,21 @@ __global__ __launch_bounds__(256, 1) void trunk_split_kernel(const TrunkParams p
         }
         slot = 8;
     }
+    // Y = pre-activations of the layer in front of the 256 -> 256 stack (2-D: layer 1; 3-D: layer 2); its ReLU, sign bits and split
+    // happen inside the first stack layer, and so on down the stack (stream_layer); the last layer's output gets the plain epilogue
+    constexpr int BASE = (KIND == 3) ? 8 : 0;          // mask slots: BASE.. = the layer in front, BASE + 4 + 4 l.. = stack layer l
+    f32x16 Z[8];
+    for (int l = 0; l < p.n_mid; ++l) {
+        stream_layer<true, true>(rsF, voff, woff, ring, p.bf[l], Y, Z, smask, BASE + 4 * l, tid, h4);
+        woff += 384 * 1024;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) Y[o] = Z[o];
+    }
+    slot = BASE + 4 * p.n_mid;
     relu_mask<8>(Y, m);
 #pragma unroll
     for (int i = 0; i < 4; ++i) smask[slot + i][tid] = m[i];
     slot += 4;
-
-    // ---- 256 -> 256 layers
-    for (int l = 0; l < p.n_mid; ++l) {
-        split_all(Y, X);
-        split_layer<true>(rsF, voff, woff, ring, p.bf[l], X, Y, h4);
-        woff += 384 * 1024;
-        relu_mask<8>(Y, m);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) smask[slot + i][tid] = m[i];
-        slot += 4;
-    }
 
     // ---- output layer (256 -> 3) on the VALU, objective gradient (as trunk_kernel)
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
@@ -307,9 +354,6 @@ __global__ __launch_bounds__(256, 1) void trunk_split_kernel(const TrunkParams p
     if (ob.use_rowcoef) g0 = p.rowcoef[(size_t)chain * p.R + r];
     if (!valid) { g0 = 0.f; g1 = 0.f; g2 = 0.f; }
 
-    slot -= 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) m[i] = smask[slot + i][tid];
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
 #pragma unroll
@@ -323,18 +367,17 @@ __global__ __launch_bounds__(256, 1) void trunk_split_kernel(const TrunkParams p
             Y[o][4 * q + 3] = fmaf(g2, w2.w, fmaf(g1, w1.w, g0 * w0.w));
         }
     }
-    apply_mask<8>(Y, m);
 
-    // ---- backward through the 256 -> 256 layers
+    // ---- backward through the 256 -> 256 layers: layer l masks its incoming gradient with the sign bits of stack layer l's output
     for (int l = p.n_mid - 1; l >= 0; --l) {
-        split_all(Y, X);
-        split_layer<false>(rsB, voff, woff, ring, nullptr, X, Y, h4);
+        stream_layer<false, false>(rsB, voff, woff, ring, nullptr, Y, Z, smask, BASE + 4 + 4 * l, tid, h4);
         woff += 384 * 1024;
-        slot -= 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) m[i] = smask[slot + i][tid];
-        apply_mask<8>(Y, m);
+        for (int o = 0; o < 8; ++o) Y[o] = Z[o];
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m[i] = smask[BASE + i][tid];
+    apply_mask<8>(Y, m);
 
     float *dst = p.partial + (size_t)tile * W1;
     if (KIND == 2) {
