@@ -40,6 +40,7 @@ from dgdm_amd.dist import gather_pairs                     # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # same guide: v_mfma_f32_32x32x16_bf16, dense (not the 2:1-sparsity figure)
+SPLIT_TERMS = 6                   # csrc/trunk_split.hip: bf16 MFMA products issued per float32 product (operands split exactly in three)
 DEFAULT_PAIRS = {"3d": 32, "2d": 4, "3d_ensemble": 8}
 STREAM_SEED = 1234
 
@@ -52,8 +53,10 @@ def parse():
     p.add_argument("--workload", choices=["3d", "2d", "3d_ensemble"], default="3d")
     p.add_argument("--pairs", type=int, default=0, help="(object x objective) pairs per GPU per step (default 32 for 3d, 4 for 2d; "
                                                         "3d_ensemble: chains per GPU per step, default 8, each averaging 4 objects' gradients)")
-    p.add_argument("--contraction", choices=["f32", "bf16"], default="f32",
-                   help="arithmetic of the dynamics-trunk contractions: f32 (the parity path, default) or bf16 operands with f32 accumulation")
+    p.add_argument("--contraction", choices=["f32", "f32_mfma", "bf16"], default="f32",
+                   help="arithmetic of the dynamics-trunk contractions: f32 (the parity path, default: float32 operands split exactly into three bf16 "
+                        "pieces, six bf16 MFMAs per product, float32 accumulation), f32_mfma (the k-ordered float32 MFMA chain) or bf16 (operands "
+                        "ROUNDED to bf16, float32 accumulation)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true", help="skip the secondary workload summary")
     p.add_argument("--train-only", action="store_true", help="print only the Trainer.step leg of the secondary summary (1 GPU)")
@@ -107,7 +110,7 @@ class Workload:
         else:
             self.dyn_sd = synth.synth_state_dict(synth.dyn2d_spec(self.L, 2 * self.N), 22)
             self.dyn = engine.Dynamics(2, self.dyn_sd, self.L, 2 * self.N)
-        self.net = engine.Unet1d(self.unet_sd, contraction_dtype=contraction)
+        self.net = engine.Unet1d(self.unet_sd, contraction_dtype="bf16" if contraction == "bf16" else "f32")
         nch = pairs * self.n_obj                           # gradient chains (= distinct objects) per launch
         self.guid = engine.Guidance(self.dyn, self.B, self.G, self.P, (-1.0, 1.0), nch, self.T, self.N, self.sub, max_objects=nch, contraction_dtype=contraction)
         self.sched = DDIMScheduler(num_train_timesteps=self.T)
@@ -209,11 +212,11 @@ def timed_loop(wl, steps, warmup, dist):
 # ---------------------------------------------------------------------------------------------------------------- roofline
 def pmc_traffic(workload, contraction, kernel):
     """HBM bytes per launch of the dominant kernel as RECORDED by this round's rocprofv3 PMC passes of this same command
-    (scripts/profile_round.sh -> profiles/r02_*_pmc_hbm.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, counter unit KB).
+    (scripts/profile_round.sh -> profiles/r03_*_pmc_hbm.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, counter unit KB).
     FETCH_SIZE is the raw counter: on gfx950 it can under-count wide coalesced reads by 2x (MI355X_MICROARCH.md §HBM), so the
     true read traffic lies between 1x and 2x of `fetch_bytes_raw`.  None when no recording exists."""
     tag = workload + ("_bf16" if contraction == "bf16" else "")
-    f = os.path.join(ROOT, "profiles", f"r02_{tag}_pmc_hbm.json")
+    f = os.path.join(ROOT, "profiles", f"r03_{tag}_pmc_hbm.json")
     if not os.path.exists(f):
         return None
     d = json.load(open(f))
@@ -240,17 +243,27 @@ def stage_profile(wl, secs_per_step, contraction):
     n, ms, flops = st["trunk"]
     if not n:
         return None, None
-    peak = BF16_MFMA_PEAK_TFLOPS if contraction == "bf16" else F32_MFMA_PEAK_TFLOPS
-    kname = "trunk_bf16_kernel" if contraction == "bf16" else "trunk_kernel"
-    ach = flops / (ms * 1e-3) / 1e12
+    # The trunk's arithmetic per mode.  'f32' (default): float32 contractions carried by the bf16 matrix
+    # pipe - SIX bf16 MFMA products are issued per algorithmic float32 product - so the kernel is priced against the bf16 dense peak
+    # with the ISSUED FLOPs (6 x algorithmic); the algorithmic float32 rate and what that is against the float32-MFMA peak (which the
+    # old k-ordered chain was bound by) are reported beside it.  'f32_mfma': that chain.  'bf16': operands rounded to bf16.
+    kname = {"bf16": "trunk_bf16_kernel", "f32_mfma": "trunk_kernel"}.get(contraction, "trunk_split_kernel")
+    issued = SPLIT_TERMS if contraction == "f32" else 1
+    peak = F32_MFMA_PEAK_TFLOPS if contraction == "f32_mfma" else BF16_MFMA_PEAK_TFLOPS
+    alg = flops / (ms * 1e-3) / 1e12
+    ach = alg * issued
     need = st["trunk"][2] + st["unet"][2]                  # necessary FLOPs of one step: trunk (real rows) + eps-net (useful MACs)
     roof = {"bound": "mfma", "kernel": kname + " (fused dynamics trunk fwd+bwd)", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
             "frac": ach / peak, "traffic": pmc_traffic(wl.kind, contraction, kname), "launches": n, "avg_launch_ms": ms / n,
-            "algorithmic_flops_per_launch": flops / n, "share_of_step": (ms * 1e-3) / secs_per_step,
-            "step_frac": need / secs_per_step / 1e12 / peak,
+            "algorithmic_flops_per_launch": flops / n, "algorithmic_tflops": alg, "issued_flops_per_algorithmic_flop": issued,
+            "algorithmic_vs_f32_mfma_peak": alg / F32_MFMA_PEAK_TFLOPS,
+            "note": ("float32 contractions as six bf16 MFMA products on exactly split operands: achieved = ISSUED bf16 TFLOP/s (6 x algorithmic) "
+                     "against the bf16 dense peak" if contraction == "f32" else "algorithmic FLOPs / time against the dense peak of the MFMA dtype"),
+            "share_of_step": (ms * 1e-3) / secs_per_step,
+            "step_frac": (st["trunk"][2] * issued + st["unet"][2]) / secs_per_step / 1e12 / peak,
             "step_necessary_tflop": need / 1e12,
-            "step_frac_note": "necessary FLOPs of one step (trunk on the real rows + eps-net useful MACs; table-build FLOPs not counted) / "
-                              "wall time of the step / peak of the trunk's MFMA dtype"}
+            "step_frac_note": "issued FLOPs of one step (trunk on the real rows x issued-per-algorithmic + eps-net useful MACs; table-build FLOPs not "
+                              "counted) / wall time of the step / peak of the trunk's matrix-pipe dtype"}
     shares = {k: {"regions": v[0], "ms_per_step": v[1], "share_of_profiled_step": v[1] / wall_ms} for k, v in st.items() if v[0]}
     shares["_profiled_step_wall_ms"] = wall_ms
     return roof, shares
@@ -557,7 +570,7 @@ def main():
         torch.cuda.empty_cache()
         # the other BASELINE configurations (not the headline: `value` above is what the driver reads)
         extras = [config0(dev), sweep_leg(dev), train_leg(dev, not a.no_cpu_baseline)]
-        for kind, contraction in ((other, "f32"), ("3d", "bf16"), ("2d", "bf16"), ("3d_ensemble", "bf16")):
+        for kind, contraction in ((other, "f32"), ("3d", "f32_mfma"), ("3d", "bf16"), ("2d", "bf16"), ("3d_ensemble", "bf16")):
             w2 = Workload(kind, DEFAULT_PAIRS[kind], dev, rank, world, contraction)
             ns = 4
             s2, _, d2 = timed_loop(w2, ns, 1, None)
@@ -566,7 +579,7 @@ def main():
             r2, sh2 = stage_profile(w2, s2 / ns, contraction)
             if r2:
                 e["roofline"], e["stage_share"] = r2, sh2
-            if contraction == "f32" and not a.no_cpu_baseline:
+            if contraction == "f32" and kind == other and not a.no_cpu_baseline:
                 e["cpu_baseline"] = cpu_baseline(w2)
             extras.append(e)
             del w2
