@@ -230,9 +230,14 @@ __device__ __forceinline__ uint32_t relu_bits(f32x16 &x) {
     return bits;
 }
 
+// g where bit r of bits is set, else +0 (two VALU: a sign-extended one-bit field as the AND mask)
+__device__ __forceinline__ float apply_bit(float g, uint32_t bits, int r) {
+    return __builtin_bit_cast(float, __builtin_bit_cast(int, g) & __builtin_amdgcn_sbfe((int)bits, r, 1));
+}
+
 __device__ __forceinline__ void apply_bits(f32x16 &g, uint32_t bits) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) g[r] = ((bits >> r) & 1u) ? g[r] : 0.f;
+    for (int r = 0; r < 16; ++r) g[r] = apply_bit(g[r], bits, r);
 }
 
 template <int NB>
@@ -250,13 +255,20 @@ __device__ __forceinline__ void apply_mask(f32x16 (&g)[NB], const uint32_t (&m)[
     }
 }
 
-// Sum over the 32 rows of the tile: afterwards every lane of a half-wave holds sum_n x[.][n].
+// Sum over the 32 rows of the tile (lanes 0..31 and, separately, 32..63), on the VALU's DPP paths - no LDS round trips.  The adds pair up
+// exactly as in an xor butterfly (1, 2, 4, 8, 16).  The total is valid on the UPPER 16 lanes of each half-wave only (n >= 16):
+// store from lane n == ROWS_SUM_LANE.
+constexpr int ROWS_SUM_LANE = 16;
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float rows_sum(float v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
-    v += __shfl_xor(v, 16);
+    v += dpp_f32<0xb1, 0xf>(v);        // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4e, 0xf>(v);        // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141, 0xf>(v);       // row_half_mirror: the other quad of the 8
+    v += dpp_f32<0x140, 0xf>(v);       // row_mirror: the other 8 of the 16
+    v += dpp_f32<0x142, 0xa>(v);       // row_bcast15 into rows 1 and 3: the other 16 of the 32
     return v;
 }
 

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256, 1) void trunk_kernel(const TrunkParams p) {
                     float4 v;
                     v.x = rows_sum(cur[o][4 * q + 0]); v.y = rows_sum(cur[o][4 * q + 1]);
                     v.z = rows_sum(cur[o][4 * q + 2]); v.w = rows_sum(cur[o][4 * q + 3]);
-                    if (n == 0) *reinterpret_cast<float4 *>(dst + 32 * o + 8 * q + h4) = v;
+                    if (n == ROWS_SUM_LANE) *reinterpret_cast<float4 *>(dst + 32 * o + 8 * q + h4) = v;
                 }
             }
         } else {
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256, 1) void trunk_kernel(const TrunkParams p) {
                         float4 v;
                         v.x = rows_sum(g[4 * q + 0]); v.y = rows_sum(g[4 * q + 1]);
                         v.z = rows_sum(g[4 * q + 2]); v.w = rows_sum(g[4 * q + 3]);
-                        if (n == 0) *reinterpret_cast<float4 *>(dst + 32 * kb + 8 * q + h4) = v;
+                        if (n == ROWS_SUM_LANE) *reinterpret_cast<float4 *>(dst + 32 * kb + 8 * q + h4) = v;
                     }
                 }
             }

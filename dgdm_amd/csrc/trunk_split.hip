@@ -168,35 +168,48 @@ __device__ __forceinline__ void stream_layer(const wrsrc_t rs, const int voff, c
 }
 
 // one 32-feature output block from a 256-feature input on two alternating accumulators (16 K-steps x 3 entries [h m l]): z = za + zb.
-// xl_lds: when set, the l pieces of the input are read from there ([K-step][lane], this wave's copy) instead of X.v[2] - the 3-D forward
-// front parks them in LDS, which takes 64 registers out of its live set (it otherwise spills)
-__device__ __forceinline__ f32x16 split_block_out(const wrsrc_t rs, const int voff, const int woff, SplitRing &ring, const Act3 &X,
-                                                  const lds_su32x4_t *xl_lds = nullptr) {
-    f32x16 za, zb;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { za[r] = 0.f; zb[r] = 0.f; }
+// za, zb come in holding whatever the block starts from (the forward front hands over its two table terms, loaded a phase ahead: no
+// exposed load, no add).  XL_LDS: the l pieces of the input are read from xl_lds ([K-step][lane], this wave's copy) instead of X.v[2] -
+// the 3-D forward front parks them in LDS, which takes 64 registers out of its live set; the term that needs them is the LAST of its
+// K-step, so the read has five MFMAs to land.  side(ks): VALU work of the caller's (the previous block's epilogue), one slice per K-step,
+// placed in the shadow of that step's MFMAs.
+template <bool XL_LDS, class Side>
+__device__ __forceinline__ f32x16 split_block_out(const wrsrc_t rs, const int voff, const int woff, SplitRing &ring, const Act3 &X, f32x16 za,
+                                                  f32x16 zb, const lds_su32x4_t *xl_lds, Side &&side) {
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
         const int E = ks * 3;
         float4 w[3];
+        su32x4_t xl;
+        if (XL_LDS) xl = xl_lds[ks * 64];
+        else xl = X.v[2][ks / 2][ks % 2];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             w[j] = ring.e[(E + j) % SRD];
             ring.e[(E + j) % SRD] = wload(rs, voff, woff + (E + j + SRD) * 1024);
         }
-        const su32x4_t xh = X.v[0][ks / 2][ks % 2], xm = X.v[1][ks / 2][ks % 2], xl = xl_lds ? xl_lds[ks * 64] : X.v[2][ks / 2][ks % 2];
+        const su32x4_t xh = X.v[0][ks / 2][ks % 2], xm = X.v[1][ks / 2][ks % 2];
+        side(ks);
         za = smfma(w[2], xh, za);
+        zb = smfma(w[1], xm, zb);
+        za = smfma(w[1], xh, za);
+        zb = smfma(w[0], xm, zb);
+        za = smfma(w[0], xh, za);
         zb = smfma(w[0], xl, zb);
-        za = smfma(w[1], xm, za);
-        zb = smfma(w[1], xh, zb);
-        za = smfma(w[0], xm, za);
-        zb = smfma(w[0], xh, zb);
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) za[r] += zb[r];
     return za;
 }
+
+#ifdef DGDM_SPLIT_STAMPS
+// experiment hook: cycle stamps of one wave at the phase boundaries (printed by trunk_split_launch)
+__device__ long long g_split_stamps[32];
+#define STAMP(i) do { if (blockIdx.x == gridDim.x / 2 && tid == 0) g_split_stamps[i] = clock64(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
 template <int KIND>
 __global__ __launch_bounds__(256, 1) void trunk_split_kernel(const TrunkParams p) {
@@ -230,6 +243,7 @@ __global__ __launch_bounds__(256, 1) void trunk_split_kernel(const TrunkParams p
     f32x16 Y[8];
     uint32_t m[4];
     int slot = 0;
+    STAMP(0);
     const wrsrc_t rsF = weight_rsrc(p.Wfwd, p.fwd_bytes);
     SplitRing ring;
     int woff = 0;
@@ -270,53 +284,90 @@ __global__ __launch_bounds__(256, 1) void trunk_split_kernel(const TrunkParams p
                 Y[o][4 * q + 0] = b4.x; Y[o][4 * q + 1] = b4.y; Y[o][4 * q + 2] = b4.z; Y[o][4 * q + 3] = b4.w;
             }
         }
-        for (int blk = 0; blk < 16; blk += 2) {
-            uint32_t bits2 = 0;
+        // Software pipeline over the 16 blocks of layer 1: while block kb + 1's 96 layer-1 MFMAs run, block kb's epilogue (ReLU, sign
+        // bits, three-way split: one register pair every other K-step) runs in their shadow; then block kb's 96 layer-2 MFMAs, during
+        // which the two table terms of block kb + 2 (finger part, pose-cell part) are loaded straight into the layer-1 accumulators -
+        // no exposed load, no add.  Stream order: L1(0) | L1(kb + 1), L2(kb) for kb = 0..14 | L2(15).
+        f32x16 za, zb;
+        auto table_terms = [&](int kb) __attribute__((always_inline)) {
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int kb = blk + e;
-                f32x16 z = split_block_out(rsF, voff, woff, ring, X, xl);
-                woff += 48 * 1024;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float4 v = *reinterpret_cast<const float4 *>(arow + 32 * kb + 8 * q + h4);
-                    const float4 w = ptile[(kb * 4 + q) * 64];
-                    z[4 * q + 0] += v.x + w.x; z[4 * q + 1] += v.y + w.y; z[4 * q + 2] += v.z + w.z; z[4 * q + 3] += v.w + w.w;
-                }
-                bits2 |= relu_bits(z) << (16 * e);
-                su32x4_t ah[2], am[2], al[2];
-                split_block(z, ah, am, al);
-                // layer 2: Y[op] += W2'[op][kb] a1[kb], two output blocks at a time, both K-steps of the block
-#pragma unroll
-                for (int pp = 0; pp < 4; ++pp) {
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const int E = (pp * 2 + s) * 6;
-                        float4 w[6];
-#pragma unroll
-                        for (int j = 0; j < 6; ++j) {
-                            w[j] = ring.e[(E + j) % SRD];
-                            ring.e[(E + j) % SRD] = wload(rsF, voff, woff + (E + j + SRD) * 1024);
-                        }
-                        SPLIT_STEP(Y[2 * pp], Y[2 * pp + 1], w, ah[s], am[s], al[s]);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                woff += 48 * 1024;
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4 *>(arow + 32 * kb + 8 * q + h4);
+                const float4 w = ptile[(kb * 4 + q) * 64];
+                za[4 * q + 0] = v.x; za[4 * q + 1] = v.y; za[4 * q + 2] = v.z; za[4 * q + 3] = v.w;
+                zb[4 * q + 0] = w.x; zb[4 * q + 1] = w.y; zb[4 * q + 2] = w.z; zb[4 * q + 3] = w.w;
             }
+        };
+        table_terms(0);
+        f32x16 z = split_block_out<true>(rsF, voff, woff, ring, X, za, zb, xl, [](int) __attribute__((always_inline)) {});
+        woff += 48 * 1024;
+        table_terms(1);
+        uint32_t bits2 = 0;
+        su32x4_t ah[2], am[2], al[2];
+        auto epi_pair = [&](const int d, const int e) __attribute__((always_inline)) {
+            float lo = z[2 * d], hi = z[2 * d + 1];
+            const int sh = 2 * d + 16 * e;
+            bits2 |= (lo > 0.f ? 1u : 0u) << sh;
+            bits2 |= (hi > 0.f ? 1u : 0u) << (sh + 1);
+            asm("v_max_f32 %0, 0, %1" : "=v"(lo) : "v"(lo));
+            asm("v_max_f32 %0, 0, %1" : "=v"(hi) : "v"(hi));
+            uint32_t a, b, c;
+            split_pair(lo, hi, a, b, c);
+            ah[d / 4][d % 4] = a; am[d / 4][d % 4] = b; al[d / 4][d % 4] = c;
+        };
+        auto layer2 = [&]() __attribute__((always_inline)) {
+            // layer 2: Y[op] += W2'[op][kb] a1[kb], two output blocks at a time, both K-steps of the block
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+#pragma unroll
+                for (int sx = 0; sx < 2; ++sx) {
+                    const int E = (pp * 2 + sx) * 6;
+                    float4 w[6];
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        w[j] = ring.e[(E + j) % SRD];
+                        ring.e[(E + j) % SRD] = wload(rsF, voff, woff + (E + j + SRD) * 1024);
+                    }
+                    SPLIT_STEP(Y[2 * pp], Y[2 * pp + 1], w, ah[sx], am[sx], al[sx]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            woff += 48 * 1024;
+        };
+        auto piped = [&](const int kb, const int e) __attribute__((always_inline)) {          // epilogue(kb) under L1(kb + 1), then L2(kb)
+            const f32x16 zn = split_block_out<true>(rsF, voff, woff, ring, X, za, zb, xl, [&](const int ks) __attribute__((always_inline)) {
+                if (ks % 2 == 0) epi_pair(ks / 2, e);
+            });
+            woff += 48 * 1024;
+            table_terms((kb + 2) & 15);
+            layer2();
+            z = zn;
+        };
+        for (int blk = 0; blk < 14; blk += 2) {
+            bits2 = 0;
+            piped(blk, 0);
+            piped(blk + 1, 1);
             smask[blk / 2][tid] = bits2;
         }
+        bits2 = 0;
+        piped(14, 0);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) epi_pair(d, 1);
+        layer2();
+        smask[7][tid] = bits2;
         slot = 8;
     }
     // Y = pre-activations of the layer in front of the 256 -> 256 stack (2-D: layer 1; 3-D: layer 2); its ReLU, sign bits and split
     // happen inside the first stack layer, and so on down the stack (stream_layer); the last layer's output gets the plain epilogue
     constexpr int BASE = (KIND == 3) ? 8 : 0;          // mask slots: BASE.. = the layer in front, BASE + 4 + 4 l.. = stack layer l
     f32x16 Z[8];
+    STAMP(1);
     for (int l = 0; l < p.n_mid; ++l) {
         stream_layer<true, true>(rsF, voff, woff, ring, p.bf[l], Y, Z, smask, BASE + 4 * l, tid, h4);
         woff += 384 * 1024;
 #pragma unroll
         for (int o = 0; o < 8; ++o) Y[o] = Z[o];
+        STAMP(2 + l);
     }
     slot = BASE + 4 * p.n_mid;
     relu_mask<8>(Y, m);
@@ -369,11 +420,13 @@ __global__ __launch_bounds__(256, 1) void trunk_split_kernel(const TrunkParams p
     }
 
     // ---- backward through the 256 -> 256 layers: layer l masks its incoming gradient with the sign bits of stack layer l's output
+    STAMP(10);
     for (int l = p.n_mid - 1; l >= 0; --l) {
         stream_layer<false, false>(rsB, voff, woff, ring, nullptr, Y, Z, smask, BASE + 4 + 4 * l, tid, h4);
         woff += 384 * 1024;
 #pragma unroll
         for (int o = 0; o < 8; ++o) Y[o] = Z[o];
+        STAMP(11 + (p.n_mid - 1 - l));
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) m[i] = smask[BASE + i][tid];
@@ -389,30 +442,40 @@ __global__ __launch_bounds__(256, 1) void trunk_split_kernel(const TrunkParams p
                 float4 v;
                 v.x = rows_sum(Y[o][4 * q + 0]); v.y = rows_sum(Y[o][4 * q + 1]);
                 v.z = rows_sum(Y[o][4 * q + 2]); v.w = rows_sum(Y[o][4 * q + 3]);
-                if (n == 0) *reinterpret_cast<float4 *>(dst + 32 * o + 8 * q + h4) = v;
+                if (n == ROWS_SUM_LANE) *reinterpret_cast<float4 *>(dst + 32 * o + 8 * q + h4) = v;
             }
         }
     } else {
-        // 3-D: one more layer back (256 -> 512), block by block, straight into the fold
+        // 3-D: one more layer back (256 -> 512), block by block, straight into the fold - block kb - 1's mask and fold (DPP adds) run in
+        // the shadow of block kb's MFMAs, one feature per K-step
         split_all(Y, X);
-        for (int blk = 0; blk < 16; blk += 2) {
-            const uint32_t bits2 = smask[blk / 2][tid];
+        f32x16 zero;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int kb = blk + e;
-                f32x16 g = split_block_out(rsB, voff, woff, ring, X);
-                woff += 48 * 1024;
-                apply_bits(g, (bits2 >> (16 * e)) & 0xffffu);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float4 v;
-                    v.x = rows_sum(g[4 * q + 0]); v.y = rows_sum(g[4 * q + 1]);
-                    v.z = rows_sum(g[4 * q + 2]); v.w = rows_sum(g[4 * q + 3]);
-                    if (n == 0) *reinterpret_cast<float4 *>(dst + 32 * kb + 8 * q + h4) = v;
-                }
+        for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+        f32x16 g = split_block_out<false>(rsB, voff, woff, ring, X, zero, zero, nullptr, [](int) __attribute__((always_inline)) {});
+        woff += 48 * 1024;
+        float4 acc;
+        auto fold_one = [&](const int r, const int kb, const uint32_t bits) __attribute__((always_inline)) {
+            const float v = rows_sum(apply_bit(g[r], bits, r));
+            if (r % 4 == 0) acc.x = v;
+            else if (r % 4 == 1) acc.y = v;
+            else if (r % 4 == 2) acc.z = v;
+            else {
+                acc.w = v;
+                if (n == ROWS_SUM_LANE) *reinterpret_cast<float4 *>(dst + 32 * kb + 8 * (r / 4) + h4) = acc;
             }
+        };
+        for (int kb = 1; kb < 16; ++kb) {
+            const uint32_t bits = smask[(kb - 1) / 2][tid] >> (16 * ((kb - 1) & 1));
+            const f32x16 gn = split_block_out<false>(rsB, voff, woff, ring, X, zero, zero, nullptr, [&](const int ks) __attribute__((always_inline)) { fold_one(ks, kb - 1, bits); });
+            woff += 48 * 1024;
+            g = gn;
         }
+        const uint32_t bits = smask[7][tid] >> 16;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fold_one(r, 15, bits);
     }
+    STAMP(20);
 }
 
 int trunk_split_launch(int kind, const TrunkParams &p, hipStream_t s) {
@@ -429,6 +492,17 @@ int trunk_split_launch(int kind, const TrunkParams &p, hipStream_t s) {
     else hipLaunchKernelGGL((trunk_split_kernel<3>), dim3(grid), dim3(256), 0, s, p);
     DGDM_HIP_CHECK(hipGetLastError());
     prof_end(s, DGDM_STAGE_TRUNK, rows * per_row);
+#ifdef DGDM_SPLIT_STAMPS
+    {
+        long long st[32];
+        hipStreamSynchronize(s);
+        hipMemcpyFromSymbol(st, HIP_SYMBOL(g_split_stamps), sizeof(st));
+        fprintf(stderr, "split stamps kind %d:", kind);
+        long long prev = st[0];
+        for (int i = 1; i <= 20; ++i) if (st[i]) { fprintf(stderr, " [%d]%lld", i, st[i] - prev); prev = st[i]; }
+        fprintf(stderr, " total %lld\n", st[20] - st[0]);
+    }
+#endif
     return DGDM_OK;
 }
 
