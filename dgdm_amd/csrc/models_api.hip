@@ -399,17 +399,11 @@ extern "C" int dgdm_dynamics_create(DgdmDynamics **out, int kind, const DgdmTens
             if ((rc = fold_linear(sd, "linears.3", "linears.4", W, W1, &l2))) return rc;
             const std::vector<float> w1o3 = cols(l1.w, W1, IN1, 0, W);
             const Split3 s1(w1o3.data(), W1, W), s2(l2.w.data(), W, W1);
-            // consumption order of the software-pipelined front: L1(0) | L1(kb + 1), L2(kb) for kb = 0..14 | L2(15)
-            auto layer1 = [&](int kb) { for (int ks = 0; ks < 16; ++ks) s1.emit(fs, kb, ks / 2, ks % 2); };   // block kb: 16 K-steps x [h m l]
-            auto layer2 = [&](int kb) {                                                                      // layer 2, input block kb
-                for (int pp = 0; pp < 4; ++pp)
+            for (int kb = 0; kb < 16; ++kb) {
+                for (int ks = 0; ks < 16; ++ks) s1.emit(fs, kb, ks / 2, ks % 2);                    // layer-1 block kb: 16 K-steps x [h m l]
+                for (int pp = 0; pp < 4; ++pp)                                                      // layer 2, input block kb
                     for (int sx = 0; sx < 2; ++sx)
                         for (int blk = 2 * pp; blk < 2 * pp + 2; ++blk) s2.emit(fs, blk, kb, sx);
-            };
-            layer1(0);
-            for (int kb = 0; kb < 16; ++kb) {
-                if (kb + 1 < 16) layer1(kb + 1);
-                layer2(kb);
             }
         }
         std::vector<std::vector<uint16_t>> back;

@@ -168,8 +168,7 @@ __device__ __forceinline__ void stream_layer(const wrsrc_t rs, const int voff, c
 }
 
 // one 32-feature output block from a 256-feature input on two alternating accumulators (16 K-steps x 3 entries [h m l]): z = za + zb.
-// za, zb come in holding whatever the block starts from (the forward front hands over its two table terms, loaded a phase ahead: no
-// exposed load, no add).  XL_LDS: the l pieces of the input are read from xl_lds ([K-step][lane], this wave's copy) instead of X.v[2] -
+// XL_LDS: the l pieces of the input are read from xl_lds ([K-step][lane], this wave's copy) instead of X.v[2] -
 // the 3-D forward front parks them in LDS, which takes 64 registers out of its live set; the term that needs them is the LAST of its
 // K-step, so the read has five MFMAs to land.  side(ks): VALU work of the caller's (the previous block's epilogue), one slice per K-step,
 // placed in the shadow of that step's MFMAs.
@@ -284,77 +283,66 @@ __global__ __launch_bounds__(256, 1) void trunk_split_kernel(const TrunkParams p
                 Y[o][4 * q + 0] = b4.x; Y[o][4 * q + 1] = b4.y; Y[o][4 * q + 2] = b4.z; Y[o][4 * q + 3] = b4.w;
             }
         }
-        // Software pipeline over the 16 blocks of layer 1: while block kb + 1's 96 layer-1 MFMAs run, block kb's epilogue (ReLU, sign
-        // bits, three-way split: one register pair every other K-step) runs in their shadow; then block kb's 96 layer-2 MFMAs, during
-        // which the two table terms of block kb + 2 (finger part, pose-cell part) are loaded straight into the layer-1 accumulators -
-        // no exposed load, no add.  Stream order: L1(0) | L1(kb + 1), L2(kb) for kb = 0..14 | L2(15).
-        f32x16 za, zb;
+        // Layers 1-2 block by block: 96 layer-1 MFMAs make one 32-feature block (accumulated from ZERO: the two table terms are added to
+        // the finished sum, one rounding - accumulating on top of them would round every MFMA's contribution at the tables' magnitude,
+        // 7x the error in the pre-activations and measurably more ReLU ties), epilogue (ReLU, sign bits, three-way split), 96 layer-2
+        // MFMAs.  The table terms of block kb + 1 (finger part + pose-cell part) are loaded and added to each other while block kb's
+        // layer-2 MFMAs run, so that neither a load nor its latency sits between the two MFMA phases.
+        f32x16 zero, tt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zero[r] = 0.f;
         auto table_terms = [&](int kb) __attribute__((always_inline)) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 v = *reinterpret_cast<const float4 *>(arow + 32 * kb + 8 * q + h4);
                 const float4 w = ptile[(kb * 4 + q) * 64];
-                za[4 * q + 0] = v.x; za[4 * q + 1] = v.y; za[4 * q + 2] = v.z; za[4 * q + 3] = v.w;
-                zb[4 * q + 0] = w.x; zb[4 * q + 1] = w.y; zb[4 * q + 2] = w.z; zb[4 * q + 3] = w.w;
+                tt[4 * q + 0] = v.x + w.x; tt[4 * q + 1] = v.y + w.y; tt[4 * q + 2] = v.z + w.z; tt[4 * q + 3] = v.w + w.w;
             }
         };
         table_terms(0);
-        f32x16 z = split_block_out<true>(rsF, voff, woff, ring, X, za, zb, xl, [](int) __attribute__((always_inline)) {});
-        woff += 48 * 1024;
-        table_terms(1);
-        uint32_t bits2 = 0;
-        su32x4_t ah[2], am[2], al[2];
-        auto epi_pair = [&](const int d, const int e) __attribute__((always_inline)) {
-            float lo = z[2 * d], hi = z[2 * d + 1];
-            const int sh = 2 * d + 16 * e;
-            bits2 |= (lo > 0.f ? 1u : 0u) << sh;
-            bits2 |= (hi > 0.f ? 1u : 0u) << (sh + 1);
-            asm("v_max_f32 %0, 0, %1" : "=v"(lo) : "v"(lo));
-            asm("v_max_f32 %0, 0, %1" : "=v"(hi) : "v"(hi));
-            uint32_t a, b, c;
-            split_pair(lo, hi, a, b, c);
-            ah[d / 4][d % 4] = a; am[d / 4][d % 4] = b; al[d / 4][d % 4] = c;
-        };
-        auto layer2 = [&]() __attribute__((always_inline)) {
-            // layer 2: Y[op] += W2'[op][kb] a1[kb], two output blocks at a time, both K-steps of the block
+        for (int blk = 0; blk < 16; blk += 2) {
+            uint32_t bits2 = 0;
 #pragma unroll
-            for (int pp = 0; pp < 4; ++pp) {
+            for (int e = 0; e < 2; ++e) {
+                const int kb = blk + e;
+                f32x16 z = split_block_out<true>(rsF, voff, woff, ring, X, zero, zero, xl, [](int) __attribute__((always_inline)) {});
+                woff += 48 * 1024;
 #pragma unroll
-                for (int sx = 0; sx < 2; ++sx) {
-                    const int E = (pp * 2 + sx) * 6;
-                    float4 w[6];
+                for (int r = 0; r < 16; ++r) z[r] += tt[r];
+                su32x4_t ah[2], am[2], al[2];
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) {
-                        w[j] = ring.e[(E + j) % SRD];
-                        ring.e[(E + j) % SRD] = wload(rsF, voff, woff + (E + j + SRD) * 1024);
-                    }
-                    SPLIT_STEP(Y[2 * pp], Y[2 * pp + 1], w, ah[sx], am[sx], al[sx]);
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int d = 0; d < 8; ++d) {
+                    float lo = z[2 * d], hi = z[2 * d + 1];
+                    const int sh = 2 * d + 16 * e;
+                    bits2 |= (lo > 0.f ? 1u : 0u) << sh;
+                    bits2 |= (hi > 0.f ? 1u : 0u) << (sh + 1);
+                    asm("v_max_f32 %0, 0, %1" : "=v"(lo) : "v"(lo));
+                    asm("v_max_f32 %0, 0, %1" : "=v"(hi) : "v"(hi));
+                    uint32_t a, b, c;
+                    split_pair(lo, hi, a, b, c);
+                    ah[d / 4][d % 4] = a; am[d / 4][d % 4] = b; al[d / 4][d % 4] = c;
                 }
+                table_terms((kb + 1) & 15);
+                // layer 2: Y[op] += W2'[op][kb] a1[kb], two output blocks at a time, both K-steps of the block
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) {
+#pragma unroll
+                    for (int sx = 0; sx < 2; ++sx) {
+                        const int E = (pp * 2 + sx) * 6;
+                        float4 w[6];
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) {
+                            w[j] = ring.e[(E + j) % SRD];
+                            ring.e[(E + j) % SRD] = wload(rsF, voff, woff + (E + j + SRD) * 1024);
+                        }
+                        SPLIT_STEP(Y[2 * pp], Y[2 * pp + 1], w, ah[sx], am[sx], al[sx]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                woff += 48 * 1024;
             }
-            woff += 48 * 1024;
-        };
-        auto piped = [&](const int kb, const int e) __attribute__((always_inline)) {          // epilogue(kb) under L1(kb + 1), then L2(kb)
-            const f32x16 zn = split_block_out<true>(rsF, voff, woff, ring, X, za, zb, xl, [&](const int ks) __attribute__((always_inline)) {
-                if (ks % 2 == 0) epi_pair(ks / 2, e);
-            });
-            woff += 48 * 1024;
-            table_terms((kb + 2) & 15);
-            layer2();
-            z = zn;
-        };
-        for (int blk = 0; blk < 14; blk += 2) {
-            bits2 = 0;
-            piped(blk, 0);
-            piped(blk + 1, 1);
             smask[blk / 2][tid] = bits2;
         }
-        bits2 = 0;
-        piped(14, 0);
-#pragma unroll
-        for (int d = 0; d < 8; ++d) epi_pair(d, 1);
-        layer2();
-        smask[7][tid] = bits2;
         slot = 8;
     }
     // Y = pre-activations of the layer in front of the 256 -> 256 stack (2-D: layer 1; 3-D: layer 2); its ReLU, sign bits and split

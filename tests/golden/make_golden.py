@@ -653,6 +653,57 @@ def g9_3d_eps(parts=("rotate", "convergence", "multi", "convergence_b", "shift_l
                             eps_floor=np.float64(max(_spread(e, ref["guided"]) for e in ends)))
 
 
+def g9_3d_arith(parts=("ccw_down", "convergence_b", "shift_left_b", "rotate", "convergence", "multi")):
+    """How far does the REFERENCE's own end point move when the arithmetic of its classifier trunk changes at rounding level?  Each
+    g9_3d chain is re-run on the recorded FPS draws with the trunk (``linears`` and ``output`` of ProfileForward3DModel: every
+    Linear + BatchNorm + ReLU after the concatenation) evaluated in float64 on the same float32 inputs and cast back - PointNet++, the
+    encoders, the eps-net and the scheduler stay the float32 they are, so index decisions and the embedding are bit-identical and
+    only the trunk's accumulation error (4e-7 .. 9e-7 of a pre-activation, scripts/exp_ties.py) is removed.  Any second float32
+    implementation of the trunk differs from the reference's by a rounding pattern of that size.  '<part>_arith.npz' keeps the end
+    point and ``arith_floor`` = its finger-L2 distance to the recorded chain."""
+    import copy
+    import time
+
+    class In64(nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.m = copy.deepcopy(m).double()
+
+        def forward(self, x):
+            return self.m(x.double()).float()
+
+    unet = make_unet()
+    objs3 = torch.stack([synth.synth_object_3d(50 + i) for i in range(2)])
+    B, G, P, L, T, S = 2, 45, 5, 42, 15, 5
+    noise = synth.synth_noise(0, B, L)
+    for part in parts:
+        o, gain, threads, multi = G9_3D[part][:4]
+        oi = G9_3D[part][4] if len(G9_3D[part]) > 4 else 0
+        ref = np.load(os.path.join(OUT, f"g9_3d_{part}.npz"))
+        d = make_diffusion('point_3d', unet, _scaled_output(make_dyn3d(), gain), T, S, L, G, P, objs3, 512)
+        xs = _unguided(d, noise, B)
+        dyn = d.classifier_model.module if hasattr(d.classifier_model, "module") else d.classifier_model
+        inner = dyn.m if hasattr(dyn, "m") else dyn                       # make_diffusion may wrap the model (see Wrapped)
+        inner.linears, inner.output = In64(inner.linears.eval()), In64(inner.output)
+        torch.set_num_threads(threads)
+        torch.manual_seed(0)
+        t0 = time.time()
+        with RandintSpy() as spy:
+            if multi:
+                d.object_vertices, d.object_ids = objs3, [0, 1]
+                res = run_chain(lambda: d.guided_sample_multi_object(0, B, noise, "/tmp/dgdm_golden", opt_obj=o, ori_range=[-1.0, 1.0]))
+            else:
+                d.object_vertices, d.object_ids = objs3[oi:oi + 1], [oi]
+                res = run_chain(lambda: d.guided_sample(0, B, noise, "/tmp/dgdm_golden", opt_obj=o, ori_range=[-1.0, 1.0], unguided_sample=xs))
+        torch.set_num_threads(8)
+        st, _ = _pack_starts16(spy)
+        assert np.array_equal(st, ref["starts"]), "the re-run must see the recorded FPS draws"
+        end = np.concatenate(res, axis=0) if multi else res[0]
+        fl = _spread(end, ref["guided"])
+        print("  3d arith", part, f"{time.time() - t0:.0f}s spread (finger L2)", fl, flush=True)
+        np.savez_compressed(os.path.join(OUT, f"g9_3d_{part}_arith.npz"), guided=end, arith_floor=np.float64(fl))
+
+
 def _guided_sample_with_centers(s, noise, obj, opt_obj, centers, starts):
     """orc.guided_sample with given convergence centres (loop body of generator/diffusion.py:570-576)."""
     B = noise.shape[0]
@@ -984,7 +1035,7 @@ if __name__ == "__main__":
     os.makedirs("/tmp/dgdm_golden", exist_ok=True)
     only = sys.argv[1:]
     for name, fn in (("g2", g2_unet), ("g3", g3_dyn2d), ("g4", g4_pointnet), ("g5", g5_dyn3d), ("g6", g6_chains),
-                     ("g7", g7_convergence), ("g8", g8_harness), ("g9_2d", g9_2d), ("g9_3d", g9_3d), ("g9_3d_eps", g9_3d_eps), ("g9_f64", g9_f64), ("g9_tiles", g9_tiles), ("g10", g10_train2d), ("g11", g11_dataset)):
+                     ("g7", g7_convergence), ("g8", g8_harness), ("g9_2d", g9_2d), ("g9_3d", g9_3d), ("g9_3d_eps", g9_3d_eps), ("g9_3d_arith", g9_3d_arith), ("g9_f64", g9_f64), ("g9_tiles", g9_tiles), ("g10", g10_train2d), ("g11", g11_dataset)):
         if only and name not in [a.split(":")[0] for a in only]:
             continue
         sub = [a.split(":", 1)[1].split(",") for a in only if a.startswith(name + ":")]
