@@ -232,13 +232,92 @@ __device__ __forceinline__ void table_sum(const TabRaw &raw, f32x16 &z) {
     }
 }
 
+// ---- the front's weight stream through LDS, shared by the workgroup's four waves.
+// In layers 1-2 of the 3-D model a weight entry feeds ONE MFMA (the phase runs per tile), i.e. 1 KiB per 32 cycles and wave = 128 B/clk/CU
+// against the 64 B/clk a CU's L1 delivers: the phase ran at 1 765 cycles per 16-entry block against 512 of MFMA issue.  All four waves
+// read the SAME 512-entry stream, twice (once per tile): each wave loads a quarter of every 16-entry chunk (16 KiB) from L2 and puts it
+// into one of three LDS chunk buffers, and every wave takes its A operands from there (ds_read_b128: 256 B/clk/CU).  Chunk cc is written
+// two chunks ahead of its use (iteration cc - 2, before that iteration's MFMAs), one workgroup barrier per chunk makes it visible, and the
+// 16-entry register ring is refilled from chunk cc + 1 while chunk cc is consumed - the same ring discipline as with buffer loads.
+// The two tile passes are one sequence of 64 chunks; the last refill comes from global memory again (the head of the stack's stream).
+typedef float f32x4v_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) f32x4v_t lds_f32x4_t;      // keeps ds_read / ds_write (a generic pointer would turn into flat accesses)
+constexpr int FRONT_CHUNKS = 64;                                      // 2 passes x 32 chunks of 16 entries
+
+#ifndef DGDM_FRONT_DEPTH
+#define DGDM_FRONT_DEPTH 1
+#endif
+constexpr int FSD = DGDM_FRONT_DEPTH;      // chunks a quarter-chunk load is given to arrive beyond the first (measured: 2-4 are no faster, and spill)
+
+struct FrontStage {
+    float4 q[FSD][4];              // this wave's quarter of chunks cc + 2 .. cc + 1 + FSD, in flight from L2; chunk k sits in slot (k - 2) % FSD
+};
+
+__device__ __forceinline__ void front_stage_load(const wrsrc_t rs, const int voff, const int wave, const int cc, float4 (&q)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q[j] = wload(rs, voff, (((cc % 32) * 16) + 4 * wave + j) * 1024);
+}
+
+__device__ __forceinline__ void front_stage_store(lds_f32x4_t *wb, const int wave, const int cc, const float4 (&q)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wb[(((cc % 3) * 16) + 4 * wave + j) * 64] = __builtin_bit_cast(f32x4v_t, q[j]);
+}
+
+// start of chunk CC's MFMAs: chunk CC + 2 goes to LDS, chunk CC + 2 + FSD is requested into the slot that frees
+template <int CC>
+__device__ __forceinline__ void front_chunk_begin(const wrsrc_t rs, const int voff, const int wave, lds_f32x4_t *wb, FrontStage &st) {
+    if constexpr (CC + 2 < FRONT_CHUNKS) front_stage_store(wb, wave, CC + 2, st.q[CC % FSD]);
+    if constexpr (CC + 2 + FSD < FRONT_CHUNKS) front_stage_load(rs, voff, wave, CC + 2 + FSD, st.q[CC % FSD]);
+}
+
+// end of chunk CC: everyone has written its part of chunk CC + 2 and finished reading chunk CC + 1's predecessor.  A bare s_barrier
+// behind an LDS-only wait: __syncthreads() would also wait for the global loads just requested (vmcnt(0)) and so undo the prefetch.
+__device__ __forceinline__ void front_chunk_end() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// The A operands of the front come out of LDS through an 8-entry register ring in CONSUMPTION order (LDS latency is ~100 cycles: eight
+// steps of cover are plenty, and the other half of the usual 16-entry ring pays for the second accumulator below).  Consumption order
+// within a chunk: a layer-1 chunk (one output block, 16 K-steps) as stored; a layer-2 chunk (8 output blocks x 2 K-steps, stored block-
+// major) K-step-major, so that consecutive MFMAs never hit the same accumulator - a dependent v_mfma_f32_32x32x16_bf16 issues only every
+// ~68 cycles, which is what this phase was really bound by (1 560 cycles per 16-MFMA chunk with the weights already in LDS).
+// Chunk sequence of a pass: z(0), z(1), l2(0), z(2), l2(1), ..., z(15), l2(14), l2(15).
+#ifdef DGDM_FRONT_STAMPS
+__device__ long long g_front_stamps[16];
+#define FSTAMP(i) do { if (T == 0 && KB == 5 && blockIdx.x == gridDim.x / 2 && tid == 0) g_front_stamps[i] = clock64(); } while (0)
+#else
+#define FSTAMP(i) do { } while (0)
+#endif
+
+constexpr bool front_is_l2(int cc) { return (cc % 32) == 31 || ((cc % 32) >= 2 && (cc % 32) % 2 == 0); }
+constexpr int front_entry(int cc, int j) { return front_is_l2(cc) ? 2 * (j % 8) + j / 8 : j; }
+
+struct FrontRing {
+    float4 r[8];
+};
+
+__device__ __forceinline__ void front_ring_fill(FrontRing &fr, lds_f32x4_t *wb) {           // chunk 0 (a layer-1 chunk), steps 0..7
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fr.r[j] = __builtin_bit_cast(float4, wb[j * 64]);
+}
+
+// step J of chunk CC: hands out its entry and requests the one eight steps on
+template <int CC, int J>
+__device__ __forceinline__ float4 front_take(FrontRing &fr, lds_f32x4_t *wb) {
+    constexpr int N = 16 * CC + J, M = N + 8, CM = M / 16, JM = M % 16;
+    const float4 a = fr.r[N % 8];
+    if constexpr (CM < FRONT_CHUNKS) fr.r[N % 8] = __builtin_bit_cast(float4, wb[(((CM % 3) * 16) + front_entry(CM, JM)) * 64]);
+    return a;
+}
+
 // 3-D layers 1 and 2 of ONE tile T (the 512-wide layer 1 does not fit in registers for two tiles at once):
 //   for each 32-feature block kb of layer 1:  z = W1o'[kb] bf(xobj) + (Atab + Ptab)[kb] ; a1 = relu ; acc2 += W2'[:, kb] bf(a1)
 // software-pipelined by one block: the stream order is z(0), z(1), l2(0), z(2), l2(1), ..., z(15), l2(14), l2(15) (16 entries each).
 // Leaves layer 2's blocks 0..6 packed in X.v[T] and block 7 pending in pipe.acc[1][T].
 template <int T>
 __device__ __forceinline__ void front3d(const wrsrc_t rs, const int voff, float4 (&ring)[CONT_DEPTH], const TrunkParams &p, const TileRows &tr,
-                                        Act16 &X, Pipe &pipe, uint32_t (*smask)[256], const int tid, const int h4) {
+                                        Act16 &X, Pipe &pipe, uint32_t (*smask)[256], const int tid, const int h4, const int wave, lds_f32x4_t *wb,
+                                        FrontStage &st, FrontRing &fr) {
     // first z1 block of the tables and the xobj row (all 32 loads in flight together), then xobj -> packed B operand
     TabRaw raw[2];
     table_load(tr, 0, h4, raw[0]);
@@ -272,33 +351,59 @@ __device__ __forceinline__ void front3d(const wrsrc_t rs, const int voff, float4
             }
         }
     }
-    f32x16 zacc[2];
+    // a layer-1 block accumulates on TWO accumulators (even / odd K-steps): the MFMAs of one accumulator are dependent
+    f32x16 zA[2], zB[2];
     u32x4_t zin[2];
     uint32_t mk = 0;
+    f32x16 zero;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
     static_for<0, 17>([&](auto kc) {
         constexpr int KB = decltype(kc)::value;          // z(KB) for KB < 16, then l2(KB - 1) for KB >= 1
         if constexpr (KB < 16) {
             f32x16 init;
             table_sum(raw[KB & 1], init);
+            constexpr int CZ = 32 * T + (KB == 0 ? 0 : 2 * KB - 1);          // chunk number of z(KB) in the two-pass sequence
+            FSTAMP(0);
+            front_chunk_begin<CZ>(rs, voff, wave, wb, st);
+            FSTAMP(1);
             static_for<0, 16>([&](auto ic) {
                 constexpr int I = decltype(ic)::value;
-                constexpr int E = (KB == 0 ? 0 : 16 + 32 * (KB - 1)) + I;
-                const float4 a = ring[E % CONT_DEPTH];
-                ring[E % CONT_DEPTH] = wload(rs, voff, (E + CONT_DEPTH) * 1024);
+                const float4 a = front_take<CZ, I>(fr, wb);
                 if constexpr (KB > 0 && I == 0) mk = 0u;
                 if constexpr (KB > 0 && I < 8) {          // epilogue of z(KB-1): one pair per step
-                    zin[I / 4][I % 4] = fwd_pair<I + 8 * T>(zacc[(KB - 1) & 1][2 * I], zacc[(KB - 1) & 1][2 * I + 1], mk);
+                    constexpr int Q = (KB - 1) & 1;
+#ifdef DGDM_FRONT_TWO_ACC
+                    zin[I / 4][I % 4] = fwd_pair<I + 8 * T>(zA[Q][2 * I] + zB[Q][2 * I], zA[Q][2 * I + 1] + zB[Q][2 * I + 1], mk);
+#else
+                    zin[I / 4][I % 4] = fwd_pair<I + 8 * T>(zA[Q][2 * I], zA[Q][2 * I + 1], mk);
+#endif
                 }
-                if constexpr (I == 0) zacc[KB & 1] = mfma_bf16(a, xin[0][0], init);
-                else zacc[KB & 1] = mfma_bf16(a, xin[I / 2][I % 2], zacc[KB & 1]);
+#ifdef DGDM_FRONT_TWO_ACC
+                if constexpr (I == 0) zA[KB & 1] = mfma_bf16(a, xin[0][0], init);
+                else if constexpr (I == 1) zB[KB & 1] = mfma_bf16(a, xin[0][1], zero);
+                else if constexpr (I % 2 == 0) zA[KB & 1] = mfma_bf16(a, xin[I / 2][0], zA[KB & 1]);
+                else zB[KB & 1] = mfma_bf16(a, xin[I / 2][1], zB[KB & 1]);
+#else
+                if constexpr (I == 0) zA[KB & 1] = mfma_bf16(a, xin[0][0], init);
+                else zA[KB & 1] = mfma_bf16(a, xin[I / 2][I % 2], zA[KB & 1]);
+#endif
                 if constexpr (I == 8 && KB < 15) table_load(tr, KB + 1, h4, raw[(KB + 1) & 1]);     // next block's table part
                 STEP_FENCE();
+                if constexpr (I == 7) FSTAMP(2);
             });
+            FSTAMP(3);
+            front_chunk_end();
+            FSTAMP(4);
         } else {
             mk = 0u;
             static_for<0, 8>([&](auto ic) {
                 constexpr int I = decltype(ic)::value;
-                zin[I / 4][I % 4] = fwd_pair<I + 8 * T>(zacc[1][2 * I], zacc[1][2 * I + 1], mk);
+#ifdef DGDM_FRONT_TWO_ACC
+                zin[I / 4][I % 4] = fwd_pair<I + 8 * T>(zA[1][2 * I] + zB[1][2 * I], zA[1][2 * I + 1] + zB[1][2 * I + 1], mk);
+#else
+                zin[I / 4][I % 4] = fwd_pair<I + 8 * T>(zA[1][2 * I], zA[1][2 * I + 1], mk);
+#endif
             });
         }
         if constexpr (KB >= 1) {
@@ -306,17 +411,22 @@ __device__ __forceinline__ void front3d(const wrsrc_t rs, const int voff, float4
             // sign bits of a1 block KP: this tile's 8 pairs; the two tile passes share the word
             if (T == 0) smask[KP][tid] = mk;
             else (void)__hip_atomic_fetch_or(&smask[KP][tid], mk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // ds_or_b32, no read-back
-            static_for<0, 16>([&](auto ic) {
-                constexpr int I = decltype(ic)::value;
-                constexpr int E = (KP == 15 ? 16 + 32 * 15 : 32 * (KP + 1)) + I;
-                constexpr int OP = I / 2, S = I % 2;
-                const float4 a = ring[E % CONT_DEPTH];
-                ring[E % CONT_DEPTH] = wload(rs, voff, (E + CONT_DEPTH) * 1024);
+            constexpr int CL = 32 * T + (KP == 15 ? 31 : 2 * KP + 2);        // chunk number of l2(KP)
+            front_chunk_begin<CL>(rs, voff, wave, wb, st);
+            FSTAMP(5);
+            static_for<0, 16>([&](auto jc) {
+                constexpr int J = decltype(jc)::value;
+                constexpr int OP = J % 8, S = J / 8;       // K-step-major: eight different accumulators in a row
+                const float4 a = front_take<CL, J>(fr, wb);
                 acc2[OP] = mfma_bf16(a, zin[S], acc2[OP]);
                 STEP_FENCE();
             });
+            FSTAMP(6);
+            front_chunk_end();
+            FSTAMP(7);
         }
     });
+    if (T == 1) ring_fill(rs, voff, 512 * 1024, ring);       // the stack's first 16 entries, in flight during the epilogue below
     // layer 2 epilogue: blocks 0..6 here, block 7 left pending
     static_for<0, 7>([&](auto oc) {
         constexpr int O = decltype(oc)::value;
@@ -339,12 +449,17 @@ __global__ __launch_bounds__(256, 1) void trunk_bf16_kernel(const TrunkParams p)
     constexpr int NSLOT = S_MID + 8 * ((KIND == 3) ? 6 : 7);
     __shared__ uint32_t smask[NSLOT][256];
     __shared__ __attribute__((aligned(16))) float red[4][32][36];       // per wave: one 32-feature block x 32 rows (+pad) for the final fold
+    __shared__ f32x4v_t wbuf[KIND == 3 ? 3 : 1][KIND == 3 ? 16 : 1][64];  // 3-D front: three 16-entry chunks of the weight stream (above)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile0 = (blockIdx.x * 4 + wave) * 2;
-    if (tile0 >= p.ntiles) return;                        // wave-uniform; the kernel has no barrier
+    int tile0 = (blockIdx.x * 4 + wave) * 2;
+    // 2-D: a wave without a tile leaves (no barrier anywhere).  3-D: the front's weight stream is staged by all four waves together,
+    // so a wave without a tile goes through the front on the last tile's rows (nothing it computes is stored) and leaves after it.
+    const bool active = tile0 < p.ntiles;
+    if (KIND != 3 && !active) return;
+    if (!active) tile0 = (p.ntiles - 1) & ~1;
     const bool has1 = tile0 + 1 < p.ntiles;               // an odd tile count leaves the last wave one real tile
     const int n = lane & 31;
     const int h4 = (lane >> 5) * 4;
@@ -367,7 +482,7 @@ __global__ __launch_bounds__(256, 1) void trunk_bf16_kernel(const TrunkParams p)
     load_f32x16(p.bf[0], h4, pipe.bias0);
     const wrsrc_t rsF = weight_rsrc(p.Wfwd, p.fwd_bytes);
     float4 ring[CONT_DEPTH];
-    ring_fill(rsF, voff, 0, ring);
+    if (KIND == 2) ring_fill(rsF, voff, 0, ring);          // 3-D: the front takes its entries out of LDS and fills the ring when it ends
     int woff = 0;
 
     if (KIND == 2) {
@@ -403,11 +518,22 @@ __global__ __launch_bounds__(256, 1) void trunk_bf16_kernel(const TrunkParams p)
             STEP_FENCE();
         });
     } else {
-        front3d<0>(rsF, voff, ring, p, tr0, X, pipe, smask, tid, h4);
-        // the second pass re-reads the same 512 entries; the ring currently holds the 16 entries AFTER them: refill
-        ring_fill(rsF, voff, 0, ring);
-        front3d<1>(rsF, voff, ring, p, tr1, X, pipe, smask, tid, h4);
+        // chunks 0 and 1 of the stream into LDS, chunk 2 requested
+        lds_f32x4_t *wb = (lds_f32x4_t *)&wbuf[0][0][lane];
+        FrontStage st;
+        FrontRing fr;
+        front_stage_load(rsF, voff, wave, 0, st.q[0]);
+        front_stage_store(wb, wave, 0, st.q[0]);
+        front_stage_load(rsF, voff, wave, 1, st.q[0]);
+        front_stage_store(wb, wave, 1, st.q[0]);
+#pragma unroll
+        for (int i = 0; i < FSD; ++i) front_stage_load(rsF, voff, wave, 2 + i, st.q[i]);
+        front_chunk_end();
+        front_ring_fill(fr, wb);
+        front3d<0>(rsF, voff, ring, p, tr0, X, pipe, smask, tid, h4, wave, wb, st, fr);
+        front3d<1>(rsF, voff, ring, p, tr1, X, pipe, smask, tid, h4, wave, wb, st, fr);
         woff = 512 * 1024;
+        if (!active) return;
     }
     int pend_slot = (KIND == 3) ? 16 + 7 : 7;
     STAMP();
@@ -577,6 +703,15 @@ int trunk_bf16_launch(int kind, const TrunkParams &p, hipStream_t s) {
     if (kind == 2) hipLaunchKernelGGL((trunk_bf16_kernel<2>), dim3(grid), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((trunk_bf16_kernel<3>), dim3(grid), dim3(256), 0, s, p);
     DGDM_HIP_CHECK(hipGetLastError());
+#ifdef DGDM_FRONT_STAMPS
+    if (kind == 3) {
+        long long st[16];
+        hipStreamSynchronize(s);
+        hipMemcpyFromSymbol(st, HIP_SYMBOL(g_front_stamps), sizeof(st));
+        fprintf(stderr, "front stamps (z(5) chunk: begin-staging %lld, steps 0-7 %lld, steps 8-15 %lld, barrier %lld | l2(4) chunk: staging %lld, 16 steps %lld, barrier %lld)\n",
+                st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[5] - st[4], st[6] - st[5], st[7] - st[6]);
+    }
+#endif
     prof_end(s, DGDM_STAGE_TRUNK, rows * per_row);
     return DGDM_OK;
 }
