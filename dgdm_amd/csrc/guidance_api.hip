@@ -53,11 +53,14 @@ struct DgdmGuidance {
     std::vector<std::unique_ptr<ObjectTables>> tables;   // 3-D
     bool bf16 = false;                           // contractions of the trunk on bf16 MFMA (dgdm_guidance_set_contraction_dtype)
     bool f32_mfma = false;                       // float32 mode on the k-ordered float32 MFMA chain (trunk.hip) instead of the split form
-    static constexpr int NBUILD = 3;             // objects whose tables are built concurrently (own stream + temporaries each)
+#ifndef DGDM_NBUILD
+#define DGDM_NBUILD 3
+#endif
+    static constexpr int NBUILD = DGDM_NBUILD;   // objects whose tables are built concurrently (own stream + temporaries each)
     DevBuf pool_xyz, pool_fps1, pool_fps2, pool_flags, pool_ncr;   // [n_objects] x per-object FPS tables (ObjectTables point into these), crowded-centre counts
     DevBuf tmpF1[NBUILD], tmpU[NBUILD], tmpY[NBUILD], tmpL2[NBUILD], tmpOff[NBUILD], tmpPairs[NBUILD], tmpRank[NBUILD], vlist;      // 3-D table-build temporaries
-    hipStream_t bstream[NBUILD] = {nullptr, nullptr, nullptr}, fstream = nullptr;    // fstream: sa2's FPS table, beside the builds
-    hipEvent_t bev[NBUILD] = {nullptr, nullptr, nullptr}, bstart = nullptr, fstart = nullptr, fdone = nullptr;
+    hipStream_t bstream[NBUILD] = {}, fstream = nullptr;    // fstream: sa2's FPS table, beside the builds
+    hipEvent_t bev[NBUILD] = {}, bstart = nullptr, fstart = nullptr, fdone = nullptr;
     // V, genc, chainbias, timepart: float64 (smallnet.h linear64: per-finger / per-chain quantities are evaluated in double precision,
     // so the A table carries one float32 rounding); ttmp64: scratch of the time encoder
     DevBuf V, genc, atab, chainbias, timepart, ttmp, ttmp64, partial, objdev, objidx, xobj, xobj16, starts, order, xchains, todo, groupoff;
