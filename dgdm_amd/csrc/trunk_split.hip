@@ -12,11 +12,14 @@
 //   Y [8] f32x16   a layer's output in the MFMA C/D layout (register r, lane (n, h)  <->  feature 32 o + rho(r, h) of row n)
 //   X [3][8][2]    the layer's input as three sets of packed bf16 B operands: K-step s of block o = registers 8s..8s+7 of Y[o],
 //                  converted pairwise (trunk_bf16.hip's operand order; the weight images are pack_chain_bf16 images of the pieces)
-// A layer computes two output blocks at a time, one accumulator each, twelve MFMAs per K-step (consecutive MFMAs never share an
-// accumulator); after it: ReLU + sign bits (exact float32 semantics, x > 0; bits kept in LDS for the backward pass) and the split of
-// Y into the next X (x - bf16(x) is exact in float32, so the three pieces reproduce x bit for bit).
-// Weight streams (host: pack_split3_stream, models_api.hip): per (block pair, K-step) six 1 KiB entries [A.h A.m A.l B.h B.m B.l],
-// read through the buffer-load ring of mfma_chain.h, 12 entries in flight.
+// A 256 -> 256 layer is input-streaming (stream_layer): the K loop runs over the input blocks while all eight output blocks accumulate,
+// twelve MFMAs per (K-step, pair of output blocks), consecutive MFMAs never on the same accumulator; the previous layer's epilogue -
+// ReLU + sign bits (exact float32 semantics, x > 0; bits kept in LDS for the backward pass), then the split of an accumulator pair
+// into the three pieces (x - bf16(x) is exact in float32, so the pieces reproduce x bit for bit) - is done just in time, one register
+// pair per group of twelve MFMAs, in the shadow of the matrix pipe.  The 512-wide first layers of the 3-D model and the last layer
+// back are produced block by block (split_block_out).
+// Weight streams (host: Split3 / split_layer_stream, models_api.hip): per (K-step, block pair) six 1 KiB entries [A.h A.m A.l B.h B.m
+// B.l] in consumption order, read through a 12-entry buffer-load ring.
 #include "common.h"
 #include <algorithm>
 #include "mfma_chain.h"
