@@ -258,7 +258,9 @@ def stage_profile(wl, secs_per_step, contraction):
             "algorithmic_flops_per_launch": flops / n, "algorithmic_tflops": alg, "issued_flops_per_algorithmic_flop": issued,
             "algorithmic_vs_f32_mfma_peak": alg / F32_MFMA_PEAK_TFLOPS,
             "note": ("float32 contractions as six bf16 MFMA products on exactly split operands: achieved = ISSUED bf16 TFLOP/s (6 x algorithmic) "
-                     "against the bf16 dense peak" if contraction == "f32" else "algorithmic FLOPs / time against the dense peak of the MFMA dtype"),
+                     "against the 2.4 GHz bf16 dense peak; recorded PMC (profiles/r03_pmc_kernels.md): matrix pipe busy 71-74 % of the cycles at the "
+                     "~2.0 GHz the chip sustains under this kernel" if contraction == "f32"
+                     else "algorithmic FLOPs / time against the dense peak of the MFMA dtype"),
             "share_of_step": (ms * 1e-3) / secs_per_step,
             "step_frac": (st["trunk"][2] * issued + st["unet"][2]) / secs_per_step / 1e12 / peak,
             "step_necessary_tflop": need / 1e12,
