@@ -30,7 +30,7 @@ struct ObjectTables {       // 3-D, per object
     const int   *flags = nullptr; // [N] that sequence is order-dependent (exact distance tie / coordinates exhausted)
     DevBuf Z;               // [N][N][256]
     bool   fast_ok = false; // no flag set: rows can take their centres from fps2 instead of running FPS
-    DevBuf crowded, clist;  // [N] int each + clist[N] = count: centres whose ball query truncates (pointnet.hip crowd_kernel)
+    int *crowded = nullptr, *clist = nullptr;   // [N] int, [N + 1] int (clist[N] = count): centres whose ball query truncates (pointnet.hip crowd_kernel); pool slices
     DevBuf M0, cl2, cnt2;   // [N][256] float, [N][128] int, [N] int: variant-independent part of the sa3 max (pointnet.hip m0_kernel)
     DevBuf cl2s;            // [N][128] cl2 as positions in clist (xobj_group_kernel)
     DevBuf X, X16;          // [N][N][256] float32 / [N][N][128] bf16 dwords: the finished embedding per (s1, start point) (pointnet.hip xtab_kernel)
@@ -57,10 +57,11 @@ struct DgdmGuidance {
 #define DGDM_NBUILD 3
 #endif
     static constexpr int NBUILD = DGDM_NBUILD;   // objects whose tables are built concurrently (own stream + temporaries each)
+    DevBuf pool_crowded, pool_clist, pool_off, pool_pairs, pool_rank, pool_F1, pool_U;   // [n_objects] x the light build stages' outputs (built by one launch per stage)
     DevBuf pool_xyz, pool_fps1, pool_fps2, pool_flags, pool_ncr;   // [n_objects] x per-object FPS tables (ObjectTables point into these), crowded-centre counts
-    DevBuf tmpF1[NBUILD], tmpU[NBUILD], tmpY[NBUILD], tmpL2[NBUILD], tmpOff[NBUILD], tmpPairs[NBUILD], tmpRank[NBUILD], vlist;      // 3-D table-build temporaries
+    DevBuf tmpY[NBUILD], tmpL2[NBUILD], vlist;      // 3-D table-build temporaries of the heavy stages (per build stream)
     hipStream_t bstream[NBUILD] = {}, fstream = nullptr;    // fstream: sa2's FPS table, beside the builds
-    hipEvent_t bev[NBUILD] = {}, bstart = nullptr, fstart = nullptr, fdone = nullptr;
+    hipEvent_t bev[NBUILD] = {}, bstart = nullptr, fstart = nullptr, fdone = nullptr, ldone = nullptr;      // ldone: the batched light build stages
     // V, genc, chainbias, timepart: float64 (smallnet.h linear64: per-finger / per-chain quantities are evaluated in double precision,
     // so the A table carries one float32 rounding); ttmp64: scratch of the time encoder
     DevBuf V, genc, atab, chainbias, timepart, ttmp, ttmp64, partial, objdev, objidx, xobj, xobj16, starts, order, xchains, todo, groupoff;
@@ -96,6 +97,7 @@ struct DgdmGuidance {
             if (bev[i]) (void)hipEventDestroy(bev[i]);
         }
         if (bstart) (void)hipEventDestroy(bstart);
+        if (ldone) (void)hipEventDestroy(ldone);
         if (fstart) (void)hipEventDestroy(fstart);
         if (fdone) (void)hipEventDestroy(fdone);
         if (fstream) (void)hipStreamDestroy(fstream);
@@ -238,46 +240,38 @@ int DgdmGuidance::build_object(int oi, int slot, hipStream_t s) {
     const PnWeights w = m->pn();
     int rc;
     if ((rc = t.Z.alloc((size_t)N * N * 256 * 4)) ||
-        (rc = t.crowded.alloc((size_t)N * sizeof(int))) || (rc = t.clist.alloc((size_t)(N + 1) * sizeof(int))) ||
         (rc = t.M0.alloc((size_t)N * 256 * 4)) || (rc = t.cl2.alloc((size_t)N * 128 * sizeof(int))) || (rc = t.cnt2.alloc((size_t)N * sizeof(int))) ||
         (rc = t.cl2s.alloc((size_t)N * 128 * sizeof(int))))
         return rc;
     t.has16 = bf16;
     if (bf16 && ((rc = t.Z16.alloc((size_t)N * N * 128 * 4)) || (rc = t.M0_16.alloc((size_t)N * 128 * 4)))) return rc;
     uint32_t *z16 = bf16 ? t.Z16.as<uint32_t>() : nullptr;
-    DevBuf &tF1 = tmpF1[slot], &tU = tmpU[slot], &tY = tmpY[slot], &tL2 = tmpL2[slot];
-    if ((rc = tF1.alloc((size_t)N * 128 * 8)) || (rc = tU.alloc((size_t)N * 128 * 8)) || (rc = tY.alloc((size_t)N * N * 256 * 4)) ||
-        (rc = tL2.alloc((size_t)N * N * 256 * 4)))
-        return rc;
+    DevBuf &tY = tmpY[slot], &tL2 = tmpL2[slot];
+    if ((rc = tY.alloc((size_t)N * N * 256 * 4)) || (rc = tL2.alloc((size_t)N * N * 256 * 4))) return rc;
     const float *xyz = t.xyz;                                                                                  // T1: set_objects, batched
-    DevBuf &tOff = tmpOff[slot], &tPairs = tmpPairs[slot], &tRank = tmpRank[slot];
-    if ((rc = tOff.alloc((size_t)(N + 1) * sizeof(int))) || (rc = tPairs.alloc((size_t)N * N * sizeof(int))) || (rc = tRank.alloc((size_t)N * N * sizeof(short))))
-        return rc;
-    if ((rc = pn_crowd(xyz, N, w, t.crowded.as<int>(), t.clist.as<int>(), t.clist.as<int>() + N, tOff.as<int>(), tPairs.as<int>(), tRank.as<short>(), s,
-                       pool_ncr.as<int>() + oi))) return rc;
+    // crowded flags / pair lists (crowd_kernel, nbr_fill_kernel), T2 (sa1) and T3 (U): set_objects, one launch per stage for all objects
+    const int *off = pool_off.as<int>() + (size_t)oi * (N + 1), *pairs = pool_pairs.as<int>() + (size_t)oi * N * N;
+    const short *rank = pool_rank.as<short>() + (size_t)oi * N * N;
+    const char *U = static_cast<const char *>(pool_U.p) + (size_t)oi * N * 128 * (bf16 ? 4 : 8);      // float32 rows in bf16 mode, float64 otherwise
     if (bf16) {
         // bf16 mode: the sa3 contraction (T6) runs on the bf16 matrix pipe and rounds its input, so T4 writes and T5 reduces bf16
         // rows (the temporaries tY / tL2 are simply used at half size); the stages in front of it stay float32
-        if ((rc = pn_sa1(xyz, N, w, tF1.as<float>(), s))) return rc;                                               // T2
-        if ((rc = linear(tF1.as<float>(), 128, w.sa2_wf_t, w.sa2_b0, nullptr, 1, tU.as<float>(), 128, N, 128, 128, ACT_NONE, false, s))) return rc;  // T3
-        if ((rc = pn_pairs(xyz, N, tU.as<float>(), w, tPairs.as<int>(), tOff.as<int>(), tY.as<float>(), tY.as<uint32_t>(), s))) return rc;   // T4
-        if ((rc = pn_l2(xyz, N, w, t.fps1, vlist.as<int>(), N, tY.as<float>(), tL2.as<float>(), t.clist.as<int>(), t.clist.as<int>() + N,
-                        tOff.as<int>(), tRank.as<short>(), true, s, l2_gather_mode ? 0 : 1))) return rc;                   // T5
-        if ((rc = pn_z16(xyz, N, N, w, tL2.as<uint32_t>(), t.Z.as<float>(), z16, t.clist.as<int>(), t.clist.as<int>() + N, s))) return rc;          // T6
+        if ((rc = pn_pairs(xyz, N, reinterpret_cast<const float *>(U), w, pairs, off, tY.as<float>(), tY.as<uint32_t>(), s))) return rc;   // T4
+        if ((rc = pn_l2(xyz, N, w, t.fps1, vlist.as<int>(), N, tY.as<float>(), tL2.as<float>(), t.clist, t.clist + N,
+                        off, rank, true, s, l2_gather_mode ? 0 : 1))) return rc;                   // T5
+        if ((rc = pn_z16(xyz, N, N, w, tL2.as<uint32_t>(), t.Z.as<float>(), z16, t.clist, t.clist + N, s))) return rc;          // T6
     } else {
         // float32 mode (the parity path): every contraction of the build accumulates in float64 and each table entry is rounded once
         // (pointnet64.hip); the max stages (T5, T7) are exact as they are
         const PnWeights64 w64 = m->pn64();
-        if ((rc = pn_sa1_64(xyz, N, w.r1sq, w64, tF1.as<double>(), s))) return rc;                                 // T2
-        if ((rc = linear64(nullptr, tF1.as<double>(), 128, w64.sa2_wf_t, w64.sa2_b0, nullptr, 1, tU.as<double>(), nullptr, 128, N, 128, 128, ACT_NONE, s))) return rc;  // T3
-        if ((rc = pn_pairs64(xyz, N, tU.as<double>(), w64, tPairs.as<int>(), tOff.as<int>(), tY.as<float>(), s))) return rc;                 // T4
-        if ((rc = pn_l2(xyz, N, w, t.fps1, vlist.as<int>(), N, tY.as<float>(), tL2.as<float>(), t.clist.as<int>(), t.clist.as<int>() + N,
-                        tOff.as<int>(), tRank.as<short>(), false, s, l2_gather_mode ? 0 : 1))) return rc;                  // T5
-        if ((rc = pn_z64(xyz, N, N, w64, tL2.as<float>(), t.Z.as<float>(), t.clist.as<int>(), t.clist.as<int>() + N, s))) return rc;                // T6
+        if ((rc = pn_pairs64(xyz, N, reinterpret_cast<const double *>(U), w64, pairs, off, tY.as<float>(), s))) return rc;                 // T4
+        if ((rc = pn_l2(xyz, N, w, t.fps1, vlist.as<int>(), N, tY.as<float>(), tL2.as<float>(), t.clist, t.clist + N,
+                        off, rank, false, s, l2_gather_mode ? 0 : 1))) return rc;                  // T5
+        if ((rc = pn_z64(xyz, N, N, w64, tL2.as<float>(), t.Z.as<float>(), t.clist, t.clist + N, s))) return rc;                // T6
     }
     DGDM_HIP_CHECK(hipStreamWaitEvent(s, fdone, 0));          // fps2 (sa2's FPS table) is built beside the other stages, on its own stream
-    if ((rc = pn_m0(t.fps2, t.crowded.as<int>(), N, t.Z.as<float>(), t.M0.as<float>(), t.cl2.as<int>(), t.cnt2.as<int>(), z16,
-                    bf16 ? t.M0_16.as<uint32_t>() : nullptr, t.clist.as<int>(), t.clist.as<int>() + N, t.cl2s.as<int>(), s))) return rc;          // T7
+    if ((rc = pn_m0(t.fps2, t.crowded, N, t.Z.as<float>(), t.M0.as<float>(), t.cl2.as<int>(), t.cnt2.as<int>(), z16,
+                    bf16 ? t.M0_16.as<uint32_t>() : nullptr, t.clist, t.clist + N, t.cl2s.as<int>(), s))) return rc;          // T7
     t.has_x = t.has_x16 = false;
     return xtab_policy == 1 ? build_xtab(oi, s) : DGDM_OK;       // eager only on request: see guidance_grad for when it pays
 }
@@ -295,8 +289,8 @@ int DgdmGuidance::build_xtab(int oi, hipStream_t s) {
     XtabObj xo{};
     xo.xyz = t.xyz; xo.fps1 = t.fps1; xo.Z = t.Z.as<float>(); xo.M0 = t.M0.as<float>();
     xo.Z16 = b16 ? t.Z16.as<uint32_t>() : nullptr; xo.M0_16 = b16 ? t.M0_16.as<uint32_t>() : nullptr;
-    xo.clist = t.clist.as<int>(); xo.ncr = t.clist.as<int>() + N; xo.cl2s = t.cl2s.as<int>(); xo.cnt2 = t.cnt2.as<int>(); xo.flags = t.flags;
-    xo.crowded = t.crowded.as<int>(); xo.X = b16 ? nullptr : t.X.as<float>(); xo.X16 = b16 ? t.X16.as<uint32_t>() : nullptr; xo.N = N;
+    xo.clist = t.clist; xo.ncr = t.clist + N; xo.cl2s = t.cl2s.as<int>(); xo.cnt2 = t.cnt2.as<int>(); xo.flags = t.flags;
+    xo.crowded = t.crowded; xo.X = b16 ? nullptr : t.X.as<float>(); xo.X16 = b16 ? t.X16.as<uint32_t>() : nullptr; xo.N = N;
     if ((rc = pn_xtab(xo, b16, s))) return rc;
     (b16 ? t.has_x16 : t.has_x) = true;
     return DGDM_OK;
@@ -326,6 +320,7 @@ extern "C" int dgdm_guidance_set_objects(DgdmGuidance *g, const float *objects_d
         // dependent iterations on 128 workgroups) of one object overlap the bandwidth/MFMA-bound stages of the others
         const int nb = std::min<int>(DgdmGuidance::NBUILD, n_objects);
         if (!g->bstart) DGDM_HIP_CHECK(hipEventCreateWithFlags(&g->bstart, hipEventDisableTiming));
+        if (!g->ldone) DGDM_HIP_CHECK(hipEventCreateWithFlags(&g->ldone, hipEventDisableTiming));
         for (int i = 0; i < nb; ++i) {
             if (!g->bstream[i]) DGDM_HIP_CHECK(hipStreamCreateWithFlags(&g->bstream[i], hipStreamNonBlocking));
             if (!g->bev[i]) DGDM_HIP_CHECK(hipEventCreateWithFlags(&g->bev[i], hipEventDisableTiming));
@@ -334,7 +329,10 @@ extern "C" int dgdm_guidance_set_objects(DgdmGuidance *g, const float *objects_d
         const size_t no = (size_t)n_objects;
         if ((rc = g->pool_xyz.alloc(no * N * 3 * 4)) || (rc = g->pool_fps1.alloc(no * N * 512 * sizeof(int))) ||
             (rc = g->pool_fps2.alloc(no * N * 128 * sizeof(int))) || (rc = g->pool_flags.alloc(no * N * sizeof(int))) ||
-            (rc = g->pool_ncr.alloc(no * sizeof(int))))
+            (rc = g->pool_ncr.alloc(no * sizeof(int))) || (rc = g->pool_crowded.alloc(no * N * sizeof(int))) ||
+            (rc = g->pool_clist.alloc(no * (N + 1) * sizeof(int))) || (rc = g->pool_off.alloc(no * (N + 1) * sizeof(int))) ||
+            (rc = g->pool_pairs.alloc(no * N * N * sizeof(int))) || (rc = g->pool_rank.alloc(no * N * N * sizeof(short))) ||
+            (rc = g->pool_F1.alloc(no * N * 128 * 8)) || (rc = g->pool_U.alloc(no * N * 128 * 8)))
             return rc;
         if (!g->fstream) {
             DGDM_HIP_CHECK(hipStreamCreateWithFlags(&g->fstream, hipStreamNonBlocking));
@@ -352,9 +350,35 @@ extern "C" int dgdm_guidance_set_objects(DgdmGuidance *g, const float *objects_d
             ObjectTables &t = *g->tables[i];
             t.xyz = g->pool_xyz.as<float>() + (size_t)i * N * 3; t.fps1 = g->pool_fps1.as<int>() + (size_t)i * N * 512;
             t.fps2 = g->pool_fps2.as<int>() + (size_t)i * N * 128; t.flags = g->pool_flags.as<int>() + (size_t)i * N;
+            t.crowded = g->pool_crowded.as<int>() + (size_t)i * N; t.clist = g->pool_clist.as<int>() + (size_t)i * (N + 1);
+        }
+        // the light, latency-bound stages - crowded flags + pair lists, T2 (sa1 features), T3 (U = sa2's first layer on the features) -
+        // for ALL objects in one launch each (per object they are 1 .. 512 small workgroups: 130-500 us of a build stream each, a third
+        // of its time), on the first build stream, beside the FPS tables; the heavy per-object stages (T4 .. T7) follow on the build streams
+        {
+            hipStream_t ls = g->bstream[0];
+            DGDM_HIP_CHECK(hipStreamWaitEvent(ls, g->fstart, 0));          // the objects' coordinates are in the pool
+            const PnWeights w = g->m->pn();
+            if ((rc = pn_crowd(g->pool_xyz.as<float>(), N, w, g->pool_crowded.as<int>(), g->pool_clist.as<int>(), g->pool_clist.as<int>() + N,
+                               g->pool_off.as<int>(), g->pool_pairs.as<int>(), g->pool_rank.as<short>(), ls, g->pool_ncr.as<int>(), n_objects)))
+                return rc;
+            if (g->bf16) {
+                if ((rc = pn_sa1(g->pool_xyz.as<float>(), N, w, g->pool_F1.as<float>(), ls, n_objects))) return rc;                                   // T2
+                if ((rc = linear(g->pool_F1.as<float>(), 128, w.sa2_wf_t, w.sa2_b0, nullptr, 1, g->pool_U.as<float>(), 128, n_objects * N, 128, 128,
+                                 ACT_NONE, false, ls))) return rc;                                                                                 // T3
+            } else {
+                const PnWeights64 w64 = g->m->pn64();
+                if ((rc = pn_sa1_64(g->pool_xyz.as<float>(), N, w.r1sq, w64, g->pool_F1.as<double>(), ls, n_objects))) return rc;                      // T2
+                if ((rc = linear64(nullptr, g->pool_F1.as<double>(), 128, w64.sa2_wf_t, w64.sa2_b0, nullptr, 1, g->pool_U.as<double>(), nullptr, 128,
+                                   n_objects * N, 128, 128, ACT_NONE, ls))) return rc;                                                             // T3
+            }
+            DGDM_HIP_CHECK(hipEventRecord(g->ldone, ls));
         }
         DGDM_HIP_CHECK(hipEventRecord(g->bstart, s));
-        for (int i = 0; i < nb; ++i) DGDM_HIP_CHECK(hipStreamWaitEvent(g->bstream[i], g->bstart, 0));
+        for (int i = 0; i < nb; ++i) {
+            DGDM_HIP_CHECK(hipStreamWaitEvent(g->bstream[i], g->bstart, 0));
+            DGDM_HIP_CHECK(hipStreamWaitEvent(g->bstream[i], g->ldone, 0));
+        }
         for (int i = 0; i < n_objects; ++i)
             if ((rc = g->build_object(i, i % nb, g->bstream[i % nb]))) return rc;
         for (int i = 0; i < nb; ++i) {
@@ -533,7 +557,7 @@ int DgdmGuidance::run_xobj(const int *objidx_host, int n_chains, int64_t rows, b
         DGDM_REQUIRE(objidx_host[i] >= 0 && objidx_host[i] < n_objects, DGDM_EINVAL, "chain %d refers to object %d of %d", i, objidx_host[i], n_objects);
         const ObjectTables &t = *tables[objidx_host[i]];
         ch[i].xyz = t.xyz; ch[i].fps1 = t.fps1; ch[i].slot_of_start = nullptr; ch[i].Z = t.Z.as<float>();
-        ch[i].fps2 = t.fps2; ch[i].flags = t.flags; ch[i].crowded = t.crowded.as<int>(); ch[i].N = cfg.num_object_points;
+        ch[i].fps2 = t.fps2; ch[i].flags = t.flags; ch[i].crowded = t.crowded; ch[i].N = cfg.num_object_points;
         ch[i].M0 = t.M0.as<float>(); ch[i].cl2 = t.cl2.as<int>(); ch[i].cnt2 = t.cnt2.as<int>();
         ch[i].Z16 = t.has16 ? t.Z16.as<uint32_t>() : nullptr; ch[i].M0_16 = t.has16 ? t.M0_16.as<uint32_t>() : nullptr;
         want16 = want16 && t.has16;          // bf16 rows only if every chain's object was built with its bf16 tables
@@ -557,7 +581,7 @@ int DgdmGuidance::run_xobj(const int *objidx_host, int n_chains, int64_t rows, b
         const ObjectTables &t = *tables[objidx_host[i]];
         const int lpr = xobj_group_lpr(t.ncr, want16);
         groups = lpr > 0 && cfg.num_object_points >= 128;
-        ch[i].clist = t.clist.as<int>(); ch[i].cl2s = t.cl2s.as<int>(); ch[i].ncr = t.ncr; ch[i].lpr = lpr; ch[i].item_base = items;
+        ch[i].clist = t.clist; ch[i].cl2s = t.cl2s.as<int>(); ch[i].ncr = t.ncr; ch[i].lpr = lpr; ch[i].item_base = items;
         items += cfg.num_object_points * ((want16 ? 32 : 64) / std::max(1, lpr));
     }
     DGDM_HIP_CHECK(hipMemcpyAsync(xchains.p, ch.data(), sizeof(XobjChain) * n_chains, hipMemcpyHostToDevice, s));     // pageable: staged before return

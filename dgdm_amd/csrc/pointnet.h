@@ -90,10 +90,10 @@ int pn_sqdist_rows(const float *src, const float *dst, int B, int S, int N, floa
 int pn_index_rows(const float *points, const int *idx, int B, int N, int M, int C, float *out, hipStream_t s);
 
 int pn_fps_table(const float *xyz, int N, int nv, int npoint, int *out, int *flags, hipStream_t s, int nobj = 1);
-int pn_sa1(const float *xyz, int N, const PnWeights &w, float *F1, hipStream_t s);
+int pn_sa1(const float *xyz, int N, const PnWeights &w, float *F1, hipStream_t s, int nobj = 1);      // nobj > 1: pools [nobj][N][..]
 // crowded/clist/ncr: centres whose ball holds > 64 points; off [N+1], pairs [<= N*N], rank [N][N]: the in-radius pair list (T4/T5)
 int pn_crowd(const float *xyz, int N, const PnWeights &w, int *crowded, int *clist, int *ncr, int *off, int *pairs, short *rank, hipStream_t s,
-             int *ncr_copy = nullptr);
+             int *ncr_copy = nullptr, int nobj = 1);
 // Y16 (optional): write bf16 operand-order rows there INSTEAD of the float32 rows (bf16 mode)
 int pn_pairs(const float *xyz, int N, const float *U, const PnWeights &w, const int *pairs, const int *off, float *Y, uint32_t *Y16, hipStream_t s);
 // crowded_mode 1: the variants >= 1 of the crowded centres by l2c_kernel (needs vlist = identity: slot v = start index v, and K <= 255
@@ -109,7 +109,7 @@ int pn_z(const float *xyz, int N, int nv, const PnWeights &w, const float *L2, f
          hipStream_t s);
 // ---- float64 table build (pointnet64.hip): same inputs, same float32 outputs (each rounded ONCE from a float64 accumulation)
 // F1_64 [N][128] doubles (sa1 features); U is then linear64(F1_64) -> U64 [N][128] doubles
-int pn_sa1_64(const float *xyz, int N, float r1sq, const PnWeights64 &w, double *F1_64, hipStream_t s);
+int pn_sa1_64(const float *xyz, int N, float r1sq, const PnWeights64 &w, double *F1_64, hipStream_t s, int nobj = 1);
 int pn_pairs64(const float *xyz, int N, const double *U64, const PnWeights64 &w, const int *pairs, const int *off, float *Y, hipStream_t s);
 int pn_z64(const float *xyz, int N, int nv, const PnWeights64 &w, const float *L2, float *Z, const int *clist, const int *ncr, hipStream_t s);
 int pn_m0(const int *fps2, const int *crowded, int N, const float *Z0, float *M0, int *cl2, int *cnt2, const uint32_t *Z0_16, uint32_t *M0_16,

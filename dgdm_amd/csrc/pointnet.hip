@@ -131,12 +131,13 @@ __global__ __launch_bounds__(256) void fps_table_kernel(const float *__restrict_
 // ------------------------------------------------------------------------------------------------ T2
 // sa1 feature of every point p as a centre: first 32 in-radius (r=0.2) points in index order, padded with
 // the first; Conv(3->64)+BN+ReLU, Conv(64->128)+BN+ReLU, max  (pointnet2.py:17, pointnet2_utils.py:95-146,203-208)
-__global__ __launch_bounds__(128) void sa1_kernel(const float *__restrict__ xyz, int N, float r2, const float *__restrict__ w0t /*[3][64]*/,
+__global__ __launch_bounds__(128) void sa1_kernel(const float *xyz, int N, float r2, const float *__restrict__ w0t /*[3][64]*/,
                                                   const float *__restrict__ b0, const float *__restrict__ w1 /*[128][64]*/,
-                                                  const float *__restrict__ b1, float *__restrict__ F1 /*[N][128]*/) {
+                                                  const float *__restrict__ b1, float *F1 /*[N][128]*/) {
     __shared__ int nbr[32];
     __shared__ __attribute__((aligned(16))) float h1[32][64];
     const int t = threadIdx.x, lane = t & 63;
+    xyz += (size_t)blockIdx.y * 3 * N; F1 += (size_t)blockIdx.y * N * 128;      // object of a batched launch
     float wrow[64];
 #pragma unroll
     for (int k = 0; k < 64; ++k) wrow[k] = w1[t * 64 + k];
@@ -236,11 +237,15 @@ __global__ __launch_bounds__(256, 1) void pair_kernel(const float *__restrict__ 
 // with it the sa3 feature Z) is the same for every variant and is computed once, in slot 0.  Only "crowded" centres
 // (more than 64 in-radius points: the ball query truncates, and which 64 survive depends on the variant's order) need
 // one value per variant.  crowded[c] in {0,1}; clist = the crowded centres, *ncr their number.
-__global__ __launch_bounds__(1024) void crowd_kernel(const float *__restrict__ xyz, int N, float r2, int *__restrict__ crowded,
-                                                     int *__restrict__ clist, int *__restrict__ ncr, int *__restrict__ off /*[N+1]*/,
-                                                     int *__restrict__ ncr_copy /* optional second home of the count (host readback pool) */) {
+__global__ __launch_bounds__(1024) void crowd_kernel(const float *xyz, int N, float r2, int *crowded,
+                                                     int *clist, int *ncr, int *off /*[N+1]*/,
+                                                     int *ncr_copy /* optional second home of the count (host readback pool) */) {
     __shared__ int wcount[16], wsum[16];
     const int c = threadIdx.x, lane = c & 63, wave = c >> 6;
+    // blockIdx.y: object of a batched launch (pooled per-object arrays at their natural strides; 0 for a single object)
+    const size_t ob = blockIdx.y;
+    xyz += ob * 3 * N; crowded += ob * N; clist += ob * (N + 1); ncr += ob * (N + 1); off += ob * (N + 1);
+    if (ncr_copy) ncr_copy += ob;
     bool cr = false;
     int cnt = 0;
     if (c < N) {
@@ -279,10 +284,12 @@ __global__ __launch_bounds__(1024) void crowd_kernel(const float *__restrict__ x
 
 // Pair list and lookup for T4/T5.  One wave per centre c: rank[c][k] = position of point k among c's in-radius points in
 // index order (or -1), pairs[off[c] + rank] = (c << 16 | k).
-__global__ __launch_bounds__(256) void nbr_fill_kernel(const float *__restrict__ xyz, int N, float r2, const int *__restrict__ off,
-                                                       int *__restrict__ pairs, short *__restrict__ rank /*[N][N]*/) {
+__global__ __launch_bounds__(256) void nbr_fill_kernel(const float *xyz, int N, float r2, const int *off,
+                                                       int *pairs, short *rank /*[N][N]*/) {
     const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= N) return;
+    const size_t ob = blockIdx.y;                      // object of a batched launch (crowd_kernel)
+    xyz += ob * 3 * N; off += ob * (N + 1); pairs += ob * N * N; rank += ob * N * N;
     const float cx = xyz[3 * c], cy = xyz[3 * c + 1], cz = xyz[3 * c + 2];
     const float cn = sq3(cx, cy, cz);
     const int o = off[c];
@@ -1349,8 +1356,8 @@ int pn_fps_table(const float *xyz, int N, int nv, int npoint, int *out, int *fla
     return DGDM_OK;
 }
 
-int pn_sa1(const float *xyz, int N, const PnWeights &w, float *F1, hipStream_t s) {
-    hipLaunchKernelGGL(sa1_kernel, dim3(std::min(N, 1024)), dim3(128), 0, s, xyz, N, w.r1sq, w.sa1_w0t, w.sa1_b0, w.sa1_w1, w.sa1_b1, F1);
+int pn_sa1(const float *xyz, int N, const PnWeights &w, float *F1, hipStream_t s, int nobj) {
+    hipLaunchKernelGGL(sa1_kernel, dim3(std::min(N, 1024), nobj), dim3(128), 0, s, xyz, N, w.r1sq, w.sa1_w0t, w.sa1_b0, w.sa1_w1, w.sa1_b1, F1);
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
 }
@@ -1363,9 +1370,10 @@ int pn_pairs(const float *xyz, int N, const float *U, const PnWeights &w, const 
 }
 
 int pn_crowd(const float *xyz, int N, const PnWeights &w, int *crowded, int *clist, int *ncr, int *off, int *pairs, short *rank, hipStream_t s,
-             int *ncr_copy) {
-    hipLaunchKernelGGL(crowd_kernel, dim3(1), dim3(1024), 0, s, xyz, N, w.r2sq, crowded, clist, ncr, off, ncr_copy);
-    hipLaunchKernelGGL(nbr_fill_kernel, dim3((N + 3) / 4), dim3(256), 0, s, xyz, N, w.r2sq, off, pairs, rank);
+             int *ncr_copy, int nobj) {
+    // nobj > 1: the arrays are pools [nobj][...] at their natural strides (clist and off: N + 1 entries per object, ncr = clist + N)
+    hipLaunchKernelGGL(crowd_kernel, dim3(1, nobj), dim3(1024), 0, s, xyz, N, w.r2sq, crowded, clist, ncr, off, ncr_copy);
+    hipLaunchKernelGGL(nbr_fill_kernel, dim3((N + 3) / 4, nobj), dim3(256), 0, s, xyz, N, w.r2sq, off, pairs, rank);
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
 }

@@ -47,12 +47,13 @@ constexpr int RING64 = 8;
 
 // ------------------------------------------------------------------------------------------------ T2
 // sa1 feature of every point as a centre (pointnet.hip sa1_kernel) -> F1 [N][128] doubles
-__global__ __launch_bounds__(128) void sa1_64_kernel(const float *__restrict__ xyz, int N, float r2, const double *__restrict__ w0t /*[3][64]*/,
+__global__ __launch_bounds__(128) void sa1_64_kernel(const float *xyz, int N, float r2, const double *__restrict__ w0t /*[3][64]*/,
                                                      const double *__restrict__ b0, const double *__restrict__ w1 /*[128][64]*/,
-                                                     const double *__restrict__ b1, double *__restrict__ F1 /*[N][128]*/) {
+                                                     const double *__restrict__ b1, double *F1 /*[N][128]*/) {
     __shared__ int nbr[32];
     __shared__ double h1[32][64];
     const int t = threadIdx.x, lane = t & 63;
+    xyz += (size_t)blockIdx.y * 3 * N; F1 += (size_t)blockIdx.y * N * 128;      // object of a batched launch
     double wrow[64];
 #pragma unroll
     for (int k = 0; k < 64; ++k) wrow[k] = w1[t * 64 + k];
@@ -195,8 +196,8 @@ __global__ __launch_bounds__(256, 2) void z64_kernel(const float *__restrict__ x
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-int pn_sa1_64(const float *xyz, int N, float r1sq, const PnWeights64 &w, double *F1_64, hipStream_t s) {
-    hipLaunchKernelGGL(sa1_64_kernel, dim3(std::min(N, 1024)), dim3(128), 0, s, xyz, N, r1sq, w.sa1_w0t, w.sa1_b0, w.sa1_w1, w.sa1_b1, F1_64);
+int pn_sa1_64(const float *xyz, int N, float r1sq, const PnWeights64 &w, double *F1_64, hipStream_t s, int nobj) {
+    hipLaunchKernelGGL(sa1_64_kernel, dim3(std::min(N, 1024), nobj), dim3(128), 0, s, xyz, N, r1sq, w.sa1_w0t, w.sa1_b0, w.sa1_w1, w.sa1_b1, F1_64);
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
 }
