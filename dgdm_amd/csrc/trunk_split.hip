@@ -287,8 +287,8 @@ __global__ __launch_bounds__(256, 1) void trunk_split_kernel(const TrunkParams p
             }
         }
         // Layers 1-2 block by block: 96 layer-1 MFMAs make one 32-feature block (accumulated from ZERO: the two table terms are added to
-        // the finished sum, one rounding - accumulating on top of them would round every MFMA's contribution at the tables' magnitude,
-        // 7x the error in the pre-activations and measurably more ReLU ties), epilogue (ReLU, sign bits, three-way split), 96 layer-2
+        // the finished sum, one rounding - accumulating on top of them would round every MFMA's contribution at the tables' magnitude
+        // instead of the running sum's: 48 roundings at that size where now there is one), epilogue (ReLU, sign bits, three-way split), 96 layer-2
         // MFMAs.  The table terms of block kb + 1 (finger part + pose-cell part) are loaded and added to each other while block kb's
         // layer-2 MFMAs run, so that neither a load nor its latency sits between the two MFMA phases.
         f32x16 zero, tt;
