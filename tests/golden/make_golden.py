@@ -761,13 +761,14 @@ def g9_f64(parts=None):
             ug = orc.unguided_sample(sc, noise)
             out[f"2d/{name}_chain"] = orc.guided_sample(sc, noise, torch.from_numpy(g["objs"][0]).double(), o, unguided=ug).numpy()
         print("  f64 2d", name, "reference float32 chain vs float64 chain (finger L2)", _spread(g[f"{name}_guided"], out[f"2d/{name}_chain"]), flush=True)
-    for part in ("rotate", "convergence", "multi", "rotate_raw"):
+    for part in ("rotate", "convergence", "multi", "rotate_raw", "convergence_b", "shift_left_b", "ccw_down"):
         f = os.path.join(OUT, f"g9_3d_{part}.npz")
         if not os.path.exists(f) or (parts and ("3d/" + part) not in parts and ("3d/" + part + "_chain") not in parts):
             continue
         g = np.load(f)
         B, G, P, L, T, S, N = [int(v) for v in g["dims"]]
         o, gain = str(g["opt_obj"]), float(g["gain"])
+        oi0 = int(g["obj"]) if "obj" in g.files else 0          # the object of a single-object chain
         sd = f64(synth.scale_output(synth.synth_state_dict(synth.dyn3d_spec(42), DYN3D_SEED), gain))
         sch = orc.DDIM(T)
         sch.set_timesteps(S)
@@ -781,8 +782,8 @@ def g9_f64(parts=None):
             sweep, calls = calls[:2], calls[2:]
             ug = torch.from_numpy(g["unguided"])
             s32 = orc.Setup('point_3d', None, synth.scale_output(synth.synth_state_dict(synth.dyn3d_spec(42), DYN3D_SEED), gain), sch, L, G, P, 512)
-            c = orc.get_convergence_centers(s32, ug, torch.from_numpy(g["objs"][0]), (-1.0, 1.0), orc.StartLog(list(sweep)))
-        objs = [0, 1] if part == "multi" else [0]
+            c = orc.get_convergence_centers(s32, ug, torch.from_numpy(g["objs"][oi0]), (-1.0, 1.0), orc.StartLog(list(sweep)))
+        objs = [0, 1] if part == "multi" else [oi0]
         t0 = time.time()
         res = []
         for k, oi in enumerate(objs):
@@ -802,9 +803,9 @@ def g9_f64(parts=None):
                 # the centre sweep decides discretely (three-class profile): take the float32 centres the recorded run used
                 if o == 'convergence':
                     log = orc.StartLog(tu.unpack_starts(g["starts"].astype(np.int64), g["start_lens"])[2:])
-                    ch = _guided_sample_with_centers(sc, noise, torch.from_numpy(g["objs"][0]).double(), o, c, log)
+                    ch = _guided_sample_with_centers(sc, noise, torch.from_numpy(g["objs"][oi0]).double(), o, c, log)
                 else:
-                    ch = orc.guided_sample(sc, noise, torch.from_numpy(g["objs"][0]).double(), o, starts=log)
+                    ch = orc.guided_sample(sc, noise, torch.from_numpy(g["objs"][oi0]).double(), o, starts=log)
             out[f"3d/{part}_chain"] = ch.numpy()
             print("  f64 3d chain", part, f"{time.time() - t0:.0f}s reference float32 chain vs float64 chain (finger L2)", _spread(g["guided"], ch.numpy()), flush=True)
             np.savez_compressed(path, **out)

@@ -160,8 +160,9 @@ def reference_floor(part):
     ``thread``: the same chain with 4 instead of 8 CPU threads (g9_3d_<part>_alt: some kernels sum in another order - often no change
     at all); ``eps``: its eps-net output perturbed by 1e-6 relative, the eps-net's own distance from a float64 evaluation
     (g9_3d_<part>_eps, two seeds); ``arith``: its classifier trunk accumulating in float64 instead of float32 on the same float32 inputs
-    (g9_3d_<part>_arith) - the rounding pattern any second implementation of the trunk changes.  Returns (max of what exists or None,
-    dict)."""
+    (g9_3d_<part>_arith) - the rounding pattern any second implementation of the trunk changes; ``f64chain``: the distance of its
+    float32 end point from the end point of the whole chain evaluated in float64 (g9_f64: what exact arithmetic gives - an
+    implementation without any rounding error would be this far from the reference).  Returns (max of what exists or None, dict)."""
     alt, eps, ari = _load3d(part + "_alt"), _load3d(part + "_eps"), _load3d(part + "_arith")
     fl = {}
     if alt is not None:
@@ -170,6 +171,9 @@ def reference_floor(part):
         fl["eps"] = float(eps["eps_floor"])
     if ari is not None:
         fl["arith"] = float(ari["arith_floor"])
+    c64, g = chain64("3d/" + part), _load3d(part)
+    if c64 is not None and g is not None:                # the reference's float32 chain against the whole chain in float64 (g9_f64)
+        fl["f64chain"] = finger_l2(g["guided"], c64)
     return (max(fl.values()) if fl else None), fl
 
 
@@ -242,10 +246,12 @@ def test_fullgrid_3d(dev, part):
     tol = None
     if floor is not None:
         tol = max(NORTH_STAR, CHAIN_GAIN * seen) if floor < FLOOR_CLEAN else max(NORTH_STAR, 2.0 * floor, CHAIN_GAIN * seen)
+    c64 = chain64(f"3d/{part}")
+    d_hip64 = finger_l2(out, c64) if c64 is not None else None
     _report({f"3d/{part}": dict(opt_obj=o, gain=gain, object=oi, reference_floors=floors, ties_seen_budget=seen, end_point_tolerance=tol,
-                                hip_vs_reference=err, step_grad_rel=[float(e) for e in errs], grad0_reference_vs_f64=noise64, grad0_hip_vs_f64=hip64)})
+                                hip_vs_reference=err, hip_vs_chain64=d_hip64, step_grad_rel=[float(e) for e in errs], grad0_reference_vs_f64=noise64, grad0_hip_vs_f64=hip64)})
     print(f"3d {part:14s} gain {gain:.4g} | end point: HIP vs reference {err:.2e} (tolerance {'none' if tol is None else '%.2e' % tol}: the reference's own floors {floors}, ties seen in the "
-          f"replayed calls push x by {seen:.1e}) | per-call gradient HIP vs reference {[float('%.1e' % e) for e in errs]}; first step vs float64: "
+          f"replayed calls push x by {seen:.1e}); HIP vs the float64 chain {d_hip64} | per-call gradient HIP vs reference {[float('%.1e' % e) for e in errs]}; first step vs float64: "
           f"reference {noise64} HIP {hip64}")
     if chaotic:
         assert np.median(errs) < TIE_GRAD          # the chain itself is chaotic: only the recorded steps are compared, at tie level
@@ -255,6 +261,8 @@ def test_fullgrid_3d(dev, part):
         assert hip64 <= max(ROUNDING, 1.5 * noise64) or hip64 < TIE_GRAD, (part, hip64, noise64)
     assert tol is not None, f"no reference floor recorded for {part} (make_golden.py g9_3d:{part}_alt / g9_3d_eps:{part})"
     assert err < tol, (part, err, floors, seen)
+    if d_hip64 is not None:       # against the chain in exact arithmetic: as close as the reference is (x 1.5), or what the seen ties explain
+        assert d_hip64 <= max(NORTH_STAR, 1.5 * floors["f64chain"], CHAIN_GAIN * seen), (part, d_hip64, floors["f64chain"], seen)
 
 
 @pytest.mark.parametrize("part", ["rotate", "convergence", "multi"])
