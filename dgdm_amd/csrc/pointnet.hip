@@ -902,6 +902,10 @@ __global__ __launch_bounds__(256) void xobj_kernel(const XobjParams p) {
 // wave at a time; a row's slot list (cl2s[q], padded with its last entry, so over-reading is idempotent) sits in registers and
 // is broadcast inside the row's lane group.  Same max, same operands: bit-identical to xobj_fast_kernel.
 constexpr int XG_LDS_BYTES = 78 * 1024;
+#ifndef DGDM_XG_WAVES
+#define DGDM_XG_WAVES 8
+#endif
+constexpr int XG_WAVES = DGDM_XG_WAVES;      // waves per workgroup: two workgroups per CU (LDS), so 16 waves per CU hide the per-row LDS round trips (4: 8 waves)
 
 int xobj_group_lpr(int ncr, bool bf16) {
     const int W = bf16 ? 128 : 256;                                   // dwords per table row
@@ -920,7 +924,7 @@ __device__ __forceinline__ void xobj_group_body(const XobjParams &p, const XobjC
     const int g0 = goff[s1], gn = goff[s1 + 1] - g0;
     if (gn == 0) return;                                               // no row of this chain drew s1 (workgroup-uniform)
     const uint32_t *Zs = (BF16 ? ch.Z16 : reinterpret_cast<const uint32_t *>(ch.Z)) + ((size_t)(ch.slot_of_start ? ch.slot_of_start[s1] : s1) * ch.N) * W + f0;
-    // ---- row metadata of this wave's rows, one row per lane (row k = kb + wave + 4 * lane, 256 rows of the group per pass): the first
+    // ---- row metadata of this wave's rows, one row per lane (row k = kb + wave + XG_WAVES * lane, 64 * XG_WAVES rows of the group per pass): the first
     //      pass issues them before the slab loads so that the chain of dependent lookups (row id -> s2 -> start point q -> flag, count)
     //      overlaps them.  A group holds ~70 rows when the launch covers one denoise step and ~350 when it covers all five.
     const int *ord = p.order + (size_t)chain * p.R + g0;
@@ -937,8 +941,8 @@ __device__ __forceinline__ void xobj_group_body(const XobjParams &p, const XobjC
         }
         return o;
     };
-    for (int kb = 0; kb < gn; kb += 256) {
-        const int myk = kb + wave + 4 * lane;
+    for (int kb = 0; kb < gn; kb += 64 * XG_WAVES) {
+        const int myk = kb + wave + XG_WAVES * lane;
         const bool have = myk < gn;
         const int r_v = have ? ord[myk] : 0;
         const int q_v = have ? ch.fps1[(size_t)s1 * 512 + st[2 * r_v + 1]] : 0;      // start point of sa2's FPS
@@ -947,16 +951,16 @@ __device__ __forceinline__ void xobj_group_body(const XobjParams &p, const XobjC
         if (kb == 0) {
             // ---- stage the slab chunk: piece i = (centre i / LPR, 16-byte part i % LPR)
             const int pieces = ch.ncr * LPR;
-            for (int i0 = threadIdx.x; i0 < pieces; i0 += 256 * 8) {
+            for (int i0 = threadIdx.x; i0 < pieces; i0 += 64 * XG_WAVES * 8) {
                 u4 v[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const int i = i0 + 256 * k;
+                    const int i = i0 + 64 * XG_WAVES * k;
                     if (i < pieces) v[k] = *reinterpret_cast<const u4 *>(Zs + (size_t)ch.clist[i / LPR] * W + (i % LPR) * 4);
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const int i = i0 + 256 * k;
+                    const int i = i0 + 64 * XG_WAVES * k;
                     if (i < pieces) *reinterpret_cast<u4 *>(slab + (size_t)i * 4) = v[k];
                 }
             }
@@ -964,7 +968,7 @@ __device__ __forceinline__ void xobj_group_body(const XobjParams &p, const XobjC
         if (chunk == 0 && have && slow_v) p.todo[atomicAdd(p.todo_count, 1)] = (int)((int64_t)chain * p.R + r_v);
         if (kb == 0) __syncthreads();
         // ---- one row at a time per wave (uniform control flow); the wave's 64 lanes read RPW slots' pieces per ds_read_b128
-        const int nmine = min(64, (gn - kb - wave + 3) / 4);               // rows of this wave held in lanes
+        const int nmine = min(64, (gn - kb - wave + XG_WAVES - 1) / XG_WAVES);               // rows of this wave held in lanes
         // rows in batches of four: the four slot lists and M0 pieces are requested together (the per-row lookups are L2-latency bound)
         for (int i0 = 0; i0 < nmine; i0 += 4) {
             int SA[4], SB[4];
@@ -1012,7 +1016,7 @@ __device__ __forceinline__ void xobj_group_body(const XobjParams &p, const XobjC
 }
 
 template <bool BF16>
-__global__ __launch_bounds__(256, 2) void xobj_group_kernel(const XobjParams p) {
+__global__ __launch_bounds__(64 * XG_WAVES, 2) void xobj_group_kernel(const XobjParams p) {
     extern __shared__ uint32_t xg_slab[];
     // work item -> (chain, s1, chunk): chains own contiguous item ranges (item_base ascending)
     const int item = blockIdx.x;
@@ -1042,8 +1046,8 @@ int pn_xobj_groups(const XobjParams &p, hipStream_t s) {
         attr_set = true;
     }
     DGDM_HIP_CHECK(hipMemsetAsync(p.todo_count, 0, sizeof(int), s));
-    if (p.xobj16) hipLaunchKernelGGL(xobj_group_kernel<true>, dim3((unsigned)p.total_items), dim3(256), XG_LDS_BYTES, s, p);
-    else hipLaunchKernelGGL(xobj_group_kernel<false>, dim3((unsigned)p.total_items), dim3(256), XG_LDS_BYTES, s, p);
+    if (p.xobj16) hipLaunchKernelGGL(xobj_group_kernel<true>, dim3((unsigned)p.total_items), dim3(64 * XG_WAVES), XG_LDS_BYTES, s, p);
+    else hipLaunchKernelGGL(xobj_group_kernel<false>, dim3((unsigned)p.total_items), dim3(64 * XG_WAVES), XG_LDS_BYTES, s, p);
     DGDM_HIP_CHECK(hipGetLastError());
     // the rows it recorded (tie-flagged start points) run their own FPS
     XobjParams q = p;
