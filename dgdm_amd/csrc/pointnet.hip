@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void l2_kernel(const float *__restrict__ xyz, 
 // staged in LDS once (in feature chunks of F floats when K KB do not fit), the first-64 selections of all variants are computed
 // once (l2_select, kept as bytes: K <= 255) and every variant's max is taken out of LDS.  Same operands, same max: bit-identical
 // to l2_kernel.  Centres with K > 255 (none on 512-point clouds so far) are left to l2_kernel (kmax tells the host).
-constexpr int L2C_YBYTES = 120 * 1024, L2C_THREADS = 512;
+constexpr int L2C_YBYTES = 120 * 1024, L2C_THREADS = 1024;     // 16 waves per CU (one workgroup per CU by LDS): the per-variant row reads are LDS-latency-bound
 
 template <bool BF16, int LPR>
 __device__ __forceinline__ void l2c_reduce(const uint32_t *ych, const unsigned char *selv, int cnt, uint32_t *dst, int lane) {
