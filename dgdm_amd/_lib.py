@@ -97,6 +97,18 @@ PROTOTYPES = {
     "dgdm_trainer2d_running_stats": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
     "dgdm_trainer2d_export": (C.c_int, [_P, C.c_int, C.POINTER(Tensor), C.c_int]),
     "dgdm_trainer2d_steps": (C.c_int64, [_P]),
+    "dgdm_unet_trainer_create": (C.c_int, [C.POINTER(_P), C.POINTER(Tensor), C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_float, C.c_float, C.c_float, C.c_float]),
+    "dgdm_unet_trainer_destroy": (None, [_P]),
+    "dgdm_unet_trainer_step": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_float, _P, C.POINTER(C.c_float), _P]),
+    "dgdm_unet_trainer_forward_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int64, C.c_int, _P, C.POINTER(C.c_float), _P]),
+    "dgdm_unet_trainer_gradient_count": (C.c_int64, [_P]),
+    "dgdm_unet_trainer_gradients": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_float, _P]),
+    "dgdm_unet_trainer_apply": (C.c_int, [_P, C.c_float, _P]),
+    "dgdm_unet_trainer_ema_step": (C.c_int, [_P, C.c_float, C.c_float, _P]),
+    "dgdm_unet_trainer_export": (C.c_int, [_P, C.c_int, C.POINTER(Tensor), C.c_int]),
+    "dgdm_unet_trainer_import": (C.c_int, [_P, C.c_int, C.POINTER(Tensor), C.c_int, C.c_int64]),
+    "dgdm_unet_trainer_steps": (C.c_int64, [_P]),
 }
 
 _lib = None

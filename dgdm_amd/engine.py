@@ -55,6 +55,83 @@ class Unet1d:
         return out
 
 
+class UnetTrainer:
+    """Training state of the eps-net on the device (csrc/unet_train.hip): parameters, gradients, Adam moments and the EMA copy, with
+    one call per ``Diffusion.get_stats`` + backward + ``torch.optim.Adam`` step (generator/diffusion.py:126-177, 711-724)."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], num_points: int, down_dims: Sequence[int] = (128, 256), step_embed_dim: int = 32,
+                 kernel_size: int = 5, n_groups: int = 8, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+        self._keys = {k: tuple(v.shape) for k, v in state_dict.items()}
+        packed = _lib.PackedStateDict(state_dict)
+        dd = (C.c_int32 * len(down_dims))(*down_dims)
+        h = C.c_void_p()
+        check(lib().dgdm_unet_trainer_create(C.byref(h), packed.array, packed.n, num_points, dd, len(down_dims), step_embed_dim, kernel_size, n_groups,
+                                             betas[0], betas[1], eps, weight_decay))
+        self._h, self.num_points = h, num_points
+
+    def __del__(self):
+        if getattr(self, "_h", None) and lib is not None:
+            lib().dgdm_unet_trainer_destroy(self._h)
+            self._h = None
+
+    def _args(self, x0, noise, sqrt_abar, sqrt_1m_abar, timesteps):
+        dev = torch.device("cuda", torch.cuda.current_device())
+        f = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()      # noqa: E731
+        x0, noise = f(x0).reshape(x0.shape[0], -1), f(noise).reshape(x0.shape[0], -1)
+        assert x0.shape[1] == self.num_points and noise.shape == x0.shape
+        return x0, noise, f(sqrt_abar), f(sqrt_1m_abar), timesteps.detach().to(device=dev, dtype=torch.int64).contiguous()
+
+    def step(self, x0, noise, sqrt_abar, sqrt_1m_abar, timesteps, lr: float, want_pred: bool = False, want_loss: bool = True):
+        """One optimisation step; returns (loss or None, noise_pred (B, L, 1) or None)."""
+        a = self._args(x0, noise, sqrt_abar, sqrt_1m_abar, timesteps)
+        B = a[0].shape[0]
+        pred = torch.empty_like(a[0]) if want_pred else None
+        loss = C.c_float()
+        check(lib().dgdm_unet_trainer_step(self._h, *[dptr(v) for v in a], B, float(lr), dptr(pred), C.byref(loss) if want_loss else None, stream_ptr()))
+        return (float(loss.value) if want_loss else None), (pred.reshape(B, -1, 1) if want_pred else None)
+
+    def forward_backward(self, x0, noise, sqrt_abar, sqrt_1m_abar, timesteps, total_samples: Optional[int] = None, backward: bool = True,
+                         want_pred: bool = False):
+        a = self._args(x0, noise, sqrt_abar, sqrt_1m_abar, timesteps)
+        B = a[0].shape[0]
+        pred = torch.empty_like(a[0]) if want_pred else None
+        loss = C.c_float()
+        check(lib().dgdm_unet_trainer_forward_backward(self._h, *[dptr(v) for v in a], B, int(total_samples or B), 1 if backward else 0, dptr(pred),
+                                                       C.byref(loss), stream_ptr()))
+        return float(loss.value), (pred.reshape(B, -1, 1) if want_pred else None)
+
+    def gradient_count(self) -> int:
+        return int(lib().dgdm_unet_trainer_gradient_count(self._h))
+
+    def read_gradients(self) -> torch.Tensor:
+        flat = torch.empty(self.gradient_count(), dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
+        check(lib().dgdm_unet_trainer_gradients(self._h, dptr(flat), flat.numel(), 0, 1.0, stream_ptr()))
+        return flat
+
+    def write_gradients(self, flat: torch.Tensor, scale: float = 1.0) -> None:
+        check(lib().dgdm_unet_trainer_gradients(self._h, dptr(flat), flat.numel(), 1, float(scale), stream_ptr()))
+
+    def apply(self, lr: float) -> None:
+        check(lib().dgdm_unet_trainer_apply(self._h, float(lr), stream_ptr()))
+
+    def ema_step(self, decay: float) -> None:
+        check(lib().dgdm_unet_trainer_ema_step(self._h, float(decay), float(1 - decay), stream_ptr()))
+
+    def steps(self) -> int:
+        return int(lib().dgdm_unet_trainer_steps(self._h))
+
+    def export(self, which: int = 0) -> Dict[str, torch.Tensor]:
+        """which: 0 parameters, 1 gradients, 2 / 3 Adam's exp_avg / exp_avg_sq, 4 the EMA copy (host tensors, the U-Net's own keys)."""
+        host = {k: torch.empty(shp, dtype=torch.float32) for k, shp in self._keys.items()}
+        packed = _lib.PackedStateDict(host)
+        check(lib().dgdm_unet_trainer_export(self._h, which, packed.array, packed.n))
+        return {n.decode(): torch.from_numpy(a.copy()).reshape(self._keys[n.decode()]) for n, a in zip(packed.names, packed.keep)}
+
+    def load(self, which: int, state_dict: Dict[str, torch.Tensor], adam_steps: int = -1) -> None:
+        packed = _lib.PackedStateDict(state_dict)
+        check(lib().dgdm_unet_trainer_import(self._h, which, packed.array, packed.n, adam_steps))
+
+
 class Dynamics:
     """``ProfileForward2DModel`` (kind 2) / ``ProfileForward3DModel`` (kind 3) on the device."""
 

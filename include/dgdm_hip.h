@@ -368,6 +368,45 @@ int dgdm_trainer2d_running_stats(DgdmTrainer2d *m, float *flat_dev, int64_t nume
 int dgdm_trainer2d_export(DgdmTrainer2d *m, int which, DgdmTensor *tensors, int n_tensors);
 int64_t dgdm_trainer2d_steps(const DgdmTrainer2d *m);      /* training steps taken = BatchNorm's num_batches_tracked increment */
 
+/* ------------------------------------------------------------------ (f) rank 4: training the eps-net
+ * Diffusion.get_stats / training_step (generator/diffusion.py:126-177) for the ConditionalUnet1D of generator/train.py:80
+ * (generator/diffusion_utils.py:123-285; input_dim 1, down_dims [128, 256], kernel 5, 8 groups), torch.optim.Adam
+ * (diffusion.py:711-714) and the EMA copy of diffusers' EMAModel (diffusion.py:716-724).  Parameters, gradients, both Adam moments and the
+ * EMA copy live on the device in the state_dict's own tensor layouts (keys as ConditionalUnet1D.state_dict() gives them).          */
+typedef struct DgdmUnetTrainer DgdmUnetTrainer;
+int dgdm_unet_trainer_create(DgdmUnetTrainer **out, const DgdmTensor *state_dict, int n_tensors, int num_points, const int32_t *down_dims,
+                             int n_down, int diffusion_step_embed_dim, int kernel_size, int n_groups, float beta1, float beta2, float eps,
+                             float weight_decay);
+void dgdm_unet_trainer_destroy(DgdmUnetTrainer *m);
+/* One training step on `samples` samples: noisy = sqrt_abar[s] * x0 + sqrt_1m_abar[s] * noise (DDIMScheduler.add_noise, :144-148),
+ * noise_pred = eps-net(noisy, timesteps) (:151-160), loss = F.mse_loss(noise_pred, noise) (:164), backward, one Adam update with
+ * learning rate lr.  x0_dev, noise_dev [samples][num_points]; sqrt_abar_dev, sqrt_1m_abar_dev [samples]; timesteps_dev [samples]
+ * int64; pred_dev (optional) [samples][num_points] receives noise_pred; loss_host (optional) receives the loss and makes the call
+ * synchronous, like loss.item().  Deterministic: same inputs, same bits.                                                           */
+int dgdm_unet_trainer_step(DgdmUnetTrainer *m, const float *x0_dev, const float *noise_dev, const float *sqrt_abar_dev,
+                           const float *sqrt_1m_abar_dev, const int64_t *timesteps_dev, int samples, float lr, float *pred_dev,
+                           float *loss_host, void *stream);
+/* The same without the update: forward (+ backward when backward != 0) on this rank's `samples` of a batch of `total_samples`
+ * (d loss / d pred = 2 (pred - noise) / (total_samples num_points); *loss_host = this rank's share of the batch loss).  With
+ * dgdm_unet_trainer_gradients (flat gradient buffer device -> flat_dev, or flat_dev -> device scaled by `scale` when to_trainer) and
+ * dgdm_unet_trainer_apply (one Adam update) this is data-parallel training, one process per GPU, with an RCCL all-reduce in between
+ * (Lightning's DDP averages the ranks' gradients: total_samples = samples, scale = 1 / world).                                      */
+int dgdm_unet_trainer_forward_backward(DgdmUnetTrainer *m, const float *x0_dev, const float *noise_dev, const float *sqrt_abar_dev,
+                                       const float *sqrt_1m_abar_dev, const int64_t *timesteps_dev, int samples, int64_t total_samples,
+                                       int backward, float *pred_dev, float *loss_host, void *stream);
+int64_t dgdm_unet_trainer_gradient_count(const DgdmUnetTrainer *m);
+int dgdm_unet_trainer_gradients(DgdmUnetTrainer *m, float *flat_dev, int64_t numel, int to_trainer, float scale, void *stream);
+int dgdm_unet_trainer_apply(DgdmUnetTrainer *m, float lr, void *stream);
+/* EMAModel.step (diffusers 0.11.1, called from on_train_batch_end, diffusion.py:716-720): ema = ema * decay + one_minus_decay * param
+ * for every parameter; the decay schedule (power, update_after_step) is the caller's.                                              */
+int dgdm_unet_trainer_ema_step(DgdmUnetTrainer *m, float decay, float one_minus_decay, void *stream);
+/* which = 0 parameters, 1 gradients of the last backward, 2 / 3 Adam's exp_avg / exp_avg_sq, 4 the EMA copy; tensors are matched by
+ * name and written (export: data is written despite the const) or read (import; adam_steps >= 0 also sets Adam's step count -
+ * resuming from a checkpoint).                                                                                                      */
+int dgdm_unet_trainer_export(DgdmUnetTrainer *m, int which, DgdmTensor *tensors, int n_tensors);
+int dgdm_unet_trainer_import(DgdmUnetTrainer *m, int which, const DgdmTensor *tensors, int n_tensors, int64_t adam_steps);
+int64_t dgdm_unet_trainer_steps(const DgdmUnetTrainer *m);      /* Adam updates taken */
+
 #ifdef __cplusplus
 }
 #endif

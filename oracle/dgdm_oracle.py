@@ -700,3 +700,85 @@ class Trainer2D:
             noisy, t = self._noisy(ctrl, forced)
             pred = self._forward(self.sd, noisy, input_ori, input_pos, t, object_vertices, False)
             return pred, float(F.mse_loss(pred, score))
+
+
+# =========================================================================== (f) rank 4  training the eps-net
+class EMAModel:
+    """``diffusers.training_utils.EMAModel`` of diffusers 0.11.1 (requirements.txt:1; constructed at generator/diffusion.py:83-87 with
+    ``power`` / ``update_after_step``, stepped from ``on_train_batch_end`` :716-720), restated from the published code over a flat
+    state_dict: ``decay = 0`` while ``step <= 0`` with ``step = max(0, optimization_step - update_after_step - 1)``, else
+    ``1 - (1 + step / inv_gamma) ** -power`` clamped to ``[min_value, max_value]``; every parameter ``ema = ema * decay + (1 - decay) *
+    param`` (``mul_`` then ``add_(param, alpha=1 - decay)``); then ``optimization_step += 1``.  diffusers is absent from this image:
+    **parity unpinned**, like the DDIM scheduler."""
+
+    def __init__(self, sd: SD, update_after_step: int = 0, inv_gamma: float = 1.0, power: float = 2 / 3, min_value: float = 0.0,
+                 max_value: float = 0.9999):
+        self.averaged = {k: v.clone() for k, v in sd.items()}
+        self.update_after_step, self.inv_gamma, self.power = update_after_step, inv_gamma, power
+        self.min_value, self.max_value = min_value, max_value
+        self.decay, self.optimization_step = 0.0, 0
+
+    def get_decay(self, optimization_step: int) -> float:
+        step = max(0, optimization_step - self.update_after_step - 1)
+        value = 1 - (1 + step / self.inv_gamma) ** -self.power
+        if step <= 0:
+            return 0.0
+        return max(self.min_value, min(value, self.max_value))
+
+    def step(self, sd: SD) -> None:
+        self.decay = self.get_decay(self.optimization_step)
+        for k, p in sd.items():
+            e = self.averaged[k]
+            e.mul_(self.decay)
+            e.add_(p, alpha=1 - self.decay)
+        self.optimization_step += 1
+
+
+class UnetTrainer:
+    """Training of the eps-net as ``Diffusion`` does it under Lightning's automatic optimisation, restated functionally over a flat
+    state_dict: ``get_stats`` (generator/diffusion.py:126-166: ``torch.randn`` noise then ``torch.randint`` timesteps from the CPU
+    generator, ``DDIMScheduler.add_noise``, the U-Net, ``F.mse_loss(noise_pred, noise)``), ``training_step`` (:168-177), the
+    optimiser of ``configure_optimizers`` (:711-714: ``torch.optim.Adam(lr)`` with torch's defaults, betas (0.9, 0.999), eps 1e-8, no
+    weight decay; written out in the single-tensor form of torch 2.x) and ``on_train_batch_end`` (:716-724: ``EMAModel.step``).
+    ``num_timesteps_per_batch`` is 1 (the constructor default, never overridden by generator/train.py)."""
+
+    def __init__(self, sd: SD, num_train_timesteps: int, num_points: int, lr: float, betas=(0.9, 0.999), eps: float = 1e-8,
+                 ema_power: float = 0.75, ema_update_after_step: int = 0):
+        self.sd = {k: v.clone() for k, v in sd.items()}
+        self.names = list(self.sd.keys())
+        self.ddim = DDIM(num_train_timesteps)
+        self.L, self.lr, self.betas, self.eps = num_points, lr, betas, eps
+        self.m = {k: torch.zeros_like(v) for k, v in self.sd.items()}
+        self.v = {k: torch.zeros_like(v) for k, v in self.sd.items()}
+        self.t = 0
+        self.grads: SD = {}
+        self.draws = None
+        self.ema = EMAModel(self.sd, update_after_step=ema_update_after_step, power=ema_power)
+
+    def get_stats(self, x0: torch.Tensor, forced=None, sd: Optional[SD] = None):
+        B = x0.shape[0]
+        if forced is None:
+            noise = torch.randn((B, self.L, 1))                                            # diffusion.py:134
+            timesteps = torch.randint(0, self.ddim.num_train_timesteps, (B,)).long()       # :137-142
+        else:
+            noise, timesteps = forced
+        self.draws = (noise, timesteps)
+        noisy = self.ddim.add_noise(x0, noise, timesteps)                                  # :146-150
+        pred = unet1d_forward(self.sd if sd is None else sd, noisy, timesteps)             # :153-157
+        return F.mse_loss(pred, noise), pred                                               # :164
+
+    def step(self, x0: torch.Tensor, forced=None):
+        leaf = {k: self.sd[k].clone().requires_grad_(True) for k in self.names}
+        loss, pred = self.get_stats(x0, forced, leaf)
+        grads = torch.autograd.grad(loss, [leaf[k] for k in self.names])
+        self.grads = dict(zip(self.names, grads))
+        self.t += 1
+        b1, b2 = self.betas
+        bc1, bc2 = 1 - b1 ** self.t, 1 - b2 ** self.t
+        for k in self.names:
+            g = self.grads[k]
+            self.m[k] = self.m[k] + (g - self.m[k]) * (1 - b1)
+            self.v[k] = self.v[k] * b2 + (1 - b2) * g * g
+            self.sd[k] = self.sd[k] - (self.lr / bc1) * self.m[k] / (self.v[k].sqrt() / math.sqrt(bc2) + self.eps)
+        self.ema.step(self.sd)
+        return float(loss.detach()), pred.detach()

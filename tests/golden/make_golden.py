@@ -610,6 +610,86 @@ def g9_3d(parts=("rotate", "rotate_alt", "convergence", "multi", "convergence_al
             np.savez_compressed(os.path.join(OUT, f"g9_3d_{part}.npz"), **out)
 
 
+# round 4: a SAMPLE of calibrated full-grid 3-D chains (objects x objectives x gains) so that the north-star statement of
+# tests/test_gpu_fullgrid.py is a statement about a distribution, not about six chains.  name -> (opt_obj, gain, object index | (i, j) for
+# the multi-object loop).  Objects are synth_object_3d(50 + i), i = 0..3.
+G9_3D_DIST = {
+    "d00": ("rotate", 0.03, 2), "d01": ("shift_up", 0.001, 0), "d02": ("clockwise_up", 0.0005, 1), "d03": ("convergence", 0.002, 2),
+    "d04": ("rotate_clockwise", 0.001, 0), "d05": ("shift_right", 0.001, 3), "d06": ("counterclockwise_left", 0.001, 0),
+    "d07": ("rotate", 0.02, 3), "d08": ("shift_down", 0.002, 2), "d09": ("rotate_counterclockwise", 0.002, 1),
+    "d10": ("clockwise_left", 0.001, 2), "d11": ("shift_left", 0.002, (2, 3)), "d12": ("counterclockwise_up", 0.0005, 3),
+    "d13": ("convergence", 0.001, 3), "d14": ("rotate", 0.03, 1), "d15": ("clockwise_down", 0.0005, 3),
+    "d16": ("rotate_clockwise", 0.0005, 2), "d17": ("counterclockwise_right", 0.001, 1), "d18": ("shift_up", 0.002, 3),
+}
+
+
+def g9_3d_dist(parts=None, B=2, tag=""):
+    """The reference's own guided_sample / guided_sample_multi_object at the full per-finger grid of BASELINE configs[2] (G=45, P=5,
+    sub_bs=512), free-running, with per-step traces and recorded FPS draws, for the chains of G9_3D_DIST (generator/diffusion.py:541-580,
+    621-647).  One file per chain, written as soon as the chain is done; a chain whose file exists is skipped.  GOLDEN_THREADS sets the
+    CPU threads (default 8).  '<name>:eps' re-runs a chain with its eps-net output multiplied by (1 + 1e-6 N(0,1)) (as g9_3d_eps does):
+    the reference's own reproducibility under a perturbation of the size of any second float32 eps-net."""
+    import time
+    threads = int(os.environ.get("GOLDEN_THREADS", "8"))
+    unet = make_unet()
+    objs = torch.stack([synth.synth_object_3d(50 + i) for i in range(4)])
+    G, P, L, T, S = 45, 5, 42, 15, 5
+    noise = synth.synth_noise(0, B, L)
+    for part in (parts or list(G9_3D_DIST)):
+        eps_run = part.endswith("+eps")
+        name = part[:-4] if eps_run else part
+        o, gain, oi = G9_3D_DIST[name]
+        multi = isinstance(oi, tuple)
+        path = os.path.join(OUT, f"g9_3d_{tag}{name}{'_eps' if eps_run else ''}.npz")
+        if os.path.exists(path):
+            continue
+        d = make_diffusion('point_3d', unet, _scaled_output(make_dyn3d(), gain), T, S, L, G, P, objs[:1], 512)
+        xs = _unguided(d, noise, B)
+        out = dict(dims=np.array([B, G, P, L, T, S, 512]), unguided=xs.numpy(), unet_seed=UNET_SEED, dyn3d_seed=DYN3D_SEED,
+                   gain=np.float64(gain), opt_obj=o, threads=threads, obj=np.array(oi, np.int64).reshape(-1), obj_seed0=np.int64(50))
+        hook = None
+        if eps_run:
+            gen = torch.Generator().manual_seed(1)
+            hook = d.noise_pred_net.register_forward_hook(lambda m, i, out_: out_ * (1.0 + 1e-6 * torch.randn(out_.shape, generator=gen)))
+        torch.set_num_threads(threads)
+        torch.manual_seed(0)
+        t0 = time.time()
+        tr = StepTrace(d)
+        with RandintSpy() as spy:
+            if multi:
+                d.object_vertices, d.object_ids = objs[list(oi)], list(oi)
+                res = run_chain(lambda: d.guided_sample_multi_object(0, B, noise, "/tmp/dgdm_golden", opt_obj=o, ori_range=[-1.0, 1.0]))
+            else:
+                d.object_vertices, d.object_ids = objs[oi:oi + 1], [oi]
+                res = run_chain(lambda: d.guided_sample(0, B, noise, "/tmp/dgdm_golden", opt_obj=o, ori_range=[-1.0, 1.0], unguided_sample=xs))
+        tr.close()
+        if hook is not None:
+            hook.remove()
+        end = np.concatenate(res, axis=0) if multi else res[0]
+        st, ln = _pack_starts16(spy)
+        if eps_run:
+            ref = np.load(os.path.join(OUT, f"g9_3d_{tag}{name}.npz"))
+            assert np.array_equal(st, ref["starts"]), "the perturbed run must see the recorded FPS draws"
+            fl = _spread(end, ref["guided"])
+            np.savez_compressed(path, guided=end, eps_floor=np.float64(fl), rel=np.float64(1e-6))
+            print("  3d dist", part, f"{time.time() - t0:.0f}s eps spread (finger L2)", fl, flush=True)
+            continue
+        tr.pack("trace", out)
+        out["guided"], out["starts"], out["start_lens"] = end, st, ln
+        # size of the guidance term against eps at the first step: the calibration the gains aim at (0.1 .. 1)
+        a0 = float((1 - d.noise_scheduler.alphas_cumprod[d.noise_scheduler.timesteps[0]]).sqrt())
+        sc = _ref_diffusion.SCALE_3D_CONV if o == 'convergence' else _ref_diffusion.SCALE_3D
+        out["guidance_over_eps"] = np.float64(a0 * sc * np.linalg.norm(out["trace_grad"][0]) / np.linalg.norm(out["trace_eps"][0]))
+        np.savez_compressed(path, **out)
+        print("  3d dist", part, o, gain, oi, f"{time.time() - t0:.0f}s guidance/eps", out["guidance_over_eps"], flush=True)
+
+
+def g9_3d_full(parts=None):
+    """ONE reference chain at BASELINE configs[2]'s own size: B = 32 fingers, G = 45, P = 5 (R = 36 000 rows, 71 sub-batches of 512 per
+    cond_fn call, 5 steps) - 'd01' of G9_3D_DIST at B = 32.  Hours of CPU; run in the background."""
+    g9_3d_dist(parts or ("d01",), B=32, tag="full_")
+
+
 def g9_3d_eps(parts=("rotate", "convergence", "multi", "convergence_b", "shift_left_b", "ccw_down"), rel=1e-6, seeds=(1, 2)):
     """How far does the REFERENCE's own end point move when its eps-net output is perturbed at the level of its own float32 rounding
     error?  The reference's eps-net is 0.8e-6 .. 1.3e-6 (relative L2) from a float64 evaluation (scripts/exp_attrib.py), and so is any
@@ -1010,6 +1090,58 @@ def g10_train2d():
     np.savez_compressed(os.path.join(OUT, "g10_train2d.npz"), **out)
 
 
+def g12_unet_train():
+    """The reference's own ``Diffusion.get_stats`` (generator/diffusion.py:126-166) driven the way Lightning's automatic optimisation
+    drives ``training_step`` (:168-177) with the optimiser / scheduler of ``configure_optimizers`` (:711-714): per batch
+    ``loss = get_stats(batch)['loss']; optimizer.zero_grad(); loss.backward(); optimizer.step()``; the cosine schedule (stepped per
+    epoch by Lightning) is stepped once before the third batch.  Two cases: 'point' (L = 14, 5 samples) and 'point_3d' (L = 42, 6
+    samples).  Kept: the batch, losses and noise predictions of the three steps, and per parameter tensor a fixed sample of entries plus
+    its float64 sum / sum of squares - of the gradients after step 1 and of the values after step 3.  (EMAModel is a diffusers class
+    and not part of this fixture: parity unpinned, see oracle.EMAModel.)"""
+    out = {"unet_seed": np.int64(UNET_SEED), "torch_seed": np.int64(4321), "lr": np.float64(1e-4), "num_epochs": np.int64(100),
+           "num_train_timesteps": np.int64(15)}
+    for tag, mode, L, B in (("p2", "point", 14, 5), ("p3", "point_3d", 42, 6)):
+        unet = make_unet().train()
+        for p_ in unet.parameters():
+            p_.requires_grad_(True)
+        sched = DDIMScheduler(num_train_timesteps=15)
+        d = Diffusion(noise_pred_net=unet, noise_scheduler=sched, num_inference_steps=5, num_epochs=100, mode=mode, input_dim=1, num_points=L,
+                      learning_rate=1e-4, lr_warmup_steps=0, ema_power=0.85)
+        d.train()
+        d.configure_optimizers()
+        x0 = torch.from_numpy(np.random.RandomState(77 + L).uniform(-1, 1, (B, L, 1)).astype(np.float32))
+        out[f"{tag}_x0"], out[f"{tag}_dims"] = x0.numpy(), np.array([B, L])
+        torch.manual_seed(4321)
+        names = [k for k, _ in unet.named_parameters()]
+        for step in range(3):
+            if step == 2:
+                d.lr_scheduler.step()
+            # the draws get_stats is about to make (torch.randn, then torch.randint): recorded by replaying them on a copy of the state
+            st = torch.get_rng_state()
+            noise = torch.randn((B, L, 1))
+            ts = torch.randint(0, 15, (B,)).long()
+            torch.set_rng_state(st)
+            stats = d.get_stats(x0)
+            loss = stats["loss"]
+            d.optimizer.zero_grad()
+            loss.backward()
+            if step == 0:
+                for k, prm in unet.named_parameters():
+                    g = prm.grad.detach().double().flatten()
+                    out[f"{tag}_grad/{k}"] = g[sample_idx(k, g.numel())].float().numpy()
+                    out[f"{tag}_gradsum/{k}"] = np.array([float(g.sum()), float((g * g).sum())])
+            d.optimizer.step()
+            out[f"{tag}_loss{step}"], out[f"{tag}_lr{step}"] = np.float64(float(loss)), np.float64(stats["lr"])
+            out[f"{tag}_noise{step}"], out[f"{tag}_t{step}"] = noise.numpy(), ts.numpy()
+        for k, v in unet.state_dict().items():
+            assert k in names
+            f = v.detach().double().flatten()
+            out[f"{tag}_final/{k}"] = f[sample_idx(k, f.numel())].float().numpy()
+            out[f"{tag}_finalsum/{k}"] = np.array([float(f.sum()), float((f * f).sum())])
+        print("g12", tag, [out[f"{tag}_loss{i}"] for i in range(3)], flush=True)
+    np.savez_compressed(os.path.join(OUT, "g12_unet_train.npz"), **out)
+
+
 
 def g11_dataset():
     """The reference's own DynamicsDataset (dynamics/dataloader.py) on three synthetic 2-D files: every tensor of every item.
@@ -1036,7 +1168,7 @@ if __name__ == "__main__":
     os.makedirs("/tmp/dgdm_golden", exist_ok=True)
     only = sys.argv[1:]
     for name, fn in (("g2", g2_unet), ("g3", g3_dyn2d), ("g4", g4_pointnet), ("g5", g5_dyn3d), ("g6", g6_chains),
-                     ("g7", g7_convergence), ("g8", g8_harness), ("g9_2d", g9_2d), ("g9_3d", g9_3d), ("g9_3d_eps", g9_3d_eps), ("g9_3d_arith", g9_3d_arith), ("g9_f64", g9_f64), ("g9_tiles", g9_tiles), ("g10", g10_train2d), ("g11", g11_dataset)):
+                     ("g7", g7_convergence), ("g8", g8_harness), ("g9_2d", g9_2d), ("g9_3d", g9_3d), ("g9_3d_dist", g9_3d_dist), ("g9_3d_full", g9_3d_full), ("g9_3d_eps", g9_3d_eps), ("g9_3d_arith", g9_3d_arith), ("g9_f64", g9_f64), ("g9_tiles", g9_tiles), ("g10", g10_train2d), ("g11", g11_dataset), ("g12", g12_unet_train)):
         if only and name not in [a.split(":")[0] for a in only]:
             continue
         sub = [a.split(":", 1)[1].split(",") for a in only if a.startswith(name + ":")]
