@@ -37,6 +37,58 @@ OBJECTIVE_SWEEP = ['convergence', 'shift_up', 'shift_down', 'shift_left', 'shift
                    'counterclockwise_left']     # generator/diffusion.py:307
 
 
+class _Adam:
+    """What callers read of ``torch.optim.Adam(self.ema_nets.parameters(), lr)`` (generator/diffusion.py:712): the param group."""
+
+    def __init__(self, lr: float):
+        self.param_groups = [{"lr": lr, "initial_lr": lr, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0, "amsgrad": False}]
+
+
+class _CosineAnnealingLR:
+    """torch.optim.lr_scheduler.CosineAnnealingLR in closed form (generator/diffusion.py:713; Lightning steps it once per epoch)."""
+
+    def __init__(self, optimizer: _Adam, T_max: int, eta_min: float):
+        self.optimizer, self.T_max, self.eta_min, self.last_epoch = optimizer, T_max, eta_min, 0
+        self.base_lr = optimizer.param_groups[0]["initial_lr"]
+
+    def step(self) -> None:
+        import math
+        self.last_epoch += 1
+        self.optimizer.param_groups[0]["lr"] = self.eta_min + (self.base_lr - self.eta_min) * (1 + math.cos(math.pi * self.last_epoch / self.T_max)) / 2
+
+    def get_last_lr(self):
+        return [self.optimizer.param_groups[0]["lr"]]
+
+
+class EMAModel:
+    """The decay schedule of ``diffusers.training_utils.EMAModel`` (0.11.1; generator/diffusion.py:83-87, 716-720) around the EMA copy
+    the library handle keeps: ``decay = 0`` while ``step = max(0, optimization_step - update_after_step - 1) <= 0``, else
+    ``1 - (1 + step / inv_gamma) ** -power`` clamped to [min_value, max_value]; ``step()`` = ema * decay + (1 - decay) * param on the
+    device.  ``averaged_model`` is what the reference saves as ``state_dict['ema_model']``."""
+
+    def __init__(self, trainer: "engine.UnetTrainer", update_after_step: int = 0, inv_gamma: float = 1.0, power: float = 2 / 3,
+                 min_value: float = 0.0, max_value: float = 0.9999):
+        self._trainer = trainer
+        self.update_after_step, self.inv_gamma, self.power, self.min_value, self.max_value = update_after_step, inv_gamma, power, min_value, max_value
+        self.decay, self.optimization_step = 0.0, 0
+
+    def get_decay(self, optimization_step: int) -> float:
+        step = max(0, optimization_step - self.update_after_step - 1)
+        value = 1 - (1 + step / self.inv_gamma) ** -self.power
+        if step <= 0:
+            return 0.0
+        return max(self.min_value, min(value, self.max_value))
+
+    def step(self, new_model=None) -> None:
+        self.decay = self.get_decay(self.optimization_step)
+        self._trainer.ema_step(self.decay)
+        self.optimization_step += 1
+
+    @property
+    def averaged_model(self) -> Dict[str, torch.Tensor]:
+        return self._trainer.export(4)
+
+
 class Diffusion(nn.Module):
     def __init__(self, noise_pred_net, noise_scheduler, num_inference_steps: int, num_epochs: int = 10000, mode: str = "point",
                  input_dim: int = 1, num_points: int = 10, H: int = 32, W: int = 32, learning_rate: float = 1e-4,
@@ -62,6 +114,7 @@ class Diffusion(nn.Module):
         self.mode, self.input_dim, self.num_points = mode, input_dim, num_points
         self.pts_x_dim, self.pts_z_dim, self.H, self.W = pts_x_dim, pts_z_dim, H, W
         self.learning_rate, self.lr_warmup_steps, self.num_epochs = learning_rate, lr_warmup_steps, num_epochs
+        self.ema_power, self.ema_update_after_step = ema_power, ema_update_after_step
         self.noise_scheduler, self.num_inference_steps = noise_scheduler, num_inference_steps
         self.num_timesteps_per_batch = num_timesteps_per_batch
         self.action_groups = action_groups if action_groups is not None else {}
@@ -117,6 +170,7 @@ class Diffusion(nn.Module):
             if isinstance(m, HipBacked):
                 m.invalidate()
         self._guidance.clear()
+        self._unet_trainer = None          # a training handle built on the previous weights is stale
         return out
 
     def _guidance_for(self, batch: int, ori_range: Sequence[float], objects: torch.Tensor, max_chains: int) -> engine.Guidance:
@@ -136,6 +190,115 @@ class Diffusion(nn.Module):
             g.set_objects(objects.to(self.device))
             g._bank = objects.detach().cpu().clone()
         return g
+
+    # ------------------------------------------------------------------ (f) rank 4: training the eps-net (generator/diffusion.py:126-177, 711-724)
+    def configure_optimizers(self):
+        """torch.optim.Adam(lr) + CosineAnnealingLR(T_max=num_epochs, eta_min=0) (:711-714); the optimiser state itself (both moments,
+        the step count) lives in the library handle, these objects carry what callers read: ``param_groups[0]['lr']``, ``get_last_lr()``."""
+        self.optimizer = _Adam(self.learning_rate)
+        self.lr_scheduler = _CosineAnnealingLR(self.optimizer, T_max=self.num_epochs, eta_min=0.0)
+        return [self.optimizer], [self.lr_scheduler]
+
+    def _trainer(self) -> engine.UnetTrainer:
+        if getattr(self, "_unet_trainer", None) is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("dgdm_amd runs on an MI355X through libdgdm_hip.so; no GPU is visible and there is no CPU path")
+            net = self.noise_pred_net
+            self._unet_trainer = engine.UnetTrainer(net.plain_state_dict(), self.num_points, net.down_dims, net.dsed, net.kernel_size, net.n_groups)
+            self.ema = EMAModel(self._unet_trainer, power=self.ema_power, update_after_step=self.ema_update_after_step)
+            self._trained = False
+        return self._unet_trainer
+
+    def _training_draws(self, tensor_data):
+        """The draws of get_stats in its order and from its generator (:134-142: torch.randn then torch.randint on self.device - the
+        device generator of torch, which PyTorch-ROCm provides as it is), and DDIMScheduler.add_noise's two coefficients per sample."""
+        dev = self.device
+        data = tensor_data.to(device=dev, non_blocking=True)
+        n = data.shape[0] * self.num_timesteps_per_batch
+        x0 = data.repeat(self.num_timesteps_per_batch, 1, 1)
+        noise = torch.randn((n, self.num_points, self.input_dim), device=dev)
+        timesteps = torch.randint(0, self.noise_scheduler.config.num_train_timesteps, (n,), device=dev).long()
+        ac = self.noise_scheduler.alphas_cumprod.to(dev)[timesteps]
+        return x0, noise, ac ** 0.5, (1 - ac) ** 0.5, timesteps
+
+    def get_stats(self, tensor_data) -> Dict[str, Any]:
+        """:126-166 - the loss of one batch (forward only: nothing is updated; ``training_step`` is the call that trains)."""
+        if not hasattr(self, "lr_scheduler"):
+            self.configure_optimizers()
+        loss, _ = self._trainer().forward_backward(*self._training_draws(tensor_data), backward=False)
+        return {"loss": torch.tensor(loss), "lr": self.lr_scheduler.get_last_lr()[0]}
+
+    def training_step(self, tensor_data, batch_idx):
+        """:168-177 plus what Lightning's automatic optimisation does with the returned loss: backward and one optimizer.step() - one
+        library call (csrc/unet_train.hip).  Under a process group (torchrun): Lightning's DDP semantics - every rank is handed ITS
+        batch, the ranks' gradients are averaged (RCCL all-reduce), every rank takes the same Adam step."""
+        if not hasattr(self, "lr_scheduler"):
+            self.configure_optimizers()
+        tr = self._trainer()
+        lr = float(self.optimizer.param_groups[0]["lr"])
+        world, _ = ddist.world_rank()
+        args = self._training_draws(tensor_data)
+        if world == 1:
+            loss, _ = tr.step(*args, lr)
+        else:
+            loss, _ = tr.forward_backward(*args)
+            tr.write_gradients(ddist.all_reduce_sum(tr.read_gradients()), 1.0 / world)
+            tr.apply(lr)
+        self._trained = True
+        self.last_stats = {"train/loss": loss, "train/lr": self.lr_scheduler.get_last_lr()[0]}
+        return torch.tensor(loss)
+
+    def on_train_batch_end(self, outputs=None, batch=None, batch_idx=None) -> None:
+        """:716-724 - EMAModel.step on the just-updated parameters."""
+        self._trainer()
+        self.ema.step()
+        self.last_stats = dict(getattr(self, "last_stats", {}), **{"train/ema_decay": self.ema.decay})
+
+    def sync_model(self) -> None:
+        """Copies the trained parameters from the library handle into ``noise_pred_net`` (the module the sampling loops read, :120-124)."""
+        if getattr(self, "_unet_trainer", None) is not None and getattr(self, "_trained", False):
+            self.noise_pred_net.load_state_dict(self._unet_trainer.export(0))
+            self._trained = False
+
+    def checkpoint(self, epoch: int = 0, global_step: int = 0) -> Dict[str, Any]:
+        """A Lightning-shaped checkpoint: ``state_dict`` (keys ``ema_nets.noise_pred_net.*``) with the nested ``ema_model`` the reference
+        adds in on_save_checkpoint (:750-753, keys ``noise_pred_net.*``), Adam's state in torch.optim's own layout, the scheduler."""
+        self.sync_model()
+        sd = {k: v.detach().cpu().clone() for k, v in self.state_dict().items()}
+        ck: Dict[str, Any] = {"epoch": epoch, "global_step": global_step, "state_dict": sd}
+        tr = getattr(self, "_unet_trainer", None)
+        if tr is not None:
+            sd["ema_model"] = {"noise_pred_net." + k: v for k, v in tr.export(4).items()}
+            names = [k for k, _ in self.noise_pred_net.named_parameters()]
+            m, v = tr.export(2), tr.export(3)
+            st = {i: {"step": torch.tensor(float(tr.steps())), "exp_avg": m[k], "exp_avg_sq": v[k]} for i, k in enumerate(names)}
+            ck["optimizer_states"] = [{"state": st, "param_groups": [dict(self.optimizer.param_groups[0], params=list(range(len(names))))]}]
+            ck["lr_schedulers"] = [{"T_max": self.lr_scheduler.T_max, "eta_min": self.lr_scheduler.eta_min, "last_epoch": self.lr_scheduler.last_epoch,
+                                    "base_lrs": [self.lr_scheduler.base_lr], "_last_lr": self.lr_scheduler.get_last_lr()}]
+            ck["ema"] = {"optimization_step": self.ema.optimization_step, "decay": self.ema.decay}
+        return ck
+
+    def load_checkpoint(self, ck: Mapping[str, Any]) -> None:
+        """Resume: parameters (and, when present, the EMA copy, Adam's moments / step count and the schedule position)."""
+        self.load_state_dict(ck["state_dict"] if "state_dict" in ck else ck)
+        self._unet_trainer = None
+        self.global_step = int(ck.get("global_step", 0))
+        if "optimizer_states" not in ck:
+            return
+        if not hasattr(self, "lr_scheduler"):
+            self.configure_optimizers()
+        tr = self._trainer()
+        names = [k for k, _ in self.noise_pred_net.named_parameters()]
+        st = ck["optimizer_states"][0]["state"]
+        tr.load(2, {k: st[i]["exp_avg"] for i, k in enumerate(names)})
+        tr.load(3, {k: st[i]["exp_avg_sq"] for i, k in enumerate(names)}, adam_steps=int(st[0]["step"]))
+        if isinstance(ck.get("state_dict", {}).get("ema_model"), Mapping):
+            tr.load(4, {k[len("noise_pred_net."):]: v for k, v in ck["state_dict"]["ema_model"].items()})
+        for sch in ck.get("lr_schedulers", [])[:1]:
+            self.lr_scheduler.last_epoch = int(sch["last_epoch"])
+            self.optimizer.param_groups[0]["lr"] = float(sch["_last_lr"][0])
+        if "ema" in ck:
+            self.ema.optimization_step, self.ema.decay = int(ck["ema"]["optimization_step"]), float(ck["ema"]["decay"])
 
     # ------------------------------------------------------------------ a5
     def deltas_to_objective(self, deltas, opt_obj, centers=None):
@@ -301,6 +464,7 @@ class Diffusion(nn.Module):
     def validation_step(self, tensor_data, batch_idx):
         """Loops of generator/diffusion.py:179-339 without plotting / simulation: denoise from the partially noised data,
         unguided chain from noise, then the 12-objective sweep (multi-object chain + per-object chains)."""
+        self.sync_model()          # after training steps: the sampling handle reads the trained parameters
         dev = self.device
         data = tensor_data.to(dev)
         B = data.shape[0]

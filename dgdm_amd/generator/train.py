@@ -3,8 +3,11 @@
 Keeps the reference's flags (dynamics/parser.py) and construction order: synthetic finger set from ``RandomState(idx)``
 (:43-58), U-Net + DDIM scheduler (:80-83), frozen dynamics model loaded from ``--checkpoint_path`` (:84-92), normalised
 object point sets (:93-124), ``Diffusion`` (:129), then - in test mode - one pass of ``validation_step`` per batch of
-fingers, which is what Lightning's ``trainer.validate`` does (:152-156).  Training (``--mode=train``) is outside the
-MI355X sampling path.
+fingers, which is what Lightning's ``trainer.validate`` does (:152-156).  ``--mode=train`` (the flags of
+``generator/train_diffusion_{2d,3d}.sh``) is ``trainer.fit`` (:158-162): epochs over the shuffled 90 % split, one
+``training_step`` + ``on_train_batch_end`` per batch on the GPU (csrc/unet_train.hip), the cosine schedule stepped per epoch,
+``validation_step`` on the held-out 10 % every ``--val_step`` epochs, a Lightning-shaped checkpoint per epoch (the last ten and
+``last.ckpt``, as the ModelCheckpoint of :137-146 keeps them).
 
 Assets the image does not have are substituted, loudly:
 * no checkpoint files  -> deterministic random-init weights (dgdm_amd.synth);
@@ -74,9 +77,75 @@ def _objects(args, fingers_3d: bool):
     return torch.stack([synth.synth_object_2d(i, nv) for i in range(len(OBJECT_IDS))]), list(OBJECT_IDS)
 
 
+def fit(model: Diffusion, pts: np.ndarray, args, bounds, dev) -> Diffusion:
+    """``trainer.fit(diffusion_model, train_loader, val_loader)`` (generator/train.py:44-45, 66-67, 147-162) without Lightning: the
+    loop its ``LightningTrainer(max_epochs=num_epochs, check_val_every_n_epoch=val_step)`` runs.  Under torchrun every rank takes the
+    slice ``indices[rank::world]`` of the epoch's permutation (DistributedSampler) and the gradients are averaged (DDP)."""
+    from torch.utils.data import DataLoader
+    from .. import dist as ddist
+    n = pts.shape[0]
+    train_ids, val_ids = list(range(int(n * 0.9))), list(range(int(n * 0.9), n))
+    train_set, val_set = GripperDataset(pts[train_ids], *bounds), GripperDataset(pts[val_ids], *bounds)
+    world, rank = ddist.world_rank()
+    if not hasattr(model, "lr_scheduler"):      # a resumed model (load_checkpoint) carries its schedule position
+        model.configure_optimizers()
+    model.to(dev)
+    ckdir = os.path.join(args.save_dir, "checkpoints") if args.save_dir else None
+    if ckdir and rank == 0:
+        os.makedirs(ckdir, exist_ok=True)
+    kept, step, log = [], int(getattr(model, "global_step", 0)), []
+    val_loader = DataLoader(val_set, batch_size=args.batch_size, shuffle=False, num_workers=0, drop_last=False)
+
+    def validate(limit=None):
+        model.eval()
+        out = []
+        with torch.no_grad():
+            for bi, batch in enumerate(val_loader):
+                if limit is not None and bi >= limit:
+                    break
+                out.append(model.validation_step(batch, bi)["stats"])
+        model.train()
+        return out
+    if len(val_set):
+        validate(limit=2)                      # Lightning's sanity check (num_sanity_val_steps = 2) before the first epoch
+    for epoch in range(model.lr_scheduler.last_epoch, args.num_epochs):
+        model.current_epoch = epoch
+        if world == 1:
+            loader = DataLoader(train_set, batch_size=args.batch_size, shuffle=True, num_workers=0, drop_last=False)
+        else:                                   # DistributedSampler(shuffle=True, seed=0): randperm from Generator(seed + epoch), padded, strided
+            gen = torch.Generator()
+            gen.manual_seed(epoch)
+            idx = torch.randperm(len(train_set), generator=gen).tolist()
+            total = -(-len(idx) // world) * world
+            idx = (idx + idx[:total - len(idx)])[rank:total:world]
+            loader = DataLoader(torch.utils.data.Subset(train_set, idx), batch_size=args.batch_size, shuffle=False, num_workers=0, drop_last=False)
+        losses = []
+        for bi, batch in enumerate(loader):
+            losses.append(float(model.training_step(batch, bi)))
+            model.on_train_batch_end(None, batch, bi)
+            step += 1
+        model.lr_scheduler.step()
+        rec = {"epoch": epoch, "train/loss": float(np.mean(losses)), "lr": model.lr_scheduler.get_last_lr()[0], "ema_decay": model.ema.decay}
+        if (epoch + 1) % max(1, args.val_step) == 0 and len(val_set):
+            vs = validate()
+            rec.update({k: float(np.mean([v[k] for v in vs])) for k in vs[0]})
+        log.append(rec)
+        if rank == 0:
+            print("[dgdm_amd] " + ", ".join(f"{k}={v:.6g}" if isinstance(v, float) else f"{k}={v}" for k, v in rec.items()), flush=True)
+            if ckdir:
+                ck = model.checkpoint(epoch=epoch + 1, global_step=step)
+                f = os.path.join(ckdir, "epoch=%04d.ckpt" % epoch)
+                torch.save(ck, f)
+                torch.save(ck, os.path.join(ckdir, "last.ckpt"))
+                kept.append(f)
+                while len(kept) > 10:          # save_top_k = 10, monitor = 'epoch', mode = 'max'
+                    os.remove(kept.pop(0))
+    model.sync_model()
+    model.train_log = log
+    return model
+
+
 def train(args):
-    if args.mode != 'test':
-        raise NotImplementedError("only --mode=test (guided sampling) runs on the MI355X path; training is out of scope")
     dev = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else int(os.environ.get("LOCAL_RANK", "0")))
     pts = finger_control_points(args.num_fingers, args.fingers_3d)
     max_y, min_y = (0.0, -0.1) if args.fingers_3d else (0.015, -0.045)
@@ -102,6 +171,13 @@ def train(args):
                       class_cond=args.classifier_guidance, classifier_model=classifier, grid_size=args.grid_size, num_pos=args.num_pos,
                       object_vertices=objects, object_ids=object_ids, num_cpus=args.num_cpus, pts_x_dim=args.ctrlpts_x_dim,
                       pts_z_dim=args.ctrlpts_z_dim, sub_batch_size=args.sub_bs, render_video=args.render_video, seed=args.seed)
+    if args.mode != 'test':                 # generator/train.py:158-162
+        if args.diffusion_checkpoint_path is not None:
+            print('loading diffusion checkpoint from', args.diffusion_checkpoint_path)
+            model.to(dev)
+            model.load_checkpoint(torch.load(args.diffusion_checkpoint_path, map_location="cpu", weights_only=False))
+        model.save_dir = args.save_dir or None
+        return fit(model, pts, args, (0.12, -0.12, max_y, min_y), dev), []
     ck = _load_or_synth(args.diffusion_checkpoint_path, [("ema_nets.noise_pred_net." + k, s) for k, s in synth.unet_spec()], 11,
                         "diffusion checkpoint")
     res = model.load_state_dict(ck)

@@ -130,3 +130,102 @@ def test_unet_trainer_deterministic_and_resume():
     assert la == lc
     pa, pc = a.export(0), c.export(0)
     assert all(torch.equal(pa[k], pc[k]) for k in pa)
+
+
+def test_diffusion_training_api():
+    """The reference-shaped calls (generator/diffusion.py:126-177, 711-724) on the mirror class: configure_optimizers, get_stats (no update),
+    training_step + on_train_batch_end (update + EMA), against the oracle fed the SAME device-generator draws; then the trained
+    weights are what validation_step's eps-net evaluates, and a checkpoint round trip continues bit for bit."""
+    from dgdm_amd import synth
+    from dgdm_amd.generator.diffusion import Diffusion
+    from dgdm_amd.generator.diffusion_utils import ConditionalUnet1D
+    from dgdm_amd.scheduler import DDIMScheduler
+    from oracle import dgdm_oracle as orc
+    dev = torch.device("cuda:0")
+    B, L, T = 12, 14, 15
+    sd = synth.synth_state_dict(synth.unet_spec(), 21)
+
+    def make():
+        net = ConditionalUnet1D(input_dim=1, global_cond_dim=0, down_dims=[128, 256], diffusion_step_embed_dim=32)
+        net.load_state_dict(sd)
+        d = Diffusion(noise_pred_net=net, noise_scheduler=DDIMScheduler(num_train_timesteps=T), num_inference_steps=5, mode='point', input_dim=1,
+                      num_points=L, learning_rate=1e-4, ema_power=0.85).to(dev)
+        d.configure_optimizers()
+        return d
+    d = make()
+    o = orc.UnetTrainer(sd, T, L, 1e-4, ema_power=0.85)
+    x0 = torch.from_numpy(np.random.RandomState(1).uniform(-1, 1, (B, L, 1)).astype(np.float32))
+    torch.manual_seed(11)
+    st = d.get_stats(x0)
+    assert set(st) == {"loss", "lr"} and st["lr"] == 1e-4
+    for step in range(3):
+        torch.manual_seed(100 + step)
+        loss = float(d.training_step(x0, step))
+        d.on_train_batch_end(None, x0, step)
+        torch.manual_seed(100 + step)                      # the same draws, in get_stats' order, from the same (device) generator
+        noise = torch.randn((B, L, 1), device=dev).cpu()
+        ts = torch.randint(0, T, (B,), device=dev).long().cpu()
+        lo, _ = o.step(x0, forced=(noise, ts))
+        assert abs(loss - lo) < 2e-5 * abs(lo), (step, loss, lo)
+        assert abs(d.ema.decay - o.ema.decay) < 1e-12
+    d.lr_scheduler.step()
+    assert abs(d.optimizer.param_groups[0]["lr"] - 1e-4 * (1 + math.cos(math.pi / 10000)) / 2) < 1e-15      # T_max = the constructor's num_epochs default
+    ema = d.ema.averaged_model
+    assert max(float((ema[k] - o.ema.averaged[k]).abs().max()) for k in ema) < 2.5e-4
+    # sampling sees the trained weights
+    d.eval()
+    out = d.validation_step(x0, 1)
+    with torch.no_grad():
+        xs = torch.from_numpy(np.random.RandomState(0).randn(B, L, 1).astype(np.float32))
+        ref_eps = orc.unet1d_forward(o.sd, xs, torch.full((B,), 3, dtype=torch.int64))
+    got = d.noise_pred_net(xs.to(dev), torch.full((B,), 3, device=dev)).cpu()
+    assert _rel(got, ref_eps) < 5e-4 and "val/denoise loss" in out["stats"]        # parameters differ by <= 2 lr where Adam's sign is rounding's
+    # checkpoint: Lightning-shaped, resumes bit for bit
+    ck = d.checkpoint(epoch=1, global_step=3)
+    assert "ema_model" in ck["state_dict"] and all(k.startswith("noise_pred_net.") for k in ck["state_dict"]["ema_model"])
+    assert all(k.startswith("ema_nets.noise_pred_net.") for k in ck["state_dict"] if k != "ema_model")
+    assert len(ck["optimizer_states"][0]["state"]) == len(list(d.noise_pred_net.parameters()))
+    d2 = make()
+    d2.load_checkpoint(ck)
+    torch.manual_seed(5)
+    la = float(d.training_step(x0, 3))
+    d.on_train_batch_end()
+    torch.manual_seed(5)
+    lb = float(d2.training_step(x0, 3))
+    d2.on_train_batch_end()
+    assert la == lb
+    pa, pb = d._trainer().export(0), d2._trainer().export(0)
+    assert all(torch.equal(pa[k], pb[k]) for k in pa)
+    ea, eb = d.ema.averaged_model, d2.ema.averaged_model
+    assert all(torch.equal(ea[k], eb[k]) for k in ea)
+
+
+def test_train_cli_end_to_end(tmp_path):
+    """`python generator/train.py <flags of train_diffusion_2d.sh>` (reduced finger count / epochs): the training loss falls, a
+    Lightning-shaped checkpoint per epoch appears, `--diffusion_checkpoint_path=last.ckpt` resumes, and the checkpoint loads into the
+    sampling entry point (`--mode=test`)."""
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    save = tmp_path / "out"
+    base = [sys.executable, "generator/train.py", "--num_fingers=640", f"--save_dir={save}", "--learning_rate=1e-3", "--lr_warmup_steps=0", "--val_step=2",
+            "--num_workers=0", "--num_train_timesteps=15", "--num_inference_steps=5", "--ema_power=0.85", "--batch_size=64", "--ctrlpts_dim=14"]
+    r = subprocess.run(base + ["--num_epochs=6"], cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if "train/loss=" in l]
+    losses = [float(l.split("train/loss=")[1].split(",")[0]) for l in lines]
+    assert len(losses) == 6 and losses[-1] < 0.6 * losses[0], losses
+    assert any("val/denoise loss" in l for l in lines)
+    ck = torch.load(save / "checkpoints" / "last.ckpt", weights_only=False)
+    assert ck["epoch"] == 6 and ck["global_step"] == 6 * 9 and "ema_model" in ck["state_dict"]
+    assert (save / "checkpoints" / "epoch=0005.ckpt").exists() and (save / "val_vis" / "1_0.png").exists()
+    r = subprocess.run(base + ["--num_epochs=7", f"--diffusion_checkpoint_path={save / 'checkpoints' / 'last.ckpt'}"], cwd=root, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if "train/loss=" in l]
+    assert len(lines) == 1 and "epoch=6" in lines[0] and float(lines[0].split("train/loss=")[1].split(",")[0]) < 1.2 * losses[-1], lines
+    r = subprocess.run([sys.executable, "generator/train.py", "--mode=test", "--num_fingers=4", "--batch_size=4", "--ctrlpts_dim=14", "--num_train_timesteps=15",
+                        "--num_inference_steps=5", f"--diffusion_checkpoint_path={save / 'checkpoints' / 'last.ckpt'}", f"--save_dir={tmp_path / 'smp'}"],
+                       cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "diffusion checkpoint" not in r.stderr          # no fallback to synthetic weights: the trained checkpoint was read

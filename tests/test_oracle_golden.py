@@ -271,3 +271,33 @@ def test_trainer2d_matches_reference(tag):
     g = util.load("g10_train2d.npz")
     rec = _train_case(g, tag, _OracleTrainer)
     check_training(g, tag, rec, 5e-6, 2e-5, 2e-6)
+
+
+@pytest.mark.parametrize("tag", ["p2", "p3"])
+def test_unet_trainer_matches_reference(tag):
+    """oracle.UnetTrainer against the reference's own Diffusion.get_stats + torch.optim.Adam (make_golden.g12_unet_train): three steps
+    on the recorded draws - losses, the gradients of step 1, the parameters after step 3."""
+    import math
+    from tests.util import sample_idx
+    g = util.load("g12_unet_train.npz")
+    B, L = [int(v) for v in g[f"{tag}_dims"]]
+    lr0, E = float(g["lr"]), int(g["num_epochs"])
+    o = orc.UnetTrainer(util.unet_sd(int(g["unet_seed"])), int(g["num_train_timesteps"]), L, lr0, ema_power=0.85)
+    x0 = torch.from_numpy(g[f"{tag}_x0"])
+    torch.manual_seed(int(g["torch_seed"]))
+    for step in range(3):
+        if step == 2:
+            o.lr = lr0 * (1 + math.cos(math.pi / E)) / 2
+        loss, _ = o.step(x0)                 # draws torch.randn / torch.randint itself, in get_stats' order
+        assert np.array_equal(o.draws[0].numpy(), g[f"{tag}_noise{step}"]) and np.array_equal(o.draws[1].numpy(), g[f"{tag}_t{step}"])
+        assert abs(loss - float(g[f"{tag}_loss{step}"])) < 1e-6
+        if step == 0:
+            for k, v in o.grads.items():
+                f = v.double().flatten().numpy()
+                rms = math.sqrt(float(g[f"{tag}_gradsum/{k}"][1]) / f.size)
+                assert np.abs(f[sample_idx(k, f.size)] - g[f"{tag}_grad/{k}"]).max() < 2e-5 * rms, k
+    for k, v in o.sd.items():
+        f = v.double().flatten().numpy()
+        assert np.abs(f[sample_idx(k, f.size)] - g[f"{tag}_final/{k}"]).max() < 4e-6, k
+    # EMAModel's schedule (diffusers 0.11.1, restated: parity unpinned): no averaging on the first two calls, then 1 - (1 + step)^-power
+    assert o.ema.optimization_step == 3 and abs(o.ema.decay - (1 - 2 ** -0.85)) < 1e-12
