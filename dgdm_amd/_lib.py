@@ -109,6 +109,11 @@ PROTOTYPES = {
     "dgdm_unet_trainer_export": (C.c_int, [_P, C.c_int, C.POINTER(Tensor), C.c_int]),
     "dgdm_unet_trainer_import": (C.c_int, [_P, C.c_int, C.POINTER(Tensor), C.c_int, C.c_int64]),
     "dgdm_unet_trainer_steps": (C.c_int64, [_P]),
+    "dgdm_trainer3d_create": (C.c_int, [C.POINTER(_P), C.POINTER(Tensor), C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "dgdm_trainer3d_destroy": (None, [_P]),
+    "dgdm_trainer3d_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_int, _P, C.POINTER(C.c_float), _P]),
+    "dgdm_trainer3d_export": (C.c_int, [_P, C.c_int, C.POINTER(Tensor), C.c_int]),
+    "dgdm_trainer3d_steps": (C.c_int64, [_P]),
 }
 
 _lib = None

@@ -407,6 +407,34 @@ int dgdm_unet_trainer_export(DgdmUnetTrainer *m, int which, DgdmTensor *tensors,
 int dgdm_unet_trainer_import(DgdmUnetTrainer *m, int which, const DgdmTensor *tensors, int n_tensors, int64_t adam_steps);
 int64_t dgdm_unet_trainer_steps(const DgdmUnetTrainer *m);      /* Adam updates taken */
 
+/* ------------------------------------------------------------------ (f) rank 4: training the 3-D dynamics model
+ * Trainer.step / Trainer.inference (dynamics/trainer.py:53-146) for ProfileForward3DModel (dynamics/profile_forward_3d.py:13-86):
+ * PointNet++ (dynamics/models/pointnet2.py:11-32, pointnet2_utils.py:169-210) with BatchNorm2d in TRAINING mode, the trunk with
+ * BatchNorm1d batch statistics, nn.MSELoss, backward with every weight gradient, torch.optim.Adam (trainer.py:46) - evaluated as
+ * written, one row = one (control points, pose, cloud) item.  state_dict: the model's tensors ("module."-prefix stripped),
+ * running statistics included; time_encoder (constructed, never called by forward) is carried unchanged.                           */
+typedef struct DgdmTrainer3d DgdmTrainer3d;
+int dgdm_trainer3d_create(DgdmTrainer3d **out, const DgdmTensor *state_dict, int n_tensors, int params_ch, int num_object_points,
+                          float beta1, float beta2, float eps, float weight_decay);
+void dgdm_trainer3d_destroy(DgdmTrainer3d *m);
+/* One forward / backward / optimizer.step() of the loop body of trainer.py:83-92 (one slice of --use_sub_batch; the whole batch when
+ * it is not sub-batched) when train != 0; train == 0: Trainer.inference's eval-mode forward + loss (:108-146).
+ *   ctrl1_dev [rows][params_ch]   channel 1 of the control points, the only one the model reads (profile_forward_3d.py:77) and the
+ *                                 only one trainer.py:68 adds noise to: noisy = sqrt_abar[r] * ctrl1 + sqrt_1m_abar[r] * noise (null: as given)
+ *   t_dev [rows] = timesteps / num_train_timesteps (:80); ori_dev [rows][1]; pos_dev [rows][2]; score_dev [rows][3]
+ *   xyz_dev [rows][num_object_points][3]  the clouds, point-major (the model's (rows, 3, N) input transposed)
+ *   start_sa1_host / start_sa2_host [rows] int64: the FPS start draws of pointnet2_utils.py:83 for sa1 and sa2, in the order the
+ *                                 reference makes them (torch.randint on the CPU generator, sa1 then sa2, per forward)
+ * pred_dev (optional) [rows][3]; loss_host (optional) receives the loss and makes the call synchronous.  Deterministic.
+ * Memory: 68 MB of activations and gradients per row (PointNet++ as written): rows <= 4096.                                        */
+int dgdm_trainer3d_step(DgdmTrainer3d *m, const float *ctrl1_dev, const float *noise_dev, const float *sqrt_abar_dev,
+                        const float *sqrt_1m_abar_dev, const float *t_dev, const float *ori_dev, const float *pos_dev, const float *xyz_dev,
+                        const int64_t *start_sa1_host, const int64_t *start_sa2_host, const float *score_dev, int64_t rows, float lr,
+                        int train, float *pred_dev, float *loss_host, void *stream);
+/* which = 0 the state_dict (parameters + running statistics), 1 gradients of the last step, 2 / 3 Adam's exp_avg / exp_avg_sq */
+int dgdm_trainer3d_export(DgdmTrainer3d *m, int which, DgdmTensor *tensors, int n_tensors);
+int64_t dgdm_trainer3d_steps(const DgdmTrainer3d *m);      /* training steps taken = num_batches_tracked increment */
+
 #ifdef __cplusplus
 }
 #endif

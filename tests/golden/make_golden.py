@@ -956,6 +956,97 @@ def g9_tiles(parts=("rotate", "convergence", "multi")):
             np.savez_compressed(path, **out)
 
 
+def _gripper_jacobian(sd64, xb):
+    """d z1 / d x for one finger (x: the 42 control values that reach the model, channel 1 of x_ctrl): z1 = the first trunk layer's
+    pre-activation (after its eval-mode BatchNorm), whose x-dependent part is W1[:, 256:512] . gripper_encoder(x)
+    (dynamics/profile_forward_3d.py:77,84).  [512][42], float64."""
+    w0, b0, w2 = sd64["gripper_encoder.0.weight"], sd64["gripper_encoder.0.bias"], sd64["gripper_encoder.2.weight"]
+    act = ((w0 @ xb + b0) > 0).double()
+    sc = sd64["linears.1.weight"] / torch.sqrt(sd64["linears.1.running_var"] + 1e-5)
+    W = w2.shape[0]
+    return (sc[:, None] * sd64["linears.0.weight"][:, W:2 * W]) @ (w2 * act[None, :]) @ w0
+
+
+def g9_calls64(parts=None):
+    """Float64 yardsticks for EVERY recorded cond_fn call and for the whole chain of every full-grid 3-D fixture (the six of round 3
+    and the g9_3d_d* sample), by oracle/fast64.py (the float64 evaluation of the as-written dataflow, checked against dgdm_oracle's
+    float64 mode).  Per chain: '<part>/chain' the float64 end point on the recorded draws; '<part>/grad' [calls][B][L] the float64
+    gradient of every recorded call AT THE REFERENCE'S recorded x; '<part>/tiles' [calls][B][tiles][L] the same gradient split by
+    32-pose-cell tile (J^T . sum over the tile's rows of d objective / d z1: what one tile of the HIP trunk contributes to the finger's
+    gradient) - a ReLU that takes the other sign in float32 than in exact arithmetic shows up in ONE tile.  Merges into
+    tests/golden/g9_calls64.npz; chains already there are skipped."""
+    import glob
+    import time
+    from tests import util as tu
+    from oracle import fast64
+    path = os.path.join(OUT, "g9_calls64.npz")
+    out = dict(np.load(path)) if os.path.exists(path) else {}
+    names = [os.path.basename(f)[len("g9_3d_"):-4] for f in sorted(glob.glob(os.path.join(OUT, "g9_3d_*.npz")))]
+    names = [n for n in names if not n.endswith(("_alt", "_eps", "_arith")) and "raw" not in n and not n.startswith("full_")]
+    if parts:
+        names = [n for n in names if n in parts]
+    todo = [n for n in names if f"{n}/chain" not in out]
+    by_obj = {}
+    for n in todo:
+        g = np.load(os.path.join(OUT, f"g9_3d_{n}.npz"))
+        objs = [int(v) for v in g["obj"].reshape(-1)] if "obj" in g.files and not n.startswith("multi") else [0]
+        if n == "multi":
+            objs = [0, 1]
+        by_obj.setdefault(tuple(objs), []).append(n)
+    all_objs = torch.stack([synth.synth_object_3d(50 + i) for i in range(4)])
+    tabs = {}
+    for objs, group in sorted(by_obj.items()):
+        for n in group:
+            g = np.load(os.path.join(OUT, f"g9_3d_{n}.npz"))
+            B, G, P, L, T, S, N = [int(v) for v in g["dims"]]
+            o, gain = str(g["opt_obj"]), float(g["gain"])
+            sd32 = synth.scale_output(synth.synth_state_dict(synth.dyn3d_spec(42), DYN3D_SEED), gain)
+            sd64 = fast64._f64(sd32)
+            for oi in objs:
+                if "objs" in g.files:
+                    assert np.array_equal(g["objs"][oi], all_objs[oi].numpy())
+                # the tables hold post-ReLU features of PointNet++ only: independent of the output-layer gain
+                if oi not in tabs:
+                    t0 = time.time()
+                    tabs[oi] = fast64.ObjectTables64(sd64, all_objs[oi])
+                    print("  calls64: tables of object", oi, f"{time.time() - t0:.0f}s", flush=True)
+            sch = orc.DDIM(T)
+            sch.set_timesteps(S)
+            calls = tu.unpack_starts(g["starts"].astype(np.int64), g["start_lens"])
+            centers = None
+            if o == 'convergence':
+                sweep, calls = calls[:2], calls[2:]
+                s32 = orc.Setup('point_3d', None, sd32, sch, L, G, P, 512)
+                centers = orc.get_convergence_centers(s32, torch.from_numpy(g["unguided"]), all_objs[objs[0]], (-1.0, 1.0), orc.StartLog(list(sweep)))
+            multi = len(objs) > 1
+            t0 = time.time()
+            usd = synth.synth_state_dict(synth.unet_spec(), UNET_SEED)
+            end = fast64.guided_chain(usd, sd32, sch, L, G, P, 512, synth.synth_noise(0, B, L), [tabs[oi] for oi in objs], o, centers, calls, multi=multi)
+            # every recorded call on the reference's own trajectory
+            s64 = orc.Setup('point_3d', None, sd64, sch, L, G, P, 512)
+            n_sub = 2 * ((B * G * P * P + 511) // 512)
+            grads, tiles, k = [], [], 0
+            for si, t in enumerate(sch.timesteps):
+                ts = t * torch.ones(B, dtype=torch.int64)
+                for oi in objs:
+                    x = torch.from_numpy(g["trace_x"][si]).double()
+                    acc = []
+                    gr = fast64.cond_fn(s64, tabs[oi], x, ts, o, centers, calls[k:k + n_sub], tiles=acc)
+                    k += n_sub
+                    contrib = torch.stack([acc[0][b] @ _gripper_jacobian(sd64, x[b, :, 0]) for b in range(B)])        # [B][tiles][L]
+                    assert float((contrib.sum(1) - gr[:, :, 0]).abs().max()) < 1e-9 * max(1.0, float(gr.abs().max()))
+                    grads.append(gr[:, :, 0].numpy())
+                    tiles.append(contrib.numpy())
+            out[f"{n}/chain"] = end.numpy()
+            out[f"{n}/grad"] = np.stack(grads)
+            out[f"{n}/tiles"] = np.stack(tiles).astype(np.float32)
+            ref_g = np.asarray(g["trace_grad"], np.float64).reshape(len(grads), B, L)
+            print("  calls64", n, o, f"{time.time() - t0:.0f}s | reference float32 end point vs float64 chain (finger L2)", _spread(g["guided"], end.numpy()),
+                  "| reference per-call gradient vs float64:", [float("%.1e" % (np.linalg.norm(ref_g[i] - grads[i]) / np.linalg.norm(grads[i]))) for i in range(len(grads))],
+                  flush=True)
+            np.savez_compressed(path, **out)
+
+
 def synth_metrics(seed, n_ori=360):
     """Synthetic stand-in for what the simulator returns per (object, gripper) pair (dynamics/sim_test_mj.py:210-232):
     three-class profiles and the motion statistics metric2objective reads.  Inputs only; the outputs come from the reference."""
@@ -1164,11 +1255,11 @@ def g11_dataset():
     np.savez_compressed(os.path.join(OUT, "g11_dataset.npz"), **out)
 
 if __name__ == "__main__":
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
     os.makedirs("/tmp/dgdm_golden", exist_ok=True)
     only = sys.argv[1:]
     for name, fn in (("g2", g2_unet), ("g3", g3_dyn2d), ("g4", g4_pointnet), ("g5", g5_dyn3d), ("g6", g6_chains),
-                     ("g7", g7_convergence), ("g8", g8_harness), ("g9_2d", g9_2d), ("g9_3d", g9_3d), ("g9_3d_dist", g9_3d_dist), ("g9_3d_full", g9_3d_full), ("g9_3d_eps", g9_3d_eps), ("g9_3d_arith", g9_3d_arith), ("g9_f64", g9_f64), ("g9_tiles", g9_tiles), ("g10", g10_train2d), ("g11", g11_dataset), ("g12", g12_unet_train)):
+                     ("g7", g7_convergence), ("g8", g8_harness), ("g9_2d", g9_2d), ("g9_3d", g9_3d), ("g9_3d_dist", g9_3d_dist), ("g9_3d_full", g9_3d_full), ("g9_3d_eps", g9_3d_eps), ("g9_3d_arith", g9_3d_arith), ("g9_f64", g9_f64), ("g9_tiles", g9_tiles), ("g9_calls64", g9_calls64), ("g10", g10_train2d), ("g11", g11_dataset), ("g12", g12_unet_train)):
         if only and name not in [a.split(":")[0] for a in only]:
             continue
         sub = [a.split(":", 1)[1].split(",") for a in only if a.startswith(name + ":")]
