@@ -13,6 +13,22 @@
 
 namespace dgdm {
 
+// a * b, a + b, a - b each rounded on its own.  HIP's __fmul_rn / __fadd_rn are plain operators defined in HIP's headers: inlined,
+// they carry the `contract` flag of the default -ffp-contract=fast whatever `#pragma clang fp contract(off)` says at the call site,
+// and the backend fuses them with a neighbouring operation when it likes the pattern (seen in the ISA of sqdist_rows_kernel: the sum of
+// squares became v_pk_mul + 2 x v_pk_fma, one rounding instead of five - 20 % of the squared distances off by an ulp from torch's, and a
+// ball-query decision flipped for a point within 1e-7 of the radius).  Inline assembly is opaque to the optimiser: these are what the
+// code that must reproduce the reference's separate float32 roundings uses.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ float mul_rn(float a, float b) { float r; asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float add_rn(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float sub_rn(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+#else
+__device__ __forceinline__ float mul_rn(float a, float b) { return a * b; }
+__device__ __forceinline__ float add_rn(float a, float b) { return a + b; }
+__device__ __forceinline__ float sub_rn(float a, float b) { return a - b; }
+#endif
+
 void set_error(const char *fmt, ...);
 
 #define DGDM_HIP_CHECK(expr)                                                              \

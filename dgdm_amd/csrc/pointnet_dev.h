@@ -3,20 +3,23 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-// No implicit a*b+c -> fma contraction: FPS and ball-query distances must round like the reference's separate float32 ops
-// (HIP's __fmul_rn/__fadd_rn are plain * and + and would be contracted).  Explicit fmaf()/fma() calls are unaffected.
+#include "common.h"
+
+// No implicit a*b+c -> fma contraction: FPS and ball-query distances must round like the reference's separate float32 ops: mul_rn /
+// add_rn (common.h).  torch.sum(v ** 2, -1) is ((x^2 + y^2) + z^2) and torch.matmul's K = 3 dot product is the fma chain
+// fma(z z', fma(y y', x x')) (both checked bitwise against torch CPU, here and on the GPU box's host).
 #pragma clang fp contract(off)
 
 namespace dgdm {
 
 __device__ __forceinline__ float sq3(float x, float y, float z) {
-    return __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+    return add_rn(add_rn(mul_rn(x, x), mul_rn(y, y)), mul_rn(z, z));
 }
 
 // square_distance(src = centre, dst = candidate) in the reference's expanded form
 __device__ __forceinline__ float sqdist_expanded(float cx, float cy, float cz, float cn, float px, float py, float pz, float pn) {
-    const float dot = fmaf(cz, pz, fmaf(cy, py, __fmul_rn(cx, px)));
-    return __fadd_rn(__fadd_rn(__fmul_rn(-2.f, dot), cn), pn);
+    const float dot = fmaf(cz, pz, fmaf(cy, py, mul_rn(cx, px)));
+    return add_rn(add_rn(mul_rn(-2.f, dot), cn), pn);
 }
 
 // query_ball_point (pointnet2_utils.py:95-115) for one centre by one wave: the first 32 in-radius indices in index order,

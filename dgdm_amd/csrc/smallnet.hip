@@ -368,17 +368,17 @@ __global__ void ddim_step_kernel(const float *__restrict__ x, const float *__res
             for (int k = 1; k < n_grad; ++k) g += grad[(size_t)k * n + i];
             g = g / (float)n_grad;
         }
-        e = e - __fmul_rn(__fmul_rn(sb, g), scale);           // eps - (sqrt(1-abar) * grad) * scale, unfused
+        e = sub_rn(e, mul_rn(mul_rn(sb, g), scale));           // eps - (sqrt(1-abar) * grad) * scale, unfused
     }
-    float x0 = __fdiv_rn(x[i] - __fmul_rn(sb, e), sa);        // (x - sqrt(1-abar) eps) / sqrt(abar)
+    float x0 = __fdiv_rn(sub_rn(x[i], mul_rn(sb, e)), sa);        // (x - sqrt(1-abar) eps) / sqrt(abar)
     x0 = fminf(fmaxf(x0, -1.f), 1.f);
-    out[i] = __fadd_rn(__fmul_rn(sap, x0), __fmul_rn(sbp, e));
+    out[i] = add_rn(mul_rn(sap, x0), mul_rn(sbp, e));
 }
 
 __global__ void add_noise_kernel(const float *__restrict__ x0, const float *__restrict__ noise, float *__restrict__ out, int64_t n,
                                  float sa, float sb) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = __fadd_rn(__fmul_rn(sa, x0[i]), __fmul_rn(sb, noise[i]));
+    if (i < n) out[i] = add_rn(mul_rn(sa, x0[i]), mul_rn(sb, noise[i]));
 }
 
 }  // namespace dgdm

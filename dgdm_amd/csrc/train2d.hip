@@ -558,7 +558,7 @@ __global__ void prep2d_kernel(const float *__restrict__ ctrl, const float *__res
     const int64_t r = e / S;
     int s = (int)(e - r * S);
     if (s < Lp) {
-        bufC[r * Lp + s] = s < L ? (noise ? __fadd_rn(__fmul_rn(sa[r], ctrl[r * L + s]), __fmul_rn(sb[r], noise[r * L + s])) : ctrl[r * L + s]) : 0.f;
+        bufC[r * Lp + s] = s < L ? (noise ? add_rn(mul_rn(sa[r], ctrl[r * L + s]), mul_rn(sb[r], noise[r * L + s])) : ctrl[r * L + s]) : 0.f;
         return;
     }
     s -= Lp;

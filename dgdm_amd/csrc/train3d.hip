@@ -245,7 +245,7 @@ __global__ void prep3d_kernel(const float *__restrict__ ctrl1, const float *__re
     const int64_t r = e / S;
     int s = (int)(e - r * S);
     if (s < Lp) {
-        bufC[r * Lp + s] = s < L ? (noise ? __fadd_rn(__fmul_rn(sa[r], ctrl1[r * L + s]), __fmul_rn(sb[r], noise[r * L + s])) : ctrl1[r * L + s]) : 0.f;
+        bufC[r * Lp + s] = s < L ? (noise ? add_rn(mul_rn(sa[r], ctrl1[r * L + s]), mul_rn(sb[r], noise[r * L + s])) : ctrl1[r * L + s]) : 0.f;
         return;
     }
     s -= Lp;
@@ -268,7 +268,7 @@ __global__ void mse_kernel(const float *__restrict__ pred, const float *__restri
     if (r >= R) return;
     float a = 0.f;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { const float d = pred[r * 3 + j] - score[r * 3 + j]; a = fmaf(d, d, a); dpred[r * 4 + j] = d * inv; }
+    for (int j = 0; j < 3; ++j) { const float d = pred[r * 4 + j] - score[r * 3 + j]; a = fmaf(d, d, a); dpred[r * 4 + j] = d * inv; }
     dpred[r * 4 + 3] = 0.f;
     part[r] = a;
 }
@@ -727,3 +727,13 @@ extern "C" int dgdm_trainer3d_export(DgdmTrainer3d *m, int which, DgdmTensor *te
 }
 
 extern "C" int64_t dgdm_trainer3d_steps(const DgdmTrainer3d *m) { return m ? m->bn_batches : -1; }
+
+// test hook: intermediate tensors of the last call (device -> out_dev): 0 X0 [R][800], 1 l1p [R*512][128], 2 l2p [R*128][256], 3 feat1 [..][4],
+// 4 y11 [..][64], 5 nx1 [R][512][3] (float), 6 fps1 (int32 bits), 7 idx1 (int32 bits), 8 dX0 [R][800], 9 pred [R][4]
+extern "C" int dgdm_trainer3d_debug_read(DgdmTrainer3d *m, int which, void *out_dev, int64_t count, void *stream) {
+    DGDM_REQUIRE(m && out_dev && count > 0, DGDM_EINVAL, "dgdm_trainer3d_debug_read: bad argument");
+    const void *src[] = {m->X0, m->l1p, m->l2p, m->feat1, m->y11, m->nx1, m->fps1, m->idx1, m->dX0, m->pred};
+    DGDM_REQUIRE(which >= 0 && which < 10, DGDM_EINVAL, "dgdm_trainer3d_debug_read: which");
+    DGDM_HIP_CHECK(hipMemcpyAsync(out_dev, src[which], (size_t)count * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return DGDM_OK;
+}

@@ -170,7 +170,7 @@ __global__ void prep_kernel(const float *__restrict__ x0, const float *__restric
     if (e >= (int64_t)S * W) return;
     const int s = (int)(e / W), k = (int)(e - (int64_t)s * W);
     if (k < L) {
-        X0[(int64_t)s * rp + pad + k] = __fadd_rn(__fmul_rn(sa[s], x0[(int64_t)s * L + k]), __fmul_rn(sb[s], noise[(int64_t)s * L + k]));
+        X0[(int64_t)s * rp + pad + k] = add_rn(mul_rn(sa[s], x0[(int64_t)s * L + k]), mul_rn(sb[s], noise[(int64_t)s * L + k]));
     } else {
         const int j = k - L, half = dsed / 2;
         const float arg = (float)t[s] * freqs[j % half];
@@ -202,7 +202,7 @@ __global__ void loss_finish_kernel(const float *__restrict__ part, int S, double
 __global__ void ema_kernel(float *__restrict__ e, const float *__restrict__ p, int64_t n, float decay, float one_minus) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    e[i] = __fadd_rn(__fmul_rn(e[i], decay), __fmul_rn(one_minus, p[i]));
+    e[i] = add_rn(mul_rn(e[i], decay), mul_rn(one_minus, p[i]));
 }
 }  // namespace
 }  // namespace dgdm

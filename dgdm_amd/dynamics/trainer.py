@@ -1,10 +1,10 @@
 """``Trainer`` of the dynamics model with the reference's interface (dynamics/trainer.py:16-146) on the HIP path.
 
-2-D (``ProfileForward2DModel``) only: parameters, gradients and the Adam state live in a ``DgdmTrainer2d`` handle inside
-libdgdm_hip.so and one ``step`` is forward (BatchNorm in training mode) + MSE loss + backward + Adam on the GPU
-(csrc/train2d.hip).  The random draws are the reference's: ``torch.randn`` for the noise, then ``torch.randint`` for the
-timesteps, both from the CPU generator (trainer.py:68-74).  The 3-D model (PointNet++ weight gradients) is not built: asking
-for ``fingers_3d`` raises.  There is no CPU path.
+Parameters, gradients and the Adam state live in a ``DgdmTrainer2d`` / ``DgdmTrainer3d`` handle inside libdgdm_hip.so and one ``step``
+is forward (BatchNorm in training mode) + MSE loss + backward + Adam on the GPU (csrc/train2d.hip; ``--fingers_3d``:
+csrc/train3d.hip, PointNet++ in training mode as written).  The random draws are the reference's: ``torch.randn`` for the noise, then
+``torch.randint`` for the timesteps, both from the CPU generator (trainer.py:68-74), and in 3-D the FPS start draws of every forward
+(pointnet2_utils.py:83).  There is no CPU path.
 
 The trained weights live in the library handle: ``Trainer.state_dict()`` / ``save_checkpoint()`` read them out; ``Trainer.model`` (the
 ``nn.Module`` the reference code pokes at for its key layout) keeps the INITIAL parameters unless ``sync_model()`` copies the trained
@@ -57,11 +57,8 @@ class Trainer(object):
         self.num_epochs = args.num_epochs
         self.ckpt_path = args.checkpoint_path
         self.fingers_3d = args.fingers_3d
-        if self.fingers_3d:
-            raise NotImplementedError("training the 3-D dynamics model (PointNet++ weight gradients) is not part of the HIP path; "
-                                      "2-D (ProfileForward2DModel) is")
         self.gripperpts_dim = args.ctrlpts_dim
-        self.object_vertices_dim = 2 * args.object_max_num_vertices
+        self.object_vertices_dim = args.object_max_num_vertices if self.fingers_3d else 2 * args.object_max_num_vertices
         self.num_timesteps_per_batch = args.num_timesteps_per_batch
         if self.num_timesteps_per_batch != 1:
             # trainer.py:68-72 sizes the noise with num_timesteps_per_batch applied twice: only 1 is shape-consistent there
@@ -75,12 +72,16 @@ class Trainer(object):
         # exact de-duplication of the time / object encoders over the rows (dgdm_trainer2d_set_groups); False = every row through both
         self.group_encoders = True
         # the next step's CPU-generator draws are made by a worker thread while the GPU runs this step (see _draw)
-        self.draw_ahead = True
+        self.draw_ahead = not self.fingers_3d      # 3-D: the FPS start draws of every forward follow on the same generator
         self._ahead = None
 
     # ------------------------------------------------------------------ model / optimizer (trainer.py:40-51)
     def create_model(self, state_dict: Optional[Dict[str, torch.Tensor]] = None):
-        self.model = ProfileForward2DModel(output_ch=3, params_ch=self.gripperpts_dim, object_ch=self.object_vertices_dim)
+        if self.fingers_3d:
+            from .profile_forward_3d import ProfileForward3DModel
+            self.model = ProfileForward3DModel(output_ch=3, params_ch=self.gripperpts_dim)
+        else:
+            self.model = ProfileForward2DModel(output_ch=3, params_ch=self.gripperpts_dim, object_ch=self.object_vertices_dim)
         if state_dict is None and self.ckpt_path is not None:
             print('loading checkpoint from', self.ckpt_path)
             state_dict = torch.load(self.ckpt_path, map_location='cpu')
@@ -93,8 +94,12 @@ class Trainer(object):
             raise RuntimeError("dgdm_amd runs on an MI355X through libdgdm_hip.so; no GPU is visible and there is no CPU path")
         self._packed = _lib.PackedStateDict(self.model.plain_state_dict())
         h = C.c_void_p()
-        check(lib().dgdm_trainer2d_create(C.byref(h), self._packed.array, self._packed.n, self.gripperpts_dim, self.object_vertices_dim,
-                                          0.9, 0.95, 1e-8, float(self.weight_decay)))
+        if self.fingers_3d:
+            check(lib().dgdm_trainer3d_create(C.byref(h), self._packed.array, self._packed.n, self.gripperpts_dim, self.object_vertices_dim,
+                                              0.9, 0.95, 1e-8, float(self.weight_decay)))
+        else:
+            check(lib().dgdm_trainer2d_create(C.byref(h), self._packed.array, self._packed.n, self.gripperpts_dim, self.object_vertices_dim,
+                                              0.9, 0.95, 1e-8, float(self.weight_decay)))
         self._h = h
         self._nbt0 = {k: int(v) for k, v in self.model.state_dict().items() if k.endswith('num_batches_tracked')}
         print('done')
@@ -102,7 +107,7 @@ class Trainer(object):
     def __del__(self):
         try:
             if getattr(self, "_h", None) and lib is not None:
-                lib().dgdm_trainer2d_destroy(self._h)
+                (lib().dgdm_trainer3d_destroy if self.fingers_3d else lib().dgdm_trainer2d_destroy)(self._h)
         except Exception:        # interpreter shutdown: module globals are already gone
             pass
         self._h = None
@@ -231,10 +236,56 @@ class Trainer(object):
         full = torch.cat([got[r, :max(0, min(rows, (r + 1) * cs) - min(rows, r * cs))] for r in range(world)])
         return float(got[:, cs, 0].sum()), full
 
+    # ------------------------------------------------------------------ 3-D (csrc/train3d.hip)
+    def _run3d(self, ctrl, score, input_ori, input_pos, object_vertices, train: bool, drawn):
+        """One forward (/ backward / optimizer step) on the rows handed in - a whole batch or one --use_sub_batch slice.  ctrl
+        (rows, 3, L): only channel 1 is noised (trainer.py:68) and read (profile_forward_3d.py:77); object_vertices (rows, 3, N)."""
+        if self._h is None:
+            raise RuntimeError("Trainer.create_model() has not been called")
+        if _dist.world_rank()[0] != 1:
+            raise NotImplementedError("data-parallel training of the 3-D model is not built (the 2-D Trainer is; one GPU holds a --sub_bs=2048 slice)")
+        dev = torch.device("cuda", torch.cuda.current_device())
+        f = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()       # noqa: E731
+        noise, timesteps = drawn
+        rows, N = ctrl.shape[0], object_vertices.shape[2]
+        ac = self.noise_scheduler.alphas_cumprod[timesteps]
+        T = self.noise_scheduler.config.num_train_timesteps
+        # the FPS start draws of this forward: sa1 over the cloud's N points, then sa2 over sa1's 512 centres (pointnet2_utils.py:83)
+        s1 = np.ascontiguousarray(torch.randint(0, N, (rows,), dtype=torch.long).numpy())
+        s2 = np.ascontiguousarray(torch.randint(0, 512, (rows,), dtype=torch.long).numpy())
+        args = [f(ctrl[:, 1, :]), f(noise), f(ac ** 0.5), f((1 - ac) ** 0.5), f(timesteps.float() / T), f(input_ori), f(input_pos),
+                f(object_vertices.permute(0, 2, 1))]
+        sc = f(score)
+        pred = torch.empty((rows, 3), dtype=torch.float32, device=dev)
+        loss = C.c_float()
+        check(lib().dgdm_trainer3d_step(self._h, *[dptr(v) for v in args], s1.ctypes.data, s2.ctypes.data, dptr(sc), rows,
+                                        float(self.optimizer.param_groups[0]["lr"]), 1 if train else 0, dptr(pred), C.byref(loss), stream_ptr()))
+        return float(loss.value), pred
+
+    def _draw3d(self, rows: int):
+        """trainer.py:68-73 for --fingers_3d: randn for channel 1's noise (the zeros around it draw nothing), then the timesteps."""
+        noise = torch.randn((rows * self.num_timesteps_per_batch, 1, self.gripperpts_dim))[:, 0, :]
+        return noise, torch.randint(0, self.noise_scheduler.config.num_train_timesteps, (rows,)).long()
+
+    def _batch3d(self, ctrl, score, input_ori, input_pos, object_vertices, train: bool):
+        n = ctrl.shape[0]
+        noise, timesteps = self._draw3d(n)
+        if not self.use_sub_batch:
+            return self._run3d(ctrl, score, input_ori, input_pos, object_vertices, train, (noise, timesteps))
+        losses, preds = [], []
+        for i in range(0, n, self.sub_batch_size):
+            sl = slice(i, i + self.sub_batch_size)
+            loss, pred = self._run3d(ctrl[sl], score[sl], input_ori[sl], input_pos[sl], object_vertices[sl], train, (noise[sl], timesteps[sl]))
+            losses.append(loss)
+            preds.append(pred)
+        return sum(losses) / (n / self.sub_batch_size), torch.cat(preds, dim=0)
+
     def step(self, ctrl, score, input_ori=None, input_pos=None, object_vertices=None, rows_per_sample: Optional[int] = None):
         """trainer.py:53-103: returns (loss.item(), pred.detach()).  rows_per_sample (not in the reference): the caller's promise that
         `object_vertices` holds runs of that many identical rows - dynamics/main.py builds its batches so - which lets the object
         encoder run once per sample."""
+        if self.fingers_3d:
+            return self._batch3d(ctrl, score, input_ori, input_pos, object_vertices, True)
         if not self.use_sub_batch:
             return self._run(ctrl, score, input_ori, input_pos, object_vertices, True, rows_per_sample)
         # --use_sub_batch (trainer.py:81-94): the draws once for the whole batch, then one optimizer step per slice of sub_bs rows;
@@ -250,6 +301,9 @@ class Trainer(object):
 
     def inference(self, ctrl, score, input_ori=None, input_pos=None, object_vertices=None, rows_per_sample: Optional[int] = None):
         """trainer.py:108-146 (eval mode, no update): returns (pred, loss)."""
+        if self.fingers_3d:
+            loss, pred = self._batch3d(ctrl, score, input_ori, input_pos, object_vertices, False)
+            return pred, loss
         if not self.use_sub_batch:
             loss, pred = self._run(ctrl, score, input_ori, input_pos, object_vertices, False, rows_per_sample)
             return pred, loss
@@ -268,12 +322,12 @@ class Trainer(object):
     def _export(self, which: int) -> Dict[str, torch.Tensor]:
         sd = {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()}
         packed = _lib.PackedStateDict({k: v for k, v in sd.items() if v.dtype == torch.float32})
-        check(lib().dgdm_trainer2d_export(self._h, which, packed.array, packed.n))
+        check((lib().dgdm_trainer3d_export if self.fingers_3d else lib().dgdm_trainer2d_export)(self._h, which, packed.array, packed.n))
         out = {}
         for name, arr in zip(packed.names, packed.keep):
             out[name.decode()] = torch.from_numpy(arr.copy()).reshape(sd[name.decode()].shape)
         if which == 0:
-            steps = int(lib().dgdm_trainer2d_steps(self._h))
+            steps = int((lib().dgdm_trainer3d_steps if self.fingers_3d else lib().dgdm_trainer2d_steps)(self._h))
             for k, v0 in self._nbt0.items():
                 out[k] = torch.tensor(v0 + steps, dtype=torch.long)
         else:

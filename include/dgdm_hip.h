@@ -434,6 +434,11 @@ int dgdm_trainer3d_step(DgdmTrainer3d *m, const float *ctrl1_dev, const float *n
 /* which = 0 the state_dict (parameters + running statistics), 1 gradients of the last step, 2 / 3 Adam's exp_avg / exp_avg_sq */
 int dgdm_trainer3d_export(DgdmTrainer3d *m, int which, DgdmTensor *tensors, int n_tensors);
 int64_t dgdm_trainer3d_steps(const DgdmTrainer3d *m);      /* training steps taken = num_batches_tracked increment */
+/* Test hook: an intermediate tensor of the last call, `count` 32-bit words device -> out_dev.  which: 0 trunk input [rows][800] =
+ * [object embedding 256 | gripper 256 | pose 27 | time 256 | 0 x 5], 1 sa1 output [rows*512][128], 2 sa2 output [rows*128][256],
+ * 3 sa1 grouped coordinates [rows*512*32][4], 4 sa1 first conv [..][64], 5 sa1 centres [rows][512][3], 6 sa1 FPS indices (int32),
+ * 7 sa1 ball lists (int32), 8 gradient of the trunk input [rows][800], 9 predictions [rows][4].                                    */
+int dgdm_trainer3d_debug_read(DgdmTrainer3d *m, int which, void *out_dev, int64_t count, void *stream);
 
 #ifdef __cplusplus
 }

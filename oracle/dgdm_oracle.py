@@ -328,7 +328,7 @@ def query_ball_point(radius: float, nsample: int, xyz: torch.Tensor, new_xyz: to
 
 
 def set_abstraction(sd: SD, p: str, xyz: torch.Tensor, points: Optional[torch.Tensor], npoint, radius, nsample,
-                    starts: Optional[StartLog]):
+                    starts: Optional[StartLog], training: bool = False, buffers: Optional[SD] = None):
     """``PointNetSetAbstraction.forward`` (pointnet2_utils.py:184-210); xyz (B,3,N), points (B,D,N)."""
     xyz = xyz.permute(0, 2, 1)
     if points is not None:
@@ -366,19 +366,22 @@ def set_abstraction(sd: SD, p: str, xyz: torch.Tensor, points: Optional[torch.Te
             i += 1
             continue
         feat = F.conv2d(feat, sd[f"{p}.mlp_convs.{i}.weight"], sd[f"{p}.mlp_convs.{i}.bias"])
-        feat = F.batch_norm(feat, sd[b + ".running_mean"], sd[b + ".running_var"], sd[b + ".weight"], sd[b + ".bias"],
-                            training=False, eps=1e-5)
+        bufs = sd if buffers is None else buffers      # training: batch statistics over (B, nsample, npoint), running statistics updated in place
+        feat = F.batch_norm(feat, bufs[b + ".running_mean"], bufs[b + ".running_var"], sd[b + ".weight"], sd[b + ".bias"],
+                            training=training, momentum=0.1, eps=1e-5)
         feat = F.relu(feat)
         i += 1
     return new_xyz.permute(0, 2, 1), torch.max(feat, 2)[0]
 
 
-def pointnet2_forward(sd: SD, xyz: torch.Tensor, starts: Optional[StartLog] = None, prefix: str = "") -> torch.Tensor:
+def pointnet2_forward(sd: SD, xyz: torch.Tensor, starts: Optional[StartLog] = None, prefix: str = "", training: bool = False,
+                      buffers: Optional[SD] = None) -> torch.Tensor:
     """``PointNet2.forward`` (dynamics/models/pointnet2.py:21-32); xyz (B,3,N) -> (B,256)."""
     starts = starts or StartLog()
-    l1x, l1p = set_abstraction(sd, prefix + "sa1", xyz, None, 512, 0.2, 32, starts)
-    l2x, l2p = set_abstraction(sd, prefix + "sa2", l1x, l1p, 128, 0.4, 64, starts)
-    _, l3p = set_abstraction(sd, prefix + "sa3", l2x, l2p, None, None, None, None)
+    kw = dict(training=training, buffers=buffers)
+    l1x, l1p = set_abstraction(sd, prefix + "sa1", xyz, None, 512, 0.2, 32, starts, **kw)
+    l2x, l2p = set_abstraction(sd, prefix + "sa2", l1x, l1p, 128, 0.4, 64, starts, **kw)
+    _, l3p = set_abstraction(sd, prefix + "sa3", l2x, l2p, None, None, None, None, **kw)
     return l3p.reshape(xyz.shape[0], -1)
 
 
@@ -782,3 +785,76 @@ class UnetTrainer:
             self.sd[k] = self.sd[k] - (self.lr / bc1) * self.m[k] / (self.v[k].sqrt() / math.sqrt(bc2) + self.eps)
         self.ema.step(self.sd)
         return float(loss.detach()), pred.detach()
+
+
+# =========================================================================== (f) rank 4  Trainer.step of the 3-D dynamics model
+class Trainer3D:
+    """``Trainer`` (dynamics/trainer.py:16-146) for ``ProfileForward3DModel``, restated functionally over a flat state_dict: one
+    ``step`` = the body of trainer.py:83-92 / :96-103 on the rows it is handed (the caller makes the ``--use_sub_batch`` slices) - the
+    model in training mode: PointNet++ with BatchNorm2d batch statistics over every grouped point of the batch
+    (pointnet2_utils.py:184-210), the trunk's BatchNorm1d, running statistics (momentum 0.1, unbiased variance) - nn.MSELoss,
+    torch.autograd, torch.optim.Adam(lr, betas=(0.9, 0.95), weight_decay) (:46) in the single-tensor form.  ``time_encoder`` is built
+    but never called by forward (profile_forward_3d.py:83): its gradient is None and Adam skips it, weight decay included.  Draws, in
+    the reference's order: ``draws`` (torch.randn for channel 1's noise, :68; torch.randint timesteps, :69-73) once per batch, then per
+    forward the FPS starts of sa1 and sa2 (pointnet2_utils.py:83), recorded in ``starts.log``."""
+
+    def __init__(self, sd: SD, num_train_timesteps: int, lr: float, weight_decay: float = 0.0, betas=(0.9, 0.95), eps: float = 1e-8):
+        self.sd = {k: v.clone() for k, v in sd.items()}
+        self.names = [k for k, v in self.sd.items() if v.dtype.is_floating_point and "running_" not in k]
+        self.ddim = DDIM(num_train_timesteps)
+        self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.m = {k: torch.zeros_like(self.sd[k]) for k in self.names}
+        self.v = {k: torch.zeros_like(self.sd[k]) for k in self.names}
+        self.t = 0
+        self.grads: SD = {}
+
+    def draw(self, ctrl: torch.Tensor):
+        """The per-batch draws of trainer.py:68-73 for ctrl (rows, 3, L): (noise (rows, L) of channel 1, timesteps (rows,))."""
+        rows, _, L = ctrl.shape
+        return torch.randn((rows, 1, L))[:, 0, :], torch.randint(0, self.ddim.num_train_timesteps, (rows,)).long()
+
+    def _noisy(self, ctrl, draws):
+        noise, timesteps = draws
+        full = torch.cat([torch.zeros_like(noise)[:, None], noise[:, None], torch.zeros_like(noise)[:, None]], dim=1)      # :68
+        return self.ddim.add_noise(ctrl, full, timesteps), timesteps.float() / self.ddim.num_train_timesteps
+
+    def _forward(self, sd, noisy, ori, pos, t, object_vertices, training, starts):
+        g = _mlp2(sd, "gripper_encoder", noisy[:, 1, :], F.relu)
+        pose = torch.cat([nerf_embed(ori), nerf_embed(pos)], dim=1)
+        o = pointnet2_forward(sd, object_vertices, starts, prefix="object_encoder.", training=training, buffers=self.sd)
+        te = timestep_embedding(t, sd["gripper_encoder.2.weight"].shape[0])
+        x = torch.cat([o, g, pose, te], dim=1)
+        i = 0
+        while f"linears.{3 * i}.weight" in sd:
+            x = F.linear(x, sd[f"linears.{3 * i}.weight"], sd[f"linears.{3 * i}.bias"])
+            b = f"linears.{3 * i + 1}"
+            x = F.relu(F.batch_norm(x, self.sd[b + ".running_mean"], self.sd[b + ".running_var"], sd[b + ".weight"], sd[b + ".bias"],
+                                    training=training, momentum=0.1, eps=1e-5))
+            i += 1
+        return F.linear(x, sd["output.weight"], sd["output.bias"])
+
+    def step(self, ctrl, score, input_ori, input_pos, object_vertices, draws, starts: Optional[StartLog] = None):
+        noisy, t = self._noisy(ctrl, draws)
+        leaf = {k: self.sd[k].clone().requires_grad_(True) for k in self.names}
+        pred = self._forward({**self.sd, **leaf}, noisy, input_ori, input_pos, t, object_vertices, True, starts or StartLog())
+        loss = F.mse_loss(pred, score)
+        grads = torch.autograd.grad(loss, [leaf[k] for k in self.names], allow_unused=True)
+        self.grads = {k: g for k, g in zip(self.names, grads) if g is not None}
+        self.t += 1
+        b1, b2 = self.betas
+        bc1, bc2 = 1 - b1 ** self.t, 1 - b2 ** self.t
+        for k, g in self.grads.items():
+            g = g + self.wd * self.sd[k] if self.wd else g
+            self.m[k] = self.m[k] + (g - self.m[k]) * (1 - b1)
+            self.v[k] = self.v[k] * b2 + (1 - b2) * g * g
+            self.sd[k] = self.sd[k] - (self.lr / bc1) * self.m[k] / (self.v[k].sqrt() / math.sqrt(bc2) + self.eps)
+        for k in self.sd:
+            if k.endswith("num_batches_tracked"):
+                self.sd[k] = self.sd[k] + 1
+        return float(loss.detach()), pred.detach()
+
+    def inference(self, ctrl, score, input_ori, input_pos, object_vertices, draws, starts: Optional[StartLog] = None):
+        with torch.no_grad():
+            noisy, t = self._noisy(ctrl, draws)
+            pred = self._forward(self.sd, noisy, input_ori, input_pos, t, object_vertices, False, starts or StartLog())
+            return pred, float(F.mse_loss(pred, score))

@@ -1,0 +1,128 @@
+"""Trainer.step / Trainer.inference of the 3-D dynamics model on the HIP path (csrc/train3d.hip) through the
+reference-shaped ``dynamics.trainer.Trainer`` (--fingers_3d), against tests/golden/g13_train3d.npz - the reference's own Trainer run on
+CPU (make_golden.py g13) - and against the oracle (oracle.Trainer3D, pinned to the same fixture) on other row counts."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import train3d_common as t3
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _args(sub, wd):
+    return argparse.Namespace(use_sub_batch=sub, sub_bs=4, grid_size=45, learning_rate=1e-4, weight_decay=wd, num_epochs=100, checkpoint_path=None,
+                              fingers_3d=True, ctrlpts_dim=42, object_max_num_vertices=512, num_timesteps_per_batch=1, num_inference_steps=5,
+                              num_train_timesteps=15)
+
+
+class _HipTrainer3D:
+    def __init__(self, sd, T, wd, sub):
+        from dgdm_amd.dynamics.trainer import Trainer
+        self.t = Trainer(_args(sub, wd))
+        self.t.create_model(sd)
+
+    def lr_step(self):
+        self.t.lr_scheduler.step()
+
+    def step(self, *a):
+        return self.t.step(*a)
+
+    def inference(self, *a):
+        return self.t.inference(*a)
+
+    def gradients(self):
+        return self.t.gradients()
+
+    def state_dict(self):
+        return self.t.state_dict()
+
+
+@pytest.mark.parametrize("tag", ["plain", "sub"])
+def test_trainer3d_matches_reference(tag):
+    """Loss / predictions of the first forward 2e-5; every sampled gradient entry of the first step within 1e-4 of its tensor's rms of the
+    reference's - or, where the reference's own float32 gradient is farther than that from the float64 gradient of the same step (the
+    set-abstraction weights: small differences of large sums), at least as close to float64 as the reference is; running statistics;
+    eval-mode inference.  Later forwards and the final parameters see the Adam steps taken on rounding-level gradient entries (+-lr each,
+    different entries in two implementations) through BatchNorm over 8 rows ('plain': 1e-2) or 4 rows with an update between the two
+    slices of every call ('sub', which is there for the slicing, the draw order and the loss averaging of --use_sub_batch: 5e-2) / only the step bound."""
+    g = util.load("g13_train3d.npz")
+    rec = t3.drive(g, tag, _HipTrainer3D)
+    if tag == "sub":
+        t3.check_sub_loosely(g, rec)
+    else:
+        t3.check(g, tag, rec, 2e-5, 3e-4, 3.1e-4, verbose=True, tol_later=1e-2, vs64=True, tol_run=2e-3, tol_inf=2e-2)
+
+
+@pytest.mark.parametrize("rows", [5, 33])
+def test_trainer3d_vs_oracle(rows):
+    """Odd row counts (a ragged last GEMM tile at every level), three different clouds: loss, prediction and EVERY gradient tensor of one
+    step against the oracle's autograd on the same draws - in float32 (the reference's arithmetic) AND in float64.  The weight gradients
+    of the set-abstraction convolutions are small differences of large sums (BatchNorm's backward subtracts the batch means of a
+    gradient that is non-zero at the arg-max sample only), and torch's float32 CPU kernels lose up to 1.5e-2 of them at 33 rows (oracle
+    float32 vs float64); the HIP path's split-and-ordered sums stay closer to exact.  Asserted per tensor:
+    rel(HIP, float64) <= max(2e-4, rel(float32 oracle, float64)) and rel(HIP, float32 oracle) <= max(2e-4, 2 rel(float32 oracle, float64))."""
+    from dgdm_amd.dynamics.trainer import Trainer
+    from dgdm_amd import synth
+    from oracle import dgdm_oracle as orc
+    sd = util.dyn3d_sd(57)
+    rs = np.random.RandomState(rows)
+    ctrl = torch.from_numpy(rs.uniform(-1, 1, (rows, 3, 42)).astype(np.float32))
+    obj = torch.stack([synth.synth_object_3d(80 + i % 3) for i in range(rows)]).permute(0, 2, 1).contiguous()
+    ori = torch.from_numpy(rs.uniform(-1, 1, (rows, 1)).astype(np.float32))
+    pos = torch.from_numpy(rs.uniform(-1, 1, (rows, 2)).astype(np.float32))
+    score = torch.from_numpy(rs.normal(0, 1, (rows, 3)).astype(np.float32))
+    o = orc.Trainer3D(sd, 15, 1e-4, 0.0)
+    torch.manual_seed(rows)
+    draws, log = o.draw(ctrl), orc.StartLog()
+    lo, po = o.step(ctrl, score, ori, pos, obj, draws, log)
+    o64 = orc.Trainer3D({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, 15, 1e-4, 0.0)
+    o64.step(ctrl.double(), score.double(), ori.double(), pos.double(), obj.double(), (draws[0].double(), draws[1]), orc.StartLog(list(log.log)))
+    t = Trainer(_args(False, 0.0))
+    t.create_model(sd)
+    torch.manual_seed(rows)
+    lh, ph = t.step(ctrl, score, ori, pos, obj)
+    assert abs(lh / lo - 1) < 2e-5, (lh, lo)
+    assert util.rel_l2(ph.cpu(), po) < 1e-4          # BatchNorm1d over as few as 5 rows amplifies the last bits of the trunk's sums (2.3e-5 at 5 rows)
+    gh = t.gradients()
+    worst = (0.0, 0.0, 0.0, "")
+    for k in o.grads:
+        if k in t3.BN_FED_BIAS:
+            continue
+        e_h64, e_o64, e_ho = util.rel_l2(gh[k], o64.grads[k]), util.rel_l2(o.grads[k], o64.grads[k]), util.rel_l2(gh[k], o.grads[k])
+        worst = max(worst, (e_ho, e_h64, e_o64, k))
+        assert e_h64 <= max(2e-4, e_o64), (k, e_h64, e_o64)
+        assert e_ho <= max(2e-4, 2 * e_o64), (k, e_ho, e_o64)
+    print(f"rows {rows}: loss {lh:.6f} (oracle {lo:.6f}); worst tensor {worst[3]}: HIP vs float32 oracle {worst[0]:.1e}, HIP vs float64 {worst[1]:.1e}, "
+          f"float32 oracle vs float64 {worst[2]:.1e}")
+    sh = t.state_dict()
+    for k in sh:
+        if "running_" in k:
+            assert float((sh[k] - o.sd[k]).abs().max()) < 1e-5 * max(1.0, float(o.sd[k].abs().max())), k
+    assert int(sh["linears.1.num_batches_tracked"]) == 1
+    # eval mode (Trainer.inference, trainer.py:108-146) on the HIP path's OWN trained weights against the oracle evaluating those weights
+    torch.manual_seed(100 + rows)
+    pi, li = t.inference(ctrl, score, ori, pos, obj)
+    oe = orc.Trainer3D({k: v.clone() for k, v in sh.items()}, 15, 1e-4, 0.0)
+    torch.manual_seed(100 + rows)
+    pe, le = oe.inference(ctrl, score, ori, pos, obj, oe.draw(ctrl), orc.StartLog())
+    assert abs(li / le - 1) < 2e-5 and util.rel_l2(pi.cpu(), pe) < 2e-5, (li, le, util.rel_l2(pi.cpu(), pe))
+
+
+def test_trainer3d_deterministic():
+    from dgdm_amd.dynamics.trainer import Trainer
+    data = util.train3d_data(3, 2, 3)
+    outs = []
+    for _ in range(2):
+        t = Trainer(_args(False, 0.0))
+        t.create_model(util.dyn3d_sd(9))
+        torch.manual_seed(1)
+        l1, _ = t.step(*data)
+        l2, _ = t.step(*data)
+        outs.append((l1, l2, t.state_dict()))
+    assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1]
+    assert all(torch.equal(outs[0][2][k], outs[1][2][k]) for k in outs[0][2])

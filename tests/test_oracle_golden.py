@@ -301,3 +301,12 @@ def test_unet_trainer_matches_reference(tag):
         assert np.abs(f[sample_idx(k, f.size)] - g[f"{tag}_final/{k}"]).max() < 4e-6, k
     # EMAModel's schedule (diffusers 0.11.1, restated: parity unpinned): no averaging on the first two calls, then 1 - (1 + step)^-power
     assert o.ema.optimization_step == 3 and abs(o.ema.decay - (1 - 2 ** -0.85)) < 1e-12
+
+
+@pytest.mark.parametrize("tag", ["plain", "sub"])
+def test_trainer3d_matches_reference(tag):
+    """oracle.Trainer3D against the reference's own Trainer.step / inference with --fingers_3d (PointNet++ in training mode; with and
+    without --use_sub_batch)."""
+    from tests import train3d_common as t3
+    g = util.load("g13_train3d.npz")
+    t3.check(g, tag, t3.drive(g, tag, t3.OracleTrainer3D), 2e-5, 5e-5, 4e-6, verbose=True)

@@ -88,6 +88,21 @@ def train2d_data(seed, n_grippers=3, n_poses=128, L=14, nv=100):
     return [torch.from_numpy(a) for a in (ctrl, score, ori, pos, obj)]
 
 
+def train3d_data(seed, n_grippers=2, n_poses=4, L=42, N=512):
+    """A synthetic 3-D training batch shaped like dynamics/main.py hands it to Trainer.step with --fingers_3d: every (gripper, object)
+    sample repeated over its pose rows - control points (rows, 3, L), scores (rows, 3), orientation (rows, 1), position (rows, 2), cloud
+    (rows, 3, N).  Inputs only."""
+    from dgdm_amd import synth
+    rs = np.random.RandomState(seed)
+    rep = lambda a: np.repeat(a, n_poses, axis=0)                                   # noqa: E731
+    ctrl = rep(rs.uniform(-1, 1, (n_grippers, 3, L))).astype(np.float32)
+    obj = rep(np.stack([synth.synth_object_3d(70 + seed + i, N).numpy().T for i in range(n_grippers)])).astype(np.float32)
+    ori = rs.uniform(-1, 1, (n_grippers * n_poses, 1)).astype(np.float32)
+    pos = rs.uniform(-1, 1, (n_grippers * n_poses, 2)).astype(np.float32)
+    score = rs.normal(0, 1, (n_grippers * n_poses, 3)).astype(np.float32)
+    return [torch.from_numpy(np.ascontiguousarray(a)) for a in (ctrl, score, ori, pos, obj)]
+
+
 def sample_idx(name, numel, k=96):
     """Which entries of a parameter tensor the training fixture keeps (all of a small one)."""
     import zlib
