@@ -18,12 +18,18 @@ from .parser import parse
 from .trainer import Trainer
 
 
-def batch_rows(batch):
-    """A DataLoader batch [samples, cells, ...] -> the row tensors Trainer.step takes (main.py:25-35, 2-D branch): every sample's
-    control ordinates and object vertices repeated over its pose cells."""
+def batch_rows(batch, fingers_3d: bool = False):
+    """A DataLoader batch [samples, cells, ...] -> the row tensors Trainer.step takes (main.py:25-35): every sample's control ordinates
+    and object vertices repeated over its pose cells.  3-D (:29-30, :143-144): control points (rows, 3, L) and clouds (rows, 3, N), built
+    as the reference builds them - the batch concatenated `cells` times along dim 0 (row = cell * samples + sample; with the shipped
+    --batch_size=1 that is the same order as the scores' (sample, cell))."""
     score = batch['scores']
     cells = score.size(1)
     ori, pos = batch['input_ori'].reshape(-1, 1), batch['input_pos'].reshape(-1, 2)
+    if fingers_3d:
+        ctrl = torch.cat([batch['ctrlpts'] for _ in range(cells)], 0).moveaxis(-1, -2)
+        obj = torch.cat([batch['object_vertices'] for _ in range(cells)], 0).moveaxis(-1, -2)
+        return ctrl, score.reshape(-1, 3), ori, pos, obj
     ctrl = batch['ctrlpts'][..., 1].repeat(1, cells).reshape(ori.shape[0], -1)        # y ordinates only (:33)
     obj = batch['object_vertices'].repeat(1, cells, 1).reshape(ori.shape[0], -1)
     return ctrl, score.reshape(-1, 3), ori, pos, obj
@@ -58,7 +64,7 @@ class _Log:
 def validate(args, val_loader, trainer, threshold_std):
     n, loss_sum, acc_sum = 0, 0.0, [0.0, 0.0, 0.0]
     for batch in val_loader:
-        ctrl, score, ori, pos, obj = batch_rows(batch)
+        ctrl, score, ori, pos, obj = batch_rows(batch, args.fingers_3d)
         pred, loss = trainer.inference(ctrl, score, ori, pos, obj, rows_per_sample=batch['scores'].size(1))
         acc = class_accuracy(score, pred.cpu(), threshold_std)
         loss_sum, acc_sum, n = loss_sum + loss, [a + b for a, b in zip(acc_sum, acc)], n + 1
@@ -73,7 +79,8 @@ def train(args):
     if torch.cuda.is_available():
         _lib.device_init(local)
     os.makedirs(args.save_dir, exist_ok=True)
-    kw = dict(object_max_num_vertices=args.object_max_num_vertices, fingers_3d=args.fingers_3d)
+    # the reference reads args.object_mesh_dir (main.py:83,101), which its parser never defines (dynamics/parser.py:22 has --object_dir): that flag it is
+    kw = dict(object_max_num_vertices=args.object_max_num_vertices, fingers_3d=args.fingers_3d, object_mesh_dir=getattr(args, 'object_mesh_dir', None) or args.object_dir)
     train_set, val_set = DynamicsDataset(args.data_dir, **kw), DynamicsDataset(args.test_data_dir, **kw)
     threshold_std = train_set.threshold / train_set.std
     train_loader = DataLoader(train_set, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers, drop_last=False)
@@ -90,7 +97,7 @@ def train(args):
     for epoch in range(args.num_epochs):
         loss_sum, acc_sum = 0.0, [0.0, 0.0, 0.0]
         for i, batch in enumerate(train_loader):
-            ctrl, score, ori, pos, obj = batch_rows(batch)
+            ctrl, score, ori, pos, obj = batch_rows(batch, args.fingers_3d)
             loss, pred = trainer.step(ctrl, score, ori, pos, obj, rows_per_sample=batch['scores'].size(1))
             acc = class_accuracy(score, pred.cpu(), threshold_std)
             loss_sum, acc_sum = loss_sum + loss, [a + b for a, b in zip(acc_sum, acc)]

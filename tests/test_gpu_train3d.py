@@ -126,3 +126,52 @@ def test_trainer3d_deterministic():
         outs.append((l1, l2, t.state_dict()))
     assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1]
     assert all(torch.equal(outs[0][2][k], outs[1][2][k]) for k in outs[0][2])
+
+
+def test_training_driver_3d_end_to_end(tmp_path):
+    """`python dynamics/main.py <flags of train_dynamics_3d.sh>` (reduced sizes) on synthetic files in the simulator's format with the objects'
+    points beside them: --batch_size=1 --use_sub_batch, 20 pose rows per file in slices of 8 / 8 / 4; the log and the checkpoints appear, the
+    training loss falls, best.pt (DataParallel key layout) loads into the sampling path's ProfileForward3DModel."""
+    import json
+    import subprocess
+    import sys
+    from dgdm_amd import synth
+    from dynamics.profile_forward_3d import ProfileForward3DModel
+    rs = np.random.RandomState(0)
+    objdir = tmp_path / "objects"
+    lo, hi = np.array([-0.1, -0.1, 0.0]), np.array([0.1, 0.1, 0.12])
+    for k in range(2):
+        (objdir / f"obj{k}").mkdir(parents=True)
+        np.save(objdir / f"obj{k}" / "points.npy", (synth.synth_object_3d(90 + k).numpy() + 1) / 2 * (hi - lo) + lo)
+    for split, n in (("train", 6), ("val", 2)):
+        root = tmp_path / split
+        root.mkdir()
+        for i in range(n):
+            cells = 20
+            y = rs.uniform(-0.1, 0.0, 42)
+            xg, zg = np.meshgrid(np.linspace(-0.12, 0.12, 7), np.linspace(0, 0.12, 3))
+            ctrl = np.stack([np.tile(xg.T.reshape(-1), 2), y, np.tile(zg.T.reshape(-1), 2)], axis=1)
+            th, pos = rs.uniform(0, 2 * np.pi, cells), rs.uniform(-0.03, 0.03, (cells, 3))
+            d = {"ctrlpts": ctrl, "obj_theta": th, "obj_pos": pos, "object_name": f"obj{i % 2}",
+                 "delta_theta": 0.03 * np.sin(th) * (1 + 10 * y.mean()), "delta_pos": 0.05 * pos[:, :2] + 0.001 * np.cos(th)[:, None]}
+            np.savez(root / f"s{i}.npz", d)
+    save = tmp_path / "out"
+    cmd = [sys.executable, "dynamics/main.py", f"--save_dir={save}", "--fingers_3d", "--batch_size=1", "--use_sub_batch", "--sub_bs=8", "--object_max_num_vertices=512",
+           f"--data_dir={tmp_path / 'train'}", f"--test_data_dir={tmp_path / 'val'}", f"--object_dir={objdir}", "--ctrlpts_dim=42", "--ctrlpts_x_dim=7",
+           "--ctrlpts_z_dim=3", "--learning_rate=1e-3", "--weight_decay=0", "--num_epochs=6", "--val_step=1", "--save_ckpt_step=1000", "--patience=100", "--num_workers=0",
+           "--num_train_timesteps=15", "--num_inference_steps=5", "--num_timesteps_per_batch=1"]
+    r = subprocess.run(cmd, cwd=str(util.GOLDEN + "/../.."), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    logs = [json.loads(l) for l in open(save / "log.jsonl")]
+    tr = [l["train/average loss"] for l in logs if "train/average loss" in l]
+    assert len(tr) == 6 and all(np.isfinite(tr)) and tr[-1] < 0.8 * tr[0], tr
+    assert (save / "best.pt").exists() and (save / "0_0.pt").exists()
+    ck = torch.load(save / "best.pt")
+    m = ProfileForward3DModel(params_ch=42)
+    missing = m.load_state_dict({k[len("module."):]: v for k, v in ck.items()})
+    assert not missing.missing_keys and not missing.unexpected_keys
+    assert int(ck["module.linears.1.num_batches_tracked"]) > 0
+    dev = torch.device("cuda:0")
+    out = m.to(dev).eval()(torch.zeros(4, 3, 42, device=dev), torch.zeros(4, 1, device=dev), torch.zeros(4, 2, device=dev), torch.zeros(4, device=dev),
+                           synth.synth_object_3d(90).t()[None].expand(4, -1, -1).contiguous().to(dev))
+    assert out.shape == (4, 3) and bool(torch.isfinite(out).all())
