@@ -161,6 +161,18 @@ def cond_fn(s: orc.Setup, tab: ObjectTables64, x: torch.Tensor, t: torch.Tensor,
         return grad
 
 
+def gripper_jacobian(sd64: SD, xb: torch.Tensor) -> torch.Tensor:
+    """d z1 / d x for one finger (x: the control values that reach the model, channel 1 of x_ctrl): z1 = the first trunk layer's
+    pre-activation (after its eval-mode BatchNorm), whose x-dependent part is W1[:, 256:512] . gripper_encoder(x)
+    (dynamics/profile_forward_3d.py:77,84).  [W1][L], float64.  A tile's share of the finger's gradient is (sum over the tile's rows of
+    d objective / d z1) @ this."""
+    w0, b0, w2 = sd64["gripper_encoder.0.weight"], sd64["gripper_encoder.0.bias"], sd64["gripper_encoder.2.weight"]
+    act = ((w0 @ xb + b0) > 0).double()
+    sc = sd64["linears.1.weight"] / torch.sqrt(sd64["linears.1.running_var"] + 1e-5)
+    W = w2.shape[0]
+    return (sc[:, None] * sd64["linears.0.weight"][:, W:2 * W]) @ (w2 * act[None, :]) @ w0
+
+
 def _f64(sd: SD) -> SD:
     return {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
 

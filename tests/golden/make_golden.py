@@ -956,17 +956,6 @@ def g9_tiles(parts=("rotate", "convergence", "multi")):
             np.savez_compressed(path, **out)
 
 
-def _gripper_jacobian(sd64, xb):
-    """d z1 / d x for one finger (x: the 42 control values that reach the model, channel 1 of x_ctrl): z1 = the first trunk layer's
-    pre-activation (after its eval-mode BatchNorm), whose x-dependent part is W1[:, 256:512] . gripper_encoder(x)
-    (dynamics/profile_forward_3d.py:77,84).  [512][42], float64."""
-    w0, b0, w2 = sd64["gripper_encoder.0.weight"], sd64["gripper_encoder.0.bias"], sd64["gripper_encoder.2.weight"]
-    act = ((w0 @ xb + b0) > 0).double()
-    sc = sd64["linears.1.weight"] / torch.sqrt(sd64["linears.1.running_var"] + 1e-5)
-    W = w2.shape[0]
-    return (sc[:, None] * sd64["linears.0.weight"][:, W:2 * W]) @ (w2 * act[None, :]) @ w0
-
-
 def g9_calls64(parts=None):
     """Float64 yardsticks for EVERY recorded cond_fn call and for the whole chain of every full-grid 3-D fixture (the six of round 3
     and the g9_3d_d* sample), by oracle/fast64.py (the float64 evaluation of the as-written dataflow, checked against dgdm_oracle's
@@ -1033,7 +1022,7 @@ def g9_calls64(parts=None):
                     acc = []
                     gr = fast64.cond_fn(s64, tabs[oi], x, ts, o, centers, calls[k:k + n_sub], tiles=acc)
                     k += n_sub
-                    contrib = torch.stack([acc[0][b] @ _gripper_jacobian(sd64, x[b, :, 0]) for b in range(B)])        # [B][tiles][L]
+                    contrib = torch.stack([acc[0][b] @ fast64.gripper_jacobian(sd64, x[b, :, 0]) for b in range(B)])        # [B][tiles][L]
                     assert float((contrib.sum(1) - gr[:, :, 0]).abs().max()) < 1e-9 * max(1.0, float(gr.abs().max()))
                     grads.append(gr[:, :, 0].numpy())
                     tiles.append(contrib.numpy())

@@ -139,6 +139,11 @@ def test_fullgrid_2d(dev):
               f"{row['reference_vs_chain64']:.2e} HIP {row['hip_vs_chain64']:.2e}; reference thread floor {floor:.2e} | gradient: max per-step HIP vs "
               f"reference {max(errs):.1e}; first step vs float64: reference {noise64:.1e} HIP {hip64:.1e}")
     _report(rows)
+    for k, r in rows.items():          # which chains the `dist(HIP, reference) < 1e-4` assertion applied to, and the rule that left the others out
+        applied = r["reference_vs_chain64"] is not None and r["reference_vs_chain64"] < 0.5 * NORTH_STAR
+        print(f"north-star rule {k}: HIP vs reference {r['hip_vs_reference']:.2e} - " + ("ASSERTED < 1e-4" if applied else
+              f"not asserted: the reference itself is {r['reference_vs_chain64']:.2e} from the float64 chain (rule: asserted where that is < 0.5e-4, since two float32 "
+              f"implementations each within d of exact can be 2 d apart; HIP is {r['hip_vs_chain64']:.2e} from it)"))
     # the north-star bound proper was checked on at least the three chains where the reference is within 0.5e-4 of exact
     assert sum(r["reference_vs_chain64"] < 0.5 * NORTH_STAR and r["hip_vs_reference"] < NORTH_STAR for r in rows.values()) >= 3
 
@@ -235,17 +240,17 @@ def test_fullgrid_3d(dev, part):
                         errs=errs, rel=1.0 if chaotic else TIE_GRAD, grads=grads)
     hip64 = util.rel_l2(torch.stack(grads[:g64.shape[0]]), g64) if g64 is not None else None
     err = finger_l2(out, ref)
-    # what the ties seen in the replayed calls explain: call i's gradient enters x as sqrt(1 - abar_t) * scale * grad (/ n_obj in the ensemble)
-    n_obj = 2 if part.startswith("multi") else 1
-    scale = sampler.SCALE_3D if part.startswith("multi") else sampler.classifier_scale('point_3d', o)
-    seen = 0.0
-    for i, e in enumerate(errs):
-        if e > ROUNDING:
-            sb = float(np.sqrt(1.0 - float(s.alphas_cumprod[int(s.timesteps[i // n_obj])])))
-            seen += e * sb * scale * float(np.sqrt((np.asarray(g["trace_grad"][i], np.float64) ** 2).sum())) / n_obj
+    # What ties explain.  Round 3 summed the HIP path's own per-call deviations from the REFERENCE into this budget - a defect below tie
+    # level would have bought its own tolerance.  Now: only deviations that tests/test_gpu_fullgrid3d.py LOCALISES to single 32-row tiles
+    # against the float64 tile split of every recorded call (tests/golden/g9_calls64.npz: no HIP input) count; a call that deviates without
+    # being localised fails there.  The tolerance is capped, and a chain on which the reference does not move under any of its own
+    # rounding-level perturbations is held to the north-star bound unconditionally.
+    from tests import test_gpu_fullgrid3d as fg3
+    seen = fg3.tie_budget(fg3.get_row(dev, part)) if part in fg3.chain_names() else 0.0
+    TOL_CAP = 5e-3
     tol = None
     if floor is not None:
-        tol = max(NORTH_STAR, CHAIN_GAIN * seen) if floor < FLOOR_CLEAN else max(NORTH_STAR, 2.0 * floor, CHAIN_GAIN * seen)
+        tol = NORTH_STAR if floor < FLOOR_CLEAN else min(TOL_CAP, max(NORTH_STAR, 2.0 * floor, CHAIN_GAIN * seen))
     c64 = chain64(f"3d/{part}")
     d_hip64 = finger_l2(out, c64) if c64 is not None else None
     _report({f"3d/{part}": dict(opt_obj=o, gain=gain, object=oi, reference_floors=floors, ties_seen_budget=seen, end_point_tolerance=tol,
@@ -262,7 +267,7 @@ def test_fullgrid_3d(dev, part):
     assert tol is not None, f"no reference floor recorded for {part} (make_golden.py g9_3d:{part}_alt / g9_3d_eps:{part})"
     assert err < tol, (part, err, floors, seen)
     if d_hip64 is not None:       # against the chain in exact arithmetic: as close as the reference is (x 1.5), or what the seen ties explain
-        assert d_hip64 <= max(NORTH_STAR, 1.5 * floors["f64chain"], CHAIN_GAIN * seen), (part, d_hip64, floors["f64chain"], seen)
+        assert d_hip64 <= min(5e-3, max(NORTH_STAR, 1.5 * floors["f64chain"], CHAIN_GAIN * seen)), (part, d_hip64, floors["f64chain"], seen)
 
 
 @pytest.mark.parametrize("part", ["rotate", "convergence", "multi"])
