@@ -60,6 +60,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true", help="skip the secondary workload summary")
     p.add_argument("--train-only", action="store_true", help="print only the Trainer.step leg of the secondary summary (1 GPU)")
+    p.add_argument("--force-group", action="store_true", help="initialise the process group and run its barriers, the gather and the max-over-ranks "
+                   "reduction also at world size 1 (test: the whole rank body on RCCL end to end on a 1-GPU box)")
     p.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                    help="collective backend for N > 1: nccl (= RCCL, one GPU per rank; the measured configuration) or gloo (launcher / sharding "
                         "test on a box with fewer GPUs than ranks: ranks share the GPUs round-robin and the final gather goes through host memory)")
@@ -160,6 +162,9 @@ class Workload:
         return sampler.guided_chains(self.net, self.guid, self.sched, self.mode, self.noise, self.chains(step), predrawn=predrawn)
 
 
+FORCE_GROUP = False
+
+
 def timed_loop(wl, steps, warmup, dist):
     """Returns (seconds for `steps` steps, last output, mean host seconds per step spent drawing).
 
@@ -195,7 +200,7 @@ def timed_loop(wl, steps, warmup, dist):
         pre = fut.result()
         fut = drawer.submit(draw, k + 1) if (k + 1 < total and k + 1 != warmup) else None
         out = wl.run(k, objs.pop(k), pre)
-        if dist is not None and dist.get_world_size() > 1:
+        if dist is not None and (dist.get_world_size() > 1 or FORCE_GROUP):
             # the path's only collective: final samples; RCCL on device tensors, or host tensors for the gloo test mode
             out = gather_pairs(out, wl.pairs * dist.get_world_size())
     torch.cuda.synchronize()
@@ -210,14 +215,27 @@ def timed_loop(wl, steps, warmup, dist):
 
 
 # ---------------------------------------------------------------------------------------------------------------- roofline
+# what the JSON's `dtype` / roofline.arithmetic say about each contraction mode of the trunk
+DTYPE_LABEL = {"f32": "f32_split_bf16x6", "f32_mfma": "f32", "bf16": "bf16"}
+ARITHMETIC = {"f32": "float32-grade: every float32 product as six bf16 MFMA products on exactly three-way-split operands (products exact, float32 "
+                     "accumulation; 1.6e-7 rms of a 256-term contraction vs float64, the v_mfma_f32 chain: 2.0e-7)",
+              "f32_mfma": "float32 MFMA (v_mfma_f32_32x32x2_f32), a k-ordered fma chain",
+              "bf16": "operands rounded to bf16, float32 accumulation"}
+# matrix pipe busy share from the recorded PMC passes (profiles/r03_pmc_kernels.md: SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE); recorded, not live
+PIPE_BUSY_RECORDED = {("3d", "f32"): 0.71, ("2d", "f32"): 0.73, ("3d", "bf16"): 0.54}
+# algorithmic HBM bytes of ONE cond_fn's trunk launch per (pair, object): the xobj rows (1 KiB per replicated row, 3-D) or nothing of size R (2-D:
+# tables only) + the weights once
+HBM_ALGORITHMIC_BYTES = {"3d": 36000 * 32 / 32 * 1024.0 + 7.2e6 / 32, "2d": 17e6 / 4}
+
+
 def pmc_traffic(workload, contraction, kernel):
     """HBM bytes per launch of the dominant kernel as RECORDED by this round's rocprofv3 PMC passes of this same command
     (scripts/profile_round.sh -> profiles/r03_*_pmc_hbm.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, counter unit KB).
     FETCH_SIZE is the raw counter: on gfx950 it can under-count wide coalesced reads by 2x (MI355X_MICROARCH.md §HBM), so the
     true read traffic lies between 1x and 2x of `fetch_bytes_raw`.  None when no recording exists."""
     tag = workload + ("_bf16" if contraction == "bf16" else "")
-    f = os.path.join(ROOT, "profiles", f"r03_{tag}_pmc_hbm.json")
-    if not os.path.exists(f):
+    f = next((c for c in (os.path.join(ROOT, "profiles", f"{r}_{tag}_pmc_hbm.json") for r in ("r04", "r03")) if os.path.exists(c)), None)
+    if f is None:
         return None
     d = json.load(open(f))
     key = next((k for k in d["fetch"] if kernel + "<" in k), None)
@@ -253,19 +271,28 @@ def stage_profile(wl, secs_per_step, contraction):
     alg = flops / (ms * 1e-3) / 1e12
     ach = alg * issued
     need = st["trunk"][2] + st["unet"][2]                  # necessary FLOPs of one step: trunk (real rows) + eps-net (useful MACs)
-    roof = {"bound": "mfma", "kernel": kname + " (fused dynamics trunk fwd+bwd)", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-            "frac": ach / peak, "traffic": pmc_traffic(wl.kind, contraction, kname), "launches": n, "avg_launch_ms": ms / n,
+    tr = pmc_traffic(wl.kind, contraction, kname)
+    # `achieved` = ALGORITHMIC TFLOP/s (the float32 contraction FLOPs the path asks for on the real rows / the kernel's time), `peak` = the dense
+    # peak of the matrix pipe the kernel runs on, `frac` = their ratio.  For the split float32 form the pipe additionally carries
+    # issued_flops_per_algorithmic_flop - 1 redundant piece products per useful one: that utilisation is `matrix_pipe_issue_frac`
+    # (issued / peak), NOT `frac`; `frac_algorithmic_vs_f32_peak` prices the same algorithmic rate against the 157.3 TFLOP/s a
+    # v_mfma_f32 kernel is bounded by (the figure comparable with the f32_mfma leg and with rounds 1-2).
+    roof = {"bound": "mfma", "kernel": kname + " (fused dynamics trunk fwd+bwd)", "achieved": alg, "peak": peak, "unit": "TFLOP/s",
+            "frac": alg / peak, "traffic": tr["bytes_per_launch"] if tr else None,
+            "traffic_fetch_bytes": tr["fetch_bytes_raw"] if tr else None, "traffic_write_bytes": tr["write_bytes"] if tr else None,
+            "traffic_vs_algorithmic": (tr["bytes_per_launch"] / (HBM_ALGORITHMIC_BYTES[wl.kind] * wl.pairs * wl.n_obj)) if tr and wl.kind in HBM_ALGORITHMIC_BYTES else None,
+            "traffic_recorded": tr["recorded"] if tr else None,
+            "launches": n, "avg_launch_ms": ms / n,
             "algorithmic_flops_per_launch": flops / n, "algorithmic_tflops": alg, "issued_flops_per_algorithmic_flop": issued,
-            "algorithmic_vs_f32_mfma_peak": alg / F32_MFMA_PEAK_TFLOPS,
-            "note": ("float32 contractions as six bf16 MFMA products on exactly split operands: achieved = ISSUED bf16 TFLOP/s (6 x algorithmic) "
-                     "against the 2.4 GHz bf16 dense peak; recorded PMC (profiles/r03_pmc_kernels.md): matrix pipe busy 71-74 % of the cycles at the "
-                     "~2.0 GHz the chip sustains under this kernel" if contraction == "f32"
-                     else "algorithmic FLOPs / time against the dense peak of the MFMA dtype"),
+            "matrix_pipe_issue_frac": ach / peak, "frac_algorithmic_vs_f32_peak": alg / F32_MFMA_PEAK_TFLOPS,
+            "pipe_busy": PIPE_BUSY_RECORDED.get((wl.kind, contraction)),
+            "arithmetic": ARITHMETIC[contraction],
             "share_of_step": (ms * 1e-3) / secs_per_step,
-            "step_frac": (st["trunk"][2] * issued + st["unet"][2]) / secs_per_step / 1e12 / peak,
+            "step_frac": (st["trunk"][2] + st["unet"][2]) / secs_per_step / 1e12 / peak,
+            "step_issue_frac": (st["trunk"][2] * issued + st["unet"][2]) / secs_per_step / 1e12 / peak,
             "step_necessary_tflop": need / 1e12,
-            "step_frac_note": "issued FLOPs of one step (trunk on the real rows x issued-per-algorithmic + eps-net useful MACs; table-build FLOPs not "
-                              "counted) / wall time of the step / peak of the trunk's matrix-pipe dtype"}
+            "step_frac_note": "algorithmic FLOPs of one step (trunk on the real rows + eps-net useful MACs; table-build FLOPs not counted) / wall time of the "
+                              "step / peak of the trunk's matrix pipe; step_issue_frac counts the trunk's issued piece products instead"}
     shares = {k: {"regions": v[0], "ms_per_step": v[1], "share_of_profiled_step": v[1] / wall_ms} for k, v in st.items() if v[0]}
     shares["_profiled_step_wall_ms"] = wall_ms
     return roof, shares
@@ -279,6 +306,13 @@ def _median3(fn):
         fn()
         ts.append(time.perf_counter() - t0)
     return statistics.median(ts), ts
+
+
+def host_view(wl):
+    """What cpu_baseline needs of a Workload, detached from its device state (the CPU legs run after every GPU leg)."""
+    import types
+    return types.SimpleNamespace(kind=wl.kind, T=wl.T, S=wl.S, B=wl.B, L=wl.L, G=wl.G, P=wl.P, N=wl.N, sub=getattr(wl, "sub", 0), noise=wl.noise.cpu(),
+                                 unet_sd=wl.unet_sd, dyn_sd=wl.dyn_sd)
 
 
 def cpu_baseline(wl):
@@ -346,7 +380,7 @@ def cpu_baseline(wl):
             "ms_per_denoise_step": chain / wl.S * 1e3, "runs_s": runs, "end_to_end_check": check}
 
 
-def config0(dev):
+def config0(dev, cpu=True):
     """BASELINE configs[0]: 2-D unconditional sampling, B = 4, L = 14, T = S = 1000 (generator/diffusion.py:249-256 with the
     parser defaults dynamics/parser.py:29,31) - the reference's CPU-runnable plumbing case: the CPU oracle chain (median of 3)
     next to the HIP unguided loop on the same noise."""
@@ -358,7 +392,9 @@ def config0(dev):
     so = orc.DDIM(T)
     so.set_timesteps(T)
     s = orc.Setup('point', usd, None, so, L, 1, 1)
-    cpu_s, runs = _median3(lambda: orc.unguided_sample(s, noise))
+    if cpu:
+        cpu_s, runs = _median3(lambda: orc.unguided_sample(s, noise))
+        return {"cpu_oracle_chain_s": cpu_s, "cpu_runs_s": runs, "cpu_cores": torch.get_num_threads(), "cpu_samples_per_s": B / cpu_s}
     net = engine.Unet1d(usd)
     sch = DDIMScheduler(num_train_timesteps=T)
     sch.set_timesteps(T)
@@ -370,7 +406,6 @@ def config0(dev):
     torch.cuda.synchronize()
     hip_s = time.perf_counter() - t0
     return {"workload": "2d_unconditional (BASELINE configs[0]: B=4, L=14, T=S=1000)", "dtype": "f32",
-            "cpu_oracle_chain_s": cpu_s, "cpu_runs_s": runs, "cpu_cores": torch.get_num_threads(), "cpu_samples_per_s": B / cpu_s,
             "hip_chain_s": hip_s, "hip_samples_per_s": B / hip_s, "hip_ms_per_denoise_step": hip_s / T * 1e3}
 
 
@@ -481,6 +516,15 @@ def train_leg(dev, with_cpu=True):
     del tr, data, inp, c, nz, sa, sb, tt, o, p, ob, sc, pred
     torch.cuda.empty_cache()
     if with_cpu:
+        out["cpu_baseline"] = train_leg_cpu()
+    return out
+
+
+def train_leg_cpu():
+    L, nv, T = 14, 100, 15
+    sd = synth.synth_state_dict(synth.dyn2d_spec(L, 2 * nv), 41)
+    out = {}
+    if True:
         from oracle import dgdm_oracle as orc
         torch.set_num_threads(min(os.cpu_count() or 1, 32))
         rs = 128 * 36
@@ -488,9 +532,102 @@ def train_leg(dev, with_cpu=True):
         small = [torch.rand(shape, generator=g) * 2 - 1 for shape in ((rs, L), (rs, 3), (rs, 1), (rs, 2), (rs, 2 * nv))]
         ot = orc.Trainer2D(sd, T, 1e-4)
         t_c, runs = _median3(lambda: ot.step(*small))
-        out["cpu_baseline"] = {"value": rs / t_c, "unit": "rows/s", "cores": torch.get_num_threads(), "kind": "port",
-                               "sample": f"median of 3 Trainer2D.step (torch CPU autograd) on {rs} rows (128 samples x 36 pose cells)", "runs_s": runs}
+        out = {"value": rs / t_c, "unit": "rows/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"median of 3 Trainer2D.step (torch CPU autograd) on {rs} rows (128 samples x 36 pose cells)", "runs_s": runs}
     return out
+
+
+def unet_train_leg(dev):
+    """Diffusion.training_step of the eps-net (generator/diffusion.py:126-177, flags of generator/train_diffusion_3d.sh:
+    batch 1024, L = 42) - one C-ABI step (noisy input, forward, MSE loss, backward with every weight gradient, Adam) on device-resident
+    inputs, HIP events.  FLOPs = 3 x 2 x 82.0 MMAC per sample (forward + input gradients + weight gradients)."""
+    B, L, T = 1024, 42, 15
+    tr = engine.UnetTrainer(synth.synth_state_dict(synth.unet_spec(), 11), L)
+    g = torch.Generator().manual_seed(5)
+    x0 = (torch.rand((B, L, 1), generator=g) * 2 - 1).to(dev)
+    noise = torch.randn((B, L, 1), generator=g).to(dev)
+    ts = torch.randint(0, T, (B,), generator=g).to(dev)
+    ac = DDIMScheduler(num_train_timesteps=T).alphas_cumprod.to(dev)[ts]
+    sa, sb = ac ** 0.5, (1 - ac) ** 0.5
+    for _ in range(2):
+        tr.step(x0, noise, sa, sb, ts, 1e-4, want_loss=False)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    n = 10
+    ev[0].record()
+    for _ in range(n):
+        tr.step(x0, noise, sa, sb, ts, 1e-4, want_loss=False)
+    ev[1].record()
+    torch.cuda.synchronize()
+    secs = ev[0].elapsed_time(ev[1]) / 1e3 / n
+    flops = B * 3 * 2 * 82.0e6
+    return {"workload": "train_eps_net (Diffusion.training_step, generator/train_diffusion_3d.sh: batch 1024, L=42, T=15)", "dtype": "f32",
+            "samples_per_s": B / secs, "ms_per_step": secs * 1e3,
+            "roofline": {"bound": "mfma", "achieved": flops / secs / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / secs / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                         "traffic": None, "note": "whole step (window GEMMs on the float32 MFMA + GroupNorm/Mish passes + reductions + Adam); useful FLOPs "
+                                                  "(padding rows of the window layout not counted)"}}
+
+
+def unet_train_leg_cpu():
+    from oracle import dgdm_oracle as orc
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    B, L = 64, 42
+    ot = orc.UnetTrainer(synth.synth_state_dict(synth.unet_spec(), 11), 15, L, 1e-4)
+    x0 = torch.rand((B, L, 1)) * 2 - 1
+    t_c, runs = _median3(lambda: ot.step(x0))
+    return {"value": B / t_c, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"median of 3 UnetTrainer.step (torch CPU autograd + Adam + EMA) on {B} samples, L={L}", "runs_s": runs}
+
+
+def train3d_leg(dev, rows=512):
+    """Trainer.step of the 3-D dynamics model (dynamics/trainer.py:53-103 with --fingers_3d: PointNet++ in training mode
+    as written) on one slice of `rows` (control points, pose, 512-point cloud) rows; dynamics/train_dynamics_3d.sh slices at --sub_bs=2048
+    (139 GB of activations: fits one MI355X; the leg runs 512 rows = 35 GB to keep the default bench short).  FLOPs = 3 x 2 x 552.7 MMAC
+    per row."""
+    import argparse
+    import contextlib
+    import io
+    from dgdm_amd.dynamics.trainer import Trainer
+    L, N, T = 42, 512, 15
+    args = argparse.Namespace(use_sub_batch=False, sub_bs=rows, grid_size=45, learning_rate=1e-4, weight_decay=0.0, num_epochs=100, checkpoint_path=None,
+                              fingers_3d=True, ctrlpts_dim=L, object_max_num_vertices=N, num_timesteps_per_batch=1, num_inference_steps=5, num_train_timesteps=T)
+    tr = Trainer(args)
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr.create_model(state_dict=synth.synth_state_dict(synth.dyn3d_spec(L), 33))
+    g = torch.Generator().manual_seed(6)
+    ctrl = torch.rand((rows, 3, L), generator=g) * 2 - 1
+    obj = torch.stack([synth.synth_object_3d(700 + i % 4, N) for i in range(rows)]).permute(0, 2, 1).contiguous()
+    ori, pos, score = torch.rand((rows, 1), generator=g) * 2 - 1, torch.rand((rows, 2), generator=g) * 2 - 1, torch.randn((rows, 3), generator=g)
+    data = [d.to(dev) for d in (ctrl, score, ori, pos, obj)]
+    tr.step(*data)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 3
+    for _ in range(n):
+        tr.step(*data)
+    torch.cuda.synchronize()
+    secs = (time.perf_counter() - t0) / n
+    flops = rows * 3 * 2 * 552.7e6
+    out = {"workload": f"train3d (Trainer.step --fingers_3d, one slice of {rows} rows x 512-point clouds; dynamics/train_dynamics_3d.sh uses --sub_bs=2048)",
+           "dtype": "f32", "rows_per_s": rows / secs, "ms_per_step_python_api": secs * 1e3,
+           "roofline": {"bound": "mfma", "achieved": flops / secs / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / secs / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                        "traffic": None, "note": "whole step through the Python API incl. the host's draws and uploads; as-written FLOPs (PointNet++ on every row)"}}
+    del tr, data
+    torch.cuda.empty_cache()
+    return out
+
+
+def train3d_leg_cpu():
+    from oracle import dgdm_oracle as orc
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    rows, L = 8, 42
+    ot = orc.Trainer3D(synth.synth_state_dict(synth.dyn3d_spec(L), 33), 15, 1e-4)
+    g = torch.Generator().manual_seed(6)
+    ctrl = torch.rand((rows, 3, L), generator=g) * 2 - 1
+    obj = torch.stack([synth.synth_object_3d(700 + i % 4, 512) for i in range(rows)]).permute(0, 2, 1).contiguous()
+    ori, pos, score = torch.rand((rows, 1), generator=g) * 2 - 1, torch.rand((rows, 2), generator=g) * 2 - 1, torch.randn((rows, 3), generator=g)
+    t_c, runs = _median3(lambda: ot.step(ctrl, score, ori, pos, obj, ot.draw(ctrl), orc.StartLog()))
+    return {"value": rows / t_c, "unit": "rows/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"median of 3 Trainer3D.step (torch CPU autograd, PointNet++ in training mode) on {rows} rows", "runs_s": runs}
 
 
 # ---------------------------------------------------------------------------------------------------------------- main
@@ -508,6 +645,8 @@ def workload_text(kind, pairs):
 
 def main():
     a = parse()
+    global FORCE_GROUP
+    FORCE_GROUP = a.force_group
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(a.gpus))                   # the parent never touches a GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -517,7 +656,7 @@ def main():
         print(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s)", file=sys.stderr)
         sys.exit(2)
     dist = None
-    if world > 1:
+    if world > 1 or a.force_group:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
@@ -550,7 +689,7 @@ def main():
     line = {
         "metric": "guided samples/sec (full DDIM chain)", "value": samples / secs, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": secs / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": a.contraction, "data": "synthetic (random-init checkpoints, synthetic objects, seeded noise; SURVEY.md §8(d))",
+        "dtype": DTYPE_LABEL[a.contraction], "contraction_flag": a.contraction, "data": "synthetic (random-init checkpoints, synthetic objects, seeded noise; SURVEY.md §8(d))",
         **({"backend_note": "gloo test mode: ranks share GPUs, not a scaling measurement"} if (world > 1 and a.backend == "gloo") else {}),
         "config": {"workload": workload_text(a.workload, pairs), "pairs_per_gpu_per_step": pairs, "fingers_per_pair": wl.B,
                    "denoise_steps": wl.S, "rows_per_cond_fn": wl.rows, "cond_fn_per_chain_step": wl.n_obj},
@@ -563,30 +702,39 @@ def main():
     if roof:
         line["roofline"] = roof
         line["stage_share"] = shares
+    # ---- every GPU leg first and back to back (so that the device is busy while the driver samples it), every CPU-baseline leg after them
+    cpu_jobs = []
     if world == 1 and not a.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(wl)
-        line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
+        hv = host_view(wl)
+        cpu_jobs.append(lambda: line.update(cpu_baseline=cpu_baseline(hv)) or line.update(speedup_vs_cpu_baseline=line["value"] / line["cpu_baseline"]["value"]))
     if world == 1 and not a.no_extra:
         other = "2d" if wl.kind == "3d" else "3d"
         del wl
         torch.cuda.empty_cache()
         # the other BASELINE configurations (not the headline: `value` above is what the driver reads)
-        extras = [config0(dev), sweep_leg(dev), train_leg(dev, not a.no_cpu_baseline)]
+        c0, tl, ul, t3 = config0(dev, cpu=False), train_leg(dev, False), unet_train_leg(dev), train3d_leg(dev)
+        extras = [c0, sweep_leg(dev), tl, ul, t3]
+        if not a.no_cpu_baseline:
+            cpu_jobs += [lambda: c0.update(config0(dev, cpu=True)), lambda: tl.update(cpu_baseline=train_leg_cpu()),
+                         lambda: ul.update(cpu_baseline=unet_train_leg_cpu()), lambda: t3.update(cpu_baseline=train3d_leg_cpu())]
         for kind, contraction in ((other, "f32"), ("3d", "f32_mfma"), ("3d", "bf16"), ("2d", "bf16"), ("3d_ensemble", "bf16")):
             w2 = Workload(kind, DEFAULT_PAIRS[kind], dev, rank, world, contraction)
             ns = 4
             s2, _, d2 = timed_loop(w2, ns, 1, None)
-            e = {"workload": kind, "dtype": contraction, "samples_per_s": w2.B * w2.pairs * ns / s2, "ms_per_step": s2 / ns * 1e3,
+            e = {"workload": kind, "dtype": DTYPE_LABEL[contraction], "contraction_flag": contraction, "samples_per_s": w2.B * w2.pairs * ns / s2, "ms_per_step": s2 / ns * 1e3,
                  "ms_per_denoise_step_per_pair": s2 / ns / w2.S / w2.pairs * 1e3, "cond_fn_per_chain_step": w2.n_obj, "host_draw_ms_per_step": d2 * 1e3}
             r2, sh2 = stage_profile(w2, s2 / ns, contraction)
             if r2:
                 e["roofline"], e["stage_share"] = r2, sh2
             if contraction == "f32" and kind == other and not a.no_cpu_baseline:
-                e["cpu_baseline"] = cpu_baseline(w2)
+                hv2 = host_view(w2)
+                cpu_jobs.append(lambda e=e, hv2=hv2: e.update(cpu_baseline=cpu_baseline(hv2)))
             extras.append(e)
             del w2
             torch.cuda.empty_cache()
         line["extra"] = extras
+    for job in cpu_jobs:
+        job()
     print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

@@ -61,6 +61,8 @@ PROTOTYPES = {
     "dgdm_query_ball_point": (C.c_int, [C.c_float, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "dgdm_square_distance": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "dgdm_index_points": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "dgdm_linear_act": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "dgdm_group_max": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, _P, _P]),
     "dgdm_guidance_create": (C.c_int, [C.POINTER(_P), _P, C.POINTER(GuidanceConfig)]),
     "dgdm_guidance_destroy": (None, [_P]),
     "dgdm_debug_chain_layer": (C.c_int, [_P, _P, _P, _P, _P]),

@@ -3,6 +3,7 @@
 #include "common.h"
 #include "mfma_chain.h"
 #include "models.h"
+#include "smallnet.h"
 
 namespace dgdm {
 __global__ __launch_bounds__(64, 1) void debug_chain_kernel(const float4 *__restrict__ Wimg, const float *__restrict__ bias,
@@ -96,4 +97,39 @@ extern "C" int dgdm_index_points(const float *points_dev, const int32_t *idx_dev
     DGDM_REQUIRE(points_dev && idx_dev && out_dev && B >= 0 && N > 0 && M >= 0 && C > 0, DGDM_EINVAL, "dgdm_index_points: bad argument");
     if (B == 0 || M == 0) return DGDM_OK;                      // empty result
     return pn_index_rows(points_dev, idx_dev, B, N, M, C, out_dev, (hipStream_t)stream);
+}
+
+
+// ------------------------------------------------------------------------------------------------ PointNetSetAbstraction.forward on its own
+// (dynamics/models/pointnet2_utils.py:184-210; include/dgdm_hip.h): the shared MLP of a set-abstraction level on grouped rows, one layer at
+// a time, and the max over a group's samples.  The guided path evaluates the three levels fused as per-object tables (pointnet.hip);
+// these two entry points exist so that the reference's layer class is callable for arbitrary inputs.
+namespace dgdm {
+__global__ void group_max_kernel(const float *__restrict__ x, int64_t G, int ns, int C, float *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= G * C) return;
+    const int64_t g = e / C;
+    const int c = (int)(e - g * C);
+    const float *p = x + g * ns * C + c;
+    float best = p[0];
+    for (int n = 1; n < ns; ++n) best = fmaxf(best, p[(int64_t)n * C]);
+    out[e] = best;
+}
+}  // namespace dgdm
+
+extern "C" int dgdm_linear_act(const float *x_dev, int ldx, const float *wt_dev, const float *bias_dev, float *y_dev, int ldy, int rows, int K, int N, int act,
+                               void *stream) {
+    using namespace dgdm;
+    DGDM_REQUIRE(x_dev && wt_dev && y_dev && rows >= 0 && K > 0 && N > 0 && ldx >= K && ldy >= N, DGDM_EINVAL, "dgdm_linear_act: bad argument");
+    DGDM_REQUIRE(act == ACT_NONE || act == ACT_RELU || act == ACT_SILU, DGDM_EINVAL, "dgdm_linear_act: activation %d", act);
+    return linear(x_dev, ldx, wt_dev, bias_dev, nullptr, 1, y_dev, ldy, rows, K, N, act, false, (hipStream_t)stream);
+}
+
+extern "C" int dgdm_group_max(const float *x_dev, int64_t groups, int nsample, int C, float *out_dev, void *stream) {
+    using namespace dgdm;
+    DGDM_REQUIRE(x_dev && out_dev && groups >= 0 && nsample > 0 && C > 0, DGDM_EINVAL, "dgdm_group_max: bad argument");
+    if (groups == 0) return DGDM_OK;
+    hipLaunchKernelGGL(group_max_kernel, dim3((unsigned)((groups * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_dev, groups, nsample, C, out_dev);
+    DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
 }

@@ -109,6 +109,7 @@ struct DgdmGuidance {
     int upload_starts(const int64_t *starts_host, int n_chains, int64_t rows, hipStream_t s, bool need_order = true, int n_calls = 1,
                       int64_t call_stride = 0);
     int ensure_rows(int n_chains, int64_t rows_per_chain);      // grows the per-row device buffers and the pinned staging area
+    size_t xobj_reserve_rows = 0;                                // rows run_xobj sizes xobj / xobj16 for at least (see there)
     // true + p filled when every chain's object has its embedding table in the wanted format: then no per-step gather runs at all
     int use_xtab(const int *objidx_host, int n_chains, int64_t rows, bool want16, dgdm::TrunkParams *p, bool *ok, hipStream_t s);
     int build_object(int oi, int slot, hipStream_t s);
@@ -177,7 +178,7 @@ extern "C" int dgdm_guidance_create(DgdmGuidance **out, DgdmDynamics *model, con
     if (model->kind == 2) {
         if ((rc = g->objpart.alloc((size_t)std::max(1, cfg->max_objects) * W1 * 8))) return rc;
     } else {
-        if ((rc = g->xobj.alloc((size_t)nc * g->R * 256 * 4)) || (rc = g->starts.alloc((size_t)nc * g->R * 2 * sizeof(int))) ||
+        if ((rc = g->starts.alloc((size_t)nc * g->R * 2 * sizeof(int))) ||
             (rc = g->order.alloc((size_t)nc * g->R * sizeof(int))) || (rc = g->xchains.alloc(sizeof(XobjChain) * nc)) ||
             (rc = g->todo.alloc(((size_t)nc * g->R + 1) * sizeof(int))))
             return rc;
@@ -445,7 +446,9 @@ int DgdmGuidance::ensure_rows(int n_chains, int64_t rows_per_chain) {
     const int N = cfg.num_object_points;
     const size_t nr = (size_t)n_chains * rows_per_chain;
     int rc;
-    if ((rc = xobj.alloc(nr * 256 * 4)) || (rc = starts.alloc(nr * 2 * sizeof(int))) || (rc = order.alloc(nr * sizeof(int))) ||
+    // (the embedding rows themselves - xobj / xobj16, 1 KiB / 512 B per row - are allocated by run_xobj, the only path that writes them:
+    // with the embedding tables X[s1][q] in place a call gathers nothing)
+    if ((rc = starts.alloc(nr * 2 * sizeof(int))) || (rc = order.alloc(nr * sizeof(int))) ||
         (rc = todo.alloc((nr + 1) * sizeof(int))) || (rc = xidx.alloc(nr * sizeof(int))))
         return rc;
     todo_capacity = (int64_t)nr;
@@ -562,8 +565,10 @@ int DgdmGuidance::run_xobj(const int *objidx_host, int n_chains, int64_t rows, b
         ch[i].Z16 = t.has16 ? t.Z16.as<uint32_t>() : nullptr; ch[i].M0_16 = t.has16 ? t.M0_16.as<uint32_t>() : nullptr;
         want16 = want16 && t.has16;          // bf16 rows only if every chain's object was built with its bf16 tables
     }
-    if (want16) {
-        int rc = xobj16.alloc((size_t)n_chains * rows * 512);
+    {   // grow-only buffers: sized for the largest embed of the run in progress (xobj_reserve_rows, set by dgdm_guided_chains_run before its
+        // first embed) so that the second, larger embed of a run does not reallocate - hipFree would wait for step 0's kernels
+        const size_t nrows = std::max<size_t>((size_t)n_chains * rows, xobj_reserve_rows);
+        int rc = want16 ? xobj16.alloc(nrows * 512) : xobj.alloc(nrows * 256 * 4);
         if (rc) return rc;
     }
     if (used16) *used16 = want16;
@@ -764,6 +769,7 @@ extern "C" int dgdm_guided_chains_run(DgdmUnet1d *unet, DgdmGuidance *g, const f
     const int64_t call_stride = (int64_t)n_chains * n_grad * spc;
     if (kind == 3) {
         for (int i = 0; i < n_chains * n_grad; ++i) oidx[i] = objectives[i].object;
+        g->xobj_reserve_rows = (size_t)n_chains * n_grad * g->R * (size_t)std::max(1, n_steps - 1);
         if ((rc = g->embed(oidx.data(), n_chains * n_grad, starts_host, 1, call_stride, &emb, s))) return rc;
     }
     for (int si = 0; si < n_steps; ++si) {

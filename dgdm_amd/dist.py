@@ -75,20 +75,28 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     return world, rank, local
 
 
+def _src0(group=None) -> int:
+    """The GLOBAL rank of the group's rank 0: what dist.broadcast's `src` means (it is 0 only for the default group)."""
+    return dist.get_global_rank(group, 0) if group is not None else 0
+
+
 def sync_start_stream_seed(group=None) -> int:
     """One seed for the torch CPU generator on every rank, so that all ranks walk the same FPS start stream
     (``guided_chains_sharded``).  The reference never seeds that generator (its 3-D results differ from run to run);
     DGDM_TORCH_SEED pins it - for one process as well - otherwise rank 0's own (random) initial seed is broadcast."""
     env = os.environ.get("DGDM_TORCH_SEED")
     seed = int(env) if env else int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
-    if dist.is_available() and dist.is_initialized():
+    grouped = dist.is_available() and dist.is_initialized()
+    if grouped:
         t = torch.tensor([seed], dtype=torch.int64)
         if dist.get_backend(group) == "nccl":
             t = t.cuda()
-        dist.broadcast(t, src=0, group=group)
+        dist.broadcast(t, src=_src0(group), group=group)
         seed = int(t.item())
-    elif not env:
-        return seed                      # single process, nothing pinned: leave the generator as torch initialised it
+    if not env and not (grouped and dist.get_world_size(group) > 1):
+        # one process (or a group of one rank), nothing pinned: leave the generator as it is - re-seeding would rewind a generator
+        # that has already been drawn from
+        return seed
     torch.manual_seed(seed)
     return seed
 
@@ -231,7 +239,7 @@ def broadcast_from_rank0(t: torch.Tensor, group=None) -> torch.Tensor:
         return t
     if t.is_cuda and dist.get_backend(group) != "nccl":
         h = t.cpu()
-        dist.broadcast(h, src=0, group=group)
+        dist.broadcast(h, src=_src0(group), group=group)
         return h.to(t.device)
-    dist.broadcast(t, src=0, group=group)
+    dist.broadcast(t, src=_src0(group), group=group)
     return t

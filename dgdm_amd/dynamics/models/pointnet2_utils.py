@@ -97,5 +97,28 @@ class PointNetSetAbstraction(nn.Module):
             in_channel = c_out
 
     def forward(self, xyz, points):
-        raise NotImplementedError("set-abstraction layers are evaluated fused, through PointNet2.forward (the reference "
-                                  "never calls them on their own: dynamics/models/pointnet2.py:28-30)")
+        """pointnet2_utils.py:184-210 on the device: xyz [B, C, N], points [B, D, N] or None -> (new_xyz [B, C, S], new_points [B, D', S]).
+        Eval mode (BatchNorm running statistics, folded into the 1x1 convolutions in float64); in training mode the layer only exists
+        inside the Trainer's fused training step (csrc/train3d.hip), which owns the batch statistics and the gradients.  The guided path
+        does not come through here: it evaluates the three levels as per-object tables (PointNet2.forward, csrc/pointnet.hip)."""
+        if self.training:
+            raise NotImplementedError("training-mode set abstraction runs inside dynamics.trainer.Trainer.step (csrc/train3d.hip); call .eval() for a forward pass")
+        xyz = xyz.permute(0, 2, 1)
+        pts = points.permute(0, 2, 1) if points is not None else None
+        if self.group_all:
+            new_xyz, new_points = sample_and_group_all(xyz, pts)
+        else:
+            new_xyz, new_points = sample_and_group(self.npoint, self.radius, self.nsample, xyz, pts)
+        B, S, ns, Cin = new_points.shape                                   # [B, npoint, nsample, C + D]
+        x = _f32(new_points).reshape(B * S * ns, Cin)
+        for conv, bn in zip(self.mlp_convs, self.mlp_bns):
+            w = conv.weight.detach().double().reshape(conv.out_channels, -1).cpu()
+            sc = bn.weight.detach().double().cpu() / torch.sqrt(bn.running_var.detach().double().cpu() + bn.eps)
+            wt = (sc[:, None] * w).t().contiguous().float().to(x.device)                        # [Cin][Cout]
+            b = (sc * (conv.bias.detach().double().cpu() - bn.running_mean.detach().double().cpu()) + bn.bias.detach().double().cpu()).float().to(x.device)
+            y = torch.empty((x.shape[0], conv.out_channels), dtype=torch.float32, device=x.device)
+            check(lib().dgdm_linear_act(dptr(x), x.shape[1], dptr(wt), dptr(b), dptr(y), y.shape[1], x.shape[0], x.shape[1], conv.out_channels, 1, stream_ptr()))
+            x = y
+        out = torch.empty((B * S, x.shape[1]), dtype=torch.float32, device=x.device)
+        check(lib().dgdm_group_max(dptr(x), B * S, ns, x.shape[1], dptr(out), stream_ptr()))
+        return new_xyz.permute(0, 2, 1), out.reshape(B, S, -1).permute(0, 2, 1)

@@ -104,8 +104,14 @@ class Trainer(object):
         self._nbt0 = {k: int(v) for k, v in self.model.state_dict().items() if k.endswith('num_batches_tracked')}
         print('done')
 
+    def _join_ahead(self):
+        ahead, self._ahead = getattr(self, "_ahead", None), None
+        if ahead is not None:
+            ahead[0].join()              # a daemon thread running torch code must not outlive the interpreter's teardown
+
     def __del__(self):
         try:
+            self._join_ahead()
             if getattr(self, "_h", None) and lib is not None:
                 (lib().dgdm_trainer3d_destroy if self.fingers_3d else lib().dgdm_trainer2d_destroy)(self._h)
         except Exception:        # interpreter shutdown: module globals are already gone
@@ -113,7 +119,7 @@ class Trainer(object):
         self._h = None
 
     # ------------------------------------------------------------------ one batch
-    def _draw(self, rows: int):
+    def _draw(self, rows: int, ahead: bool = True):
         """The reference's draws, in its order, from the CPU generator (trainer.py:68-74): ``torch.randn`` for the noise, then
         ``torch.randint`` for the timesteps.  16 M normals per 1.15 M-row step take as long on one host core as the GPU step itself,
         and they depend on nothing but the generator: after every step a worker thread draws the NEXT step's numbers (same row
@@ -132,7 +138,7 @@ class Trainer(object):
             noise = torch.randn((rows * self.num_timesteps_per_batch, self.gripperpts_dim))
             timesteps = torch.randint(0, self.noise_scheduler.config.num_train_timesteps, (rows,)).long()
             out = (noise, timesteps)
-        if self.draw_ahead:
+        if self.draw_ahead and ahead:
             self._start_draw_ahead(rows)
         return out
 
@@ -144,8 +150,14 @@ class Trainer(object):
         def work():
             g = torch.Generator()
             g.set_state(box["state_before"])
-            pin = torch.cuda.is_available()
-            noise = torch.empty((rows * n, dim), pin_memory=pin)
+            # two pinned buffers, used alternately and kept while the shape stays the same: the previous draw may still be on its way to
+            # the device (non-blocking copy) when this one is written
+            pins = getattr(self, "_pins", None)
+            if pins is None or pins[0].shape != (rows * n, dim):
+                pins = self._pins = [torch.empty((rows * n, dim), pin_memory=torch.cuda.is_available()) for _ in range(2)]
+                self._pin_turn = 0
+            self._pin_turn ^= 1
+            noise = pins[self._pin_turn]
             torch.randn((rows * n, dim), generator=g, out=noise)
             box["noise"] = noise
             box["timesteps"] = torch.randint(0, T, (rows,), generator=g).long()
@@ -154,14 +166,14 @@ class Trainer(object):
         th.start()
         self._ahead = (th, box)
 
-    def _inputs(self, ctrl, score, input_ori, input_pos, object_vertices, drawn=None):
+    def _inputs(self, ctrl, score, input_ori, input_pos, object_vertices, drawn=None, ahead=True):
         dev = torch.device("cuda", torch.cuda.current_device())
         n = self.num_timesteps_per_batch
         f = lambda t: t.detach().to(device=dev, dtype=torch.float32, non_blocking=t.is_pinned()).contiguous()       # noqa: E731
         ctrl_all, obj_all = f(ctrl.repeat(n, 1)), f(object_vertices.repeat(n, 1))
         ori_all, pos_all, score_all = f(input_ori.repeat(n, 1)), f(input_pos.repeat(n, 1)), f(score.repeat(n, 1))
         rows = ctrl_all.shape[0]
-        noise, timesteps = drawn if drawn is not None else self._draw(rows)
+        noise, timesteps = drawn if drawn is not None else self._draw(rows, ahead)
         ac = self.noise_scheduler.alphas_cumprod[timesteps]
         sa, sb = f(ac ** 0.5), f((1 - ac) ** 0.5)                                       # DDIMScheduler.add_noise (diffusers 0.11.1)
         T = self.noise_scheduler.config.num_train_timesteps
@@ -186,7 +198,7 @@ class Trainer(object):
         if self._h is None:
             raise RuntimeError("Trainer.create_model() has not been called")
         world, rank = _dist.world_rank()
-        c, nz, sa, sb, t, o, p, ob, sc, rows = self._inputs(ctrl, score, input_ori, input_pos, object_vertices, drawn)
+        c, nz, sa, sb, t, o, p, ob, sc, rows = self._inputs(ctrl, score, input_ori, input_pos, object_vertices, drawn, ahead=train)
         lr = float(self.optimizer.param_groups[0]["lr"])
         loss = C.c_float()
         if world == 1:
@@ -310,7 +322,7 @@ class Trainer(object):
         # --use_sub_batch (trainer.py:132-141): the draws once for the whole batch, one forward per slice of sub_bs rows, the slices'
         # losses summed and divided by rows / sub_bs (so a ragged last slice weighs like a full one, as in the reference)
         losses, preds, n = [], [], ctrl.shape[0]
-        noise, timesteps = self._draw(n)
+        noise, timesteps = self._draw(n, ahead=False)
         for i in range(0, n, self.sub_batch_size):
             sl = slice(i, i + self.sub_batch_size)
             loss, pred = self._run(ctrl[sl], score[sl], input_ori[sl], input_pos[sl], object_vertices[sl], False, None, (noise[sl], timesteps[sl]))

@@ -115,21 +115,26 @@ class StartPlan:
         self._rng_after: Optional[TorchRng] = None      # stream position after the last consumed job
         self.draw_seconds = 0.0
 
+    def _put(self, item) -> None:
+        while not self._stop.is_set():
+            try:
+                self._q.put(item, timeout=0.05)
+                return
+            except Exception:           # queue.Full
+                continue
+
     def _work(self, rng: TorchRng):
         import time
-        for rows, n, keep in self.jobs:
-            if self._stop.is_set():
-                return
-            t0 = time.perf_counter()
-            arr = rng.fps_starts(self.N, self.sub, rows, n, skip=not keep)
-            self.draw_seconds += time.perf_counter() - t0
-            item = (arr, TorchRng(state=rng._blob))
-            while not self._stop.is_set():
-                try:
-                    self._q.put(item, timeout=0.05)
-                    break
-                except Exception:           # queue.Full
-                    continue
+        try:
+            for rows, n, keep in self.jobs:
+                if self._stop.is_set():
+                    return
+                t0 = time.perf_counter()
+                arr = rng.fps_starts(self.N, self.sub, rows, n, skip=not keep)
+                self.draw_seconds += time.perf_counter() - t0
+                self._put((arr, TorchRng(state=rng._blob)))
+        except BaseException as e:      # a bad blob / argument raises in the library: tell the consumer instead of leaving it waiting
+            self._put(e)
 
     def __enter__(self):
         import threading
@@ -162,7 +167,20 @@ class StartPlan:
     def take(self, num_points: int, sub: int, rows: int, n_calls: int, keep: bool):
         """The next job's draws if it is the job asked for; otherwise cancels the plan (returns False)."""
         if self._pos < len(self.jobs) and (self.N, self.sub) == (int(num_points), int(sub)) and self.jobs[self._pos] == (int(rows), int(n_calls), bool(keep)):
-            arr, after = self._q.get()
+            item = None
+            while item is None:
+                try:
+                    item = self._q.get(timeout=0.5)
+                except Exception:       # queue.Empty: still drawing - or the worker died without a word
+                    if self._thread is None or not self._thread.is_alive():
+                        try:
+                            item = self._q.get_nowait()
+                        except Exception:
+                            item = RuntimeError("the draw-ahead worker ended without delivering this job")
+            if isinstance(item, BaseException):      # fall back on the synchronous draw from the last consumed state
+                self._close()
+                return False, None
+            arr, after = item
             self._pos += 1
             self._rng_after = after
             return True, arr

@@ -140,6 +140,13 @@ int dgdm_query_ball_point(float radius_squared, int nsample, const float *xyz_de
                           int32_t *out_dev, void *stream);
 int dgdm_square_distance(const float *src_dev, const float *dst_dev, int B, int S, int N, float *out_dev, void *stream);
 int dgdm_index_points(const float *points_dev, const int32_t *idx_dev, int B, int N, int M, int C, float *out_dev, void *stream);
+/* PointNetSetAbstraction.forward on its own (pointnet2_utils.py:184-210, eval mode): after sample_and_group (the functions above) the shared
+ * MLP is applied to the grouped rows layer by layer - y = act(x W^T + b) with the eval-mode BatchNorm folded into W, b by the caller;
+ * wt_dev [K][N] (W transposed), x_dev [rows][ldx], y_dev [rows][ldy], act 0 none / 1 ReLU / 2 SiLU - and the result is reduced with the
+ * max over each group's nsample rows (:206): x_dev [groups][nsample][C] -> out_dev [groups][C].                                       */
+int dgdm_linear_act(const float *x_dev, int ldx, const float *wt_dev, const float *bias_dev, float *y_dev, int ldy, int rows, int K, int N,
+                    int act, void *stream);
+int dgdm_group_max(const float *x_dev, int64_t groups, int nsample, int C, float *out_dev, void *stream);
 
 /* ------------------------------------------------------------------ a4-a6: guidance gradient
  * One DgdmGuidance serves up to max_chains independent chains (object x objective pairs) that

@@ -313,3 +313,34 @@ def test_reload_invalidates_device_weights(dev):
     dyn.load_state_dict(util.dyn2d_sd(77, nv))
     third = d.guided_sample(0, B, noise, None, opt_obj='shift_up')
     assert not torch.equal(third, other)
+
+
+def test_set_abstraction_layers_standalone(dev):
+    """``PointNetSetAbstraction.forward`` (dynamics/models/pointnet2_utils.py:184-210) called on its own, level by level, the way
+    ``PointNet2.forward`` chains them (dynamics/models/pointnet2.py:28-30), against the oracle's set_abstraction on the same FPS draws -
+    and the chained result against the fused table path (``PointNet2.forward``) on the same draws."""
+    from dynamics.models.pointnet2 import PointNet2
+    from oracle import dgdm_oracle as orc
+    sd = {k[len("object_encoder."):]: v for k, v in util.dyn3d_sd(33).items() if k.startswith("object_encoder.")}
+    net = PointNet2(256)
+    net.load_state_dict(sd)
+    net.eval().to(dev)
+    xyz = torch.stack([synth.synth_object_3d(120 + i) for i in range(3)]).permute(0, 2, 1).contiguous()      # [3, 3, 512]
+    torch.manual_seed(77)
+    l1x, l1p = net.sa1(xyz.to(dev), None)
+    l2x, l2p = net.sa2(l1x, l1p)
+    l3x, l3p = net.sa3(l2x, l2p)
+    assert l1p.shape == (3, 128, 512) and l2p.shape == (3, 256, 128) and l3p.shape == (3, 256, 1)
+    torch.manual_seed(77)
+    log = orc.StartLog()
+    o1x, o1p = orc.set_abstraction(sd, "sa1", xyz, None, 512, 0.2, 32, log)
+    o2x, o2p = orc.set_abstraction(sd, "sa2", o1x, o1p, 128, 0.4, 64, log)
+    _, o3p = orc.set_abstraction(sd, "sa3", o2x, o2p, None, None, None, None)
+    assert torch.equal(l1x.cpu(), o1x) and torch.equal(l2x.cpu(), o2x)
+    for a, b in ((l1p, o1p), (l2p, o2p), (l3p, o3p)):
+        assert util.rel_l2(a.cpu(), b) < 2e-6
+    torch.manual_seed(77)
+    fused, _ = net(xyz.to(dev))
+    assert util.rel_l2(fused.cpu(), o3p.reshape(3, -1)) < 2e-6
+    with pytest.raises(NotImplementedError):
+        net.train().sa1(xyz.to(dev), None)

@@ -78,3 +78,23 @@ def test_config3_rank_blocks_equal_one_batch(dev):      # noqa: F811
     assert torch.equal(out[:32], outs[0]) and torch.equal(out[32:], outs[7])
     # and the gather puts the blocks back in pair order (single process: identity; the 2-rank version is tests/test_dist_gloo.py)
     assert torch.equal(ddist.gather_pairs(outs[0], 32), outs[0])
+
+
+def test_bench_rank_body_on_rccl_world_size_1():
+    """The WHOLE rank body of bench.py on RCCL at world size 1 (`--force-group`: nccl process group, the barriers around the timed region, the
+    gather of the final samples, the max-over-ranks reduction, the JSON line) against the plain single-process run: the same value
+    within 3 % (box-to-box noise of two back-to-back runs is 1-2 %).  What an 8-GPU node adds to this is the transport."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    vals = {}
+    for tag, extra in (("plain", []), ("rccl", ["--force-group"])):
+        r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extra"] + extra, cwd=root, env=env,
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["n_gpus"] == 1 and line["steps"] == 3 and line["roofline"]["frac"] > 0
+        vals[tag] = line["value"]
+    assert abs(vals["rccl"] / vals["plain"] - 1) < 0.03, vals
