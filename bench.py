@@ -53,7 +53,7 @@ def parse():
     p.add_argument("--workload", choices=["3d", "2d", "3d_ensemble"], default="3d")
     p.add_argument("--pairs", type=int, default=0, help="(object x objective) pairs per GPU per step (default 32 for 3d, 4 for 2d; "
                                                         "3d_ensemble: chains per GPU per step, default 8, each averaging 4 objects' gradients)")
-    p.add_argument("--contraction", choices=["f32", "f32_mfma", "bf16"], default="f32",
+    p.add_argument("--contraction", choices=["f32", "f32_mfma", "bf16", "f32_f16x3", "f32_bf16x6"], default="f32",
                    help="arithmetic of the dynamics-trunk contractions: f32 (the parity path, default: float32 operands split exactly into three bf16 "
                         "pieces, six bf16 MFMAs per product, float32 accumulation), f32_mfma (the k-ordered float32 MFMA chain) or bf16 (operands "
                         "ROUNDED to bf16, float32 accumulation)")
@@ -216,13 +216,16 @@ def timed_loop(wl, steps, warmup, dist):
 
 # ---------------------------------------------------------------------------------------------------------------- roofline
 # what the JSON's `dtype` / roofline.arithmetic say about each contraction mode of the trunk
-DTYPE_LABEL = {"f32": "f32_split_bf16x6", "f32_mfma": "f32", "bf16": "bf16"}
-ARITHMETIC = {"f32": "float32-grade: every float32 product as six bf16 MFMA products on exactly three-way-split operands (products exact, float32 "
+DEFAULT_F32_FORM = "f32_bf16x6"          # what the library's DGDM_DTYPE_F32 selects (csrc/guidance_api.hip DGDM_DEFAULT_F16X3)
+DTYPE_LABEL = {"f32": "f32_split_bf16x6", "f32_bf16x6": "f32_split_bf16x6", "f32_f16x3": "f32_split_f16x3", "f32_mfma": "f32", "bf16": "bf16"}
+ARITHMETIC = {"f32_bf16x6": "float32-grade: every float32 product as six bf16 MFMA products on exactly three-way-split operands (products exact, float32 "
                      "accumulation; 1.6e-7 rms of a 256-term contraction vs float64, the v_mfma_f32 chain: 2.0e-7)",
+              "f32_f16x3": "float32-grade: every float32 product as three f16 MFMA products on two-way-split operands after exact power-of-two scaling "
+                           "(per weight matrix, per tile row; float32 accumulation; 1.9e-7 rms of a 256-term contraction vs float64)",
               "f32_mfma": "float32 MFMA (v_mfma_f32_32x32x2_f32), a k-ordered fma chain",
               "bf16": "operands rounded to bf16, float32 accumulation"}
 # matrix pipe busy share from the recorded PMC passes (profiles/r03_pmc_kernels.md: SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE); recorded, not live
-PIPE_BUSY_RECORDED = {("3d", "f32"): 0.71, ("2d", "f32"): 0.73, ("3d", "bf16"): 0.54}
+PIPE_BUSY_RECORDED = {("3d", "f32_bf16x6"): 0.71, ("2d", "f32_bf16x6"): 0.73, ("3d", "bf16"): 0.54}
 # algorithmic HBM bytes of ONE cond_fn's trunk launch per (pair, object): the xobj rows (1 KiB per replicated row, 3-D) or nothing of size R (2-D:
 # tables only) + the weights once
 HBM_ALGORITHMIC_BYTES = {"3d": 36000 * 32 / 32 * 1024.0 + 7.2e6 / 32, "2d": 17e6 / 4}
@@ -265,8 +268,9 @@ def stage_profile(wl, secs_per_step, contraction):
     # pipe - SIX bf16 MFMA products are issued per algorithmic float32 product - so the kernel is priced against the bf16 dense peak
     # with the ISSUED FLOPs (6 x algorithmic); the algorithmic float32 rate and what that is against the float32-MFMA peak (which the
     # old k-ordered chain was bound by) are reported beside it.  'f32_mfma': that chain.  'bf16': operands rounded to bf16.
-    kname = {"bf16": "trunk_bf16_kernel", "f32_mfma": "trunk_kernel"}.get(contraction, "trunk_split_kernel")
-    issued = SPLIT_TERMS if contraction == "f32" else 1
+    form = DEFAULT_F32_FORM if contraction == "f32" else contraction
+    kname = {"bf16": "trunk_bf16_kernel", "f32_mfma": "trunk_kernel", "f32_f16x3": "trunk_f16_kernel"}.get(form, "trunk_split_kernel")
+    issued = {"f32_bf16x6": SPLIT_TERMS, "f32_f16x3": 3}.get(form, 1)
     peak = F32_MFMA_PEAK_TFLOPS if contraction == "f32_mfma" else BF16_MFMA_PEAK_TFLOPS
     alg = flops / (ms * 1e-3) / 1e12
     ach = alg * issued
@@ -285,8 +289,8 @@ def stage_profile(wl, secs_per_step, contraction):
             "launches": n, "avg_launch_ms": ms / n,
             "algorithmic_flops_per_launch": flops / n, "algorithmic_tflops": alg, "issued_flops_per_algorithmic_flop": issued,
             "matrix_pipe_issue_frac": ach / peak, "frac_algorithmic_vs_f32_peak": alg / F32_MFMA_PEAK_TFLOPS,
-            "pipe_busy": PIPE_BUSY_RECORDED.get((wl.kind, contraction)),
-            "arithmetic": ARITHMETIC[contraction],
+            "pipe_busy": PIPE_BUSY_RECORDED.get((wl.kind, form)),
+            "arithmetic": ARITHMETIC[form],
             "share_of_step": (ms * 1e-3) / secs_per_step,
             "step_frac": (st["trunk"][2] + st["unet"][2]) / secs_per_step / 1e12 / peak,
             "step_issue_frac": (st["trunk"][2] * issued + st["unet"][2]) / secs_per_step / 1e12 / peak,

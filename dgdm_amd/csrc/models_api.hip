@@ -256,6 +256,45 @@ struct Split3 {
     }
 };
 
+// ---- two-way f16 split streams (csrc/trunk_f16.hip): w 2^ew = h + l, both f16, max |w 2^ew| in [2^12, 2^13)
+struct Split2 {
+    std::vector<float> p[2];
+    int K = 0, ew = 0;
+    static float f16(float x) { const _Float16 h = (_Float16)x; return (float)h; }
+    static uint16_t bits(float x) { const _Float16 h = (_Float16)x; uint16_t u; memcpy(&u, &h, 2); return u; }      // exact: x is an f16 value
+    Split2(const float *src, int M, int K_) : K(K_) {
+        float mx = 0.f;
+        for (size_t i = 0; i < (size_t)M * K_; ++i) mx = std::max(mx, std::fabs(src[i]));
+        int e = 0;
+        if (mx > 0.f) std::frexp(mx, &e);           // mx = f 2^e, f in [0.5, 1)
+        ew = 13 - e;
+        for (auto &v : p) v.resize((size_t)M * K_);
+        for (size_t i = 0; i < (size_t)M * K_; ++i) {
+            const float w = std::ldexp(src[i], ew), h = f16(w);
+            p[0][i] = h; p[1][i] = f16(w - h);
+        }
+    }
+    // the two 1 KiB entries [h l] of (output block op, input block ib, K-step s), operand layout of Split3::emit
+    void emit(std::vector<uint16_t> &dst, int op, int ib, int s) const {
+        for (int q = 0; q < 2; ++q)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int i = lane & 31, hh = lane >> 5;
+                for (int j = 0; j < 8; ++j) {
+                    const int rr = 8 * s + j, f = (rr & 3) + 8 * (rr >> 2) + 4 * hh;
+                    dst.push_back(bits(p[q][(size_t)(32 * op + i) * K + 32 * ib + f]));
+                }
+            }
+    }
+};
+// 256 -> 256 layer (trunk_f16.hip stream_layer): 16 K-steps x 4 output-block pairs x [A.h A.l B.h B.l]; returns the matrix' scale exponent
+int f16_layer_stream(std::vector<uint16_t> &dst, const float *w /*[256][256]*/) {
+    const Split2 sp(w, 256, 256);
+    for (int ks = 0; ks < 16; ++ks)
+        for (int pp = 0; pp < 4; ++pp)
+            for (int blk = 2 * pp; blk < 2 * pp + 2; ++blk) sp.emit(dst, blk, ks / 2, ks % 2);
+    return sp.ew;
+}
+
 // 256 -> 256 layer (trunk_split.hip stream_layer): 16 K-steps x 4 output-block pairs x [A.h A.m A.l B.h B.m B.l]
 void split_layer_stream(std::vector<uint16_t> &dst, const float *w /*[256][256]*/) {
     const Split3 sp(w, 256, 256);
@@ -428,6 +467,46 @@ extern "C" int dgdm_dynamics_create(DgdmDynamics **out, int kind, const DgdmTens
         fs.insert(fs.end(), bs.begin(), bs.end());
         if ((rc = m->wsplit.upload(fs.data(), fs.size() * 2))) return rc;
     }
+    {   // two-way f16 split streams (trunk_f16.hip), in consumption order; 3-D layer 2 keeps the three-way bf16 form (see that file)
+        std::vector<uint16_t> fs, bs;
+        TrunkF16Scales &sc = m->f16_scales;
+        sc = TrunkF16Scales{};
+        Folded l2;
+        if (kind == 3) {
+            if ((rc = fold_linear(sd, "linears.3", "linears.4", W, W1, &l2))) return rc;
+            const std::vector<float> w1o3 = cols(l1.w, W1, IN1, 0, W);
+            const Split2 s1(w1o3.data(), W1, W);
+            const Split3 s2(l2.w.data(), W, W1);
+            sc.ew_l1 = s1.ew;
+            for (int kb = 0; kb < 16; ++kb) {
+                for (int ks = 0; ks < 16; ++ks) s1.emit(fs, kb, ks / 2, ks % 2);                    // layer-1 block kb: 16 K-steps x [h l]
+                for (int pp = 0; pp < 4; ++pp)                                                      // layer 2, input block kb (bf16 x 3)
+                    for (int sx = 0; sx < 2; ++sx)
+                        for (int blk = 2 * pp; blk < 2 * pp + 2; ++blk) s2.emit(fs, blk, kb, sx);
+            }
+        }
+        std::vector<std::vector<uint16_t>> back;
+        for (int i = 0; i < m->n_mid; ++i) {
+            const int li = 3 * (first_mid + i);
+            Folded f;
+            if ((rc = fold_linear(sd, "linears." + std::to_string(li), "linears." + std::to_string(li + 1), W, W, &f))) return rc;
+            sc.ew_mid[i] = f16_layer_stream(fs, f.w.data());
+            back.emplace_back();
+            const int et = f16_layer_stream(back.back(), transpose(f.w.data(), W, W).data());
+            DGDM_REQUIRE(et == sc.ew_mid[i], DGDM_EINVAL, "f16 split: a matrix and its transpose disagree about their scale");
+        }
+        for (int i = m->n_mid - 1; i >= 0; --i) bs.insert(bs.end(), back[i].begin(), back[i].end());               // last layer first
+        if (kind == 3) {
+            const std::vector<float> w2t = transpose(l2.w.data(), W, W1);                                          // [512][256]
+            const Split2 st(w2t.data(), W1, W);
+            sc.ew_l2 = st.ew;
+            for (int kb = 0; kb < 16; ++kb)
+                for (int ks = 0; ks < 16; ++ks) st.emit(bs, kb, ks / 2, ks % 2);
+        }
+        m->fwdh_bytes = fs.size() * 2; m->bwdh_bytes = bs.size() * 2;
+        fs.insert(fs.end(), bs.begin(), bs.end());
+        if ((rc = m->wf16.upload(fs.data(), fs.size() * 2))) return rc;
+    }
     std::vector<float> bwd;
     for (int i = m->n_mid - 1; i >= 0; --i) bwd.insert(bwd.end(), bwd_imgs[i].begin(), bwd_imgs[i].end());     // last layer first
     bwd.insert(bwd.end(), bwd_tail.begin(), bwd_tail.end());
@@ -496,6 +575,12 @@ void DgdmDynamics::fill_trunk(TrunkParams *p) const {
 void DgdmDynamics::fill_trunk_bf16(TrunkParams *p) const {     // after fill_trunk: swaps the two weight streams only
     p->Wfwd = reinterpret_cast<const float4 *>(static_cast<const char *>(w16.p)); p->fwd_bytes = (unsigned)fwd16_bytes;
     p->Wbwd = reinterpret_cast<const float4 *>(static_cast<const char *>(w16.p) + fwd16_bytes); p->bwd_bytes = (unsigned)bwd16_bytes;
+}
+
+void DgdmDynamics::fill_trunk_f16(TrunkParams *p, TrunkF16Scales *sc) const {     // after fill_trunk: swaps the two weight streams only
+    p->Wfwd = reinterpret_cast<const float4 *>(static_cast<const char *>(wf16.p)); p->fwd_bytes = (unsigned)fwdh_bytes;
+    p->Wbwd = reinterpret_cast<const float4 *>(static_cast<const char *>(wf16.p) + fwdh_bytes); p->bwd_bytes = (unsigned)bwdh_bytes;
+    *sc = f16_scales;
 }
 
 void DgdmDynamics::fill_trunk_split(TrunkParams *p) const {    // after fill_trunk: swaps the two weight streams only

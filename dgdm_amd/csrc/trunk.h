@@ -53,6 +53,14 @@ int trunk_launch(int kind, bool rows_mode, bool fwd_only, const TrunkParams &p, 
 // backward.  p.Wfwd / p.Wbwd point at the split streams (DgdmDynamics::fill_trunk_split).
 int trunk_split_launch(int kind, const TrunkParams &p, hipStream_t s);
 
+// float32 contractions as three f16 MFMA products on two-way split, power-of-two scaled operands (trunk_f16.hip): table mode, forward +
+// backward.  p.Wfwd / p.Wbwd point at the f16 streams (DgdmDynamics::fill_trunk_f16), sc carries the weight matrices' scale exponents.
+struct TrunkF16Scales {
+    int ew_mid[8];            // 256 -> 256 stack layer l (the same for W and its transpose)
+    int ew_l1, ew_l2;         // 3-D: layer 1's object-embedding columns (forward), layer 2 transposed (the last layer back)
+};
+int trunk_f16_launch(int kind, const TrunkParams &p, const TrunkF16Scales &sc, hipStream_t s);
+
 // bf16-contraction variant (trunk_bf16.hip): table mode, forward + backward only.  p.Wfwd / p.Wbwd point at the bf16 streams
 // (DgdmDynamics::fill_trunk_bf16); everything else in TrunkParams means the same.
 int trunk_bf16_launch(int kind, const TrunkParams &p, hipStream_t s);

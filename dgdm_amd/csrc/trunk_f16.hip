@@ -1,0 +1,491 @@
+// Fused dynamics trunk, forward + input-gradient backward (same contract as trunk_split_kernel, trunk_split.hip), with the float32
+// contractions carried by THREE f16 MFMAs per K-step instead of six bf16 ones:
+//     x = x_h + x_l,  x_h = f16(x),  x_l = f16(x - x_h)   (x - x_h is exact in float32; 11 + 11 significant bits, 2^-23 of x at worst)
+//     w x  ~  w_h x_h + w_h x_l + w_l x_h                  (each exact in float32; the dropped w_l x_l is below 2^-22 of the product)
+// on v_mfma_f32_32x32x16_f16 with float32 accumulation.  f16 has five exponent bits where bf16 has float32's eight, so both operands
+// are brought into its range by EXACT powers of two first:
+//   * weights: one scale per matrix, chosen on the host so that max |w 2^ew| lies in [2^12, 2^13) (Split2, models_api.hip);
+//   * activations / gradients: one scale per ROW of the 32-row tile, from the row's largest magnitude at the layer's input (128
+//     v_max per lane + one exchange with the lane that holds the row's other half), max |x 2^k| in [2^12, 2^13); entries 2^16 below
+//     their row's maximum keep their full 22 bits, smaller ones an absolute error of 2^-38 of the maximum.
+// The accumulators then hold the true pre-activations times 2^E, E = (input scale) + ew per row; ReLU and its sign bits do not care, the
+// bias is added as b 2^E, and E is taken out where true values are needed (the output layer, the folded tile sums).  Measured against
+// float64 (scripts/micro/split_mfma.hip, K = 256, He-init weights, post-ReLU inputs): rms error 1.9e-7 of the rms output, between the
+// 1.6e-7 of the six-product bf16 form and the 2.0e-7 of the v_mfma_f32 chain.  Half the matrix-pipe instructions and two thirds of the
+// weight bytes of trunk_split.hip.
+//
+// What is NOT converted: layer 2 of the 3-D front consumes layer 1's output block by block while layer 1 is still being produced, so a
+// row's scale cannot be fixed from the whole input; that layer keeps the six-product bf16 form (bf16 needs no scale).  Everything else
+// - the 256 -> 256 stack forward and backward, the 3-D layer 1 (input: the embedding row) and the last layer back - is f16.
+// Structure, register residency, sign-bit masks, ring and stream order are those of trunk_split.hip (read that file's header first);
+// stream entries per (K-step, output-block pair): [A.h A.l B.h B.l], per block-out K-step: [h l]; ring depth 8 (divides every pass length).
+#include "common.h"
+#include <algorithm>
+#include "mfma_chain.h"
+#include "trunk.h"
+
+namespace dgdm {
+namespace f16t {
+
+typedef _Float16 hf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 hf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 hb16x8_t __attribute__((ext_vector_type(8)));
+typedef float hf32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t hu32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x16 hmfma(const float4 a, const hu32x4_t b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8_t, a), __builtin_bit_cast(hf16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 bmfma(const float4 a, const hu32x4_t b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hb16x8_t, a), __builtin_bit_cast(hb16x8_t, b), c, 0, 0, 0);
+}
+
+// 2^e as a float (e clamped to the normal range)
+__device__ __forceinline__ float pow2f(int e) { return __uint_as_float((uint32_t)(min(max(e, -126), 127) + 127) << 23); }
+
+// k with m 2^k in [2^12, 2^13) for the row whose two half-wave lanes hold m; 0 for a row of zeros.  lo..hi: the range k may take
+__device__ __forceinline__ int scale_exp(float m, int lo, int hi) {
+    m = fmaxf(m, __shfl_xor(m, 32));
+    const int e = (int)((__float_as_uint(m) >> 23) & 0xffu);
+    const int k = (m > 0.f && e < 255) ? 12 + 127 - e : 0;
+    return min(max(k, lo), hi);
+}
+
+// an already scaled pair -> packed f16 (h | l), h + l == the pair to 2^-23
+__device__ __forceinline__ void split2(float lo, float hi, uint32_t &ph, uint32_t &pl) {
+    const hf32x2_t v = {lo, hi};
+    const hf16x2_t h = __builtin_convertvector(v, hf16x2_t);            // v_cvt_pk_f16_f32 (round to nearest even)
+    const hf32x2_t d = v - __builtin_convertvector(h, hf32x2_t);        // exact
+    ph = __builtin_bit_cast(uint32_t, h);
+    pl = __builtin_bit_cast(uint32_t, __builtin_convertvector(d, hf16x2_t));
+}
+// bf16 three-way split of trunk_split.hip (3-D layer 2)
+__device__ __forceinline__ void split3(float lo, float hi, uint32_t &ph, uint32_t &pm, uint32_t &pl) {
+    ph = pack_bf16(lo, hi);
+    const float r0 = lo - __uint_as_float(ph << 16), r1 = hi - __uint_as_float(ph & 0xffff0000u);
+    pm = pack_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(pm << 16), s1 = r1 - __uint_as_float(pm & 0xffff0000u);
+    pl = pack_bf16(s0, s1);
+}
+
+struct Act2 {
+    hu32x4_t v[2][8][2];      // [piece][32-feature block][K-step]
+};
+
+constexpr int HRD = 8;       // ring depth in 1 KiB entries (16 spills: the kernel sits at the 512-register limit)
+struct HRing {
+    float4 e[HRD];
+};
+__device__ __forceinline__ void hring_fill(wrsrc_t rs, int voff, int base, HRing &r) {
+#pragma unroll
+    for (int i = 0; i < HRD; ++i) r.e[i] = wload(rs, voff, base + i * 1024);
+}
+
+// the three terms of one K-step for two accumulators (w: [A.h A.l B.h B.l]); small terms first
+#define F16_STEP(accA, accB, w, xh, xl)      \
+    do {                                     \
+        accA = hmfma(w[1], xh, accA);        \
+        accB = hmfma(w[3], xh, accB);        \
+        accA = hmfma(w[0], xl, accA);        \
+        accB = hmfma(w[2], xl, accB);        \
+        accA = hmfma(w[0], xh, accA);        \
+        accB = hmfma(w[2], xh, accB);        \
+    } while (0)
+// six-product bf16 step of trunk_split.hip (w: [A.h A.m A.l B.h B.m B.l])
+#define B16_STEP(accA, accB, w, xh, xm, xl)  \
+    do {                                     \
+        accA = bmfma(w[2], xh, accA);        \
+        accB = bmfma(w[5], xh, accB);        \
+        accA = bmfma(w[0], xl, accA);        \
+        accB = bmfma(w[3], xl, accB);        \
+        accA = bmfma(w[1], xm, accA);        \
+        accB = bmfma(w[4], xm, accB);        \
+        accA = bmfma(w[1], xh, accA);        \
+        accB = bmfma(w[4], xh, accB);        \
+        accA = bmfma(w[0], xm, accA);        \
+        accB = bmfma(w[3], xm, accB);        \
+        accA = bmfma(w[0], xh, accA);        \
+        accB = bmfma(w[3], xh, accB);        \
+    } while (0)
+
+// One 256 -> 256 layer, input-streaming (trunk_split.hip stream_layer).  Yp: the previous layer's accumulators = true values x 2^E per
+// row (E: this lane's row); on return Y = this layer's accumulators and E their scale.  ew: the weight matrix' scale exponent.
+template <bool FWD, bool BIAS>
+__device__ __forceinline__ void stream_layer(const wrsrc_t rs, const int voff, const int woff, HRing &ring, const float *__restrict__ bias,
+                                             const f32x16 (&Yp)[8], f32x16 (&Y)[8], uint32_t (*smask)[256], const int slot_in, const int tid,
+                                             const int h4, int &E, const int ew) {
+    // the row's largest input magnitude (forward: the largest positive pre-activation, what ReLU lets through; backward: before the mask)
+    float mx = 0.f;
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = FWD ? fmaxf(mx, Yp[o][r]) : fmaxf(mx, fabsf(Yp[o][r]));
+    const int k = scale_exp(mx, -100 - E - ew, 100 - E - ew);
+    const float f = pow2f(k);
+    E += k + ew;
+    const float fb = pow2f(E);
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        if (BIAS) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 a = feat4(bias, o, q, h4);
+                Y[o][4 * q + 0] = a.x * fb; Y[o][4 * q + 1] = a.y * fb; Y[o][4 * q + 2] = a.z * fb; Y[o][4 * q + 3] = a.w * fb;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Y[o][r] = 0.f;
+        }
+    }
+    hu32x4_t P[2][2][2];                           // [block parity][piece][K-step]
+    uint32_t mk = FWD ? 0u : smask[slot_in][tid];
+    auto item = [&](const f32x16 &y, const int blk, const int d) __attribute__((always_inline)) {
+        float lo = y[2 * d], hi = y[2 * d + 1];
+        const int sh = 2 * d + 16 * (blk & 1);
+        if (FWD) {
+            mk |= (lo > 0.f ? 1u : 0u) << sh;
+            mk |= (hi > 0.f ? 1u : 0u) << (sh + 1);
+            asm("v_max_f32 %0, 0, %1" : "=v"(lo) : "v"(lo));
+            asm("v_max_f32 %0, 0, %1" : "=v"(hi) : "v"(hi));
+        } else {
+            lo = ((mk >> sh) & 1u) ? lo : 0.f;
+            hi = ((mk >> (sh + 1)) & 1u) ? hi : 0.f;
+        }
+        uint32_t a, b;
+        split2(lo * f, hi * f, a, b);
+        P[blk & 1][0][d / 4][d % 4] = a; P[blk & 1][1][d / 4][d % 4] = b;
+    };
+#pragma unroll
+    for (int d = 0; d < 8; ++d) item(Yp[0], 0, d);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                const int En = (((b * 2 + sx) * 4) + pp) * 4;
+                float4 w[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    w[j] = ring.e[(En + j) % HRD];
+                    ring.e[(En + j) % HRD] = wload(rs, voff, woff + (En + j + HRD) * 1024);
+                }
+                if (b < 7) {                       // the next input block's pair q, in the shadow of this group's MFMAs
+                    const int q = sx * 4 + pp, nb = b + 1;
+                    if (q == 0 && (nb & 1) == 0) mk = FWD ? 0u : smask[slot_in + nb / 2][tid];
+                    item(Yp[nb], nb, q);
+                    if (FWD && q == 7 && (nb & 1) == 1) smask[slot_in + nb / 2][tid] = mk;
+                }
+                F16_STEP(Y[2 * pp], Y[2 * pp + 1], w, P[b & 1][0][sx], P[b & 1][1][sx]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
+// one 32-feature output block from a 256-feature input on two alternating accumulators (16 K-steps x [h l]): z = za + zb
+template <class Side>
+__device__ __forceinline__ f32x16 block_out(const wrsrc_t rs, const int voff, const int woff, HRing &ring, const Act2 &X, f32x16 za, f32x16 zb,
+                                            Side &&side) {
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        const int En = ks * 2;
+        float4 w[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            w[j] = ring.e[(En + j) % HRD];
+            ring.e[(En + j) % HRD] = wload(rs, voff, woff + (En + j + HRD) * 1024);
+        }
+        const hu32x4_t xh = X.v[0][ks / 2][ks % 2], xl = X.v[1][ks / 2][ks % 2];
+        side(ks);
+        za = hmfma(w[1], xh, za);
+        zb = hmfma(w[0], xl, zb);
+        za = hmfma(w[0], xh, za);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) za[r] += zb[r];
+    return za;
+}
+
+// true values x 2^k of a whole activation matrix -> the two f16 pieces; returns k (row scale)
+__device__ __forceinline__ int split_rows(const f32x16 (&Y)[8], Act2 &X) {
+    float mx = 0.f;
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(Y[o][r]));
+    const int k = scale_exp(mx, -100, 100);
+    const float f = pow2f(k);
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            uint32_t a, b;
+            split2(Y[o][2 * d] * f, Y[o][2 * d + 1] * f, a, b);
+            X.v[0][o][d / 4][d % 4] = a; X.v[1][o][d / 4][d % 4] = b;
+        }
+    return k;
+}
+
+}  // namespace f16t
+
+using namespace f16t;
+
+template <int KIND>
+__global__ __launch_bounds__(256, 1) void trunk_f16_kernel(const TrunkParams p, const TrunkF16Scales sc) {
+    constexpr int W1B = (KIND == 3) ? 16 : 8;
+    constexpr int W1 = W1B * 32;
+    constexpr int NSLOT = (KIND == 3) ? 8 + 7 * 4 : 8 * 4;
+    __shared__ uint32_t smask[NSLOT][256];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= p.ntiles) return;                             // wave-uniform; the kernel has no barrier
+    const int n = lane & 31;
+    const int h4 = (lane >> 5) * 4;
+    const int voff = lane * 16;
+
+    const int per_chain = p.B * p.tiles_per_b;
+    const int chain = tile / per_chain;
+    const int rem = tile - chain * per_chain;
+    const int b = rem / p.tiles_per_b;
+    const int c = (rem - b * p.tiles_per_b) * 32 + n;
+    const bool valid = c < p.C;
+    const int64_t r = (int64_t)(valid ? c : p.C - 1) * p.B + b;
+    const float *arow = p.Atab + (size_t)(chain * p.B + b) * W1;
+    const float4 *ptile = reinterpret_cast<const float4 *>(p.PtabT) + (size_t)(rem - b * p.tiles_per_b) * W1B * 4 * 64 + lane;
+
+    f32x16 Y[8];
+    uint32_t m[4];
+    int slot = 0;
+    int E = 0;                                                // Y = true values x 2^E for this lane's row
+    const wrsrc_t rsF = weight_rsrc(p.Wfwd, p.fwd_bytes);
+    HRing ring;
+    int woff = 0;
+    hring_fill(rsF, voff, 0, ring);
+
+    if (KIND == 2) {
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 v = feat4(arow, o, q, h4);
+                const float4 w = ptile[(o * 4 + q) * 64];
+                Y[o][4 * q + 0] = v.x + w.x; Y[o][4 * q + 1] = v.y + w.y; Y[o][4 * q + 2] = v.z + w.z; Y[o][4 * q + 3] = v.w + w.w;
+            }
+        }
+    } else {
+        // ---- 3-D layers 1 and 2, streamed over the 16 blocks of the 512-wide layer 1.  Layer 1 (input: the embedding row, scale known up
+        // front): f16; layer 2 (input arrives block by block): six-product bf16 on true values, as trunk_split.hip
+        const float *xrow = p.xtab ? p.xtab[chain] + (size_t)p.xidx[(size_t)chain * p.xstride + r] * 256 : p.xobj + ((size_t)chain * p.xstride + r) * 256;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = feat4(xrow, o, q, h4);
+                Y[o][4 * q + 0] = v.x; Y[o][4 * q + 1] = v.y; Y[o][4 * q + 2] = v.z; Y[o][4 * q + 3] = v.w;
+            }
+        }
+        Act2 X;
+        const int kx = split_rows(Y, X);
+        const float un1 = pow2f(-(kx + sc.ew_l1));            // layer-1 accumulators -> true values
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 b4 = feat4(p.b2, o, q, h4);
+                Y[o][4 * q + 0] = b4.x; Y[o][4 * q + 1] = b4.y; Y[o][4 * q + 2] = b4.z; Y[o][4 * q + 3] = b4.w;
+            }
+        }
+        f32x16 zero, tt;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) zero[rr] = 0.f;
+        auto table_terms = [&](int kb) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4 *>(arow + 32 * kb + 8 * q + h4);
+                const float4 w = ptile[(kb * 4 + q) * 64];
+                tt[4 * q + 0] = v.x + w.x; tt[4 * q + 1] = v.y + w.y; tt[4 * q + 2] = v.z + w.z; tt[4 * q + 3] = v.w + w.w;
+            }
+        };
+        table_terms(0);
+        for (int blk = 0; blk < 16; blk += 2) {
+            uint32_t bits2 = 0;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int kb = blk + e;
+                f32x16 z = block_out(rsF, voff, woff, ring, X, zero, zero, [](int) __attribute__((always_inline)) {});
+                woff += 32 * 1024;
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) z[rr] = fmaf(z[rr], un1, tt[rr]);       // the scaled sum back to true units (exact) + the table terms: one rounding
+                hu32x4_t ah[2], am[2], al[2];
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    float lo = z[2 * d], hi = z[2 * d + 1];
+                    const int sh = 2 * d + 16 * e;
+                    bits2 |= (lo > 0.f ? 1u : 0u) << sh;
+                    bits2 |= (hi > 0.f ? 1u : 0u) << (sh + 1);
+                    asm("v_max_f32 %0, 0, %1" : "=v"(lo) : "v"(lo));
+                    asm("v_max_f32 %0, 0, %1" : "=v"(hi) : "v"(hi));
+                    uint32_t a, bb, cc;
+                    split3(lo, hi, a, bb, cc);
+                    ah[d / 4][d % 4] = a; am[d / 4][d % 4] = bb; al[d / 4][d % 4] = cc;
+                }
+                table_terms((kb + 1) & 15);
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) {
+#pragma unroll
+                    for (int sx = 0; sx < 2; ++sx) {
+                        const int En = (pp * 2 + sx) * 6;
+                        float4 w[6];
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) {
+                            w[j] = ring.e[(En + j) % HRD];
+                            ring.e[(En + j) % HRD] = wload(rsF, voff, woff + (En + j + HRD) * 1024);
+                        }
+                        B16_STEP(Y[2 * pp], Y[2 * pp + 1], w, ah[sx], am[sx], al[sx]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                woff += 48 * 1024;
+            }
+            smask[blk / 2][tid] = bits2;
+        }
+        slot = 8;
+    }
+    constexpr int BASE = (KIND == 3) ? 8 : 0;
+    f32x16 Z[8];
+    for (int l = 0; l < p.n_mid; ++l) {
+        stream_layer<true, true>(rsF, voff, woff, ring, p.bf[l], Y, Z, smask, BASE + 4 * l, tid, h4, E, sc.ew_mid[l]);
+        woff += 256 * 1024;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) Y[o] = Z[o];
+    }
+    slot = BASE + 4 * p.n_mid;
+    relu_mask<8>(Y, m);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) smask[slot + i][tid] = m[i];
+    slot += 4;
+
+    // ---- output layer (256 -> 3) on the VALU on the scaled activations, 2^-E taken out of the three sums
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 w0 = feat4(p.Wout, o, q, h4);
+            const float4 w1 = feat4(p.Wout + 256, o, q, h4);
+            const float4 w2 = feat4(p.Wout + 512, o, q, h4);
+            const float x0 = Y[o][4 * q + 0], x1 = Y[o][4 * q + 1], x2 = Y[o][4 * q + 2], x3 = Y[o][4 * q + 3];
+            s0 = fmaf(w0.w, x3, fmaf(w0.z, x2, fmaf(w0.y, x1, fmaf(w0.x, x0, s0))));
+            s1 = fmaf(w1.w, x3, fmaf(w1.z, x2, fmaf(w1.y, x1, fmaf(w1.x, x0, s1))));
+            s2 = fmaf(w2.w, x3, fmaf(w2.z, x2, fmaf(w2.y, x1, fmaf(w2.x, x0, s2))));
+        }
+    }
+    s0 += __shfl_xor(s0, 32);
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 32);
+    const float unE = pow2f(-E);
+    const float d0 = fmaf(s0, unE, p.bout[0]), d1 = fmaf(s1, unE, p.bout[1]), d2 = fmaf(s2, unE, p.bout[2]);
+
+    const wrsrc_t rsB = weight_rsrc(p.Wbwd, p.bwd_bytes);
+    woff = 0;
+    hring_fill(rsB, voff, 0, ring);
+    const TrunkObjective ob = p.obj[chain];
+    float g0 = ob.lin[0] + 2.f * ob.quad[0] * d0;
+    float g1 = ob.lin[1] + 2.f * ob.quad[1] * d1;
+    float g2 = ob.lin[2] + 2.f * ob.quad[2] * d2;
+    if (ob.use_rowcoef) g0 = p.rowcoef[(size_t)chain * p.R + r];
+    if (!valid) { g0 = 0.f; g1 = 0.f; g2 = 0.f; }
+
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 w0 = feat4(p.Wout, o, q, h4);
+            const float4 w1 = feat4(p.Wout + 256, o, q, h4);
+            const float4 w2 = feat4(p.Wout + 512, o, q, h4);
+            Y[o][4 * q + 0] = fmaf(g2, w2.x, fmaf(g1, w1.x, g0 * w0.x));
+            Y[o][4 * q + 1] = fmaf(g2, w2.y, fmaf(g1, w1.y, g0 * w0.y));
+            Y[o][4 * q + 2] = fmaf(g2, w2.z, fmaf(g1, w1.z, g0 * w0.z));
+            Y[o][4 * q + 3] = fmaf(g2, w2.w, fmaf(g1, w1.w, g0 * w0.w));
+        }
+    }
+    E = 0;                                                    // the gradient seed is in true units
+
+    // ---- backward through the 256 -> 256 layers
+    for (int l = p.n_mid - 1; l >= 0; --l) {
+        stream_layer<false, false>(rsB, voff, woff, ring, nullptr, Y, Z, smask, BASE + 4 + 4 * l, tid, h4, E, sc.ew_mid[l]);
+        woff += 256 * 1024;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) Y[o] = Z[o];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m[i] = smask[BASE + i][tid];
+    apply_mask<8>(Y, m);
+
+    float *dst = p.partial + (size_t)tile * W1;
+    if (KIND == 2) {
+        const float un = pow2f(-E);                           // per row: back to true units before the 32 rows are folded
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 v;
+                v.x = rows_sum(Y[o][4 * q + 0] * un); v.y = rows_sum(Y[o][4 * q + 1] * un);
+                v.z = rows_sum(Y[o][4 * q + 2] * un); v.w = rows_sum(Y[o][4 * q + 3] * un);
+                if (n == ROWS_SUM_LANE) *reinterpret_cast<float4 *>(dst + 32 * o + 8 * q + h4) = v;
+            }
+        }
+    } else {
+        // 3-D: one more layer back (256 -> 512), block by block, straight into the fold (trunk_split.hip)
+        Act2 X;
+        const int kt = split_rows(Y, X);
+        const float un = pow2f(-(E + kt + sc.ew_l2));
+        f32x16 zero;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) zero[rr] = 0.f;
+        f32x16 g = block_out(rsB, voff, woff, ring, X, zero, zero, [](int) __attribute__((always_inline)) {});
+        woff += 32 * 1024;
+        float4 acc;
+        auto fold_one = [&](const int rr, const int kb, const uint32_t bits) __attribute__((always_inline)) {
+            const float v = rows_sum(apply_bit(g[rr] * un, bits, rr));
+            if (rr % 4 == 0) acc.x = v;
+            else if (rr % 4 == 1) acc.y = v;
+            else if (rr % 4 == 2) acc.z = v;
+            else {
+                acc.w = v;
+                if (n == ROWS_SUM_LANE) *reinterpret_cast<float4 *>(dst + 32 * kb + 8 * (rr / 4) + h4) = acc;
+            }
+        };
+        for (int kb = 1; kb < 16; ++kb) {
+            const uint32_t bits = smask[(kb - 1) / 2][tid] >> (16 * ((kb - 1) & 1));
+            const f32x16 gn = block_out(rsB, voff, woff, ring, X, zero, zero, [&](const int ks) __attribute__((always_inline)) { fold_one(ks, kb - 1, bits); });
+            woff += 32 * 1024;
+            g = gn;
+        }
+        const uint32_t bits = smask[7][tid] >> 16;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) fold_one(rr, 15, bits);
+    }
+}
+
+int trunk_f16_launch(int kind, const TrunkParams &p, const TrunkF16Scales &sc, hipStream_t s) {
+    if (p.n_mid != (kind == 3 ? 6 : 7)) return DGDM_EINVAL;
+    const int grid = (p.ntiles + 3) / 4;
+    if (grid == 0) return DGDM_OK;
+    const double rows = (double)(p.ntiles / std::max(1, p.tiles_per_b)) * p.C;
+    const double mid = 2.0 * 256 * 256 * p.n_mid;
+    const double per_row = (kind == 3) ? (2.0 * 256 * 512 * 2 + mid) + (2.0 * 256 * 512 + mid) : 2.0 * mid;
+    prof_begin(s, DGDM_STAGE_TRUNK);
+    if (kind == 2) hipLaunchKernelGGL((trunk_f16_kernel<2>), dim3(grid), dim3(256), 0, s, p, sc);
+    else hipLaunchKernelGGL((trunk_f16_kernel<3>), dim3(grid), dim3(256), 0, s, p, sc);
+    DGDM_HIP_CHECK(hipGetLastError());
+    prof_end(s, DGDM_STAGE_TRUNK, rows * per_row);
+    return DGDM_OK;
+}
+
+}  // namespace dgdm

@@ -214,8 +214,9 @@ class Guidance:
     def set_contraction_dtype(self, dtype: str) -> None:
         """Arithmetic of the trunk of cond_fn: 'f32' (default: float32 operands split exactly into three bf16 pieces, six bf16 MFMAs per
         product, float32 accumulation - float32-grade, csrc/trunk_split.hip), 'f32_mfma' (the k-ordered float32 MFMA chain,
-        csrc/trunk.hip) or 'bf16' (operands ROUNDED to bf16, float32 accumulation)."""
-        codes = {"f32": 0, "bf16": 1, "f32_mfma": 2}
+        csrc/trunk.hip), 'f32_f16x3' (float32 operands as two exactly scaled f16 pieces, three f16 MFMAs per product, csrc/trunk_f16.hip),
+        'f32_bf16x6' (the six-product form by name) or 'bf16' (operands ROUNDED to bf16, float32 accumulation)."""
+        codes = {"f32": 0, "bf16": 1, "f32_mfma": 2, "f32_f16x3": 3, "f32_bf16x6": 4}
         if dtype not in codes:
             raise ValueError(f"contraction dtype {dtype!r} not supported")
         check(lib().dgdm_guidance_set_contraction_dtype(self._h, codes[dtype]))

@@ -36,7 +36,7 @@ extern "C" {
 
 /* One host tensor of a reference-format state_dict (torch layout, contiguous). */
 /* contraction dtypes of dgdm_unet1d_set_contraction_dtype / dgdm_guidance_set_contraction_dtype */
-enum { DGDM_DTYPE_F32 = 0, DGDM_DTYPE_BF16 = 1, DGDM_DTYPE_F32_MFMA = 2 };
+enum { DGDM_DTYPE_F32 = 0, DGDM_DTYPE_BF16 = 1, DGDM_DTYPE_F32_MFMA = 2, DGDM_DTYPE_F32_F16X3 = 3, DGDM_DTYPE_F32_BF16X6 = 4 };
 
 typedef struct DgdmTensor {
     const char *name;     /* e.g. "linears.3.weight", "module."-prefix already stripped     */
@@ -171,7 +171,10 @@ void dgdm_guidance_destroy(DgdmGuidance *g);
  * f32 accumulate").  DGDM_DTYPE_F32 (default, the parity path): float32 operands split EXACTLY into three bf16 pieces each, six
  * bf16 MFMAs per product with float32 accumulation - float32-grade results (slightly closer to float64 than a k-ordered float32
  * fma chain) at 2.7x fewer matrix-pipe cycles.  DGDM_DTYPE_F32_MFMA: the k-ordered float32 fma chain itself
- * (v_mfma_f32_32x32x2_f32).  DGDM_DTYPE_BF16: weights and the
+ * (v_mfma_f32_32x32x2_f32).  DGDM_DTYPE_F32_F16X3: float32 operands as two f16 pieces each after exact power-of-two scaling (per weight
+ * matrix, per tile row), three f16 MFMAs per product (csrc/trunk_f16.hip: 1.9e-7 rms of a 256-term contraction vs float64, between the
+ * two forms above; half the matrix-pipe instructions of the six-product form).  DGDM_DTYPE_F32_BF16X6: the six-product form by name
+ * (DGDM_DTYPE_F32 selects the library's default float32-grade form).  DGDM_DTYPE_BF16: weights and the
  * activations/gradients entering a contraction rounded to bf16 (nearest even), float32 accumulation; first-layer tables,
  * biases, objective and row sums stay float32.  The reference has no such switch (it calls
  * torch.set_float32_matmul_precision('high'), generator/diffusion.py:102, which is a no-op on its CPU path).          */

@@ -98,6 +98,38 @@ __global__ void k_bf16_2acc(const float *W, const float *X, const float *bias, f
     for (int r = 0; r < 16; ++r) out[((size_t)t * 32 + crow(r, h)) * 32 + i] = a0[r] + a1[r];
 }
 
+// (e) the form a register-resident trunk can afford with f16: ONE accumulator per output, both operands pre-scaled by powers of two so
+//     that their low pieces stay in f16's normal range (weights: one scale per layer, max |w_s| in [2^12, 2^13); activations: one scale per
+//     row, max |x_s| in [2^12, 2^13)), three MFMAs per K-step (lh, hl, hh), the scale taken out of the result.  mode 1: hi pieces rounded
+//     toward zero (v_cvt_pkrtz), lo pieces to nearest.
+__global__ void k_f16_1acc(const float *W, const float *X, const float *bias, float *out, float wscale, int rtz) {
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5, t = blockIdx.x;
+    // per-row (column i of X) scale from the row's maximum
+    float m = 0.f;
+    for (int k = 0; k < K; ++k) m = fmaxf(m, fabsf(X[((size_t)t * K + k) * 32 + i]));
+    const int e = (int)((__float_as_uint(m) >> 23) & 0xff) - 127;
+    const float xs = m > 0.f ? __uint_as_float((uint32_t)(12 - e + 127) << 23) : 1.f;
+    f32x16 a0;
+    for (int r = 0; r < 16; ++r) a0[r] = bias[crow(r, h)] * wscale * xs;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        f16x8 wh, wl, xh, xl;
+        for (int j = 0; j < 8; ++j) {
+            const float w = W[((size_t)t * 32 + i) * K + k0 + 8 * h + j] * wscale, x = X[((size_t)t * K + k0 + 8 * h + j) * 32 + i] * xs;
+            if (rtz) {
+                wh[j] = __builtin_bit_cast(_Float16, (unsigned short)(__builtin_bit_cast(unsigned short, (_Float16)w)));      // weights: host side, nearest
+                xh[j] = __builtin_amdgcn_cvt_pkrtz(x, 0.f)[0];
+            } else { wh[j] = (_Float16)w; xh[j] = (_Float16)x; }
+            wl[j] = (_Float16)(w - (float)wh[j]);
+            xl[j] = (_Float16)(x - (float)xh[j]);
+        }
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, a0, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, a0, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, a0, 0, 0, 0);
+    }
+    const float un = 1.f / (wscale * xs);
+    for (int r = 0; r < 16; ++r) out[((size_t)t * 32 + crow(r, h)) * 32 + i] = a0[r] * un;
+}
+
 int main() {
     std::mt19937 gen(7);
     std::normal_distribution<float> nd(0.f, 1.f);
@@ -143,6 +175,14 @@ int main() {
     report("float32(exact)");
     hipLaunchKernelGGL(k_f32, dim3(TILES), dim3(64), 0, 0, dW, dX, db, dout); report("mfma f32 32x32x2 chain");
     hipLaunchKernelGGL(k_f16, dim3(TILES), dim3(64), 0, 0, dW, dX, db, dout, 0); report("split-f16, 3 mfma / K-step");
+    {
+        float wmax = 0.f;
+        for (float v : W) wmax = std::max(wmax, std::fabs(v));
+        int e; std::frexp(wmax, &e);                               // wmax = f * 2^e, f in [0.5, 1)
+        const float wscale = std::ldexp(1.f, 13 - e);              // max |w_s| in [2^12, 2^13)
+        hipLaunchKernelGGL(k_f16_1acc, dim3(TILES), dim3(64), 0, 0, dW, dX, db, dout, wscale, 0); report("split-f16 scaled, 1 acc, rne");
+        hipLaunchKernelGGL(k_f16_1acc, dim3(TILES), dim3(64), 0, 0, dW, dX, db, dout, wscale, 1); report("split-f16 scaled, 1 acc, rtz hi");
+    }
     hipLaunchKernelGGL(k_bf16, dim3(TILES), dim3(64), 0, 0, dW, dX, db, dout); report("split-bf16, 6 mfma / K-step");
     hipLaunchKernelGGL(k_bf16_2acc, dim3(TILES), dim3(64), 0, 0, dW, dX, db, dout); report("split-bf16, 6 mfma, 2 acc");
     return 0;
