@@ -72,13 +72,29 @@ struct Act2 {
     hu32x4_t v[2][8][2];      // [piece][32-feature block][K-step]
 };
 
-constexpr int HRD = 8;       // ring depth in 1 KiB entries (16 spills: the kernel sits at the 512-register limit)
+// Weight ring: D entries of 1 KiB in flight per wave.  The depth is per PHASE (every depth divides every pass length it meets: 32, 48,
+// 256): the 256 -> 256 stack holds two activation matrices in registers and is bound by the L1's delivery, not by latency - 8; the
+// 3-D front (2-6 entries per 96-384 cycles of MFMA issue, one activation matrix less in registers) is latency-bound with a shallow
+// ring - 16 (158 k -> 126 k cycles per tile); the last layer back, like the stack, moves 683 bytes per MFMA and is bandwidth-bound - 8
+// (32 measured SLOWER: 57 k -> 68 k).  A phase change refills the ring (one L2 latency per change).
+#ifndef DGDM_F16_RING_MID
+#define DGDM_F16_RING_MID 8
+#endif
+#ifndef DGDM_F16_RING_FRONT
+#define DGDM_F16_RING_FRONT 16
+#endif
+#ifndef DGDM_F16_RING_TAIL
+#define DGDM_F16_RING_TAIL 8
+#endif
+template <int D>
 struct HRing {
-    float4 e[HRD];
+    static constexpr int depth = D;
+    float4 e[D];
 };
-__device__ __forceinline__ void hring_fill(wrsrc_t rs, int voff, int base, HRing &r) {
+template <int D>
+__device__ __forceinline__ void hring_fill(wrsrc_t rs, int voff, int base, HRing<D> &r) {
 #pragma unroll
-    for (int i = 0; i < HRD; ++i) r.e[i] = wload(rs, voff, base + i * 1024);
+    for (int i = 0; i < D; ++i) r.e[i] = wload(rs, voff, base + i * 1024);
 }
 
 // the three terms of one K-step for two accumulators (w: [A.h A.l B.h B.l]); small terms first
@@ -110,8 +126,8 @@ __device__ __forceinline__ void hring_fill(wrsrc_t rs, int voff, int base, HRing
 
 // One 256 -> 256 layer, input-streaming (trunk_split.hip stream_layer).  Yp: the previous layer's accumulators = true values x 2^E per
 // row (E: this lane's row); on return Y = this layer's accumulators and E their scale.  ew: the weight matrix' scale exponent.
-template <bool FWD, bool BIAS>
-__device__ __forceinline__ void stream_layer(const wrsrc_t rs, const int voff, const int woff, HRing &ring, const float *__restrict__ bias,
+template <bool FWD, bool BIAS, int HRD>
+__device__ __forceinline__ void stream_layer(const wrsrc_t rs, const int voff, const int woff, HRing<HRD> &ring, const float *__restrict__ bias,
                                              const f32x16 (&Yp)[8], f32x16 (&Y)[8], uint32_t (*smask)[256], const int slot_in, const int tid,
                                              const int h4, int &E, const int ew) {
     // the row's largest input magnitude (forward: the largest positive pre-activation, what ReLU lets through; backward: before the mask)
@@ -184,8 +200,8 @@ __device__ __forceinline__ void stream_layer(const wrsrc_t rs, const int voff, c
 }
 
 // one 32-feature output block from a 256-feature input on two alternating accumulators (16 K-steps x [h l]): z = za + zb
-template <class Side>
-__device__ __forceinline__ f32x16 block_out(const wrsrc_t rs, const int voff, const int woff, HRing &ring, const Act2 &X, f32x16 za, f32x16 zb,
+template <int HRD, class Side>
+__device__ __forceinline__ f32x16 block_out(const wrsrc_t rs, const int voff, const int woff, HRing<HRD> &ring, const Act2 &X, f32x16 za, f32x16 zb,
                                             Side &&side) {
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
@@ -232,6 +248,14 @@ __device__ __forceinline__ int split_rows(const f32x16 (&Y)[8], Act2 &X) {
 
 using namespace f16t;
 
+#ifdef DGDM_F16_STAMPS
+// experiment hook: cycle stamps of one wave at the phase boundaries (printed by trunk_f16_launch)
+__device__ long long g_f16_stamps[32];
+#define HSTAMP(i) do { if (blockIdx.x == gridDim.x / 2 && tid == 0) g_f16_stamps[i] = clock64(); } while (0)
+#else
+#define HSTAMP(i) do { } while (0)
+#endif
+
 template <int KIND>
 __global__ __launch_bounds__(256, 1) void trunk_f16_kernel(const TrunkParams p, const TrunkF16Scales sc) {
     constexpr int W1B = (KIND == 3) ? 16 : 8;
@@ -262,12 +286,13 @@ __global__ __launch_bounds__(256, 1) void trunk_f16_kernel(const TrunkParams p, 
     uint32_t m[4];
     int slot = 0;
     int E = 0;                                                // Y = true values x 2^E for this lane's row
+    HSTAMP(0);
     const wrsrc_t rsF = weight_rsrc(p.Wfwd, p.fwd_bytes);
-    HRing ring;
+    HRing<DGDM_F16_RING_MID> ring;
     int woff = 0;
-    hring_fill(rsF, voff, 0, ring);
 
     if (KIND == 2) {
+        hring_fill(rsF, voff, 0, ring);
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
 #pragma unroll
@@ -280,6 +305,8 @@ __global__ __launch_bounds__(256, 1) void trunk_f16_kernel(const TrunkParams p, 
     } else {
         // ---- 3-D layers 1 and 2, streamed over the 16 blocks of the 512-wide layer 1.  Layer 1 (input: the embedding row, scale known up
         // front): f16; layer 2 (input arrives block by block): six-product bf16 on true values, as trunk_split.hip
+        HRing<DGDM_F16_RING_FRONT> fring;
+        hring_fill(rsF, voff, 0, fring);
         const float *xrow = p.xtab ? p.xtab[chain] + (size_t)p.xidx[(size_t)chain * p.xstride + r] * 256 : p.xobj + ((size_t)chain * p.xstride + r) * 256;
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
@@ -317,7 +344,7 @@ __global__ __launch_bounds__(256, 1) void trunk_f16_kernel(const TrunkParams p, 
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int kb = blk + e;
-                f32x16 z = block_out(rsF, voff, woff, ring, X, zero, zero, [](int) __attribute__((always_inline)) {});
+                f32x16 z = block_out(rsF, voff, woff, fring, X, zero, zero, [](int) __attribute__((always_inline)) {});
                 woff += 32 * 1024;
 #pragma unroll
                 for (int rr = 0; rr < 16; ++rr) z[rr] = fmaf(z[rr], un1, tt[rr]);       // the scaled sum back to true units (exact) + the table terms: one rounding
@@ -343,8 +370,9 @@ __global__ __launch_bounds__(256, 1) void trunk_f16_kernel(const TrunkParams p, 
                         float4 w[6];
 #pragma unroll
                         for (int j = 0; j < 6; ++j) {
-                            w[j] = ring.e[(En + j) % HRD];
-                            ring.e[(En + j) % HRD] = wload(rsF, voff, woff + (En + j + HRD) * 1024);
+                            constexpr int FD = DGDM_F16_RING_FRONT;
+                            w[j] = fring.e[(En + j) % FD];
+                            fring.e[(En + j) % FD] = wload(rsF, voff, woff + (En + j + FD) * 1024);
                         }
                         B16_STEP(Y[2 * pp], Y[2 * pp + 1], w, ah[sx], am[sx], al[sx]);
                         __builtin_amdgcn_sched_barrier(0);
@@ -355,14 +383,17 @@ __global__ __launch_bounds__(256, 1) void trunk_f16_kernel(const TrunkParams p, 
             smask[blk / 2][tid] = bits2;
         }
         slot = 8;
+        hring_fill(rsF, voff, woff, ring);                    // the stack's ring (the front's loads past its own end are dropped with fring)
     }
     constexpr int BASE = (KIND == 3) ? 8 : 0;
     f32x16 Z[8];
+    HSTAMP(1);
     for (int l = 0; l < p.n_mid; ++l) {
         stream_layer<true, true>(rsF, voff, woff, ring, p.bf[l], Y, Z, smask, BASE + 4 * l, tid, h4, E, sc.ew_mid[l]);
         woff += 256 * 1024;
 #pragma unroll
         for (int o = 0; o < 8; ++o) Y[o] = Z[o];
+        HSTAMP(2 + l);
     }
     slot = BASE + 4 * p.n_mid;
     relu_mask<8>(Y, m);
@@ -417,11 +448,13 @@ __global__ __launch_bounds__(256, 1) void trunk_f16_kernel(const TrunkParams p, 
     E = 0;                                                    // the gradient seed is in true units
 
     // ---- backward through the 256 -> 256 layers
+    HSTAMP(10);
     for (int l = p.n_mid - 1; l >= 0; --l) {
         stream_layer<false, false>(rsB, voff, woff, ring, nullptr, Y, Z, smask, BASE + 4 + 4 * l, tid, h4, E, sc.ew_mid[l]);
         woff += 256 * 1024;
 #pragma unroll
         for (int o = 0; o < 8; ++o) Y[o] = Z[o];
+        HSTAMP(11 + (p.n_mid - 1 - l));
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) m[i] = smask[BASE + i][tid];
@@ -448,7 +481,9 @@ __global__ __launch_bounds__(256, 1) void trunk_f16_kernel(const TrunkParams p, 
         f32x16 zero;
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) zero[rr] = 0.f;
-        f32x16 g = block_out(rsB, voff, woff, ring, X, zero, zero, [](int) __attribute__((always_inline)) {});
+        HRing<DGDM_F16_RING_TAIL> tring;
+        hring_fill(rsB, voff, woff, tring);
+        f32x16 g = block_out(rsB, voff, woff, tring, X, zero, zero, [](int) __attribute__((always_inline)) {});
         woff += 32 * 1024;
         float4 acc;
         auto fold_one = [&](const int rr, const int kb, const uint32_t bits) __attribute__((always_inline)) {
@@ -463,7 +498,7 @@ __global__ __launch_bounds__(256, 1) void trunk_f16_kernel(const TrunkParams p, 
         };
         for (int kb = 1; kb < 16; ++kb) {
             const uint32_t bits = smask[(kb - 1) / 2][tid] >> (16 * ((kb - 1) & 1));
-            const f32x16 gn = block_out(rsB, voff, woff, ring, X, zero, zero, [&](const int ks) __attribute__((always_inline)) { fold_one(ks, kb - 1, bits); });
+            const f32x16 gn = block_out(rsB, voff, woff, tring, X, zero, zero, [&](const int ks) __attribute__((always_inline)) { fold_one(ks, kb - 1, bits); });
             woff += 32 * 1024;
             g = gn;
         }
@@ -471,6 +506,7 @@ __global__ __launch_bounds__(256, 1) void trunk_f16_kernel(const TrunkParams p, 
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) fold_one(rr, 15, bits);
     }
+    HSTAMP(20);
 }
 
 int trunk_f16_launch(int kind, const TrunkParams &p, const TrunkF16Scales &sc, hipStream_t s) {
@@ -485,6 +521,17 @@ int trunk_f16_launch(int kind, const TrunkParams &p, const TrunkF16Scales &sc, h
     else hipLaunchKernelGGL((trunk_f16_kernel<3>), dim3(grid), dim3(256), 0, s, p, sc);
     DGDM_HIP_CHECK(hipGetLastError());
     prof_end(s, DGDM_STAGE_TRUNK, rows * per_row);
+#ifdef DGDM_F16_STAMPS
+    {
+        long long st[32];
+        hipStreamSynchronize(s);
+        hipMemcpyFromSymbol(st, HIP_SYMBOL(g_f16_stamps), sizeof(st));
+        fprintf(stderr, "f16 stamps kind %d:", kind);
+        long long prev = st[0];
+        for (int i = 1; i <= 20; ++i) if (st[i]) { fprintf(stderr, " [%d]%lld", i, st[i] - prev); prev = st[i]; }
+        fprintf(stderr, " total %lld\n", st[20] - st[0]);
+    }
+#endif
     return DGDM_OK;
 }
 
