@@ -1,7 +1,7 @@
 // Diffusion.cond_fn / get_convergence_centers (generator/diffusion.py:473-539) for batches of chains,
 // and the PointNet++-backed forward entry points.
 #ifndef DGDM_DEFAULT_F16X3
-#define DGDM_DEFAULT_F16X3 0      // which float32-grade form DGDM_DTYPE_F32 selects: 0 six bf16 products (trunk_split.hip), 1 three f16 products (trunk_f16.hip)
+#define DGDM_DEFAULT_F16X3 1      // which float32-grade form DGDM_DTYPE_F32 selects: 0 six bf16 products (trunk_split.hip), 1 three f16 products (trunk_f16.hip)
 #endif
 #include "common.h"
 #include "models.h"
@@ -703,7 +703,8 @@ static int guidance_grad(DgdmGuidance *g, int kind, const float *x_dev, int time
     } else if (g->f16x3) {
         TrunkF16Scales sc;
         g->m->fill_trunk_f16(&p, &sc);   // only the two weight streams differ (+ their scale exponents)
-        if ((rc = trunk_f16_launch(kind, p, sc, s))) return rc;
+        static const bool ring_form = getenv("DGDM_F16_RING") != nullptr;      // experiment switch: the per-wave ring form (trunk_f16.hip)
+        if ((rc = ring_form ? trunk_f16_launch(kind, p, sc, s) : trunk_f16l_launch(kind, p, sc, s))) return rc;
     } else {
         g->m->fill_trunk_split(&p);      // only the two weight streams differ
         if ((rc = trunk_split_launch(kind, p, s))) return rc;

@@ -60,6 +60,8 @@ struct TrunkF16Scales {
     int ew_l1, ew_l2;         // 3-D: layer 1's object-embedding columns (forward), layer 2 transposed (the last layer back)
 };
 int trunk_f16_launch(int kind, const TrunkParams &p, const TrunkF16Scales &sc, hipStream_t s);
+// the same with the weight stream shared by the workgroup's four waves through LDS (trunk_f16l.hip)
+int trunk_f16l_launch(int kind, const TrunkParams &p, const TrunkF16Scales &sc, hipStream_t s);
 
 // bf16-contraction variant (trunk_bf16.hip): table mode, forward + backward only.  p.Wfwd / p.Wbwd point at the bf16 streams
 // (DgdmDynamics::fill_trunk_bf16); everything else in TrunkParams means the same.

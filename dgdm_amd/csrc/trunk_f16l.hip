@@ -1,0 +1,589 @@
+// trunk_f16.hip with the weight stream SHARED by the workgroup's four waves through LDS: the float32 trunk the library runs by default
+// (DGDM_F16_RING=1 in the environment selects the per-wave ring form of trunk_f16.hip, same results bit for bit).
+//
+// trunk_f16_kernel pulls the whole weight stream - 683 bytes per MFMA - through the CU's L1 once per wave, 85 B/clk/CU asked of a path that
+// delivers ~50 (phase stamps: a 256 -> 256 layer takes 22 k cycles for 12.3 k of MFMA issue).  The four waves of a workgroup consume the
+// SAME stream, so here each wave fetches a QUARTER of every 16 KiB chunk, straight into LDS (buffer_load_dwordx4 ... lds: no staging
+// registers), and all four read their MFMA A operands from there (ds_read_b128, 1 KiB per instruction, linear: conflict-free): a quarter
+// of the L1 traffic.  Pipeline (chunk = 16 entries = one K-step of all four output-block pairs): four LDS slots; while chunk c is
+// consumed, c + 1 and c + 2 are in flight; before the LAST group of chunk c every wave waits for its own quarter of c + 1 (s_waitcnt
+// vmcnt(4): c + 2's four loads may stay in flight), one s_barrier makes the whole chunk visible - and proves every wave done reading
+// chunk c - 1 ... c (a group's operands are read one group ahead) - then c + 3 is issued into the slot of c - 1.  One barrier per 768
+// cycles of MFMA issue.  A wave without a tile runs the last tile again and stores nothing (the barriers need all four).  Arithmetic,
+// scaling, masks, stream layout: trunk_f16.hip.
+//
+// The LDS-DMA loads are issued from inline assembly (LStream::issue says why: hipcc puts s_waitcnt vmcnt(0) in front of every LDS read
+// that follows an LDS-DMA load it knows of).  Measured (MI355X, -DDGDM_F16_STAMPS, 3-D): front 135 k cycles, a 256 -> 256 layer forward
+// 22.5 k / backward 19 k (12.3 k of MFMA issue; the counted wait + barrier of advance() are 30 k of the kernel's 465 k), last layer back +
+// fold 62 k: 7.9 ms per 32-pair launch against the ring form's 8.5, 2-D 10.8 against 11.6.  scripts/micro/mfma_dep.hip: the group of six
+// MFMAs + the splitting + four ds_read_b128 runs at 223 cycles on its own (14.3 k per layer), so what is left is the stream itself (LDS
+// written by the DMA while it is read, barrier skew between the four waves), not the instruction mix.
+#include "common.h"
+#include <algorithm>
+#include "mfma_chain.h"
+#include "trunk.h"
+
+namespace dgdm {
+#ifdef DGDM_F16_STAMPS
+// experiment hook: cycle stamps of one wave at the phase boundaries (printed by trunk_f16l_launch)
+__device__ long long g_f16l_stamps[32];
+#define HSTAMP(i) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) g_f16l_stamps[i] = clock64(); } while (0)
+#else
+#define HSTAMP(i) do { } while (0)
+#endif
+namespace f16l {
+
+typedef _Float16 hf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 hf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 hb16x8_t __attribute__((ext_vector_type(8)));
+typedef float hf32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t hu32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x16 hmfma(const v4f32 a, const hu32x4_t b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8_t, a), __builtin_bit_cast(hf16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 bmfma(const v4f32 a, const hu32x4_t b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hb16x8_t, a), __builtin_bit_cast(hb16x8_t, b), c, 0, 0, 0);
+}
+
+// 2^e as a float (e clamped to the normal range)
+__device__ __forceinline__ float pow2f(int e) { return __uint_as_float((uint32_t)(min(max(e, -126), 127) + 127) << 23); }
+
+// k with m 2^k in [2^12, 2^13) for the row whose two half-wave lanes hold m; 0 for a row of zeros.  lo..hi: the range k may take
+__device__ __forceinline__ int scale_exp(float m, int lo, int hi) {
+    m = fmaxf(m, __shfl_xor(m, 32));
+    const int e = (int)((__float_as_uint(m) >> 23) & 0xffu);
+    const int k = (m > 0.f && e < 255) ? 12 + 127 - e : 0;
+    return min(max(k, lo), hi);
+}
+
+// an already scaled pair -> packed f16 (h | l), h + l == the pair to 2^-23
+__device__ __forceinline__ void split2(float lo, float hi, uint32_t &ph, uint32_t &pl) {
+    const hf32x2_t v = {lo, hi};
+    const hf16x2_t h = __builtin_convertvector(v, hf16x2_t);            // v_cvt_pk_f16_f32 (round to nearest even)
+    const hf32x2_t d = v - __builtin_convertvector(h, hf32x2_t);        // exact
+    ph = __builtin_bit_cast(uint32_t, h);
+    pl = __builtin_bit_cast(uint32_t, __builtin_convertvector(d, hf16x2_t));
+}
+// bf16 three-way split of trunk_split.hip (3-D layer 2)
+__device__ __forceinline__ void split3(float lo, float hi, uint32_t &ph, uint32_t &pm, uint32_t &pl) {
+    ph = pack_bf16(lo, hi);
+    const float r0 = lo - __uint_as_float(ph << 16), r1 = hi - __uint_as_float(ph & 0xffff0000u);
+    pm = pack_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(pm << 16), s1 = r1 - __uint_as_float(pm & 0xffff0000u);
+    pl = pack_bf16(s0, s1);
+}
+
+struct Act2 {
+    hu32x4_t v[2][8][2];      // [piece][32-feature block][K-step]
+};
+
+// The shared weight stream (see the file header).
+constexpr int CH = 16, NBUF = 4;
+typedef __attribute__((address_space(3))) v4f32 lds_f4_t;      // (a plain vector type: HIP's float4 class has no address-space-qualified copy)
+__device__ void llvm_amdgcn_raw_buffer_load_lds(wrsrc_t rsrc, __attribute__((address_space(3))) void *lds, int size, int voffset, int soffset, int offset, int aux)
+    __asm("llvm.amdgcn.raw.buffer.load.lds");
+
+struct LStream {
+    wrsrc_t rs;
+    lds_f4_t *buf;           // [NBUF][CH][64 lanes]
+    int voff, wave, lane;
+    int base;                // byte offset of the stream's chunk 0
+    int cur;                 // chunk whose entries read() addresses (relative to base)
+#ifdef DGDM_F16_STAMPS
+    long long stall_vm = 0, stall_bar = 0;
+#endif
+    // This wave's quarter of chunk c, straight into LDS.  Inline assembly on purpose: behind an LDS-DMA load hipcc can see, it orders EVERY
+    // LDS read after ALL such loads in flight (s_waitcnt vmcnt(0) in front of each ds_read_b128 - it cannot tell the four slots apart),
+    // which serialises the stream with its own prefetch; the first version of this kernel was 20 % slower than the per-wave ring for that.
+    // Unseen by the compiler the loads only make its own vmcnt waits longer than necessary (memory returns in order), never too short;
+    // what makes a slot safe to read is advance()'s counted wait + barrier.
+    __device__ __forceinline__ void issue(int c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = 4 * wave + j;
+            const uint32_t la = (uint32_t)(uintptr_t)(buf + ((c & (NBUF - 1)) * CH + e) * 64);
+            const int so = base + (c * CH + e) * 1024;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(la), "v"(voff), "s"(rs), "s"(so) : "memory", "m0");
+        }
+    }
+    // a new stream: chunks 0 .. 2 on their way, chunk 0 readable on return
+    __device__ __forceinline__ void start(const wrsrc_t rs_, int base_) {
+        __builtin_amdgcn_s_barrier();                      // nobody reads the previous stream's slots any more
+        rs = rs_; base = base_; cur = 0;
+        issue(0); issue(1); issue(2);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    // chunk cur + 1 becomes readable, chunk cur + 3 is requested; cur moves on
+    __device__ __forceinline__ void advance() {
+#ifdef DGDM_F16_STAMPS
+        const long long t0 = clock64();
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        const long long t1 = clock64();
+        __builtin_amdgcn_s_barrier();
+        const long long t2 = clock64();
+        stall_vm += t1 - t0; stall_bar += t2 - t1;
+#else
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#endif
+        issue(cur + 3);
+        ++cur;
+    }
+    // entry e (0 .. 15) of chunk cur
+    __device__ __forceinline__ v4f32 read(const int e) const { return buf[((cur & (NBUF - 1)) * CH + e) * 64 + lane]; }
+};
+
+// the three terms of one K-step for two accumulators (w: [A.h A.l B.h B.l]); small terms first
+#define F16_STEP(accA, accB, w, xh, xl)      \
+    do {                                     \
+        accA = hmfma(w[1], xh, accA);        \
+        accB = hmfma(w[3], xh, accB);        \
+        accA = hmfma(w[0], xl, accA);        \
+        accB = hmfma(w[2], xl, accB);        \
+        accA = hmfma(w[0], xh, accA);        \
+        accB = hmfma(w[2], xh, accB);        \
+    } while (0)
+// six-product bf16 step of trunk_split.hip (w: [A.h A.m A.l B.h B.m B.l])
+#define B16_STEP(accA, accB, w, xh, xm, xl)  \
+    do {                                     \
+        accA = bmfma(w[2], xh, accA);        \
+        accB = bmfma(w[5], xh, accB);        \
+        accA = bmfma(w[0], xl, accA);        \
+        accB = bmfma(w[3], xl, accB);        \
+        accA = bmfma(w[1], xm, accA);        \
+        accB = bmfma(w[4], xm, accB);        \
+        accA = bmfma(w[1], xh, accA);        \
+        accB = bmfma(w[4], xh, accB);        \
+        accA = bmfma(w[0], xm, accA);        \
+        accB = bmfma(w[3], xm, accB);        \
+        accA = bmfma(w[0], xh, accA);        \
+        accB = bmfma(w[3], xh, accB);        \
+    } while (0)
+
+// One 256 -> 256 layer, input-streaming (trunk_split.hip stream_layer).  Yp: the previous layer's accumulators = true values x 2^E per
+// row (E: this lane's row); on return Y = this layer's accumulators and E their scale.  ew: the weight matrix' scale exponent.
+// wn: the operands of the NEXT group to be consumed (read from LDS one group ahead); precondition of every consumer below: wn holds the
+// first group of the pass about to start, postcondition: the first group of the pass that follows in the stream.
+template <bool FWD, bool BIAS>
+__device__ __forceinline__ void stream_layer(LStream &ls, v4f32 (&wn)[4], const float *__restrict__ bias, const f32x16 (&Yp)[8], f32x16 (&Y)[8],
+                                             uint32_t (*smask)[256], const int slot_in, const int tid, const int h4, int &E, const int ew) {
+    float mx = 0.f;
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = FWD ? fmaxf(mx, Yp[o][r]) : fmaxf(mx, fabsf(Yp[o][r]));
+    const int k = scale_exp(mx, -100 - E - ew, 100 - E - ew);
+    const float f = pow2f(k);
+    E += k + ew;
+    const float fb = pow2f(E);
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        if (BIAS) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 a = feat4(bias, o, q, h4);
+                Y[o][4 * q + 0] = a.x * fb; Y[o][4 * q + 1] = a.y * fb; Y[o][4 * q + 2] = a.z * fb; Y[o][4 * q + 3] = a.w * fb;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Y[o][r] = 0.f;
+        }
+    }
+    hu32x4_t P[2][2][2];                           // [block parity][piece][K-step]
+    HSTAMP(FWD ? 23 : 26);
+    uint32_t mk = FWD ? 0u : smask[slot_in][tid];
+    auto item = [&](const f32x16 &y, const int blk, const int d) __attribute__((always_inline)) {
+        float lo = y[2 * d], hi = y[2 * d + 1];
+        const int sh = 2 * d + 16 * (blk & 1);
+        if (FWD) {
+            mk |= (lo > 0.f ? 1u : 0u) << sh;
+            mk |= (hi > 0.f ? 1u : 0u) << (sh + 1);
+            asm("v_max_f32 %0, 0, %1" : "=v"(lo) : "v"(lo));
+            asm("v_max_f32 %0, 0, %1" : "=v"(hi) : "v"(hi));
+        } else {
+            lo = ((mk >> sh) & 1u) ? lo : 0.f;
+            hi = ((mk >> (sh + 1)) & 1u) ? hi : 0.f;
+        }
+        uint32_t a, b;
+        split2(lo * f, hi * f, a, b);
+        P[blk & 1][0][d / 4][d % 4] = a; P[blk & 1][1][d / 4][d % 4] = b;
+    };
+#pragma unroll
+    for (int d = 0; d < 8; ++d) item(Yp[0], 0, d);
+    HSTAMP(FWD ? 24 : 27);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {           // one chunk: the K-step's four output-block pairs
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                v4f32 w[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = wn[j];
+                if (pp == 3) ls.advance();         // the next chunk (the next layer's first, after the last one)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wn[j] = ls.read(((pp + 1) & 3) * 4 + j);
+                if (b < 7) {
+                    const int q = sx * 4 + pp, nb = b + 1;
+                    if (q == 0 && (nb & 1) == 0) mk = FWD ? 0u : smask[slot_in + nb / 2][tid];
+                    item(Yp[nb], nb, q);
+                    if (FWD && q == 7 && (nb & 1) == 1) smask[slot_in + nb / 2][tid] = mk;
+                }
+                F16_STEP(Y[2 * pp], Y[2 * pp + 1], w, P[b & 1][0][sx], P[b & 1][1][sx]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    HSTAMP(FWD ? 25 : 28);
+}
+
+// one 32-feature output block from a 256-feature input on two alternating accumulators (16 K-steps x [h l]): z = za + zb
+// (32 entries = two chunks; wn[0..1] = the K-step's [h l], one K-step ahead)
+template <class Side>
+__device__ __forceinline__ f32x16 block_out(LStream &ls, v4f32 (&wn)[4], const Act2 &X, f32x16 za, f32x16 zb, Side &&side) {
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        const v4f32 w0 = wn[0], w1 = wn[1];
+        if ((ks & 7) == 7) ls.advance();
+        wn[0] = ls.read(((ks + 1) & 7) * 2); wn[1] = ls.read(((ks + 1) & 7) * 2 + 1);
+        const hu32x4_t xh = X.v[0][ks / 2][ks % 2], xl = X.v[1][ks / 2][ks % 2];
+        side(ks);
+        za = hmfma(w1, xh, za);
+        zb = hmfma(w0, xl, zb);
+        za = hmfma(w0, xh, za);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) za[r] += zb[r];
+    return za;
+}
+
+// true values x 2^k of a whole activation matrix -> the two f16 pieces; returns k (row scale)
+__device__ __forceinline__ int split_rows(const f32x16 (&Y)[8], Act2 &X) {
+    float mx = 0.f;
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(Y[o][r]));
+    const int k = scale_exp(mx, -100, 100);
+    const float f = pow2f(k);
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            uint32_t a, b;
+            split2(Y[o][2 * d] * f, Y[o][2 * d + 1] * f, a, b);
+            X.v[0][o][d / 4][d % 4] = a; X.v[1][o][d / 4][d % 4] = b;
+        }
+    return k;
+}
+
+}  // namespace f16l
+
+using namespace f16l;
+
+
+template <int KIND>
+__global__ __launch_bounds__(256, 1) void trunk_f16l_kernel(const TrunkParams p, const TrunkF16Scales sc) {
+    constexpr int W1B = (KIND == 3) ? 16 : 8;
+    constexpr int W1 = W1B * 32;
+    constexpr int NSLOT = (KIND == 3) ? 8 + 7 * 4 : 8 * 4;
+    __shared__ uint32_t smask[NSLOT][256];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __shared__ __attribute__((aligned(16))) v4f32 wbuf[NBUF * CH * 64];      // the shared weight stream: 4 slots of 16 KiB
+    const bool live = blockIdx.x * 4 + wave < p.ntiles;      // a wave without a tile runs the last tile again (the barriers need all four waves)
+    const int tile = min(blockIdx.x * 4 + wave, p.ntiles - 1);
+    const int n = lane & 31;
+    const int h4 = (lane >> 5) * 4;
+    const int voff = lane * 16;
+
+    const int per_chain = p.B * p.tiles_per_b;
+    const int chain = tile / per_chain;
+    const int rem = tile - chain * per_chain;
+    const int b = rem / p.tiles_per_b;
+    const int c = (rem - b * p.tiles_per_b) * 32 + n;
+    const bool valid = c < p.C;
+    const int64_t r = (int64_t)(valid ? c : p.C - 1) * p.B + b;
+    const float *arow = p.Atab + (size_t)(chain * p.B + b) * W1;
+    const float4 *ptile = reinterpret_cast<const float4 *>(p.PtabT) + (size_t)(rem - b * p.tiles_per_b) * W1B * 4 * 64 + lane;
+
+    f32x16 Y[8];
+    uint32_t m[4];
+    int slot = 0;
+    int E = 0;                                                // Y = true values x 2^E for this lane's row
+    HSTAMP(0);
+    const wrsrc_t rsF = weight_rsrc(p.Wfwd, p.fwd_bytes);
+    LStream ls;
+    ls.buf = (lds_f4_t *)wbuf; ls.voff = voff; ls.wave = wave; ls.lane = lane;
+    v4f32 wn[4];
+    ls.start(rsF, 0);
+
+    if (KIND == 2) {
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 v = feat4(arow, o, q, h4);
+                const float4 w = ptile[(o * 4 + q) * 64];
+                Y[o][4 * q + 0] = v.x + w.x; Y[o][4 * q + 1] = v.y + w.y; Y[o][4 * q + 2] = v.z + w.z; Y[o][4 * q + 3] = v.w + w.w;
+            }
+        }
+    } else {
+        // ---- 3-D layers 1 and 2, streamed over the 16 blocks of the 512-wide layer 1.  Layer 1 (input: the embedding row, scale known up
+        // front): f16; layer 2 (input arrives block by block): six-product bf16 on true values, as trunk_split.hip
+        wn[0] = ls.read(0); wn[1] = ls.read(1);
+        const float *xrow = p.xtab ? p.xtab[chain] + (size_t)p.xidx[(size_t)chain * p.xstride + r] * 256 : p.xobj + ((size_t)chain * p.xstride + r) * 256;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = feat4(xrow, o, q, h4);
+                Y[o][4 * q + 0] = v.x; Y[o][4 * q + 1] = v.y; Y[o][4 * q + 2] = v.z; Y[o][4 * q + 3] = v.w;
+            }
+        }
+        Act2 X;
+        const int kx = split_rows(Y, X);
+        const float un1 = pow2f(-(kx + sc.ew_l1));            // layer-1 accumulators -> true values
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 b4 = feat4(p.b2, o, q, h4);
+                Y[o][4 * q + 0] = b4.x; Y[o][4 * q + 1] = b4.y; Y[o][4 * q + 2] = b4.z; Y[o][4 * q + 3] = b4.w;
+            }
+        }
+        f32x16 zero, tt;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) zero[rr] = 0.f;
+        // the block's table terms: requested a whole block ahead, added up where they are used - the wait for these loads is a wait for every
+        // load issued before them (vmcnt counts in order), stream chunks included, so it must not come right behind the request
+        float4 tv[4], tw[4];
+        auto table_terms_request = [&](int kb) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                tv[q] = *reinterpret_cast<const float4 *>(arow + 32 * kb + 8 * q + h4);
+                tw[q] = ptile[(kb * 4 + q) * 64];
+            }
+        };
+        auto table_terms = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                tt[4 * q + 0] = tv[q].x + tw[q].x; tt[4 * q + 1] = tv[q].y + tw[q].y; tt[4 * q + 2] = tv[q].z + tw[q].z; tt[4 * q + 3] = tv[q].w + tw[q].w;
+            }
+        };
+        table_terms_request(0);
+        for (int blk = 0; blk < 16; blk += 2) {
+            uint32_t bits2 = 0;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int kb = blk + e;
+                f32x16 z = block_out(ls, wn, X, zero, zero, [](int) __attribute__((always_inline)) {});      // leaves wn[0..1] = entries 0, 1 of layer 2's pass
+                table_terms();
+                table_terms_request((kb + 1) & 15);
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) z[rr] = fmaf(z[rr], un1, tt[rr]);       // the scaled sum back to true units (exact) + the table terms: one rounding
+                hu32x4_t ah[2], am[2], al[2];
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    float lo = z[2 * d], hi = z[2 * d + 1];
+                    const int sh = 2 * d + 16 * e;
+                    bits2 |= (lo > 0.f ? 1u : 0u) << sh;
+                    bits2 |= (hi > 0.f ? 1u : 0u) << (sh + 1);
+                    asm("v_max_f32 %0, 0, %1" : "=v"(lo) : "v"(lo));
+                    asm("v_max_f32 %0, 0, %1" : "=v"(hi) : "v"(hi));
+                    uint32_t a, bb, cc;
+                    split3(lo, hi, a, bb, cc);
+                    ah[d / 4][d % 4] = a; am[d / 4][d % 4] = bb; al[d / 4][d % 4] = cc;
+                }
+                // layer 2 (six-product bf16): 48 entries = three chunks, eight groups of six; the group's operands are read one group ahead,
+                // crossing into the next chunk where the group does (entry e of the pass lives in chunk e / 16)
+                {
+                    v4f32 w6[6];
+                    w6[0] = wn[0]; w6[1] = wn[1];
+#pragma unroll
+                    for (int j = 2; j < 6; ++j) w6[j] = ls.read(j);
+                    int ready = 0;                                       // chunks of this pass already made readable beyond the first
+#pragma unroll
+                    for (int gq = 0; gq < 8; ++gq) {
+                        const int pp = gq / 2, sx = gq % 2;
+                        v4f32 w[6];
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) w[j] = w6[j];
+                        // next group's entries (the following pass' first K-step after the last group: [h l] of layer 1's next block)
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) {
+                            const int e = 6 * (gq + 1) + j;              // entry of this pass; 48, 49 = entries 0, 1 of the next pass
+                            if (gq == 7 && j >= 2) break;
+                            if (e / 16 > ready) { ls.advance(); ++ready; }
+                            w6[j] = ls.read(e % 16);
+                        }
+                        B16_STEP(Y[2 * pp], Y[2 * pp + 1], w, ah[sx], am[sx], al[sx]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    wn[0] = w6[0]; wn[1] = w6[1];
+                }
+            }
+            smask[blk / 2][tid] = bits2;
+        }
+        slot = 8;
+        wn[2] = ls.read(2); wn[3] = ls.read(3);               // wn[0..1] are entries 0, 1 of the stack's first chunk already
+    }
+    if (KIND == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wn[j] = ls.read(j);
+    }
+    constexpr int BASE = (KIND == 3) ? 8 : 0;
+    f32x16 Z[8];
+    HSTAMP(1);
+    for (int l = 0; l < p.n_mid; ++l) {
+        stream_layer<true, true>(ls, wn, p.bf[l], Y, Z, smask, BASE + 4 * l, tid, h4, E, sc.ew_mid[l]);
+#pragma unroll
+        for (int o = 0; o < 8; ++o) Y[o] = Z[o];
+        HSTAMP(2 + l);
+    }
+    slot = BASE + 4 * p.n_mid;
+    relu_mask<8>(Y, m);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) smask[slot + i][tid] = m[i];
+    slot += 4;
+
+    // ---- output layer (256 -> 3) on the VALU on the scaled activations, 2^-E taken out of the three sums
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 w0 = feat4(p.Wout, o, q, h4);
+            const float4 w1 = feat4(p.Wout + 256, o, q, h4);
+            const float4 w2 = feat4(p.Wout + 512, o, q, h4);
+            const float x0 = Y[o][4 * q + 0], x1 = Y[o][4 * q + 1], x2 = Y[o][4 * q + 2], x3 = Y[o][4 * q + 3];
+            s0 = fmaf(w0.w, x3, fmaf(w0.z, x2, fmaf(w0.y, x1, fmaf(w0.x, x0, s0))));
+            s1 = fmaf(w1.w, x3, fmaf(w1.z, x2, fmaf(w1.y, x1, fmaf(w1.x, x0, s1))));
+            s2 = fmaf(w2.w, x3, fmaf(w2.z, x2, fmaf(w2.y, x1, fmaf(w2.x, x0, s2))));
+        }
+    }
+    s0 += __shfl_xor(s0, 32);
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 32);
+    const float unE = pow2f(-E);
+    const float d0 = fmaf(s0, unE, p.bout[0]), d1 = fmaf(s1, unE, p.bout[1]), d2 = fmaf(s2, unE, p.bout[2]);
+
+    const wrsrc_t rsB = weight_rsrc(p.Wbwd, p.bwd_bytes);
+    ls.start(rsB, 0);                                         // in flight while the objective runs on the VALU
+    const TrunkObjective ob = p.obj[chain];
+    float g0 = ob.lin[0] + 2.f * ob.quad[0] * d0;
+    float g1 = ob.lin[1] + 2.f * ob.quad[1] * d1;
+    float g2 = ob.lin[2] + 2.f * ob.quad[2] * d2;
+    if (ob.use_rowcoef) g0 = p.rowcoef[(size_t)chain * p.R + r];
+    if (!valid) { g0 = 0.f; g1 = 0.f; g2 = 0.f; }
+
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 w0 = feat4(p.Wout, o, q, h4);
+            const float4 w1 = feat4(p.Wout + 256, o, q, h4);
+            const float4 w2 = feat4(p.Wout + 512, o, q, h4);
+            Y[o][4 * q + 0] = fmaf(g2, w2.x, fmaf(g1, w1.x, g0 * w0.x));
+            Y[o][4 * q + 1] = fmaf(g2, w2.y, fmaf(g1, w1.y, g0 * w0.y));
+            Y[o][4 * q + 2] = fmaf(g2, w2.z, fmaf(g1, w1.z, g0 * w0.z));
+            Y[o][4 * q + 3] = fmaf(g2, w2.w, fmaf(g1, w1.w, g0 * w0.w));
+        }
+    }
+    E = 0;                                                    // the gradient seed is in true units
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wn[j] = ls.read(j);
+
+    // ---- backward through the 256 -> 256 layers
+    HSTAMP(10);
+    for (int l = p.n_mid - 1; l >= 0; --l) {
+        stream_layer<false, false>(ls, wn, nullptr, Y, Z, smask, BASE + 4 + 4 * l, tid, h4, E, sc.ew_mid[l]);
+#pragma unroll
+        for (int o = 0; o < 8; ++o) Y[o] = Z[o];
+        HSTAMP(11 + (p.n_mid - 1 - l));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m[i] = smask[BASE + i][tid];
+    apply_mask<8>(Y, m);
+
+    float *dst = p.partial + (size_t)tile * W1;
+    if (KIND == 2) {
+        const float un = pow2f(-E);                           // per row: back to true units before the 32 rows are folded
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 v;
+                v.x = rows_sum(Y[o][4 * q + 0] * un); v.y = rows_sum(Y[o][4 * q + 1] * un);
+                v.z = rows_sum(Y[o][4 * q + 2] * un); v.w = rows_sum(Y[o][4 * q + 3] * un);
+                if (n == ROWS_SUM_LANE && live) *reinterpret_cast<float4 *>(dst + 32 * o + 8 * q + h4) = v;
+            }
+        }
+    } else {
+        // 3-D: one more layer back (256 -> 512), block by block, straight into the fold (trunk_split.hip)
+        Act2 X;
+        const int kt = split_rows(Y, X);
+        const float un = pow2f(-(E + kt + sc.ew_l2));
+        f32x16 zero;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) zero[rr] = 0.f;
+        f32x16 g = block_out(ls, wn, X, zero, zero, [](int) __attribute__((always_inline)) {});
+        float4 acc;
+        auto fold_one = [&](const int rr, const int kb, const uint32_t bits) __attribute__((always_inline)) {
+            const float v = rows_sum(apply_bit(g[rr] * un, bits, rr));
+            if (rr % 4 == 0) acc.x = v;
+            else if (rr % 4 == 1) acc.y = v;
+            else if (rr % 4 == 2) acc.z = v;
+            else {
+                acc.w = v;
+                if (n == ROWS_SUM_LANE && live) *reinterpret_cast<float4 *>(dst + 32 * kb + 8 * (rr / 4) + h4) = acc;
+            }
+        };
+        for (int kb = 1; kb < 16; ++kb) {
+            const uint32_t bits = smask[(kb - 1) / 2][tid] >> (16 * ((kb - 1) & 1));
+            const f32x16 gn = block_out(ls, wn, X, zero, zero, [&](const int ks) __attribute__((always_inline)) { fold_one(ks, kb - 1, bits); });
+            g = gn;
+        }
+        const uint32_t bits = smask[7][tid] >> 16;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) fold_one(rr, 15, bits);
+    }
+    HSTAMP(20);
+#ifdef DGDM_F16_STAMPS
+    if (blockIdx.x == gridDim.x / 2 && tid == 0) { g_f16l_stamps[21] = ls.stall_vm; g_f16l_stamps[22] = ls.stall_bar; }
+#endif
+}
+
+int trunk_f16l_launch(int kind, const TrunkParams &p, const TrunkF16Scales &sc, hipStream_t s) {
+    if (p.n_mid != (kind == 3 ? 6 : 7)) return DGDM_EINVAL;
+    const int grid = (p.ntiles + 3) / 4;
+    if (grid == 0) return DGDM_OK;
+    const double rows = (double)(p.ntiles / std::max(1, p.tiles_per_b)) * p.C;
+    const double mid = 2.0 * 256 * 256 * p.n_mid;
+    const double per_row = (kind == 3) ? (2.0 * 256 * 512 * 2 + mid) + (2.0 * 256 * 512 + mid) : 2.0 * mid;
+    prof_begin(s, DGDM_STAGE_TRUNK);
+    if (kind == 2) hipLaunchKernelGGL((trunk_f16l_kernel<2>), dim3(grid), dim3(256), 0, s, p, sc);
+    else hipLaunchKernelGGL((trunk_f16l_kernel<3>), dim3(grid), dim3(256), 0, s, p, sc);
+    DGDM_HIP_CHECK(hipGetLastError());
+    prof_end(s, DGDM_STAGE_TRUNK, rows * per_row);
+#ifdef DGDM_F16_STAMPS
+    {
+        long long st[32];
+        hipStreamSynchronize(s);
+        hipMemcpyFromSymbol(st, HIP_SYMBOL(g_f16l_stamps), sizeof(st));
+        fprintf(stderr, "f16l stamps kind %d:", kind);
+        long long prev = st[0];
+        for (int i = 1; i <= 20; ++i) if (st[i]) { fprintf(stderr, " [%d]%lld", i, st[i] - prev); prev = st[i]; }
+        fprintf(stderr, " total %lld; advance(): counted wait %lld, barrier %lld; last fwd layer: prologue %lld first items %lld loop %lld; bwd: %lld %lld %lld\n", st[20] - st[0], st[21], st[22],
+                st[23] - st[1 + p.n_mid - 1], st[24] - st[23], st[25] - st[24], st[26] - st[10 + p.n_mid - 1], st[27] - st[26], st[28] - st[27]);
+    }
+#endif
+    return DGDM_OK;
+}
+
+}  // namespace dgdm
