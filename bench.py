@@ -54,9 +54,10 @@ def parse():
     p.add_argument("--pairs", type=int, default=0, help="(object x objective) pairs per GPU per step (default 32 for 3d, 4 for 2d; "
                                                         "3d_ensemble: chains per GPU per step, default 8, each averaging 4 objects' gradients)")
     p.add_argument("--contraction", choices=["f32", "f32_mfma", "bf16", "f32_f16x3", "f32_bf16x6"], default="f32",
-                   help="arithmetic of the dynamics-trunk contractions: f32 (the parity path, default: float32 operands split exactly into three bf16 "
-                        "pieces, six bf16 MFMAs per product, float32 accumulation), f32_mfma (the k-ordered float32 MFMA chain) or bf16 (operands "
-                        "ROUNDED to bf16, float32 accumulation)")
+                   help="arithmetic of the dynamics-trunk contractions: f32 (the parity path, the library default = f32_f16x3: float32 operands "
+                        "scaled by exact powers of two and split into two f16 pieces, three f16 MFMAs per product, float32 accumulation), "
+                        "f32_bf16x6 (exact three-way bf16 split, six bf16 MFMAs per product), f32_mfma (the k-ordered float32 MFMA chain) or "
+                        "bf16 (operands ROUNDED to bf16, float32 accumulation)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true", help="skip the secondary workload summary")
     p.add_argument("--train-only", action="store_true", help="print only the Trainer.step leg of the secondary summary (1 GPU)")
@@ -216,8 +217,8 @@ def timed_loop(wl, steps, warmup, dist):
 
 # ---------------------------------------------------------------------------------------------------------------- roofline
 # what the JSON's `dtype` / roofline.arithmetic say about each contraction mode of the trunk
-DEFAULT_F32_FORM = "f32_bf16x6"          # what the library's DGDM_DTYPE_F32 selects (csrc/guidance_api.hip DGDM_DEFAULT_F16X3)
-DTYPE_LABEL = {"f32": "f32_split_bf16x6", "f32_bf16x6": "f32_split_bf16x6", "f32_f16x3": "f32_split_f16x3", "f32_mfma": "f32", "bf16": "bf16"}
+DEFAULT_F32_FORM = "f32_f16x3"           # what the library's DGDM_DTYPE_F32 selects (csrc/guidance_api.hip DGDM_DEFAULT_F16X3)
+DTYPE_LABEL = {"f32": "f32_split_f16x3", "f32_bf16x6": "f32_split_bf16x6", "f32_f16x3": "f32_split_f16x3", "f32_mfma": "f32", "bf16": "bf16"}
 ARITHMETIC = {"f32_bf16x6": "float32-grade: every float32 product as six bf16 MFMA products on exactly three-way-split operands (products exact, float32 "
                      "accumulation; 1.6e-7 rms of a 256-term contraction vs float64, the v_mfma_f32 chain: 2.0e-7)",
               "f32_f16x3": "float32-grade: every float32 product as three f16 MFMA products on two-way-split operands after exact power-of-two scaling "
@@ -269,7 +270,7 @@ def stage_profile(wl, secs_per_step, contraction):
     # with the ISSUED FLOPs (6 x algorithmic); the algorithmic float32 rate and what that is against the float32-MFMA peak (which the
     # old k-ordered chain was bound by) are reported beside it.  'f32_mfma': that chain.  'bf16': operands rounded to bf16.
     form = DEFAULT_F32_FORM if contraction == "f32" else contraction
-    kname = {"bf16": "trunk_bf16_kernel", "f32_mfma": "trunk_kernel", "f32_f16x3": "trunk_f16_kernel"}.get(form, "trunk_split_kernel")
+    kname = {"bf16": "trunk_bf16_kernel", "f32_mfma": "trunk_kernel", "f32_f16x3": "trunk_f16l_kernel"}.get(form, "trunk_split_kernel")
     issued = {"f32_bf16x6": SPLIT_TERMS, "f32_f16x3": 3}.get(form, 1)
     peak = F32_MFMA_PEAK_TFLOPS if contraction == "f32_mfma" else BF16_MFMA_PEAK_TFLOPS
     alg = flops / (ms * 1e-3) / 1e12
@@ -721,7 +722,7 @@ def main():
         if not a.no_cpu_baseline:
             cpu_jobs += [lambda: c0.update(config0(dev, cpu=True)), lambda: tl.update(cpu_baseline=train_leg_cpu()),
                          lambda: ul.update(cpu_baseline=unet_train_leg_cpu()), lambda: t3.update(cpu_baseline=train3d_leg_cpu())]
-        for kind, contraction in ((other, "f32"), ("3d", "f32_mfma"), ("3d", "bf16"), ("2d", "bf16"), ("3d_ensemble", "bf16")):
+        for kind, contraction in ((other, "f32"), ("3d", "f32_bf16x6"), ("3d", "f32_mfma"), ("3d", "bf16"), ("2d", "bf16"), ("3d_ensemble", "bf16")):
             w2 = Workload(kind, DEFAULT_PAIRS[kind], dev, rank, world, contraction)
             ns = 4
             s2, _, d2 = timed_loop(w2, ns, 1, None)

@@ -126,10 +126,10 @@ class Trainer(object):
         count) from a private generator that starts at the global generator's state; the next call adopts them - and moves the
         global generator to where those draws leave it - if the global state is still the one the worker started from (nobody else
         drew in between, e.g. a DataLoader reshuffle) and the row count matches; otherwise they are thrown away and drawn here."""
-        ahead, self._ahead = getattr(self, "_ahead", None), None
+        pending, self._ahead = getattr(self, "_ahead", None), None
         out = None
-        if ahead is not None:
-            th, box = ahead
+        if pending is not None:
+            th, box = pending
             th.join()
             if box.get("rows") == rows and "state_after" in box and torch.equal(torch.get_rng_state(), box["state_before"]):
                 torch.set_rng_state(box["state_after"])

@@ -44,7 +44,8 @@ def _mlp_layer(sd: SD, p: str, i: int, rows: torch.Tensor) -> torch.Tensor:
 class ObjectTables64:
     """The per-object tables above.  `sd64`: the dynamics state_dict in float64; `xyz`: the object's (512, 3) points (float32 values)."""
 
-    def __init__(self, sd64: SD, xyz: torch.Tensor, prefix: str = "object_encoder."):
+    def __init__(self, sd64: SD, xyz: torch.Tensor, prefix: str = "object_encoder.", s1_only: Optional[Sequence[int]] = None):
+        """`s1_only`: build the per-s1 part (crowded centres) for these sa1 start draws only (tests; embed() then takes no other s1)."""
         xyz32 = xyz.float().contiguous()
         x64 = xyz32.double()
         N = xyz32.shape[0]
@@ -79,10 +80,10 @@ class ObjectTables64:
         self.cr_slot = torch.full((N,), -1, dtype=torch.long)
         self.cr_slot[self.cr_ids] = torch.arange(self.cr_ids.numel())
         ncr = self.cr_ids.numel()
-        self.Zc = torch.empty(N, ncr, self.Z0.shape[1], dtype=torch.float64)                                       # [s1][slot][256]
+        self.Zc = torch.full((N, ncr, self.Z0.shape[1]), float("nan"), dtype=torch.float64)                        # [s1][slot][256]
         if ncr:
             Ycr, Mcr = Y[self.cr_ids], self.M2[self.cr_ids]                                                         # [ncr][k][256], [ncr][k]
-            for s1 in range(N):
+            for s1 in (range(N) if s1_only is None else s1_only):
                 order = self.fps1[s1]
                 mo = Mcr[:, order]
                 sel_pos = mo & (mo.cumsum(1) <= 64)                                                                 # [ncr][pos]

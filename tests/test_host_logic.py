@@ -234,3 +234,42 @@ def test_finger_dataset_is_the_reference_recipe():
     item = GripperDataset(pts, 0.12, -0.12, 0.0, -0.1)[2]
     assert item.shape == (42, 1) and item.dtype == np.float32 and np.abs(item).max() <= 1.0
     assert np.allclose(item[:21, 0], (yl.astype(np.float32) + 0.1) / 0.1 * 2 - 1)
+
+
+def test_trainer_draws_ahead_and_adopts_them():
+    """Trainer._draw (dynamics/trainer.py:68-74 of the reference: torch.randn for the noise, then torch.randint for the timesteps, on the
+    global CPU generator): after every call a worker draws the next call's numbers; the next call must ADOPT them (not draw again) when
+    nobody touched the generator in between, throw them away when somebody did or the row count changed, and either way hand back exactly
+    what the reference's two calls give."""
+    import argparse
+    from dgdm_amd.dynamics.trainer import Trainer
+    t = Trainer(argparse.Namespace(use_sub_batch=False, sub_bs=1024, grid_size=360, learning_rate=1e-4, weight_decay=0.0, num_epochs=100,
+                                   checkpoint_path=None, fingers_3d=False, ctrlpts_dim=14, object_max_num_vertices=100,
+                                   num_timesteps_per_batch=1, num_inference_steps=5, num_train_timesteps=15))
+    rows = 1000
+
+    def ref(n):
+        return torch.randn((n, 14)), torch.randint(0, 15, (n,)).long()
+
+    torch.manual_seed(5)
+    want = [ref(rows), ref(rows), torch.rand(3), ref(rows), ref(70), ref(70)]
+    torch.manual_seed(5)
+    def draw(n, adopted):
+        pending = t._ahead[1] if t._ahead is not None else None
+        noise, ts = t._draw(n)
+        assert (pending is not None and noise.data_ptr() == pending["noise"].data_ptr()) == adopted       # the very buffer the worker filled
+        return noise.clone(), ts      # (the worker's two pinned buffers alternate: the caller uploads a draw before the one after next is made)
+
+    got = [draw(rows, False)]
+    assert t._ahead is not None                                   # the worker is on its way
+    got.append(draw(rows, True))
+    got.append(torch.rand(3))                                     # somebody else draws: the pending numbers are stale
+    got.append(draw(rows, False))
+    got.append(draw(70, False))                                   # another row count: stale as well
+    got.append(draw(70, True))
+    t._join_ahead()
+    for w, g in zip(want, got):
+        if isinstance(w, tuple):
+            assert torch.equal(w[0], g[0]) and torch.equal(w[1], g[1])
+        else:
+            assert torch.equal(w, g)
