@@ -26,7 +26,7 @@
 namespace dgdm {
 #ifdef DGDM_F16_STAMPS
 // experiment hook: cycle stamps of one wave at the phase boundaries (printed by trunk_f16l_launch)
-__device__ long long g_f16l_stamps[32];
+__device__ long long g_f16l_stamps[40];
 #define HSTAMP(i) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) g_f16l_stamps[i] = clock64(); } while (0)
 #else
 #define HSTAMP(i) do { } while (0)
@@ -240,14 +240,17 @@ __device__ __forceinline__ void stream_layer(LStream &ls, v4f32 (&wn)[4], const 
 }
 
 // one 32-feature output block from a 256-feature input on two alternating accumulators (16 K-steps x [h l]): z = za + zb
-// (32 entries = two chunks; wn[0..1] = the K-step's [h l], one K-step ahead)
+// (32 entries = two chunks).  Three MFMAs per K-step are 96 cycles - less than an LDS round trip under load - so the operands are read TWO
+// K-steps ahead: on entry wn[0..1] / wn[2..3] hold K-steps 0 / 1 of this pass (= its entries 0 .. 3, the same precondition as a stack
+// layer's), on return entries 0 .. 3 of the pass that follows.
 template <class Side>
 __device__ __forceinline__ f32x16 block_out(LStream &ls, v4f32 (&wn)[4], const Act2 &X, f32x16 za, f32x16 zb, Side &&side) {
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
-        const v4f32 w0 = wn[0], w1 = wn[1];
-        if ((ks & 7) == 7) ls.advance();
-        wn[0] = ls.read(((ks + 1) & 7) * 2); wn[1] = ls.read(((ks + 1) & 7) * 2 + 1);
+        const int s = (ks & 1) * 2;
+        const v4f32 w0 = wn[s], w1 = wn[s + 1];
+        if ((ks & 7) == 6) ls.advance();
+        wn[s] = ls.read(((ks + 2) & 7) * 2); wn[s + 1] = ls.read(((ks + 2) & 7) * 2 + 1);
         const hu32x4_t xh = X.v[0][ks / 2][ks % 2], xl = X.v[1][ks / 2][ks % 2];
         side(ks);
         za = hmfma(w1, xh, za);
@@ -321,8 +324,8 @@ __global__ __launch_bounds__(256, 1) void trunk_f16l_kernel(const TrunkParams p,
     LStream ls;
     ls.buf = (lds_f4_t *)wbuf; ls.voff = voff; ls.wave = wave; ls.lane = lane;
     v4f32 wn[4];
-    ls.start(rsF, 0);
-
+    // the tile's own input first (2-D: the two table terms; 3-D: the embedding row - HBM, the kernel's only traffic of size R): its latency
+    // runs beside the stream's first chunks
     if (KIND == 2) {
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
@@ -334,9 +337,6 @@ __global__ __launch_bounds__(256, 1) void trunk_f16l_kernel(const TrunkParams p,
             }
         }
     } else {
-        // ---- 3-D layers 1 and 2, streamed over the 16 blocks of the 512-wide layer 1.  Layer 1 (input: the embedding row, scale known up
-        // front): f16; layer 2 (input arrives block by block): six-product bf16 on true values, as trunk_split.hip
-        wn[0] = ls.read(0); wn[1] = ls.read(1);
         const float *xrow = p.xtab ? p.xtab[chain] + (size_t)p.xidx[(size_t)chain * p.xstride + r] * 256 : p.xobj + ((size_t)chain * p.xstride + r) * 256;
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
@@ -346,8 +346,18 @@ __global__ __launch_bounds__(256, 1) void trunk_f16l_kernel(const TrunkParams p,
                 Y[o][4 * q + 0] = v.x; Y[o][4 * q + 1] = v.y; Y[o][4 * q + 2] = v.z; Y[o][4 * q + 3] = v.w;
             }
         }
+    }
+    ls.start(rsF, 0);
+
+    if (KIND == 3) {
+        // ---- 3-D layers 1 and 2, streamed over the 16 blocks of the 512-wide layer 1.  Layer 1 (input: the embedding row, scale known up
+        // front): f16; layer 2 (input arrives block by block): six-product bf16 on true values, as trunk_split.hip
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wn[j] = ls.read(j);
+        HSTAMP(36);
         Act2 X;
         const int kx = split_rows(Y, X);
+        HSTAMP(37);
         const float un1 = pow2f(-(kx + sc.ew_l1));            // layer-1 accumulators -> true values
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
@@ -377,12 +387,15 @@ __global__ __launch_bounds__(256, 1) void trunk_f16l_kernel(const TrunkParams p,
             }
         };
         table_terms_request(0);
+        HSTAMP(38);
         for (int blk = 0; blk < 16; blk += 2) {
             uint32_t bits2 = 0;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int kb = blk + e;
-                f32x16 z = block_out(ls, wn, X, zero, zero, [](int) __attribute__((always_inline)) {});      // leaves wn[0..1] = entries 0, 1 of layer 2's pass
+                if (kb == 8) HSTAMP(32);
+                f32x16 z = block_out(ls, wn, X, zero, zero, [](int) __attribute__((always_inline)) {});      // leaves wn = entries 0 .. 3 of layer 2's pass
+                if (kb == 8) HSTAMP(33);
                 table_terms();
                 table_terms_request((kb + 1) & 15);
 #pragma unroll
@@ -400,13 +413,14 @@ __global__ __launch_bounds__(256, 1) void trunk_f16l_kernel(const TrunkParams p,
                     split3(lo, hi, a, bb, cc);
                     ah[d / 4][d % 4] = a; am[d / 4][d % 4] = bb; al[d / 4][d % 4] = cc;
                 }
+                if (kb == 8) HSTAMP(34);
                 // layer 2 (six-product bf16): 48 entries = three chunks, eight groups of six; the group's operands are read one group ahead,
                 // crossing into the next chunk where the group does (entry e of the pass lives in chunk e / 16)
                 {
                     v4f32 w6[6];
-                    w6[0] = wn[0]; w6[1] = wn[1];
 #pragma unroll
-                    for (int j = 2; j < 6; ++j) w6[j] = ls.read(j);
+                    for (int j = 0; j < 4; ++j) w6[j] = wn[j];
+                    w6[4] = ls.read(4); w6[5] = ls.read(5);
                     int ready = 0;                                       // chunks of this pass already made readable beyond the first
 #pragma unroll
                     for (int gq = 0; gq < 8; ++gq) {
@@ -414,24 +428,25 @@ __global__ __launch_bounds__(256, 1) void trunk_f16l_kernel(const TrunkParams p,
                         v4f32 w[6];
 #pragma unroll
                         for (int j = 0; j < 6; ++j) w[j] = w6[j];
-                        // next group's entries (the following pass' first K-step after the last group: [h l] of layer 1's next block)
+                        // next group's entries (the following pass' first two K-steps after the last group: [h l] [h l] of layer 1's next block)
 #pragma unroll
                         for (int j = 0; j < 6; ++j) {
-                            const int e = 6 * (gq + 1) + j;              // entry of this pass; 48, 49 = entries 0, 1 of the next pass
-                            if (gq == 7 && j >= 2) break;
+                            const int e = 6 * (gq + 1) + j;              // entry of this pass; 48 .. 51 = entries 0 .. 3 of the next pass
+                            if (gq == 7 && j >= 4) break;
                             if (e / 16 > ready) { ls.advance(); ++ready; }
                             w6[j] = ls.read(e % 16);
                         }
                         B16_STEP(Y[2 * pp], Y[2 * pp + 1], w, ah[sx], am[sx], al[sx]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    wn[0] = w6[0]; wn[1] = w6[1];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) wn[j] = w6[j];
                 }
+                if (kb == 8) HSTAMP(35);
             }
             smask[blk / 2][tid] = bits2;
         }
-        slot = 8;
-        wn[2] = ls.read(2); wn[3] = ls.read(3);               // wn[0..1] are entries 0, 1 of the stack's first chunk already
+        slot = 8;                                             // wn: entries 0 .. 3 of the stack's first chunk already
     }
     if (KIND == 2) {
 #pragma unroll
@@ -573,14 +588,14 @@ int trunk_f16l_launch(int kind, const TrunkParams &p, const TrunkF16Scales &sc, 
     prof_end(s, DGDM_STAGE_TRUNK, rows * per_row);
 #ifdef DGDM_F16_STAMPS
     {
-        long long st[32];
+        long long st[40];
         hipStreamSynchronize(s);
         hipMemcpyFromSymbol(st, HIP_SYMBOL(g_f16l_stamps), sizeof(st));
         fprintf(stderr, "f16l stamps kind %d:", kind);
         long long prev = st[0];
         for (int i = 1; i <= 20; ++i) if (st[i]) { fprintf(stderr, " [%d]%lld", i, st[i] - prev); prev = st[i]; }
-        fprintf(stderr, " total %lld; advance(): counted wait %lld, barrier %lld; last fwd layer: prologue %lld first items %lld loop %lld; bwd: %lld %lld %lld\n", st[20] - st[0], st[21], st[22],
-                st[23] - st[1 + p.n_mid - 1], st[24] - st[23], st[25] - st[24], st[26] - st[10 + p.n_mid - 1], st[27] - st[26], st[28] - st[27]);
+        fprintf(stderr, " total %lld; advance(): counted wait %lld, barrier %lld; last fwd layer: prologue %lld first items %lld loop %lld; bwd: %lld %lld %lld; front block 8: layer-1 block %lld, epilogue %lld, layer-2 pass %lld; before the front loop: stream start + embedding row %lld, its split %lld, bias + first table terms %lld\n", st[20] - st[0], st[21], st[22],
+                st[23] - st[1 + p.n_mid - 1], st[24] - st[23], st[25] - st[24], st[26] - st[10 + p.n_mid - 1], st[27] - st[26], st[28] - st[27], st[33] - st[32], st[34] - st[33], st[35] - st[34], st[36] - st[0], st[37] - st[36], st[38] - st[37]);
     }
 #endif
     return DGDM_OK;
