@@ -113,7 +113,7 @@ class Workload:
         else:
             self.dyn_sd = synth.synth_state_dict(synth.dyn2d_spec(self.L, 2 * self.N), 22)
             self.dyn = engine.Dynamics(2, self.dyn_sd, self.L, 2 * self.N)
-        self.net = engine.Unet1d(self.unet_sd, contraction_dtype="bf16" if contraction == "bf16" else "f32")
+        self.net = engine.Unet1d(self.unet_sd, contraction_dtype=contraction)
         nch = pairs * self.n_obj                           # gradient chains (= distinct objects) per launch
         self.guid = engine.Guidance(self.dyn, self.B, self.G, self.P, (-1.0, 1.0), nch, self.T, self.N, self.sub, max_objects=nch, contraction_dtype=contraction)
         self.sched = DDIMScheduler(num_train_timesteps=self.T)

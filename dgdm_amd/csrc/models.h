@@ -13,7 +13,9 @@ struct DgdmUnet1d {
     dgdm::DevBuf p_dev;     // copy of `p` in device memory (kernel argument)
     dgdm::DevBuf w16;       // bf16 images of the MFMA convolutions
     dgdm::DevBuf p16_dev;   // `p` with those images (bf16 = 1)
-    bool bf16 = false;      // dgdm_unet1d_set_contraction_dtype
+    dgdm::DevBuf wf16;      // two-piece f16 images of the MFMA convolutions (unet.hip conv_mfma_f16x3)
+    dgdm::DevBuf pf16_dev;  // `p` with those images (bf16 = 2) and their scale exponents
+    int mode = 2;           // dgdm_unet1d_set_contraction_dtype: 0 float32 MFMA chain, 1 bf16, 2 f16x3 (the default float32 form)
 };
 
 namespace dgdm {

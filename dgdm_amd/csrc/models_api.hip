@@ -46,6 +46,43 @@ size_t conv_image16(std::vector<uint16_t> &dst, int cout, int cin, const std::ve
     return off;
 }
 
+// Two-piece f16 image for conv_mfma_f16x3: the weights times 2^ew (max |w 2^ew| in [2^12, 2^13): f16 has five exponent bits) as h = f16(.)
+// and l = f16(. - h); conv_image16's lane layout, the two pieces of an entry side by side, channel groups outside the taps:
+// [Cout/16][Cin/32][ntaps][h | l][64 lanes][8].
+// Appended to `dst`; returns the element offset, the exponent in *ew.
+template <class At>
+size_t conv_image_f16x3(std::vector<uint16_t> &dst, int cout, int cin, const std::vector<int> &taps, At at, int *ew) {
+    const size_t off = dst.size();
+    const int mt = cout / 16, g = cin / 32, nt = (int)taps.size();
+    float mx = 0.f;
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int t = 0; t < nt; ++t) mx = std::max(mx, std::fabs(at(co, ci, taps[t])));
+    int e = 0;
+    if (mx > 0.f) std::frexp(mx, &e);               // mx = f 2^e, f in [0.5, 1)
+    *ew = 13 - e;
+    auto bits = [](float x) { const _Float16 h = (_Float16)x; uint16_t u; memcpy(&u, &h, 2); return u; };
+    dst.resize(off + (size_t)2 * cout * cin * nt);
+    for (int m = 0; m < mt; ++m)
+        for (int t = 0; t < nt; ++t)
+            for (int gg = 0; gg < g; ++gg)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const float w = std::ldexp(at(16 * m + (lane & 15), 32 * gg + (j < 4 ? 4 * (lane >> 4) + j : 16 + 4 * (lane >> 4) + j - 4), taps[t]), *ew);
+                        const float h = (float)(_Float16)w;
+                        const size_t entry = (((size_t)m * g + gg) * nt + t) * 2;             // channel-group-major: the kernel's K order
+                        dst[off + (entry * 64 + lane) * 8 + j] = bits(h);
+                        dst[off + ((entry + 1) * 64 + lane) * 8 + j] = bits(w - h);
+                    }
+    return off;
+}
+
+size_t conv1d_image_f16x3(std::vector<uint16_t> &dst, const float *w, int cout, int cin, int kw, int *ew) {
+    std::vector<int> taps(kw);
+    for (int k = 0; k < kw; ++k) taps[k] = k;
+    return conv_image_f16x3(dst, cout, cin, taps, [=](int co, int ci, int k) { return w[((size_t)co * cin + ci) * kw + k]; }, ew);
+}
+
 size_t conv1d_image16(std::vector<uint16_t> &dst, const float *w, int cout, int cin, int kw) {
     std::vector<int> taps(kw);
     for (int k = 0; k < kw; ++k) taps[k] = k;
@@ -59,9 +96,11 @@ std::vector<float> conv1d_image(const float *w, int cout, int cin, int kw) {
 }
 
 struct ResOff { size_t c0w, c0b, g0w, g0b, c1w, c1b, g1w, g1b, cw, cb, rw, rb; bool has_res; int cin, cout;
-                size_t c0w16 = 0, c1w16 = 0, rw16 = 0; };      // element offsets of the bf16 images (MFMA convolutions only)
+                size_t c0w16 = 0, c1w16 = 0, rw16 = 0;         // element offsets of the bf16 images (MFMA convolutions only)
+                size_t c0wh = 0, c1wh = 0, rwh = 0; int c0e = 0, c1e = 0, re = 0; };      // ... of the f16x3 images and their scale exponents
 
-int pack_res(const StateDict &sd, Blob &bl, std::vector<uint16_t> &b16, const std::string &p, int cin, int cout, int cond, int kw, ResOff *o) {
+int pack_res(const StateDict &sd, Blob &bl, std::vector<uint16_t> &b16, std::vector<uint16_t> &bh, const std::string &p, int cin, int cout, int cond, int kw,
+             ResOff *o) {
     auto vec = [&](const std::string &k, int64_t n, size_t *off) -> int {
         const float *d = sd.f32(k, n);
         if (!d) return DGDM_EKEY;
@@ -79,10 +118,12 @@ int pack_res(const StateDict &sd, Blob &bl, std::vector<uint16_t> &b16, const st
     } else {
         o->c0w = bl.add(conv1d_image(w, cout, cin, kw));
         o->c0w16 = conv1d_image16(b16, w, cout, cin, kw);
+        o->c0wh = conv1d_image_f16x3(bh, w, cout, cin, kw, &o->c0e);
     }
     if (!(w = sd.f32(p + ".blocks.1.block.0.weight", (int64_t)cout * cout * kw))) return DGDM_EKEY;
     o->c1w = bl.add(conv1d_image(w, cout, cout, kw));
     o->c1w16 = conv1d_image16(b16, w, cout, cout, kw);
+    o->c1wh = conv1d_image_f16x3(bh, w, cout, cout, kw, &o->c1e);
     int rc;
     if ((rc = vec(p + ".blocks.0.block.0.bias", cout, &o->c0b))) return rc;
     if ((rc = vec(p + ".blocks.0.block.1.weight", cout, &o->g0w))) return rc;
@@ -97,7 +138,7 @@ int pack_res(const StateDict &sd, Blob &bl, std::vector<uint16_t> &b16, const st
     if (o->has_res) {
         if (!(w = sd.f32(p + ".residual_conv.weight", (int64_t)cout * cin))) return DGDM_EKEY;
         o->rw = cin == 1 ? bl.add(w, (size_t)cout) : bl.add(conv1d_image(w, cout, cin, 1));
-        if (cin != 1) o->rw16 = conv1d_image16(b16, w, cout, cin, 1);
+        if (cin != 1) { o->rw16 = conv1d_image16(b16, w, cout, cin, 1); o->rwh = conv1d_image_f16x3(bh, w, cout, cin, 1, &o->re); }
         if ((rc = vec(p + ".residual_conv.bias", cout, &o->rb))) return rc;
     }
     return DGDM_OK;
@@ -118,12 +159,13 @@ extern "C" int dgdm_unet1d_create(DgdmUnet1d **out, const DgdmTensor *tensors, i
     Blob &bl = m->blob;
     ResOff ro[8];
     std::vector<uint16_t> b16;                       // bf16 images of every MFMA convolution (unet.hip conv_mfma_bf16)
+    std::vector<uint16_t> bh;                        // two-piece f16 images of the same (conv_mfma_f16x3)
     const struct { const char *name; int cin, cout; } spec[8] = {
         {"down_modules.0.0", 1, d0}, {"down_modules.0.1", d0, d0}, {"down_modules.1.0", d0, d1}, {"down_modules.1.1", d1, d1},
         {"mid_modules.0", d1, d1}, {"mid_modules.1", d1, d1}, {"up_modules.0.0", 2 * d1, d0}, {"up_modules.0.1", d0, d0}};
     int rc;
     for (int i = 0; i < 8; ++i)
-        if ((rc = pack_res(sd, bl, b16, spec[i].name, spec[i].cin, spec[i].cout, dsed, kernel_size, &ro[i]))) return rc;
+        if ((rc = pack_res(sd, bl, b16, bh, spec[i].name, spec[i].cin, spec[i].cout, dsed, kernel_size, &ro[i]))) return rc;
     const float *w, *b;
     // diffusion_step_encoder
     std::vector<float> fr(dsed / 2);
@@ -140,6 +182,8 @@ extern "C" int dgdm_unet1d_create(DgdmUnet1d **out, const DgdmTensor *tensors, i
     if (!(w = sd.f32("down_modules.0.2.conv.weight", (int64_t)d0 * d0 * 3)) || !(b = sd.f32("down_modules.0.2.conv.bias", d0))) return DGDM_EKEY;
     const size_t o_dw = bl.add(conv1d_image(w, d0, d0, 3)), o_db = bl.add(b, d0);
     const size_t o_dw16 = conv1d_image16(b16, w, d0, d0, 3);
+    int e_dw = 0, e_uwe = 0, e_uwo = 0, e_fw = 0;
+    const size_t o_dwh = conv1d_image_f16x3(bh, w, d0, d0, 3, &e_dw);
     if (!(w = sd.f32("up_modules.0.2.conv.weight", (int64_t)d0 * d0 * 4)) || !(b = sd.f32("up_modules.0.2.conv.bias", d0))) return DGDM_EKEY;
     // ConvTranspose1d weight is [Cin][Cout][4]; even outputs use taps (1, 3), odd outputs taps (2, 0)
     const float *wt = w;
@@ -147,9 +191,11 @@ extern "C" int dgdm_unet1d_create(DgdmUnet1d **out, const DgdmTensor *tensors, i
     const size_t o_uwe = bl.add(conv_image(d0, d0, std::vector<int>{1, 3}, atT)), o_uwo = bl.add(conv_image(d0, d0, std::vector<int>{2, 0}, atT)),
                  o_ub = bl.add(b, d0);
     const size_t o_uwe16 = conv_image16(b16, d0, d0, std::vector<int>{1, 3}, atT), o_uwo16 = conv_image16(b16, d0, d0, std::vector<int>{2, 0}, atT);
+    const size_t o_uweh = conv_image_f16x3(bh, d0, d0, std::vector<int>{1, 3}, atT, &e_uwe), o_uwoh = conv_image_f16x3(bh, d0, d0, std::vector<int>{2, 0}, atT, &e_uwo);
     if (!(w = sd.f32("final_conv.0.block.0.weight", (int64_t)d0 * d0 * kernel_size)) || !(b = sd.f32("final_conv.0.block.0.bias", d0))) return DGDM_EKEY;
     const size_t o_fw = bl.add(conv1d_image(w, d0, d0, kernel_size)), o_fb = bl.add(b, d0);
     const size_t o_fw16 = conv1d_image16(b16, w, d0, d0, kernel_size);
+    const size_t o_fwh = conv1d_image_f16x3(bh, w, d0, d0, kernel_size, &e_fw);
     const float *gw, *gb;
     if (!(gw = sd.f32("final_conv.0.block.1.weight", d0)) || !(gb = sd.f32("final_conv.0.block.1.bias", d0))) return DGDM_EKEY;
     const size_t o_fgw = bl.add(gw, d0), o_fgb = bl.add(gb, d0);
@@ -188,6 +234,20 @@ extern "C" int dgdm_unet1d_create(DgdmUnet1d **out, const DgdmTensor *tensors, i
         q.down_w = at16(o_dw16); q.up_w_even = at16(o_uwe16); q.up_w_odd = at16(o_uwo16); q.fin_w = at16(o_fw16);
         if ((rc = m->p16_dev.upload(&q, sizeof q))) return rc;
     }
+    {   // ... and at their two-piece f16 images, with the scale exponents
+        if ((rc = m->wf16.upload(bh.data(), bh.size() * sizeof(uint16_t)))) return rc;
+        auto ath = [&](size_t off) { return reinterpret_cast<const float *>(static_cast<const uint16_t *>(m->wf16.p) + off); };
+        UnetParams q = p;
+        q.bf16 = 2;
+        for (int i = 0; i < 8; ++i) {
+            if (ro[i].cin != 1) { q.res[i].c0_w = ath(ro[i].c0wh); q.res[i].c0_e = ro[i].c0e; }
+            q.res[i].c1_w = ath(ro[i].c1wh); q.res[i].c1_e = ro[i].c1e;
+            if (ro[i].has_res && ro[i].cin != 1) { q.res[i].res_w = ath(ro[i].rwh); q.res[i].res_e = ro[i].re; }
+        }
+        q.down_w = ath(o_dwh); q.up_w_even = ath(o_uweh); q.up_w_odd = ath(o_uwoh); q.fin_w = ath(o_fwh);
+        q.down_e = e_dw; q.up_e_even = e_uwe; q.up_e_odd = e_uwo; q.fin_e = e_fw;
+        if ((rc = m->pf16_dev.upload(&q, sizeof q))) return rc;
+    }
     *out = m.release();
     return DGDM_OK;
 }
@@ -201,15 +261,19 @@ extern "C" int dgdm_unet1d_forward(DgdmUnet1d *m, const float *sample_dev, const
     // scale with L, the step encoder / FiLM linears are a 0.3 M constant)
     const double macs = 0.3e6 + (82.0e6 - 0.3e6) * (double)L / 42.0;
     prof_begin((hipStream_t)stream, DGDM_STAGE_UNET);
-    const int rc = unet_launch(m->p, (m->bf16 ? m->p16_dev : m->p_dev).as<UnetParams>(), sample_dev, timestep_dev, eps_dev, B, L, (hipStream_t)stream);
+    // the f16x3 form needs 12 KB of LDS beside one sample's activations: where that does not fit (L = 44, 46) the float32 MFMA chain runs
+    const int mode = (m->mode == 2 && !unet_f16x3_fits(m->p, L)) ? 0 : m->mode;
+    const int rc = unet_launch(m->p, (mode == 1 ? m->p16_dev : mode == 2 ? m->pf16_dev : m->p_dev).as<UnetParams>(), mode == 2, sample_dev, timestep_dev, eps_dev, B, L, (hipStream_t)stream);
     prof_end((hipStream_t)stream, DGDM_STAGE_UNET, 2.0 * macs * B);
     return rc;
 }
 
 extern "C" int dgdm_unet1d_set_contraction_dtype(DgdmUnet1d *m, int dtype) {
     DGDM_REQUIRE(m, DGDM_EINVAL, "dgdm_unet1d_set_contraction_dtype: null handle");
-    DGDM_REQUIRE(dtype == DGDM_DTYPE_F32 || dtype == DGDM_DTYPE_BF16, DGDM_EINVAL, "contraction dtype %d unsupported (0 = f32, 1 = bf16)", dtype);
-    m->bf16 = dtype == DGDM_DTYPE_BF16;
+    // DGDM_DTYPE_F32 (the default) and both split forms: float32-grade convolutions as three f16 MFMA products (the eps-net has one split
+    // form); DGDM_DTYPE_F32_MFMA: the float32 MFMA chain of rounds 1-3; DGDM_DTYPE_BF16: operands rounded to bf16
+    DGDM_REQUIRE(dtype >= DGDM_DTYPE_F32 && dtype <= DGDM_DTYPE_F32_BF16X6, DGDM_EINVAL, "contraction dtype %d unsupported", dtype);
+    m->mode = dtype == DGDM_DTYPE_BF16 ? 1 : dtype == DGDM_DTYPE_F32_MFMA ? 0 : 2;
     return DGDM_OK;
 }
 

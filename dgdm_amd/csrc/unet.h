@@ -11,11 +11,13 @@ struct UnetRes {
     const float *c1_w, *c1_b, *g1_w, *g1_b;      // blocks.1
     const float *cond_wt, *cond_b;               // cond_encoder.1: Linear(cond_dim, 2*cout)
     const float *res_w, *res_b;                  // residual_conv 1x1 (image; [cout] when cin == 1) or null
+    int c0_e, c1_e, res_e;                       // f16x3 images: the convolution's weights are stored times 2^e (unet.hip conv_mfma_f16x3)
 };
 
 struct UnetParams {
     int d0, d1, dsed, groups, cmax;
-    int bf16;                                    // 1: the MFMA convolution images are bf16 (unet.hip conv_mfma_bf16)
+    int bf16;                                    // what the MFMA convolution images are: 0 float32 (conv_mfma), 1 bf16 (conv_mfma_bf16), 2 two f16 pieces (conv_mfma_f16x3)
+    int down_e, up_e_even, up_e_odd, fin_e;      // f16x3: scale exponents of the images below
     const float *freqs;                          // SinusoidalPosEmb frequencies [dsed/2]
     const float *se1_wt, *se1_b, *se3_wt, *se3_b;
     UnetRes res[8];                              // down0.0 down0.1 down1.0 down1.1 mid0 mid1 up0.0 up0.1
@@ -26,6 +28,8 @@ struct UnetParams {
 };
 
 // p: host copy (sizes); p_dev: the same struct in device memory (what the kernel reads)
-int unet_launch(const UnetParams &p, const UnetParams *p_dev, const float *sample, const int *timestep, float *eps, int B, int L, hipStream_t s);
+// f16x3: p_dev holds the two-piece f16 images (the kernel then needs LDS for the split slabs: unet_f16x3_fits)
+int unet_launch(const UnetParams &p, const UnetParams *p_dev, bool f16x3, const float *sample, const int *timestep, float *eps, int B, int L, hipStream_t s);
+bool unet_f16x3_fits(const UnetParams &p, int L);
 
 }  // namespace dgdm

@@ -24,6 +24,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef UNET_THREADS
 #define UNET_THREADS 512
 #endif
+#ifndef DGDM_UNET_SLAB_GROUPS
+#define DGDM_UNET_SLAB_GROUPS 2
+#endif
+// f16x3 convolutions: channel groups of 32 split per slab pass (conv_mfma_f16x3; every width is a multiple of 64).  Measured per 1024
+// samples at L = 42: 1.52 ms with one group per pass, 1.43 with two (half the barriers).
+constexpr int UNET_SLAB_GROUPS = DGDM_UNET_SLAB_GROUPS;
 constexpr int UNET_ROW_PAD = 8;      // LDS activation rows are C + 8 floats: see the header comment (bank mapping of the B-operand reads)
 // Activations live in LDS.  The device functions below are real calls (not inlined into the kernel), so a plain `float *`
 // parameter would be a generic pointer: every access a flat_load/flat_store with 64-bit address arithmetic on the VALU
@@ -79,7 +85,11 @@ struct ConvArgs {
     const float  *bias;
     int cin, cout, ntaps, istride, ostride, ooff;
     int ioff0, iostep;        // input row offset of tap t = ioff0 + t*iostep (an indexed array here ends up in scratch)
-    int bf16;                 // img is a bf16 image: conv_mfma_bf16
+    int bf16;                 // what img is: 0 float32 image (conv_mfma), 1 bf16 image (conv_mfma_bf16), 2 two-piece f16 image (conv_mfma_f16x3)
+    int ew;                   // f16x3: the image holds the weights times 2^ew
+    lds_f *red;               // f16x3: 16 floats of LDS scratch (input_scale_exp)
+    lds_f *slab;              // f16x3: the split activations of slab_groups channel groups (conv_mfma_f16x3)
+    int slab_groups;
 };
 
 template <int NT, int MT, int MODE>
@@ -249,9 +259,176 @@ __device__ void conv_mfma_bf16(const ConvArgs a, const lds_f *in, int CPi, lds_f
     }
 }
 
+// The same convolution, float32-grade, on the f16 matrix pipe (the default): every float32 product as THREE f16 products,
+//     w x ~ w_h x_h + w_h x_l + w_l x_h,   x_h = f16(x), x_l = f16(x - x_h) (exact residual; 11 + 11 significant bits),
+// on v_mfma_f32_16x16x32_f16 with float32 accumulation - the arithmetic of the dynamics trunk (trunk_f16.hip) and the same two exact
+// power-of-two scales that keep both operands inside f16's five exponent bits: one per convolution's weights, fixed on the host (a.ew,
+// models_api.hip conv_image_f16x3), and one per (sample, convolution input), from the largest magnitude among the rows the convolution
+// reads (input_scale_exp).
+// The activations stay float32 in LDS.  Splitting them where they are read would be done ntaps x (output tiles / MT) times over - as
+// much VALU time as the MFMAs take (measured: 1.75 ms per 1024 samples that way, 1.43 this way) - so the K loop runs
+// channel-group-major: for every 64 input channels the workgroup splits the rows the
+// convolution reads ONCE into two 6 KB slabs ([h | l][4 k-groups][rows] x 8 halves each: a lane's B operand is one ds_read_b128 per piece,
+// linear in the position = conflict-free), and every tap and output tile consumes the slab.  Image: [Cout/16][Cin/32][ntaps][h | l]
+// [64 lanes][8] (group-major to match).  The three products of a K-step run product-major over the wave's NT x MT accumulators (no MFMA
+// waits for the one before it), small terms first; the chain is cut after every channel group.  Against float64 the eps-net's output
+// is closer than with the float32 MFMA chain (4.3e-7 against 5.6e-7, scripts/unet_check.py) at 1/5 of its matrix-pipe cycles.
+typedef _Float16 f16x8_u __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_u __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) u32x4_u lds_u4;
+
+__device__ __forceinline__ float pow2_f(int e) { return __uint_as_float((uint32_t)(min(max(e, -126), 127) + 127) << 23); }
+
+// an already scaled pair -> packed f16 (h | l), h + l == the pair to 2^-23
+__device__ __forceinline__ void split2_f16(const f32x2_u v, uint32_t &ph, uint32_t &pl) {
+    const f16x2_u h = __builtin_convertvector(v, f16x2_u);              // v_cvt_pk_f16_f32 (round to nearest even)
+    const f32x2_u d = v - __builtin_convertvector(h, f32x2_u);          // exact
+    ph = __builtin_bit_cast(uint32_t, h);
+    pl = __builtin_bit_cast(uint32_t, __builtin_convertvector(d, f16x2_u));
+}
+
+// first / last input row (halo included) a convolution reads
+__device__ __forceinline__ int conv_row_lo(const ConvArgs &a) { return a.ioff0 + min(0, (a.ntaps - 1) * a.iostep) + 2; }
+__device__ __forceinline__ int conv_row_hi(const ConvArgs &a, int Lout) { return (Lout - 1) * a.istride + a.ioff0 + max(0, (a.ntaps - 1) * a.iostep) + 2; }
+
+// k with max |x| 2^k in [2^12, 2^13) over the input rows a convolution reads (halo rows: zeros); 0 for an all-zero input.
+// Called by the whole workgroup; two barriers.
+__device__ int input_scale_exp(const ConvArgs &a, const lds_f *in, int CPi, int Lout) {
+    lds_f *red = a.red;
+    const int r0 = conv_row_lo(a), r1 = conv_row_hi(a, Lout);
+    const int c4 = a.cin >> 2, n = (r1 - r0 + 1) * c4;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int r = i / c4, c = i - r * c4;
+        const f32x4 v = *(const lds_f4 *)(in + (r0 + r) * CPi + 4 * c);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __syncthreads();                                        // the previous call's readers of red[] are done
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    float mm = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) mm = fmaxf(mm, red[w]);
+    const int e = (int)((__float_as_uint(mm) >> 23) & 0xffu);
+    return __builtin_amdgcn_readfirstlane((mm > 0.f && e < 255) ? 12 + 127 - e : 0);
+}
+
+template <int NT, int MT, int MODE>
+__device__ void conv_mfma_f16x3(const ConvArgs a, const lds_f *in, int CPi, lds_f *out, int CPo, int Lout, const int kx) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int groups = __builtin_amdgcn_readfirstlane(a.cin >> 5), mtiles = __builtin_amdgcn_readfirstlane(a.cout >> 4);
+    const int ntaps = __builtin_amdgcn_readfirstlane(a.ntaps);
+    const int rlo = conv_row_lo(a), R = conv_row_hi(a, Lout) - rlo + 1;
+    lds_u4 *slab = (lds_u4 *)a.slab;                             // [GS channel groups][h | l][4 k-groups][R rows]
+    constexpr int GS = UNET_SLAB_GROUPS;                         // channel groups per slab pass
+    int brow[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) brow[nt] = q * R + min(nt * 16 + j, Lout - 1) * a.istride + a.ioff0 + 2 - rlo;
+    const int iters = __builtin_amdgcn_readfirstlane(ntaps * groups);
+    const float f = pow2_f(kx), un = pow2_f(-(kx + a.ew));
+    const f32x2_u f2 = {f, f};
+    for (int mp0 = 0; mp0 * MT < mtiles; mp0 += nwave) {        // the same trip count for every wave (barriers inside)
+        const int mp = mp0 + wave;
+        int mt[MT];
+        glb_f4 *w[MT];
+        f32x4 nh[MT], nl[MT], n2h[MT], n2l[MT];                  // [h | l] weight fragments of the next two K-steps
+        f32x4 acc[MT][NT], tot[MT][NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            mt[m] = min(mp * MT + m, mtiles - 1);
+            w[m] = (glb_f4 *)a.img + (size_t)mt[m] * iters * 128 + lane;
+            nh[m] = w[m][0]; nl[m] = w[m][64];
+            const size_t o1 = (size_t)min(1, iters - 1) * 128;
+            n2h[m] = w[m][o1]; n2l[m] = w[m][o1 + 64];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { acc[m][nt] = (f32x4)(0.f); tot[m][nt] = (f32x4)(0.f); }
+        }
+        int it = 0;
+        for (int g0 = 0; g0 < groups; g0 += GS) {
+            __syncthreads();                                     // the previous pass' readers of the slab are done
+            for (int i = threadIdx.x; i < GS * 4 * R; i += blockDim.x) {
+                const int gg = i / (4 * R), i1 = i - gg * 4 * R, qq = i1 / R, row = i1 - qq * R;
+                const lds_f *src = in + (rlo + row) * CPi + (g0 + gg) * 32 + 4 * qq;
+                const f32x4 lo = *(const lds_f4 *)src, hi = *(const lds_f4 *)(src + 16);
+                uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+                split2_f16(f32x2_u{lo[0], lo[1]} * f2, h0, l0);
+                split2_f16(f32x2_u{lo[2], lo[3]} * f2, h1, l1);
+                split2_f16(f32x2_u{hi[0], hi[1]} * f2, h2, l2);
+                split2_f16(f32x2_u{hi[2], hi[3]} * f2, h3, l3);
+                slab[gg * 8 * R + i1] = u32x4_u{h0, h1, h2, h3};
+                slab[gg * 8 * R + 4 * R + i1] = u32x4_u{l0, l1, l2, l3};
+            }
+            __syncthreads();
+            for (int gt = 0; gt < GS * ntaps; ++gt, ++it) {
+                const int gg = (GS > 1 && gt >= ntaps) ? 1 : 0, t = gt - gg * ntaps;
+                f16x8_u ah[MT], al[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    ah[m] = __builtin_bit_cast(f16x8_u, nh[m]); al[m] = __builtin_bit_cast(f16x8_u, nl[m]);
+                    nh[m] = n2h[m]; nl[m] = n2l[m];
+                }
+                // hipcc otherwise proves nh == w[it] and turns the two-deep prefetch back into load-then-use; an opaque index keeps it
+                int pre = min(it + 2, iters - 1);
+                asm volatile("" : "+v"(pre));
+#pragma unroll
+                for (int m = 0; m < MT; ++m) { n2h[m] = w[m][(size_t)pre * 128]; n2l[m] = w[m][(size_t)pre * 128 + 64]; }
+                const int ro = gg * 8 * R + t * a.iostep;
+                f16x8_u bh[NT], bl[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    bh[nt] = __builtin_bit_cast(f16x8_u, (u32x4_u)slab[brow[nt] + ro]);
+                    bl[nt] = __builtin_bit_cast(f16x8_u, (u32x4_u)slab[4 * R + brow[nt] + ro]);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh[nt], acc[m][nt], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl[nt], acc[m][nt], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh[nt], acc[m][nt], 0, 0, 0);
+                if (t == ntaps - 1) {                            // the chain is cut after every channel group
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) { tot[m][nt] += acc[m][nt]; acc[m][nt] = (f32x4)(0.f); }
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (mp * MT + m >= mtiles) break;
+            const float4 b4 = *reinterpret_cast<const float4 *>(a.bias + mt[m] * 16 + 4 * q);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int l = nt * 16 + j;
+                if (l < Lout) {
+                    lds_f4 *p = (lds_f4 *)(out + ((l * a.ostride + a.ooff) + 2) * CPo + 4 * q + mt[m] * 16);
+                    const f32x4 sum = tot[m][nt];
+                    f32x4 v = {fmaf(sum[0], un, b4.x), fmaf(sum[1], un, b4.y), fmaf(sum[2], un, b4.z), fmaf(sum[3], un, b4.w)};      // (x 2^-k exact: one rounding, the bias add's)
+                    if (MODE == 1) v += *p;
+                    *p = v;
+                }
+            }
+        }
+    }
+}
+
 template <int NT, int MODE>
 __device__ void conv_nt(const ConvArgs &a, const lds_f *in, int CPi, lds_f *out, int CPo, int Lout) {
     // two output tiles per wave share the activation fragments when there are enough tiles to keep every wave busy
+    if (a.bf16 == 2) {
+        const int kx = input_scale_exp(a, in, CPi, Lout);
+        if ((a.cout >> 4) >= 2 * (int)(blockDim.x >> 6)) conv_mfma_f16x3<NT, 2, MODE>(a, in, CPi, out, CPo, Lout, kx);
+        else conv_mfma_f16x3<NT, 1, MODE>(a, in, CPi, out, CPo, Lout, kx);
+        return;
+    }
     if (a.bf16) {
         if ((a.cout >> 4) >= 2 * (int)(blockDim.x >> 6)) conv_mfma_bf16<NT, 2, MODE>(a, in, CPi, out, CPo, Lout);
         else conv_mfma_bf16<NT, 1, MODE>(a, in, CPi, out, CPo, Lout);
@@ -269,9 +446,10 @@ __device__ void conv(const ConvArgs &a, const lds_f *in, int CPi, lds_f *out, in
     else conv_nt<4, MODE>(a, in, CPi, out, CPo, Lout);
 }
 
-__device__ ConvArgs conv_args(const float *img, const float *bias, int cin, int cout, int ntaps, int pad, int istride, int bf16) {
+__device__ ConvArgs conv_args(const float *img, const float *bias, int cin, int cout, int ntaps, int pad, int istride, int bf16, int ew, lds_f *red,
+                              int slab_groups) {
     ConvArgs a;
-    a.bf16 = bf16;
+    a.bf16 = bf16; a.ew = ew; a.red = red; a.slab = red + 16; a.slab_groups = slab_groups;
     a.img = reinterpret_cast<const float4 *>(img); a.bias = bias; a.cin = cin; a.cout = cout; a.ntaps = ntaps;
     a.istride = istride; a.ostride = 1; a.ooff = 0;
     a.ioff0 = -pad; a.iostep = 1;
@@ -345,7 +523,7 @@ __device__ void matvec(const float *__restrict__ WT, const float *__restrict__ b
     for (int n = threadIdx.x; n < N; n += blockDim.x) y[n] = dot_kn(WT, N, n, x, K) + b[n];
 }
 
-struct Bufs { lds_f *A, *B, *C, *D, *film, *cond, *tmp, *xin; int bf16; };      // film: [8 blocks][2 * cmax] FiLM scale|shift, all computed up front
+struct Bufs { lds_f *A, *B, *C, *D, *film, *cond, *tmp, *xin, *scr; int bf16, slab_groups; };      // film: [8 blocks][2 * cmax] FiLM scale|shift, all computed up front
 
 // ConditionalResidualBlock1D.forward (diffusion_utils.py:101-120): x(in, cin channels) -> out; t1 scratch.
 // `out` may be a wider buffer (row stride CPout >= cout + 4): the concat buffer of the up path.
@@ -362,7 +540,7 @@ __device__ void res_block(const UnetRes &w, const lds_f *in, lds_f *t1, lds_f *o
             t1[(l + 2) * CPo + co] = acc + w.c0_b[co];
         }
     } else {
-        conv<0>(conv_args(w.c0_w, w.c0_b, w.cin, w.cout, 5, 2, 1, s.bf16), in, CPi, t1, CPo, L);
+        conv<0>(conv_args(w.c0_w, w.c0_b, w.cin, w.cout, 5, 2, 1, s.bf16, w.c0_e, s.scr, s.slab_groups), in, CPi, t1, CPo, L);
     }
     zero_halo(t1, CPo, w.cout, L);
     __syncthreads();
@@ -370,7 +548,7 @@ __device__ void res_block(const UnetRes &w, const lds_f *in, lds_f *t1, lds_f *o
     gn_mish_film(t1, CPo, w.cout, L, groups, w.g0_w, w.g0_b, film);
     __syncthreads();
     UCLK();
-    conv<0>(conv_args(w.c1_w, w.c1_b, w.cout, w.cout, 5, 2, 1, s.bf16), t1, CPo, out, CPout, L);
+    conv<0>(conv_args(w.c1_w, w.c1_b, w.cout, w.cout, 5, 2, 1, s.bf16, w.c1_e, s.scr, s.slab_groups), t1, CPo, out, CPout, L);
     zero_halo(out, CPout, w.cout, L);
     __syncthreads();
     UCLK();
@@ -383,7 +561,7 @@ __device__ void res_block(const UnetRes &w, const lds_f *in, lds_f *t1, lds_f *o
             out[(l + 2) * CPout + co] += fmaf(w.res_w[co], s.xin[l + 2], w.res_b[co]);
         }
     } else if (w.res_w) {
-        conv<1>(conv_args(w.res_w, w.res_b, w.cin, w.cout, 1, 0, 1, s.bf16), in, CPi, out, CPout, L);   // residual 1x1 conv, added in place
+        conv<1>(conv_args(w.res_w, w.res_b, w.cin, w.cout, 1, 0, 1, s.bf16, w.res_e, s.scr, s.slab_groups), in, CPi, out, CPout, L);   // residual 1x1 conv, added in place
     } else {
         for (int i = threadIdx.x; i < L * w.cout; i += blockDim.x) {
             const int l = i / w.cout, c = i - l * w.cout;
@@ -397,7 +575,7 @@ __device__ void res_block(const UnetRes &w, const lds_f *in, lds_f *t1, lds_f *o
 // `pp` points at the UnetParams in device memory: passing the struct by value and handing references to its members to the
 // (non-inlined) block functions made the compiler copy all 1.1 KB of it to scratch in every thread.
 __global__ __launch_bounds__(UNET_THREADS) void unet_kernel(const UnetParams *__restrict__ pp, int bufA, int bufS, const float *__restrict__ sample,
-                                                   const int *__restrict__ timestep, float *__restrict__ eps, int L) {
+                                                   const int *__restrict__ timestep, float *__restrict__ eps, int L, int slab_groups) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     lds_f *lds = (lds_f *)lds_raw;
     const UnetParams &p = *pp;
@@ -412,7 +590,9 @@ __global__ __launch_bounds__(UNET_THREADS) void unet_kernel(const UnetParams *__
     s.cond = s.film + 8 * 2 * p.cmax;
     s.tmp = s.cond + p.dsed;
     s.xin = s.tmp + 4 * p.dsed;
+    s.scr = s.xin + ((L + 4 + 3) & ~3);            // f16x3: 16 floats for the scale reduction, then the activation slab(s)
     s.bf16 = p.bf16;
+    s.slab_groups = slab_groups;
     const int G = p.groups;
 #ifdef DGDM_UNET_CLOCKS
     int clk_i = 0;
@@ -457,7 +637,7 @@ __global__ __launch_bounds__(UNET_THREADS) void unet_kernel(const UnetParams *__
     const int CP0 = p.d0 + UNET_ROW_PAD, CP1 = p.d1 + UNET_ROW_PAD, CPcat = 2 * p.d1 + UNET_ROW_PAD;
     res_block(p.res[0], nullptr, s.B, s.C, CP0, L, p.dsed, G, s, s.film + 0 * 2 * p.cmax UCLK_PASS);     // down0.0   1 -> d0
     res_block(p.res[1], s.C, s.B, s.D, CP0, L, p.dsed, G, s, s.film + 1 * 2 * p.cmax UCLK_PASS);         // down0.1   d0 -> d0   (its skip is never consumed, :264-278)
-    conv<0>(conv_args(p.down_w, p.down_b, p.d0, p.d0, 3, 1, 2, p.bf16), s.D, CP0, s.B, CP0, L2);       // Downsample1d (:42)
+    conv<0>(conv_args(p.down_w, p.down_b, p.d0, p.d0, 3, 1, 2, p.bf16, p.down_e, s.scr, s.slab_groups), s.D, CP0, s.B, CP0, L2);       // Downsample1d (:42)
     zero_halo(s.B, CP0, p.d0, L2);
     __syncthreads();
     UCLK();      // downsample conv
@@ -474,9 +654,9 @@ __global__ __launch_bounds__(UNET_THREADS) void unet_kernel(const UnetParams *__
     res_block(p.res[6], s.A, s.B, s.D, CP0, L2, p.dsed, G, s, s.film + 6 * 2 * p.cmax UCLK_PASS);        // up0.0   2*d1 -> d0
     res_block(p.res[7], s.D, s.B, s.C, CP0, L2, p.dsed, G, s, s.film + 7 * 2 * p.cmax UCLK_PASS);        // up0.1
     {   // Upsample1d: ConvTranspose1d(d0, d0, 4, 2, 1) (:51): out[2 li] = W1 in[li] + W3 in[li-1];  out[2 li + 1] = W2 in[li] + W0 in[li+1]
-        ConvArgs e = conv_args(p.up_w_even, p.up_b, p.d0, p.d0, 2, 0, 1, p.bf16);
+        ConvArgs e = conv_args(p.up_w_even, p.up_b, p.d0, p.d0, 2, 0, 1, p.bf16, p.up_e_even, s.scr, s.slab_groups);
         e.ioff0 = 0; e.iostep = -1; e.ostride = 2; e.ooff = 0;
-        ConvArgs o = conv_args(p.up_w_odd, p.up_b, p.d0, p.d0, 2, 0, 1, p.bf16);
+        ConvArgs o = conv_args(p.up_w_odd, p.up_b, p.d0, p.d0, 2, 0, 1, p.bf16, p.up_e_odd, s.scr, s.slab_groups);
         o.ioff0 = 0; o.iostep = 1; o.ostride = 2; o.ooff = 1;
         conv<0>(e, s.C, CP0, s.A, CP0, L2);
         conv<0>(o, s.C, CP0, s.A, CP0, L2);
@@ -484,7 +664,7 @@ __global__ __launch_bounds__(UNET_THREADS) void unet_kernel(const UnetParams *__
         __syncthreads();
         UCLK();  // upsample convs
     }
-    conv<0>(conv_args(p.fin_w, p.fin_b, p.d0, p.d0, 5, 2, 1, p.bf16), s.A, CP0, s.B, CP0, L);          // final_conv.0
+    conv<0>(conv_args(p.fin_w, p.fin_b, p.d0, p.d0, 5, 2, 1, p.bf16, p.fin_e, s.scr, s.slab_groups), s.A, CP0, s.B, CP0, L);          // final_conv.0
     __syncthreads();
     UCLK();      // final conv
     gn_mish_film(s.B, CP0, p.d0, L, G, p.fin_gw, p.fin_gb, nullptr);
@@ -498,7 +678,17 @@ __global__ __launch_bounds__(UNET_THREADS) void unet_kernel(const UnetParams *__
     UCLK();          // output conv
 }
 
-int unet_launch(const UnetParams &p, const UnetParams *p_dev, const float *sample, const int *timestep, float *eps, int B, int L, hipStream_t s) {
+static size_t unet_lds_floats(const UnetParams &p, int L) {
+    const int L2 = (L - 1) / 2 + 1;
+    const int bufS = std::max((L + 4) * (p.d0 + UNET_ROW_PAD), (L2 + 4) * (p.d1 + UNET_ROW_PAD));
+    const int bufA = std::max((L + 4) * (p.d0 + UNET_ROW_PAD), (L2 + 4) * (2 * p.d1 + UNET_ROW_PAD));
+    return (size_t)bufA + 3 * (size_t)bufS + 8 * 2 * p.cmax + p.dsed + 4 * p.dsed + (L + 4 + 3) + 16;
+}
+static size_t unet_slab_floats(int L) { return 16 + (size_t)UNET_SLAB_GROUPS * (L + 4) * 32; }
+
+bool unet_f16x3_fits(const UnetParams &p, int L) { return (unet_lds_floats(p, L) + unet_slab_floats(L)) * 4 <= 160 * 1024; }
+
+int unet_launch(const UnetParams &p, const UnetParams *p_dev, bool f16x3, const float *sample, const int *timestep, float *eps, int B, int L, hipStream_t s) {
     if (B <= 0) return DGDM_OK;
     const int L2 = (L - 1) / 2 + 1;
     DGDM_REQUIRE(2 * L2 == L, DGDM_EINVAL, "U-Net needs an even number of control points (got %d): the skip concat of the reference "
@@ -506,14 +696,15 @@ int unet_launch(const UnetParams &p, const UnetParams *p_dev, const float *sampl
     DGDM_REQUIRE(L <= 64, DGDM_EINVAL, "U-Net kernel supports up to 64 control points (got %d)", L);
     const int bufS = std::max((L + 4) * (p.d0 + UNET_ROW_PAD), (L2 + 4) * (p.d1 + UNET_ROW_PAD));
     const int bufA = std::max((L + 4) * (p.d0 + UNET_ROW_PAD), (L2 + 4) * (2 * p.d1 + UNET_ROW_PAD));
-    const size_t lds_floats = (size_t)bufA + 3 * (size_t)bufS + 8 * 2 * p.cmax + p.dsed + 4 * p.dsed + (L + 4) + 16;
+    // (+ the f16x3 convolutions' scratch: 16 floats + the split slabs, UNET_SLAB_GROUPS x (L + 4) rows x 128 B; the caller checked that they fit)
+    const size_t lds_floats = unet_lds_floats(p, L) + (f16x3 ? unet_slab_floats(L) : 0);
     DGDM_REQUIRE(lds_floats * 4 <= 160 * 1024, DGDM_EINVAL, "U-Net activations (%zu B) exceed the 160 KiB LDS", lds_floats * 4);
     static bool attr_set = false;
     if (!attr_set) {
         DGDM_HIP_CHECK(hipFuncSetAttribute((const void *)unet_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(unet_kernel, dim3(B), dim3(UNET_THREADS), lds_floats * 4, s, p_dev, bufA, bufS, sample, timestep, eps, L);
+    hipLaunchKernelGGL(unet_kernel, dim3(B), dim3(UNET_THREADS), lds_floats * 4, s, p_dev, bufA, bufS, sample, timestep, eps, L, UNET_SLAB_GROUPS);
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
 }

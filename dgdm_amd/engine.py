@@ -33,10 +33,13 @@ class Unet1d:
         self.set_contraction_dtype(contraction_dtype)
 
     def set_contraction_dtype(self, dtype: str) -> None:
-        """'f32' (default, the parity path) or 'bf16': bf16 operands / float32 accumulation in the multi-channel convolutions."""
-        if dtype not in ("f32", "bf16"):
+        """Arithmetic of the multi-channel convolutions: 'f32' (default, the parity path: float32-grade, every product as three f16 MFMA
+        products on exactly scaled two-way split operands, csrc/unet.hip conv_mfma_f16x3; 'f32_f16x3' / 'f32_bf16x6' name the same form -
+        the eps-net has one split form), 'f32_mfma' (the float32 MFMA chain of rounds 1-3) or 'bf16' (operands ROUNDED to bf16)."""
+        codes = {"f32": 0, "bf16": 1, "f32_mfma": 2, "f32_f16x3": 3, "f32_bf16x6": 4}
+        if dtype not in codes:
             raise ValueError(f"contraction dtype {dtype!r} not supported")
-        check(lib().dgdm_unet1d_set_contraction_dtype(self._h, 1 if dtype == "bf16" else 0))
+        check(lib().dgdm_unet1d_set_contraction_dtype(self._h, codes[dtype]))
         self.contraction_dtype = dtype
 
     def __del__(self):
@@ -212,10 +215,10 @@ class Guidance:
         self.set_contraction_dtype(contraction_dtype)
 
     def set_contraction_dtype(self, dtype: str) -> None:
-        """Arithmetic of the trunk of cond_fn: 'f32' (default: float32 operands split exactly into three bf16 pieces, six bf16 MFMAs per
-        product, float32 accumulation - float32-grade, csrc/trunk_split.hip), 'f32_mfma' (the k-ordered float32 MFMA chain,
-        csrc/trunk.hip), 'f32_f16x3' (float32 operands as two exactly scaled f16 pieces, three f16 MFMAs per product, csrc/trunk_f16.hip),
-        'f32_bf16x6' (the six-product form by name) or 'bf16' (operands ROUNDED to bf16, float32 accumulation)."""
+        """Arithmetic of the trunk of cond_fn: 'f32' (default, = 'f32_f16x3': float32 operands as two exactly scaled f16 pieces, three f16
+        MFMAs per product, float32 accumulation - float32-grade, csrc/trunk_f16l.hip), 'f32_bf16x6' (float32 operands split exactly into
+        three bf16 pieces, six bf16 MFMAs per product, csrc/trunk_split.hip), 'f32_mfma' (the k-ordered float32 MFMA chain,
+        csrc/trunk.hip) or 'bf16' (operands ROUNDED to bf16, float32 accumulation)."""
         codes = {"f32": 0, "bf16": 1, "f32_mfma": 2, "f32_f16x3": 3, "f32_bf16x6": 4}
         if dtype not in codes:
             raise ValueError(f"contraction dtype {dtype!r} not supported")
