@@ -971,9 +971,8 @@ def g9_calls64(parts=None):
     path = os.path.join(OUT, "g9_calls64.npz")
     out = dict(np.load(path)) if os.path.exists(path) else {}
     names = [os.path.basename(f)[len("g9_3d_"):-4] for f in sorted(glob.glob(os.path.join(OUT, "g9_3d_*.npz")))]
-    names = [n for n in names if not n.endswith(("_alt", "_eps", "_arith")) and "raw" not in n and not n.startswith("full_")]
-    if parts:
-        names = [n for n in names if n in parts]
+    names = [n for n in names if not n.endswith(("_alt", "_eps", "_arith")) and "raw" not in n]
+    names = [n for n in names if n in parts] if parts else [n for n in names if not n.startswith("full_")]      # the B = 32 chain (6 CPU minutes) on request
     todo = [n for n in names if f"{n}/chain" not in out]
     by_obj = {}
     for n in todo:
