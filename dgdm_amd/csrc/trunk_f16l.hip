@@ -167,7 +167,7 @@ struct LStream {
 // wn: the operands of the NEXT group to be consumed (read from LDS one group ahead); precondition of every consumer below: wn holds the
 // first group of the pass about to start, postcondition: the first group of the pass that follows in the stream.
 template <bool FWD, bool BIAS>
-__device__ __forceinline__ void stream_layer(LStream &ls, v4f32 (&wn)[4], const float *__restrict__ bias, const f32x16 (&Yp)[8], f32x16 (&Y)[8],
+__device__ __forceinline__ void stream_layer(LStream &ls, v4f32 (&wn)[4], const lds_f4_t *bias /* LDS: the layer's 256 values */, const f32x16 (&Yp)[8], f32x16 (&Y)[8],
                                              uint32_t (*smask)[256], const int slot_in, const int tid, const int h4, int &E, const int ew) {
     float mx = 0.f;
 #pragma unroll
@@ -183,7 +183,7 @@ __device__ __forceinline__ void stream_layer(LStream &ls, v4f32 (&wn)[4], const 
         if (BIAS) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 a = feat4(bias, o, q, h4);
+                const v4f32 a = bias[(32 * o + 8 * q + h4) >> 2];
                 Y[o][4 * q + 0] = a.x * fb; Y[o][4 * q + 1] = a.y * fb; Y[o][4 * q + 2] = a.z * fb; Y[o][4 * q + 3] = a.w * fb;
             }
         } else {
@@ -299,6 +299,9 @@ __global__ __launch_bounds__(256, 1) void trunk_f16l_kernel(const TrunkParams p,
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     __shared__ __attribute__((aligned(16))) v4f32 wbuf[NBUF * CH * 64];      // the shared weight stream: 4 slots of 16 KiB
+    // the stack's biases and the output layer's three rows, copied once: read from global memory where they are used, every one of these
+    // 32-load bursts is a full memory round trip behind the stream's prefetches (3.5 k cycles per layer prologue, 15 k for the output phase)
+    __shared__ __attribute__((aligned(16))) v4f32 small[(8 * 256 + 768) / 4];
     const bool live = blockIdx.x * 4 + wave < p.ntiles;      // a wave without a tile runs the last tile again (the barriers need all four waves)
     const int tile = min(blockIdx.x * 4 + wave, p.ntiles - 1);
     const int n = lane & 31;
@@ -347,7 +350,10 @@ __global__ __launch_bounds__(256, 1) void trunk_f16l_kernel(const TrunkParams p,
             }
         }
     }
-    ls.start(rsF, 0);
+    for (int i = tid; i < p.n_mid * 64; i += 256) small[i] = *reinterpret_cast<const v4f32 *>(p.bf[i >> 6] + 4 * (i & 63));
+    if (tid < 192) small[512 + tid] = *reinterpret_cast<const v4f32 *>(p.Wout + 4 * tid);
+    ls.start(rsF, 0);                                         // (its barriers publish `small`)
+    const lds_f4_t *sbias = (const lds_f4_t *)small, *swout = (const lds_f4_t *)small + 512;
 
     if (KIND == 3) {
         // ---- 3-D layers 1 and 2, streamed over the 16 blocks of the 512-wide layer 1.  Layer 1 (input: the embedding row, scale known up
@@ -456,7 +462,7 @@ __global__ __launch_bounds__(256, 1) void trunk_f16l_kernel(const TrunkParams p,
     f32x16 Z[8];
     HSTAMP(1);
     for (int l = 0; l < p.n_mid; ++l) {
-        stream_layer<true, true>(ls, wn, p.bf[l], Y, Z, smask, BASE + 4 * l, tid, h4, E, sc.ew_mid[l]);
+        stream_layer<true, true>(ls, wn, sbias + 64 * l, Y, Z, smask, BASE + 4 * l, tid, h4, E, sc.ew_mid[l]);
 #pragma unroll
         for (int o = 0; o < 8; ++o) Y[o] = Z[o];
         HSTAMP(2 + l);
@@ -473,9 +479,7 @@ __global__ __launch_bounds__(256, 1) void trunk_f16l_kernel(const TrunkParams p,
     for (int o = 0; o < 8; ++o) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 w0 = feat4(p.Wout, o, q, h4);
-            const float4 w1 = feat4(p.Wout + 256, o, q, h4);
-            const float4 w2 = feat4(p.Wout + 512, o, q, h4);
+            const v4f32 w0 = swout[(32 * o + 8 * q + h4) >> 2], w1 = swout[64 + ((32 * o + 8 * q + h4) >> 2)], w2 = swout[128 + ((32 * o + 8 * q + h4) >> 2)];
             const float x0 = Y[o][4 * q + 0], x1 = Y[o][4 * q + 1], x2 = Y[o][4 * q + 2], x3 = Y[o][4 * q + 3];
             s0 = fmaf(w0.w, x3, fmaf(w0.z, x2, fmaf(w0.y, x1, fmaf(w0.x, x0, s0))));
             s1 = fmaf(w1.w, x3, fmaf(w1.z, x2, fmaf(w1.y, x1, fmaf(w1.x, x0, s1))));
@@ -501,9 +505,7 @@ __global__ __launch_bounds__(256, 1) void trunk_f16l_kernel(const TrunkParams p,
     for (int o = 0; o < 8; ++o) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 w0 = feat4(p.Wout, o, q, h4);
-            const float4 w1 = feat4(p.Wout + 256, o, q, h4);
-            const float4 w2 = feat4(p.Wout + 512, o, q, h4);
+            const v4f32 w0 = swout[(32 * o + 8 * q + h4) >> 2], w1 = swout[64 + ((32 * o + 8 * q + h4) >> 2)], w2 = swout[128 + ((32 * o + 8 * q + h4) >> 2)];
             Y[o][4 * q + 0] = fmaf(g2, w2.x, fmaf(g1, w1.x, g0 * w0.x));
             Y[o][4 * q + 1] = fmaf(g2, w2.y, fmaf(g1, w1.y, g0 * w0.y));
             Y[o][4 * q + 2] = fmaf(g2, w2.z, fmaf(g1, w1.z, g0 * w0.z));
