@@ -1,7 +1,7 @@
 // Diffusion.cond_fn / get_convergence_centers (generator/diffusion.py:473-539) for batches of chains,
 // and the PointNet++-backed forward entry points.
 #ifndef DGDM_DEFAULT_F16X3
-#define DGDM_DEFAULT_F16X3 1      // which float32-grade form DGDM_DTYPE_F32 selects: 0 six bf16 products (trunk_split.hip), 1 three f16 products (trunk_f16.hip)
+#define DGDM_DEFAULT_F16X3 1      // which float32-grade form DGDM_DTYPE_F32 selects: 0 six bf16 products (trunk_split.hip), 1 three f16 products (trunk_f16l.hip)
 #endif
 #include "common.h"
 #include "models.h"
@@ -52,11 +52,12 @@ struct DgdmGuidance {
     int64_t R = 0, Rs = 0;                       // rows per chain: cond_fn grid, orientation sweep
     DevBuf ptab, ptab_sweep;                     // [C][W1], [G][W1]
     DevBuf ptab_t, ptab_sweep_t;                 // the same tables tiled for the trunk kernels (smallnet.h tile_table)
+    DevBuf pmax;                                 // [C] largest magnitude of a cell's row of ptab (trunk_f16l.hip: f16 scale of 3-D layer 2's input)
     DevBuf objpart;                              // 2-D: [max_objects][W1] doubles
     std::vector<std::unique_ptr<ObjectTables>> tables;   // 3-D
     bool bf16 = false;                           // contractions of the trunk on bf16 MFMA (dgdm_guidance_set_contraction_dtype)
     bool f32_mfma = false;                       // float32 mode on the k-ordered float32 MFMA chain (trunk.hip) instead of the split form
-    bool f16x3 = DGDM_DEFAULT_F16X3 != 0;        // float32 mode: three f16 products on scaled two-way split operands (trunk_f16.hip) instead of six bf16 ones
+    bool f16x3 = DGDM_DEFAULT_F16X3 != 0;        // float32 mode: three f16 products on scaled two-way split operands (trunk_f16l.hip) instead of six bf16 ones
 #ifndef DGDM_NBUILD
 #define DGDM_NBUILD 3
 #endif
@@ -169,6 +170,13 @@ extern "C" int dgdm_guidance_create(DgdmGuidance **out, DgdmDynamics *model, con
             }
     int rc;
     if ((rc = g->build_pose_table(ori, pos, &g->ptab, &g->ptab_t, nullptr))) return rc;
+    {   // per-cell magnitude bound of the pose table (built once: the pose grid is fixed)
+        std::vector<float> tab((size_t)g->C * model->W1), mx(g->C, 0.f);
+        DGDM_HIP_CHECK(hipMemcpy(tab.data(), g->ptab.p, tab.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (int c = 0; c < g->C; ++c)
+            for (int j = 0; j < model->W1; ++j) mx[c] = std::max(mx[c], std::fabs(tab[(size_t)c * model->W1 + j]));
+        if ((rc = g->pmax.upload(mx.data(), mx.size() * sizeof(float)))) return rc;
+    }
     std::vector<float> pos0(2 * (size_t)g->G, 0.f);                       // get_convergence_centers: pos = 0 (:511)
     if ((rc = g->build_pose_table(lo, pos0, &g->ptab_sweep, &g->ptab_sweep_t, nullptr))) return rc;
     const int W1 = model->W1, nc = cfg->max_chains;
@@ -686,7 +694,7 @@ static int guidance_grad(DgdmGuidance *g, int kind, const float *x_dev, int time
             p.xobj16 = emb->used16 ? g->xobj16.as<uint32_t>() + row0 * 128 : nullptr;
         }
     }
-    p.Atab = g->atab.as<float>(); p.Ptab = g->ptab.as<float>(); p.PtabT = g->ptab_t.as<float>(); p.obj = g->objdev.as<TrunkObjective>(); p.rowcoef = rowcoef_dev;
+    p.Atab = g->atab.as<float>(); p.Ptab = g->ptab.as<float>(); p.PtabT = g->ptab_t.as<float>(); p.Pmax = g->pmax.as<float>(); p.obj = g->objdev.as<TrunkObjective>(); p.rowcoef = rowcoef_dev;
     p.partial = g->partial.as<float>();
     p.B = g->B; p.C = g->C; p.tiles_per_b = g->tiles_per_b; p.ntiles = n_chains * g->B * g->tiles_per_b; p.R = g->R;
     if (kind != 3) p.xstride = g->R;
@@ -703,8 +711,7 @@ static int guidance_grad(DgdmGuidance *g, int kind, const float *x_dev, int time
     } else if (g->f16x3) {
         TrunkF16Scales sc;
         g->m->fill_trunk_f16(&p, &sc);   // only the two weight streams differ (+ their scale exponents)
-        static const bool ring_form = getenv("DGDM_F16_RING") != nullptr;      // experiment switch: the per-wave ring form (trunk_f16.hip)
-        if ((rc = ring_form ? trunk_f16_launch(kind, p, sc, s) : trunk_f16l_launch(kind, p, sc, s))) return rc;
+        if ((rc = trunk_f16l_launch(kind, p, sc, s))) return rc;
     } else {
         g->m->fill_trunk_split(&p);      // only the two weight streams differ
         if ((rc = trunk_split_launch(kind, p, s))) return rc;

@@ -531,7 +531,7 @@ extern "C" int dgdm_dynamics_create(DgdmDynamics **out, int kind, const DgdmTens
         fs.insert(fs.end(), bs.begin(), bs.end());
         if ((rc = m->wsplit.upload(fs.data(), fs.size() * 2))) return rc;
     }
-    {   // two-way f16 split streams (trunk_f16.hip), in consumption order; 3-D layer 2 keeps the three-way bf16 form (see that file)
+    {   // two-way f16 split streams (trunk_f16l.hip), in consumption order
         std::vector<uint16_t> fs, bs;
         TrunkF16Scales &sc = m->f16_scales;
         sc = TrunkF16Scales{};
@@ -540,11 +540,21 @@ extern "C" int dgdm_dynamics_create(DgdmDynamics **out, int kind, const DgdmTens
             if ((rc = fold_linear(sd, "linears.3", "linears.4", W, W1, &l2))) return rc;
             const std::vector<float> w1o3 = cols(l1.w, W1, IN1, 0, W);
             const Split2 s1(w1o3.data(), W1, W);
-            const Split3 s2(l2.w.data(), W, W1);
+            const Split2 s2(l2.w.data(), W, W1);
             sc.ew_l1 = s1.ew;
+            sc.ew_l2 = s2.ew;                             // (the transposed image of the last layer back has the same largest entry: checked below)
+            // the largest absolute row sum of layer 1's embedding columns: |W1o x| <= l1_norm1 max |x| bounds a row of layer 1 before it exists,
+            // which is what fixes the row's f16 scale for layer 2 (trunk_f16l.hip, front)
+            float n1 = 0.f;
+            for (int j = 0; j < W1; ++j) {
+                double a = 0.0;
+                for (int k = 0; k < W; ++k) a += std::fabs((double)w1o3[(size_t)j * W + k]);
+                n1 = std::max(n1, (float)(a * (1.0 + 1e-6)));
+            }
+            sc.l1_norm1 = n1;
             for (int kb = 0; kb < 16; ++kb) {
                 for (int ks = 0; ks < 16; ++ks) s1.emit(fs, kb, ks / 2, ks % 2);                    // layer-1 block kb: 16 K-steps x [h l]
-                for (int pp = 0; pp < 4; ++pp)                                                      // layer 2, input block kb (bf16 x 3)
+                for (int pp = 0; pp < 4; ++pp)                                                      // layer 2, input block kb: 2 K-steps x 4 pairs x [A.h A.l B.h B.l]
                     for (int sx = 0; sx < 2; ++sx)
                         for (int blk = 2 * pp; blk < 2 * pp + 2; ++blk) s2.emit(fs, blk, kb, sx);
             }
@@ -563,7 +573,7 @@ extern "C" int dgdm_dynamics_create(DgdmDynamics **out, int kind, const DgdmTens
         if (kind == 3) {
             const std::vector<float> w2t = transpose(l2.w.data(), W, W1);                                          // [512][256]
             const Split2 st(w2t.data(), W1, W);
-            sc.ew_l2 = st.ew;
+            DGDM_REQUIRE(st.ew == sc.ew_l2, DGDM_EINVAL, "f16 split: layer 2 and its transpose disagree about their scale");
             for (int kb = 0; kb < 16; ++kb)
                 for (int ks = 0; ks < 16; ++ks) st.emit(bs, kb, ks / 2, ks % 2);
         }

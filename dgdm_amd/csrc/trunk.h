@@ -35,6 +35,7 @@ struct TrunkParams {
     const float  *Atab;       // table mode: [nchain*B][W1]; rows mode: [rows][W1]
     const float  *Ptab;       // [C][W1]  (table mode)
     const float  *PtabT;      // the same, tiled per 32 cells in operand layout (smallnet.h tile_table)
+    const float  *Pmax;       // [C] largest magnitude of a cell's row of Ptab (trunk_f16l.hip: the f16 scale of 3-D layer 2's input); may be null elsewhere
     const TrunkObjective *obj;// [nchain]
     const float  *rowcoef;    // [nchain][R] or null
     float        *partial;    // [ntiles][W1]
@@ -53,14 +54,14 @@ int trunk_launch(int kind, bool rows_mode, bool fwd_only, const TrunkParams &p, 
 // backward.  p.Wfwd / p.Wbwd point at the split streams (DgdmDynamics::fill_trunk_split).
 int trunk_split_launch(int kind, const TrunkParams &p, hipStream_t s);
 
-// float32 contractions as three f16 MFMA products on two-way split, power-of-two scaled operands (trunk_f16.hip): table mode, forward +
+// float32 contractions as three f16 MFMA products on two-way split, power-of-two scaled operands (trunk_f16l.hip): table mode, forward +
 // backward.  p.Wfwd / p.Wbwd point at the f16 streams (DgdmDynamics::fill_trunk_f16), sc carries the weight matrices' scale exponents.
 struct TrunkF16Scales {
     int ew_mid[8];            // 256 -> 256 stack layer l (the same for W and its transpose)
-    int ew_l1, ew_l2;         // 3-D: layer 1's object-embedding columns (forward), layer 2 transposed (the last layer back)
+    int ew_l1, ew_l2;         // 3-D: layer 1's object-embedding columns; layer 2 (the same for its transpose, the last layer back)
+    float l1_norm1;           // 3-D: largest absolute row sum of layer 1's object-embedding columns (bounds a row of layer 1 from its input)
 };
-int trunk_f16_launch(int kind, const TrunkParams &p, const TrunkF16Scales &sc, hipStream_t s);
-// the same with the weight stream shared by the workgroup's four waves through LDS (trunk_f16l.hip)
+// (the weight stream is shared by the workgroup's four waves through LDS: trunk_f16l.hip)
 int trunk_f16l_launch(int kind, const TrunkParams &p, const TrunkF16Scales &sc, hipStream_t s);
 
 // bf16-contraction variant (trunk_bf16.hip): table mode, forward + backward only.  p.Wfwd / p.Wbwd point at the bf16 streams

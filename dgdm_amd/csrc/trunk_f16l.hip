@@ -1,23 +1,41 @@
-// trunk_f16.hip with the weight stream SHARED by the workgroup's four waves through LDS: the float32 trunk the library runs by default
-// (DGDM_F16_RING=1 in the environment selects the per-wave ring form of trunk_f16.hip, same results bit for bit).
+// Fused dynamics trunk, forward + input-gradient backward (same contract as trunk_split_kernel, trunk_split.hip), float32-grade on the f16
+// matrix pipe: the float32 trunk the library runs by default.
 //
-// trunk_f16_kernel pulls the whole weight stream - 683 bytes per MFMA - through the CU's L1 once per wave, 85 B/clk/CU asked of a path that
-// delivers ~50 (phase stamps: a 256 -> 256 layer takes 22 k cycles for 12.3 k of MFMA issue).  The four waves of a workgroup consume the
-// SAME stream, so here each wave fetches a QUARTER of every 16 KiB chunk, straight into LDS (buffer_load_dwordx4 ... lds: no staging
-// registers), and all four read their MFMA A operands from there (ds_read_b128, 1 KiB per instruction, linear: conflict-free): a quarter
-// of the L1 traffic.  Pipeline (chunk = 16 entries = one K-step of all four output-block pairs): four LDS slots; while chunk c is
-// consumed, c + 1 and c + 2 are in flight; before the LAST group of chunk c every wave waits for its own quarter of c + 1 (s_waitcnt
-// vmcnt(4): c + 2's four loads may stay in flight), one s_barrier makes the whole chunk visible - and proves every wave done reading
-// chunk c - 1 ... c (a group's operands are read one group ahead) - then c + 3 is issued into the slot of c - 1.  One barrier per 768
-// cycles of MFMA issue.  A wave without a tile runs the last tile again and stores nothing (the barriers need all four).  Arithmetic,
-// scaling, masks, stream layout: trunk_f16.hip.
+// Arithmetic.  Every float32 product as THREE f16 MFMAs instead of six bf16 ones:
+//     x = x_h + x_l,  x_h = f16(x),  x_l = f16(x - x_h)   (x - x_h is exact in float32; 11 + 11 significant bits, 2^-23 of x at worst)
+//     w x  ~  w_h x_h + w_h x_l + w_l x_h                  (each exact in float32; the dropped w_l x_l is below 2^-22 of the product)
+// on v_mfma_f32_32x32x16_f16 with float32 accumulation.  f16 has five exponent bits where bf16 has float32's eight, so both operands
+// are brought into its range by EXACT powers of two first:
+//   * weights: one scale per matrix, chosen on the host so that max |w 2^ew| lies in [2^12, 2^13) (Split2, models_api.hip);
+//   * activations / gradients: one scale per ROW of the 32-row tile, from the row's largest magnitude at the layer's input (128
+//     v_max per lane + one exchange with the lane that holds the row's other half), max |x 2^k| in [2^12, 2^13); entries 2^16 below
+//     their row's maximum keep their full 22 bits, smaller ones an absolute error of 2^-38 of the maximum;
+//   * the one input that is consumed while it is still being produced - 3-D layer 1's output, block by block into layer 2 - takes its
+//     row scale from an upper BOUND known before the first block exists: |z_j| <= max |A[finger]| + max |P[cell]| + ||W1o_j||_1 max |x|
+//     (the two table terms' largest magnitudes: one reduction per tile, one array built with the pose table; the largest absolute row
+//     sum of the weights: host).  A bound 2^b above the true maximum only lifts the absolute floor from 2^-38 to 2^(b - 38) of it.
+// The accumulators then hold the true pre-activations times 2^E, E = (input scale) + ew per row; ReLU and its sign bits do not care, the
+// bias is added as b 2^E, and E is taken out where true values are needed (the output layer, the folded tile sums).  Measured against
+// float64 (scripts/micro/split_mfma.hip, K = 256, He-init weights, post-ReLU inputs): rms error 1.9e-7 of the rms output, between the
+// 1.6e-7 of the six-product bf16 form and the 2.0e-7 of the v_mfma_f32 chain.  Half the matrix-pipe instructions and two thirds of the
+// weight bytes of trunk_split.hip.  Structure, register residency and sign-bit masks are those of trunk_split.hip (read that file's
+// header first); stream entries per (K-step, output-block pair): [A.h A.l B.h B.l], per block-out K-step: [h l].
+//
+// The weight stream is SHARED by the workgroup's four waves through LDS.  Pulled through the CU's L1 once per wave (the ring form of
+// round 4's first version, 683 bytes per MFMA) it arrived at ~50 of the 85 B/clk/CU the MFMAs ask for: a 256 -> 256 layer took 22 k
+// cycles for 12.3 k of MFMA issue.  The four waves consume the SAME stream, so each wave fetches a QUARTER of every 16 KiB chunk,
+// straight into LDS (buffer_load_dwordx4 ... lds: no staging registers), and all four read their MFMA A operands from there
+// (ds_read_b128, 1 KiB per instruction, linear: conflict-free): a quarter of the L1 traffic.  Pipeline (chunk = 16 entries = one K-step
+// of all four output-block pairs): four LDS slots; while chunk c is consumed, c + 1 and c + 2 are in flight; before the LAST group of
+// chunk c every wave waits for its own quarter of c + 1 (s_waitcnt vmcnt(4): c + 2's four loads may stay in flight), one s_barrier
+// makes the whole chunk visible - and proves every wave done reading chunk c - 1 ... c (a group's operands are read one group ahead) -
+// then c + 3 is issued into the slot of c - 1.  One barrier per 768 cycles of MFMA issue.  A wave without a tile runs the last tile
+// again and stores nothing (the barriers need all four).
 //
 // The LDS-DMA loads are issued from inline assembly (LStream::issue says why: hipcc puts s_waitcnt vmcnt(0) in front of every LDS read
-// that follows an LDS-DMA load it knows of).  Measured (MI355X, -DDGDM_F16_STAMPS, 3-D): front 135 k cycles, a 256 -> 256 layer forward
-// 22.5 k / backward 19 k (12.3 k of MFMA issue; the counted wait + barrier of advance() are 30 k of the kernel's 465 k), last layer back +
-// fold 62 k: 7.9 ms per 32-pair launch against the ring form's 8.5, 2-D 10.8 against 11.6.  scripts/micro/mfma_dep.hip: the group of six
-// MFMAs + the splitting + four ds_read_b128 runs at 223 cycles on its own (14.3 k per layer), so what is left is the stream itself (LDS
-// written by the DMA while it is read, barrier skew between the four waves), not the instruction mix.
+// that follows an LDS-DMA load it knows of).  scripts/micro/mfma_dep.hip: the group of six MFMAs + the splitting + four ds_read_b128
+// runs at 223 cycles on its own (14.3 k per layer); in the kernel a group takes 270-295: what is left is the stream itself (LDS written
+// by the DMA while it is read, barrier skew between the four waves), not the instruction mix.  Measured numbers: DESIGN.md 4.12.
 #include "common.h"
 #include <algorithm>
 #include "mfma_chain.h"
@@ -35,15 +53,11 @@ namespace f16l {
 
 typedef _Float16 hf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 hf16x2_t __attribute__((ext_vector_type(2)));
-typedef __bf16 hb16x8_t __attribute__((ext_vector_type(8)));
 typedef float hf32x2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t hu32x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x16 hmfma(const v4f32 a, const hu32x4_t b, const f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8_t, a), __builtin_bit_cast(hf16x8_t, b), c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x16 bmfma(const v4f32 a, const hu32x4_t b, const f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hb16x8_t, a), __builtin_bit_cast(hb16x8_t, b), c, 0, 0, 0);
 }
 
 // 2^e as a float (e clamped to the normal range)
@@ -65,15 +79,6 @@ __device__ __forceinline__ void split2(float lo, float hi, uint32_t &ph, uint32_
     ph = __builtin_bit_cast(uint32_t, h);
     pl = __builtin_bit_cast(uint32_t, __builtin_convertvector(d, hf16x2_t));
 }
-// bf16 three-way split of trunk_split.hip (3-D layer 2)
-__device__ __forceinline__ void split3(float lo, float hi, uint32_t &ph, uint32_t &pm, uint32_t &pl) {
-    ph = pack_bf16(lo, hi);
-    const float r0 = lo - __uint_as_float(ph << 16), r1 = hi - __uint_as_float(ph & 0xffff0000u);
-    pm = pack_bf16(r0, r1);
-    const float s0 = r0 - __uint_as_float(pm << 16), s1 = r1 - __uint_as_float(pm & 0xffff0000u);
-    pl = pack_bf16(s0, s1);
-}
-
 struct Act2 {
     hu32x4_t v[2][8][2];      // [piece][32-feature block][K-step]
 };
@@ -145,23 +150,6 @@ struct LStream {
         accA = hmfma(w[0], xh, accA);        \
         accB = hmfma(w[2], xh, accB);        \
     } while (0)
-// six-product bf16 step of trunk_split.hip (w: [A.h A.m A.l B.h B.m B.l])
-#define B16_STEP(accA, accB, w, xh, xm, xl)  \
-    do {                                     \
-        accA = bmfma(w[2], xh, accA);        \
-        accB = bmfma(w[5], xh, accB);        \
-        accA = bmfma(w[0], xl, accA);        \
-        accB = bmfma(w[3], xl, accB);        \
-        accA = bmfma(w[1], xm, accA);        \
-        accB = bmfma(w[4], xm, accB);        \
-        accA = bmfma(w[1], xh, accA);        \
-        accB = bmfma(w[4], xh, accB);        \
-        accA = bmfma(w[0], xm, accA);        \
-        accB = bmfma(w[3], xm, accB);        \
-        accA = bmfma(w[0], xh, accA);        \
-        accB = bmfma(w[3], xh, accB);        \
-    } while (0)
-
 // One 256 -> 256 layer, input-streaming (trunk_split.hip stream_layer).  Yp: the previous layer's accumulators = true values x 2^E per
 // row (E: this lane's row); on return Y = this layer's accumulators and E their scale.  ew: the weight matrix' scale exponent.
 // wn: the operands of the NEXT group to be consumed (read from LDS one group ahead); precondition of every consumer below: wn holds the
@@ -356,8 +344,8 @@ __global__ __launch_bounds__(256, 1) void trunk_f16l_kernel(const TrunkParams p,
     const lds_f4_t *sbias = (const lds_f4_t *)small, *swout = (const lds_f4_t *)small + 512;
 
     if (KIND == 3) {
-        // ---- 3-D layers 1 and 2, streamed over the 16 blocks of the 512-wide layer 1.  Layer 1 (input: the embedding row, scale known up
-        // front): f16; layer 2 (input arrives block by block): six-product bf16 on true values, as trunk_split.hip
+        // ---- 3-D layers 1 and 2, streamed over the 16 blocks of the 512-wide layer 1.  Layer 1's input is the embedding row (scale from its
+        // largest entry); layer 2's input arrives block by block and takes its row scale from a bound (below)
 #pragma unroll
         for (int j = 0; j < 4; ++j) wn[j] = ls.read(j);
         HSTAMP(36);
@@ -365,12 +353,27 @@ __global__ __launch_bounds__(256, 1) void trunk_f16l_kernel(const TrunkParams p,
         const int kx = split_rows(Y, X);
         HSTAMP(37);
         const float un1 = pow2f(-(kx + sc.ew_l1));            // layer-1 accumulators -> true values
+        // The f16 scale of layer 2's input rows, from a bound on layer 1's output that is known now (the file header says why a bound
+        // does): |z_j| <= max |A[finger]| + max |P[cell]| + ||W1o_j||_1 max |x|, and max |x| < 2^(13 - kx) by the choice of kx.
+        float am = 0.f;
+        {
+            const float4 a0 = *reinterpret_cast<const float4 *>(arow + 8 * lane), a1 = *reinterpret_cast<const float4 *>(arow + 8 * lane + 4);
+            am = fmaxf(fmaxf(fmaxf(fabsf(a0.x), fabsf(a0.y)), fmaxf(fabsf(a0.z), fabsf(a0.w))), fmaxf(fmaxf(fabsf(a1.x), fabsf(a1.y)), fmaxf(fabsf(a1.z), fabsf(a1.w))));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
+        }
+        const float zb = am + p.Pmax[valid ? c : p.C - 1] + sc.l1_norm1 * pow2f(13 - kx);
+        const int eb = (int)((__float_as_uint(zb) >> 23) & 0xffu);
+        const int k2 = (zb > 0.f && eb < 255) ? min(max(12 + 127 - eb, -100), 100) : 0;      // zb 2^k2 in [2^12, 2^13)
+        const float f2 = pow2f(k2);
+        E = k2 + sc.ew_l2;                                    // layer-2 accumulators = true values x 2^E
+        const float fb2 = pow2f(E);
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 b4 = feat4(p.b2, o, q, h4);
-                Y[o][4 * q + 0] = b4.x; Y[o][4 * q + 1] = b4.y; Y[o][4 * q + 2] = b4.z; Y[o][4 * q + 3] = b4.w;
+                Y[o][4 * q + 0] = b4.x * fb2; Y[o][4 * q + 1] = b4.y * fb2; Y[o][4 * q + 2] = b4.z * fb2; Y[o][4 * q + 3] = b4.w * fb2;
             }
         }
         f32x16 zero, tt;
@@ -406,7 +409,7 @@ __global__ __launch_bounds__(256, 1) void trunk_f16l_kernel(const TrunkParams p,
                 table_terms_request((kb + 1) & 15);
 #pragma unroll
                 for (int rr = 0; rr < 16; ++rr) z[rr] = fmaf(z[rr], un1, tt[rr]);       // the scaled sum back to true units (exact) + the table terms: one rounding
-                hu32x4_t ah[2], am[2], al[2];
+                hu32x4_t ah[2], al[2];
 #pragma unroll
                 for (int d = 0; d < 8; ++d) {
                     float lo = z[2 * d], hi = z[2 * d + 1];
@@ -415,44 +418,30 @@ __global__ __launch_bounds__(256, 1) void trunk_f16l_kernel(const TrunkParams p,
                     bits2 |= (hi > 0.f ? 1u : 0u) << (sh + 1);
                     asm("v_max_f32 %0, 0, %1" : "=v"(lo) : "v"(lo));
                     asm("v_max_f32 %0, 0, %1" : "=v"(hi) : "v"(hi));
-                    uint32_t a, bb, cc;
-                    split3(lo, hi, a, bb, cc);
-                    ah[d / 4][d % 4] = a; am[d / 4][d % 4] = bb; al[d / 4][d % 4] = cc;
+                    uint32_t a, bb;
+                    split2(lo * f2, hi * f2, a, bb);
+                    ah[d / 4][d % 4] = a; al[d / 4][d % 4] = bb;
                 }
                 if (kb == 8) HSTAMP(34);
-                // layer 2 (six-product bf16): 48 entries = three chunks, eight groups of six; the group's operands are read one group ahead,
-                // crossing into the next chunk where the group does (entry e of the pass lives in chunk e / 16)
-                {
-                    v4f32 w6[6];
+                // layer 2: 32 entries = two chunks, eight groups of [A.h A.l B.h B.l]; the group's operands are read one group ahead (wn holds
+                // the first group on entry, the next pass' entries 0 .. 3 - layer 1's next block, or the stack's first group - on return)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) w6[j] = wn[j];
-                    w6[4] = ls.read(4); w6[5] = ls.read(5);
-                    int ready = 0;                                       // chunks of this pass already made readable beyond the first
+                for (int gq = 0; gq < 8; ++gq) {
+                    const int pp = gq / 2, sx = gq % 2;
+                    v4f32 w[4];
 #pragma unroll
-                    for (int gq = 0; gq < 8; ++gq) {
-                        const int pp = gq / 2, sx = gq % 2;
-                        v4f32 w[6];
+                    for (int j = 0; j < 4; ++j) w[j] = wn[j];
+                    if ((gq & 3) == 3) ls.advance();
 #pragma unroll
-                        for (int j = 0; j < 6; ++j) w[j] = w6[j];
-                        // next group's entries (the following pass' first two K-steps after the last group: [h l] [h l] of layer 1's next block)
-#pragma unroll
-                        for (int j = 0; j < 6; ++j) {
-                            const int e = 6 * (gq + 1) + j;              // entry of this pass; 48 .. 51 = entries 0 .. 3 of the next pass
-                            if (gq == 7 && j >= 4) break;
-                            if (e / 16 > ready) { ls.advance(); ++ready; }
-                            w6[j] = ls.read(e % 16);
-                        }
-                        B16_STEP(Y[2 * pp], Y[2 * pp + 1], w, ah[sx], am[sx], al[sx]);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) wn[j] = w6[j];
+                    for (int j = 0; j < 4; ++j) wn[j] = ls.read(((gq + 1) & 3) * 4 + j);
+                    F16_STEP(Y[2 * pp], Y[2 * pp + 1], w, ah[sx], al[sx]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 if (kb == 8) HSTAMP(35);
             }
             smask[blk / 2][tid] = bits2;
         }
-        slot = 8;                                             // wn: entries 0 .. 3 of the stack's first chunk already
+        slot = 8;                                             // wn: entries 0 .. 3 of the stack's first chunk already; E: layer 2's row scale
     }
     if (KIND == 2) {
 #pragma unroll
