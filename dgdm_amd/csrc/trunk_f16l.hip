@@ -44,7 +44,7 @@
 namespace dgdm {
 #ifdef DGDM_F16_STAMPS
 // experiment hook: cycle stamps of one wave at the phase boundaries (printed by trunk_f16l_launch)
-__device__ long long g_f16l_stamps[40];
+__device__ long long g_f16l_stamps[48];
 #define HSTAMP(i) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) g_f16l_stamps[i] = clock64(); } while (0)
 #else
 #define HSTAMP(i) do { } while (0)
@@ -269,6 +269,25 @@ __device__ __forceinline__ int split_rows(const f32x16 (&Y)[8], Act2 &X) {
             X.v[0][o][d / 4][d % 4] = a; X.v[1][o][d / 4][d % 4] = b;
         }
     return k;
+}
+
+// rows_sum (mfma_chain.h: the sum over the tile's 32 rows, five DPP adds pairing up as an xor butterfly) of TWO values, as v_add_f32_dpp
+// - one instruction per step where update_dpp + add compile to a v_mov_b32_dpp, an add and a zero fill - with the two dependent chains
+// interleaved (a DPP read needs two wait states behind the VALU write of its source: the other chain's instruction and one s_nop).
+// Same operations in the same order: bit-identical.  Valid on the upper 16 lanes of each half-wave (ROWS_SUM_LANE).
+__device__ __forceinline__ void rows_sum2(float &a, float &b) {
+    asm("s_nop 1\n\t"             // (the compiler does not know that what follows reads its operands through DPP)
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf"
+        : "+v"(a), "+v"(b));
 }
 
 }  // namespace f16l
@@ -532,6 +551,7 @@ __global__ __launch_bounds__(256, 1) void trunk_f16l_kernel(const TrunkParams p,
         }
     } else {
         // 3-D: one more layer back (256 -> 512), block by block, straight into the fold (trunk_split.hip)
+        HSTAMP(40);
         Act2 X;
         const int kt = split_rows(Y, X);
         const float un = pow2f(-(E + kt + sc.ew_l2));
@@ -540,20 +560,24 @@ __global__ __launch_bounds__(256, 1) void trunk_f16l_kernel(const TrunkParams p,
         for (int rr = 0; rr < 16; ++rr) zero[rr] = 0.f;
         f32x16 g = block_out(ls, wn, X, zero, zero, [](int) __attribute__((always_inline)) {});
         float4 acc;
+        // two values at a time (odd K-steps): the two sums' dependent DPP chains interleaved in one block of assembly (rows_sum2)
         auto fold_one = [&](const int rr, const int kb, const uint32_t bits) __attribute__((always_inline)) {
-            const float v = rows_sum(apply_bit(g[rr] * un, bits, rr));
-            if (rr % 4 == 0) acc.x = v;
-            else if (rr % 4 == 1) acc.y = v;
-            else if (rr % 4 == 2) acc.z = v;
+            if ((rr & 1) == 0) return;
+            float a = apply_bit(g[rr - 1] * un, bits, rr - 1), b = apply_bit(g[rr] * un, bits, rr);
+            rows_sum2(a, b);
+            if (rr % 4 == 1) { acc.x = a; acc.y = b; }
             else {
-                acc.w = v;
+                acc.z = a; acc.w = b;
                 if (n == ROWS_SUM_LANE && live) *reinterpret_cast<float4 *>(dst + 32 * kb + 8 * (rr / 4) + h4) = acc;
             }
         };
+        HSTAMP(41);
         for (int kb = 1; kb < 16; ++kb) {
+            if (kb == 8) HSTAMP(42);
             const uint32_t bits = smask[(kb - 1) / 2][tid] >> (16 * ((kb - 1) & 1));
             const f32x16 gn = block_out(ls, wn, X, zero, zero, [&](const int ks) __attribute__((always_inline)) { fold_one(ks, kb - 1, bits); });
             g = gn;
+            if (kb == 8) HSTAMP(43);
         }
         const uint32_t bits = smask[7][tid] >> 16;
 #pragma unroll
@@ -579,14 +603,14 @@ int trunk_f16l_launch(int kind, const TrunkParams &p, const TrunkF16Scales &sc, 
     prof_end(s, DGDM_STAGE_TRUNK, rows * per_row);
 #ifdef DGDM_F16_STAMPS
     {
-        long long st[40];
+        long long st[48];
         hipStreamSynchronize(s);
         hipMemcpyFromSymbol(st, HIP_SYMBOL(g_f16l_stamps), sizeof(st));
         fprintf(stderr, "f16l stamps kind %d:", kind);
         long long prev = st[0];
         for (int i = 1; i <= 20; ++i) if (st[i]) { fprintf(stderr, " [%d]%lld", i, st[i] - prev); prev = st[i]; }
-        fprintf(stderr, " total %lld; advance(): counted wait %lld, barrier %lld; last fwd layer: prologue %lld first items %lld loop %lld; bwd: %lld %lld %lld; front block 8: layer-1 block %lld, epilogue %lld, layer-2 pass %lld; before the front loop: stream start + embedding row %lld, its split %lld, bias + first table terms %lld\n", st[20] - st[0], st[21], st[22],
-                st[23] - st[1 + p.n_mid - 1], st[24] - st[23], st[25] - st[24], st[26] - st[10 + p.n_mid - 1], st[27] - st[26], st[28] - st[27], st[33] - st[32], st[34] - st[33], st[35] - st[34], st[36] - st[0], st[37] - st[36], st[38] - st[37]);
+        fprintf(stderr, " total %lld; advance(): counted wait %lld, barrier %lld; last fwd layer: prologue %lld first items %lld loop %lld; bwd: %lld %lld %lld; front block 8: layer-1 block %lld, epilogue %lld, layer-2 pass %lld; before the front loop: stream start + embedding row %lld, its split %lld, bias + first table terms %lld; tail: split + first block %lld, block 8 with the fold of block 7 %lld\n", st[20] - st[0], st[21], st[22],
+                st[23] - st[1 + p.n_mid - 1], st[24] - st[23], st[25] - st[24], st[26] - st[10 + p.n_mid - 1], st[27] - st[26], st[28] - st[27], st[33] - st[32], st[34] - st[33], st[35] - st[34], st[36] - st[0], st[37] - st[36], st[38] - st[37], st[41] - st[40], st[43] - st[42]);
     }
 #endif
     return DGDM_OK;
