@@ -227,7 +227,7 @@ ARITHMETIC = {"f32_bf16x6": "float32-grade: every float32 product as six bf16 MF
               "bf16": "operands rounded to bf16, float32 accumulation"}
 # matrix pipe busy share from the recorded PMC passes (profiles/r04_pmc_kernels.md, r03 for the six-product kernel:
 # SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE); recorded, not live
-PIPE_BUSY_RECORDED = {("3d", "f32_f16x3"): 0.53, ("2d", "f32_f16x3"): 0.54, ("3d", "f32_bf16x6"): 0.71, ("2d", "f32_bf16x6"): 0.73, ("3d", "bf16"): 0.54}
+PIPE_BUSY_RECORDED = {("3d", "f32_f16x3"): 0.54, ("2d", "f32_f16x3"): 0.54, ("3d", "f32_bf16x6"): 0.71, ("2d", "f32_bf16x6"): 0.73, ("3d", "bf16"): 0.54}
 # algorithmic HBM bytes of ONE cond_fn's trunk launch per (pair, object): the xobj rows (1 KiB per replicated row, 3-D) or nothing of size R (2-D:
 # tables only) + the weights once
 HBM_ALGORITHMIC_BYTES = {"3d": 36000 * 32 / 32 * 1024.0 + 7.2e6 / 32, "2d": 17e6 / 4}
