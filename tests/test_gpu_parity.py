@@ -59,6 +59,26 @@ def test_unet_mixed_timesteps_and_batch(dev):
     assert util.rel_l2(y.cpu(), orc.unet1d_forward(sd, x, t)) < REL
 
 
+@pytest.mark.parametrize("L", [14, 42, 44])
+def test_unet_arithmetic_modes_vs_float64(dev, L):
+    """The eps-net's three float32-grade statements against the oracle evaluated in float64 (generator/diffusion_utils.py:238-285): the
+    default (three f16 MFMA products on exactly scaled two-way splits, csrc/unet.hip conv_mfma_f16x3) and the float32 MFMA chain both
+    within 1e-6 - the default no farther than the chain + 1e-7 - and within 2e-6 of each other; bf16 mode at its own level (1e-2).
+    L = 44: the split form's LDS slabs do not fit beside one sample's activations there, the library runs the chain (same numbers)."""
+    sd = util.unet_sd(7)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    x = torch.randn(64, L, 1, generator=torch.Generator().manual_seed(3))
+    t = torch.randint(0, 15, (64,), generator=torch.Generator().manual_seed(1))
+    ref = orc.unet1d_forward(sd64, x.double(), t)
+    out = {m: engine.Unet1d(sd, contraction_dtype=m).forward(x.to(dev), t.to(dev)).cpu().double() for m in ("f32", "f32_mfma", "bf16")}
+    err = {m: float((o - ref).norm() / ref.norm()) for m, o in out.items()}
+    assert err["f32_mfma"] < 1e-6 and err["f32"] < 1e-6 and err["f32"] <= err["f32_mfma"] + 1e-7, err
+    assert float((out["f32"] - out["f32_mfma"]).norm() / ref.norm()) < 2e-6
+    assert 1e-4 < err["bf16"] < 2e-2, err
+    if L == 44:
+        assert torch.equal(out["f32"], out["f32_mfma"])
+
+
 def test_ddim_step_and_unguided_chain(dev):
     sd = util.unet_sd(11)
     net = engine.Unet1d(sd)
