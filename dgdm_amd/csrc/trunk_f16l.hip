@@ -104,6 +104,9 @@ struct LStream {
     // Unseen by the compiler the loads only make its own vmcnt waits longer than necessary (memory returns in order), never too short;
     // what makes a slot safe to read is advance()'s counted wait + barrier.
     __device__ __forceinline__ void issue(int c) {
+#ifdef DGDM_EXP_NODMA
+        if (c > 2) return;         // timing experiment (wrong results): no LDS-DMA traffic beside the reads
+#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int e = 4 * wave + j;
