@@ -50,7 +50,7 @@ struct DgdmDynamics {
     size_t fwd16_bytes = 0, bwd16_bytes = 0, sa3_16_offset = 0;     // sa3 bf16 image (z16_kernel) follows the two trunk streams
     dgdm::DevBuf wsplit;    // split-float32 weight streams of the trunk (trunk_split.hip): forward then backward
     size_t fwds_bytes = 0, bwds_bytes = 0;
-    dgdm::DevBuf wf16;      // two-way f16 split streams of the trunk (trunk_f16.hip): forward then backward
+    dgdm::DevBuf wf16;      // two-way f16 split streams of the trunk (trunk_f16l.hip): forward then backward
     size_t fwdh_bytes = 0, bwdh_bytes = 0;
     dgdm::TrunkF16Scales f16_scales{};
 

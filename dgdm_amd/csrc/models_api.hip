@@ -320,7 +320,7 @@ struct Split3 {
     }
 };
 
-// ---- two-way f16 split streams (csrc/trunk_f16.hip): w 2^ew = h + l, both f16, max |w 2^ew| in [2^12, 2^13)
+// ---- two-way f16 split streams (csrc/trunk_f16l.hip): w 2^ew = h + l, both f16, max |w 2^ew| in [2^12, 2^13)
 struct Split2 {
     std::vector<float> p[2];
     int K = 0, ew = 0;
@@ -350,7 +350,7 @@ struct Split2 {
             }
     }
 };
-// 256 -> 256 layer (trunk_f16.hip stream_layer): 16 K-steps x 4 output-block pairs x [A.h A.l B.h B.l]; returns the matrix' scale exponent
+// 256 -> 256 layer (trunk_f16l.hip stream_layer): 16 K-steps x 4 output-block pairs x [A.h A.l B.h B.l]; returns the matrix' scale exponent
 int f16_layer_stream(std::vector<uint16_t> &dst, const float *w /*[256][256]*/) {
     const Split2 sp(w, 256, 256);
     for (int ks = 0; ks < 16; ++ks)

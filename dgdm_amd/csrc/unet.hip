@@ -261,7 +261,7 @@ __device__ void conv_mfma_bf16(const ConvArgs a, const lds_f *in, int CPi, lds_f
 
 // The same convolution, float32-grade, on the f16 matrix pipe (the default): every float32 product as THREE f16 products,
 //     w x ~ w_h x_h + w_h x_l + w_l x_h,   x_h = f16(x), x_l = f16(x - x_h) (exact residual; 11 + 11 significant bits),
-// on v_mfma_f32_16x16x32_f16 with float32 accumulation - the arithmetic of the dynamics trunk (trunk_f16.hip) and the same two exact
+// on v_mfma_f32_16x16x32_f16 with float32 accumulation - the arithmetic of the dynamics trunk (trunk_f16l.hip) and the same two exact
 // power-of-two scales that keep both operands inside f16's five exponent bits: one per convolution's weights, fixed on the host (a.ew,
 // models_api.hip conv_image_f16x3), and one per (sample, convolution input), from the largest magnitude among the rows the convolution
 // reads (input_scale_exp).

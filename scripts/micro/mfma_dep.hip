@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256, 1) void k(float *out, long long *cyc, float a0
     if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
 }
 
-// the f16x3 trunk's group: six f16 MFMAs on two accumulators + the splitting of one input pair (trunk_f16.hip item()); VARIANT 0: as the
+// the f16x3 trunk's group: six f16 MFMAs on two accumulators + the splitting of one input pair (trunk_f16l.hip item()); VARIANT 0: as the
 // kernel has it, 1: without the splitting, 2: the splitting's results do not feed the MFMAs, 3: 0 + the four A operands of every group
 // read from LDS one group ahead (ds_read_b128), 4: 1 + those reads, 5: 4 with the reads' results unused (MFMAs on constant operands)
 typedef _Float16 hf16x8 __attribute__((ext_vector_type(8)));
