@@ -186,19 +186,21 @@ __device__ __forceinline__ void stream_layer(LStream &ls, v4f32 (&wn)[4], const 
     HSTAMP(FWD ? 23 : 26);
     uint32_t mk = FWD ? 0u : smask[slot_in][tid];
     auto item = [&](const f32x16 &y, const int blk, const int d) __attribute__((always_inline)) {
-        float lo = y[2 * d], hi = y[2 * d + 1];
+        // scale first (one packed multiply; exact, f is a power of two), then ReLU / mask: the same values as the other way round
+        const hf32x2_t v = hf32x2_t{y[2 * d], y[2 * d + 1]} * hf32x2_t{f, f};
+        float lo = v.x, hi = v.y;
         const int sh = 2 * d + 16 * (blk & 1);
         if (FWD) {
-            mk |= (lo > 0.f ? 1u : 0u) << sh;
-            mk |= (hi > 0.f ? 1u : 0u) << (sh + 1);
+            mk |= (y[2 * d] > 0.f ? 1u : 0u) << sh;
+            mk |= (y[2 * d + 1] > 0.f ? 1u : 0u) << (sh + 1);
             asm("v_max_f32 %0, 0, %1" : "=v"(lo) : "v"(lo));
             asm("v_max_f32 %0, 0, %1" : "=v"(hi) : "v"(hi));
         } else {
-            lo = ((mk >> sh) & 1u) ? lo : 0.f;
-            hi = ((mk >> (sh + 1)) & 1u) ? hi : 0.f;
+            lo = apply_bit(lo, mk, sh);
+            hi = apply_bit(hi, mk, sh + 1);
         }
         uint32_t a, b;
-        split2(lo * f, hi * f, a, b);
+        split2(lo, hi, a, b);
         P[blk & 1][0][d / 4][d % 4] = a; P[blk & 1][1][d / 4][d % 4] = b;
     };
 #pragma unroll
