@@ -253,8 +253,18 @@ def test_bench_spawns_ranks_itself(dev):
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--pairs", "2", "--backend", "gloo",
                         "--no-cpu-baseline", "--no-extra"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
+    out = r.stdout.strip().splitlines()
+    assert len(out) == 1 and len(out[0]) < 4096, (len(out), [len(o) for o in out])      # only rank 0 writes stdout, and only the headline
+    line = json.loads(out[-1])
     assert line["n_gpus"] == 2 and line["steps"] == 1 and line["value"] > 0 and line["config"]["pairs_per_gpu_per_step"] == 2
+    assert "cpu_baseline" not in line and line["roofline"]["frac"] > 0
+    # a rank that dies after the rendezvous: the parent stops the other rank and exits non-zero instead of waiting for ever
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--pairs", "2", "--backend", "gloo",
+                        "--no-cpu-baseline"], capture_output=True, text=True, env=dict(env, DGDM_BENCH_TEST_DIE_RANK="1"), timeout=300)
+    assert r.returncode != 0 and "rank process 1 exited" in r.stderr and time.time() - t0 < 240
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]           # no headline from a broken run
     # without the test backend the launcher refuses to put two RCCL ranks on one GPU
     if torch.cuda.device_count() < 2:
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env, timeout=120)

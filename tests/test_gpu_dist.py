@@ -94,7 +94,10 @@ def test_bench_rank_body_on_rccl_world_size_1():
         r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extra"] + extra, cwd=root, env=env,
                            capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]
-        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-        assert line["n_gpus"] == 1 and line["steps"] == 3 and line["roofline"]["frac"] > 0
+        last = r.stdout.strip().splitlines()[-1]                      # what a tail-capturing driver keeps
+        assert len(last) < 4096, len(last)
+        line = json.loads(last)
+        assert line["n_gpus"] == 1 and line["steps"] == 3 and line["roofline"]["frac"] > 0 and line["roofline"]["avg_launch_ms"] > 0
+        assert all(not isinstance(v, (dict, list)) for v in line["roofline"].values())
         vals[tag] = line["value"]
     assert abs(vals["rccl"] / vals["plain"] - 1) < 0.03, vals

@@ -273,3 +273,37 @@ def test_trainer_draws_ahead_and_adopts_them():
             assert torch.equal(w[0], g[0]) and torch.equal(w[1], g[1])
         else:
             assert torch.equal(w, g)
+
+
+def test_bench_headline_is_compact_and_parses():
+    """The bench contract's one JSON line, built from canned numbers: under 4 KB (round 4's 20 KB line was cut by the driver's tail
+    capture and parsed as nothing), scalars only inside roofline / cpu_baseline, and it carries every key the driver reads."""
+    import json
+    import bench
+    m = {"samples": 20480, "secs": 1.2345678901, "world": 8, "steps": 20, "warmup": 5, "contraction": "f32", "workload": "3d", "pairs": 32, "B": 32, "S": 5,
+         "rows": 36000, "n_obj": 1, "draw_secs": 0.0123456789, "gloo": True}
+    roof = {"bound": "mfma", "kernel": "trunk_f16l_kernel", "achieved": 376.61438352316435, "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.15064575340926575,
+            "traffic": 1742654688.0, "traffic_fetch_bytes_raw": 1667157216.0, "traffic_write_bytes": 75497472.0, "traffic_vs_algorithmic": 1.4683048612796248,
+            "traffic_recorded": "profiles/r04_3d_pmc_hbm.json", "launches": 5, "avg_launch_ms": 7.2166893005371096, "algorithmic_flops_per_launch": 2717908992000.0,
+            "issued_flops_per_algorithmic_flop": 3, "matrix_pipe_issue_frac": 0.4519372602277972, "frac_algorithmic_vs_f32_peak": 2.394242743313187,
+            "pipe_busy_recorded": 0.54, "arithmetic": "f32_f16x3", "share_of_step": 0.5735658003847591, "step_frac": 0.09070971299343188,
+            "step_issue_frac": 0.263520217250933, "step_necessary_tflop": 14.26653696}
+    stages = {"trunk": 36.0834, "unet": 7.0088, "xobj": 7.4601, "tables": 11.5487, "guide_misc": 1.4827, "ddim": 0.0324, "profiled_step_wall": 64.45}
+    cpu = {"value": 0.0064026135, "unit": "samples/s", "cores": 32, "kind": "port", "sample": "1 run of 1 of the 71 sub-batches (512 of 36000 replicated rows) of one "
+           "cond_fn call (PointNet++ + trunk fwd, autograd bwd) + 1 eps-net forward, extrapolated to 36000 rows x 5 steps", "ms_per_denoise_step": 999591.8,
+           "cpu_seconds": 14.2}
+    line = json.dumps(bench.headline(m, roof, stages, cpu))
+    assert len(line) < 4096 and "\\n" not in line
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 8 and d["vs_baseline"] is None and d["scaling"] == "weak" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 20480 / 1.2345678901) < 1e-2 and abs(d["ms_per_step"] - 1234.5678901 / 20) < 1e-4
+    assert d["roofline"]["frac"] == pytest.approx(0.15064575, rel=1e-6) and d["roofline"]["bound"] == "mfma"
+    assert all(not isinstance(v, (dict, list)) for v in d["roofline"].values()) and all(not isinstance(v, (dict, list)) for v in d["cpu_baseline"].values())
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"])
+    # every workload / contraction label stays short enough
+    for w in bench.WORKLOAD_NAME:
+        for c in bench.DTYPE_LABEL:
+            assert len(json.dumps(bench.headline(dict(m, workload=w, contraction=c), roof, stages, cpu))) < 4096
