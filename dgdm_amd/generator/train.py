@@ -90,10 +90,22 @@ def fit(model: Diffusion, pts: np.ndarray, args, bounds, dev) -> Diffusion:
     if not hasattr(model, "lr_scheduler"):      # a resumed model (load_checkpoint) carries its schedule position
         model.configure_optimizers()
     model.to(dev)
+    if world > 1:
+        # Lightning wraps the module in DistributedDataParallel, whose constructor broadcasts rank 0's parameters and buffers (generator/
+        # train.py:147-162 with strategy 'ddp'): without it every rank would start from its own random eps-net and the averaged gradients
+        # would be taken at different weights.  A resumed model (same checkpoint file on every rank) already agrees and keeps its handle.
+        if getattr(model, "_unet_trainer", None) is None:
+            with torch.no_grad():
+                for t in list(model.noise_pred_net.parameters()) + list(model.noise_pred_net.buffers()):
+                    t.copy_(ddist.broadcast_from_rank0(t.detach().clone()))
+        # the noise / timestep draws of get_stats come from the device generator: a different stream per rank, as DDP workers have
+        torch.cuda.manual_seed((int(torch.initial_seed()) + 7919 * rank) & 0x7FFFFFFFFFFFFFFF)
     ckdir = os.path.join(args.save_dir, "checkpoints") if args.save_dir else None
     if ckdir and rank == 0:
         os.makedirs(ckdir, exist_ok=True)
-    kept, step, log = [], int(getattr(model, "global_step", 0)), []
+    step, log = int(getattr(model, "global_step", 0)), []
+    # save_top_k = 10 also counts the epoch files a resumed run finds in place
+    kept = sorted(os.path.join(ckdir, f) for f in os.listdir(ckdir) if f.startswith("epoch=") and f.endswith(".ckpt")) if ckdir and os.path.isdir(ckdir) else []
     val_loader = DataLoader(val_set, batch_size=args.batch_size, shuffle=False, num_workers=0, drop_last=False)
 
     def validate(limit=None):
@@ -142,6 +154,14 @@ def fit(model: Diffusion, pts: np.ndarray, args, bounds, dev) -> Diffusion:
                     os.remove(kept.pop(0))
     model.sync_model()
     model.train_log = log
+    if world > 1:
+        # every rank took the same Adam steps on the same averaged gradients from the same start: the replicas must be bit-identical
+        flat = torch.cat([p.detach().reshape(-1).double() for p in model.noise_pred_net.parameters()])
+        sums = ddist.all_gather_rows(torch.stack([flat.sum(), flat.abs().sum(), (flat * torch.arange(1, flat.numel() + 1, device=flat.device, dtype=flat.dtype)).sum()]))
+        if not bool((sums == sums[0]).all()):
+            raise RuntimeError(f"data-parallel replicas of the eps-net diverged: per-rank parameter checksums {sums.tolist()}")
+        if rank == 0:
+            print(f"[dgdm_amd] {world} ranks hold identical eps-net parameters (checksum {float(sums[0][1]):.9g})", flush=True)
     return model
 
 

@@ -229,3 +229,30 @@ def test_train_cli_end_to_end(tmp_path):
                        cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     assert "diffusion checkpoint" not in r.stderr          # no fallback to synthetic weights: the trained checkpoint was read
+
+
+def test_train_cli_two_ranks_hold_identical_replicas(tmp_path):
+    """`--mode=train` under a launcher (two ranks sharing this box's GPU, gloo for the collectives): rank 0's random eps-net is broadcast
+    before the first step (what Lightning's DDP wrap does, generator/train.py:147-162), every rank trains on its slice of the epoch's
+    permutation with averaged gradients, and fit() itself checks at the end that the replicas are bit-identical (it raises otherwise)."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "generator/train.py", "--num_fingers=320", f"--save_dir={tmp_path / 'out'}", "--learning_rate=1e-3", "--lr_warmup_steps=0",
+           "--val_step=100", "--num_workers=0", "--num_train_timesteps=15", "--num_inference_steps=5", "--ema_power=0.85", "--batch_size=32",
+           "--ctrlpts_dim=14", "--num_epochs=3"]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DGDM_DIST_BACKEND="gloo",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
+    assert "2 ranks hold identical eps-net parameters" in outs[0][0], outs[0][0][-2000:]
+    losses = [float(l.split("train/loss=")[1].split(",")[0]) for l in outs[0][0].splitlines() if "train/loss=" in l]
+    assert len(losses) == 3 and losses[-1] < losses[0], losses
+    assert "train/loss=" not in outs[1][0]                      # only rank 0 reports
