@@ -1,5 +1,6 @@
 // Model handles: weight packing/upload and the plain forward entry points of the C-ABI.
 #include "common.h"
+#include <climits>
 #include "blob.h"
 #include "models.h"
 #include <algorithm>
@@ -46,34 +47,43 @@ size_t conv_image16(std::vector<uint16_t> &dst, int cout, int cin, const std::ve
     return off;
 }
 
-// Two-piece f16 image for conv_mfma_f16x3: the weights times 2^ew (max |w 2^ew| in [2^12, 2^13): f16 has five exponent bits) as h = f16(.)
-// and l = f16(. - h); conv_image16's lane layout, the two pieces of an entry side by side, channel groups outside the taps:
-// [Cout/16][Cin/32][ntaps][h | l][64 lanes][8].
-// Appended to `dst`; returns the element offset, the exponent in *ew.
+// Two-piece f16 image for conv_mfma_f16x3: every OUTPUT CHANNEL's weights times its own exact power of two 2^e_co (max |w 2^e_co| over the
+// channel's row in [2^12, 2^13): f16 has five exponent bits, and a checkpoint whose per-channel gains span more than 2^16 inside one
+// convolution would otherwise push its small rows under f16's subnormal floor) as h = f16(.) and l = f16(. - h); conv_image16's lane layout,
+// the two pieces of an entry side by side, channel groups outside the taps: [Cout/16][Cin/32][ntaps][h | l][64 lanes][8], followed by the
+// Cout float32 factors 2^-e_co the kernel multiplies its sums by (it finds them right behind the image: 4 Cout Cin ntaps bytes in).
+// Appended to `dst`; returns the element offset.  *ew: always 0 (the per-matrix exponent of the first version, kept in the parameter block).
 template <class At>
 size_t conv_image_f16x3(std::vector<uint16_t> &dst, int cout, int cin, const std::vector<int> &taps, At at, int *ew) {
     const size_t off = dst.size();
     const int mt = cout / 16, g = cin / 32, nt = (int)taps.size();
-    float mx = 0.f;
-    for (int co = 0; co < cout; ++co)
+    std::vector<int> er(cout, 0);
+    for (int co = 0; co < cout; ++co) {
+        float mx = 0.f;
         for (int ci = 0; ci < cin; ++ci)
             for (int t = 0; t < nt; ++t) mx = std::max(mx, std::fabs(at(co, ci, taps[t])));
-    int e = 0;
-    if (mx > 0.f) std::frexp(mx, &e);               // mx = f 2^e, f in [0.5, 1)
-    *ew = 13 - e;
+        int e = 0;
+        if (mx > 0.f && std::isfinite(mx)) { std::frexp(mx, &e); er[co] = std::min(std::max(13 - e, -100), 100); }     // mx = f 2^e, f in [0.5, 1)
+    }
+    *ew = 0;
     auto bits = [](float x) { const _Float16 h = (_Float16)x; uint16_t u; memcpy(&u, &h, 2); return u; };
-    dst.resize(off + (size_t)2 * cout * cin * nt);
+    dst.resize(off + (size_t)2 * cout * cin * nt + (size_t)2 * cout);
     for (int m = 0; m < mt; ++m)
         for (int t = 0; t < nt; ++t)
             for (int gg = 0; gg < g; ++gg)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 8; ++j) {
-                        const float w = std::ldexp(at(16 * m + (lane & 15), 32 * gg + (j < 4 ? 4 * (lane >> 4) + j : 16 + 4 * (lane >> 4) + j - 4), taps[t]), *ew);
+                        const int co = 16 * m + (lane & 15);
+                        const float w = std::ldexp(at(co, 32 * gg + (j < 4 ? 4 * (lane >> 4) + j : 16 + 4 * (lane >> 4) + j - 4), taps[t]), er[co]);
                         const float h = (float)(_Float16)w;
                         const size_t entry = (((size_t)m * g + gg) * nt + t) * 2;             // channel-group-major: the kernel's K order
                         dst[off + (entry * 64 + lane) * 8 + j] = bits(h);
                         dst[off + ((entry + 1) * 64 + lane) * 8 + j] = bits(w - h);
                     }
+    for (int co = 0; co < cout; ++co) {
+        const float u = std::ldexp(1.0f, -er[co]);
+        memcpy(&dst[off + (size_t)2 * cout * cin * nt + 2 * co], &u, 4);
+    }
     return off;
 }
 
@@ -375,6 +385,76 @@ std::vector<float> tfreqs(int half) {
     return f;
 }
 
+// ---- Equilibration of the dynamics trunk (exact).  Hidden unit j of trunk layer l is carried as (its true value) x 2^e[l][j]: row j of
+// the folded layer l (weights and bias) is multiplied by 2^e[l][j] and column j of layer l + 1 (of the output layer after the last one) by
+// 2^-e[l][j].  ReLU commutes with a positive factor and a power of two changes no rounding, so in exact arithmetic AND in float32 (no
+// overflow / underflow) the network computes the same function bit for bit - every float32 form of the trunk (MFMA chain, bf16-rounded
+// operands, six-product split), the float64 tables of layer 1 and the Jacobian of the finger part see the same scaled fold and return
+// what they returned before.  What it buys: the f16 pieces of trunk_f16l.hip have ONE power-of-two scale per weight matrix; a
+// checkpoint whose BatchNorm-folded per-channel gains span more than ~2^16 inside a matrix would leave its small rows below f16's
+// subnormal floor (an absolute error where float32 has a relative one).  e[l][j] lifts every row's largest |w| into the binade of the
+// matrix' largest (after the previous layer's column factors), so rows - and, through the column factors, the next layer's inputs - are
+// balanced whatever the checkpoint's gains.  tests/test_gpu_range.py.
+struct TrunkEquil {
+    std::vector<std::vector<int>> e;         // [layer 0 .. 7][unit]
+    // units that are provably dead - a zero weight row and a bias <= 0, e.g. a BatchNorm channel with gamma = 0: relu gives exactly 0 for
+    // every input.  Their COLUMN of the next layer multiplies that zero and is dropped from it (bit-neutral for every float32 form: the
+    // products were +-0, the gradient into the unit is masked); left in place such a column - any size, it never mattered to the
+    // function - could set the next matrix' f16 scale and push the live weights under f16's floor.
+    std::vector<std::vector<char>> dead;
+    int W1 = 0;
+    static std::string lin(int l) { return "linears." + std::to_string(3 * l); }
+    static std::string bn(int l) { return "linears." + std::to_string(3 * l + 1); }
+    int out_of(int l) const { return l == 0 ? W1 : 256; }
+    int build(const StateDict &sd, int W1_, int IN1) {
+        W1 = W1_;
+        e.assign(8, {});
+        dead.assign(8, {});
+        for (int l = 0; l < 8; ++l) {
+            const int out = out_of(l), in = l == 0 ? IN1 : out_of(l - 1);
+            Folded64 f;
+            const int rc = fold_linear64(sd, lin(l), bn(l), out, in, &f);
+            if (rc) return rc;
+            std::vector<int> re(out, INT_MIN);
+            int top = INT_MIN;
+            for (int j = 0; j < out; ++j) {
+                double mx = 0.0;
+                for (int k = 0; k < in; ++k) {
+                    const double w = std::fabs(f.w[(size_t)j * in + k]);
+                    if (l && dead[l - 1][k]) continue;
+                    if (std::isfinite(w)) mx = std::max(mx, l ? std::ldexp(w, -e[l - 1][k]) : w);
+                }
+                if (mx > 0.0) { std::frexp(mx, &re[j]); top = std::max(top, re[j]); }
+            }
+            dead[l].assign(out, 0);
+            for (int j = 0; j < out; ++j) dead[l][j] = re[j] == INT_MIN && f.b[j] <= 0.0;
+            e[l].assign(out, 0);
+            for (int j = 0; j < out; ++j)
+                if (re[j] != INT_MIN) e[l][j] = std::min(top - re[j], 60);      // >= 0: rows are only ever scaled up, to the top row's binade
+        }
+        return DGDM_OK;
+    }
+    // trunk layer l (0 .. 7; 8 = the output layer) folded and scaled
+    template <class F>
+    int apply(F *f, int l) const {
+        for (int j = 0; j < f->out; ++j) {
+            const int ej = l < 8 ? e[l][j] : 0;
+            for (int k = 0; k < f->in; ++k)
+                f->w[(size_t)j * f->in + k] = (l && dead[l - 1][k]) ? 0 : std::ldexp(f->w[(size_t)j * f->in + k], ej - (l ? e[l - 1][k] : 0));
+            f->b[j] = std::ldexp(f->b[j], ej);
+        }
+        return DGDM_OK;
+    }
+    int fold(const StateDict &sd, int l, int out, int in, Folded *dst) const {
+        const int rc = l < 8 ? fold_linear(sd, lin(l), bn(l), out, in, dst) : fold_linear(sd, "output", "", out, in, dst);
+        return rc ? rc : apply(dst, l);
+    }
+    int fold64(const StateDict &sd, int l, int out, int in, Folded64 *dst) const {
+        const int rc = l < 8 ? fold_linear64(sd, lin(l), bn(l), out, in, dst) : fold_linear64(sd, "output", "", out, in, dst);
+        return rc ? rc : apply(dst, l);
+    }
+};
+
 }  // namespace
 
 extern "C" int dgdm_dynamics_create(DgdmDynamics **out, int kind, const DgdmTensor *tensors, int n_tensors, int params_ch, int object_ch) {
@@ -387,11 +467,14 @@ extern "C" int dgdm_dynamics_create(DgdmDynamics **out, int kind, const DgdmTens
     const int W = 256, W1 = m->W1, IN1 = 3 * W + 27;
     Blob &bl = m->blob;
     int rc;
+    TrunkEquil eq;
+    if ((rc = eq.build(sd, W1, IN1))) return rc;
+    if (getenv("DGDM_NO_EQUILIBRATION")) for (int l = 0; l < 8; ++l) { std::fill(eq.e[l].begin(), eq.e[l].end(), 0); std::fill(eq.dead[l].begin(), eq.dead[l].end(), 0); }      // test hook: the trunk as the checkpoint scales it
     Folded g0, g2, l1, lout;
     if ((rc = fold_linear(sd, "gripper_encoder.0", "", W, params_ch, &g0))) return rc;
     if ((rc = fold_linear(sd, "gripper_encoder.2", "", W, W, &g2))) return rc;
-    if ((rc = fold_linear(sd, "linears.0", "linears.1", W1, IN1, &l1))) return rc;
-    if ((rc = fold_linear(sd, "output", "", 3, W, &lout))) return rc;
+    if ((rc = eq.fold(sd, 0, W1, IN1, &l1))) return rc;
+    if ((rc = eq.fold(sd, 8, 3, W, &lout))) return rc;
     DynOff &o = m->off;
     std::vector<float> fwd, bwd_tail;                             // continuous trunk weight streams (csrc/trunk.h)
     std::vector<uint16_t> fwd16, bwd16_tail, sa3_img16;           // the same in bf16 (csrc/trunk_bf16.hip); sa3 image for z16_kernel
@@ -422,7 +505,7 @@ extern "C" int dgdm_dynamics_create(DgdmDynamics **out, int kind, const DgdmTens
         m->thalf = W / 4;
     } else {
         Folded l2;
-        if ((rc = fold_linear(sd, "linears.3", "linears.4", W, W1, &l2))) return rc;
+        if ((rc = eq.fold(sd, 1, W, W1, &l2))) return rc;
         o.b2 = bl.add(l2.b);
         // forward stream head: per 32-feature block of the 512-wide layer 1, its W1o' rows (32 entries) and then the matching
         // column block of W2' (8 output blocks x 4 entries)
@@ -471,7 +554,7 @@ extern "C" int dgdm_dynamics_create(DgdmDynamics **out, int kind, const DgdmTens
     for (int i = 0; i < m->n_mid; ++i) {
         const int li = 3 * (first_mid + i);
         Folded f;
-        if ((rc = fold_linear(sd, "linears." + std::to_string(li), "linears." + std::to_string(li + 1), W, W, &f))) return rc;
+        if ((rc = eq.fold(sd, li / 3, W, W, &f))) return rc;
         const std::vector<float> fi = pack_chain(f.w.data(), W, W);
         fwd.insert(fwd.end(), fi.begin(), fi.end());
         o.bf[i] = bl.add(f.b);
@@ -499,7 +582,7 @@ extern "C" int dgdm_dynamics_create(DgdmDynamics **out, int kind, const DgdmTens
         std::vector<uint16_t> fs, bs;
         if (kind == 3) {
             Folded l2;
-            if ((rc = fold_linear(sd, "linears.3", "linears.4", W, W1, &l2))) return rc;
+            if ((rc = eq.fold(sd, 1, W, W1, &l2))) return rc;
             const std::vector<float> w1o3 = cols(l1.w, W1, IN1, 0, W);
             const Split3 s1(w1o3.data(), W1, W), s2(l2.w.data(), W, W1);
             for (int kb = 0; kb < 16; ++kb) {
@@ -513,7 +596,7 @@ extern "C" int dgdm_dynamics_create(DgdmDynamics **out, int kind, const DgdmTens
         for (int i = 0; i < m->n_mid; ++i) {
             const int li = 3 * (first_mid + i);
             Folded f;
-            if ((rc = fold_linear(sd, "linears." + std::to_string(li), "linears." + std::to_string(li + 1), W, W, &f))) return rc;
+            if ((rc = eq.fold(sd, li / 3, W, W, &f))) return rc;
             split_layer_stream(fs, f.w.data());
             back.emplace_back();
             split_layer_stream(back.back(), transpose(f.w.data(), W, W).data());
@@ -521,7 +604,7 @@ extern "C" int dgdm_dynamics_create(DgdmDynamics **out, int kind, const DgdmTens
         for (int i = m->n_mid - 1; i >= 0; --i) bs.insert(bs.end(), back[i].begin(), back[i].end());               // last layer first
         if (kind == 3) {
             Folded l2;
-            if ((rc = fold_linear(sd, "linears.3", "linears.4", W, W1, &l2))) return rc;
+            if ((rc = eq.fold(sd, 1, W, W1, &l2))) return rc;
             const std::vector<float> w2t = transpose(l2.w.data(), W, W1);                                          // [512][256]
             const Split3 st(w2t.data(), W1, W);
             for (int kb = 0; kb < 16; ++kb)
@@ -537,7 +620,7 @@ extern "C" int dgdm_dynamics_create(DgdmDynamics **out, int kind, const DgdmTens
         sc = TrunkF16Scales{};
         Folded l2;
         if (kind == 3) {
-            if ((rc = fold_linear(sd, "linears.3", "linears.4", W, W1, &l2))) return rc;
+            if ((rc = eq.fold(sd, 1, W, W1, &l2))) return rc;
             const std::vector<float> w1o3 = cols(l1.w, W1, IN1, 0, W);
             const Split2 s1(w1o3.data(), W1, W);
             const Split2 s2(l2.w.data(), W, W1);
@@ -563,7 +646,7 @@ extern "C" int dgdm_dynamics_create(DgdmDynamics **out, int kind, const DgdmTens
         for (int i = 0; i < m->n_mid; ++i) {
             const int li = 3 * (first_mid + i);
             Folded f;
-            if ((rc = fold_linear(sd, "linears." + std::to_string(li), "linears." + std::to_string(li + 1), W, W, &f))) return rc;
+            if ((rc = eq.fold(sd, li / 3, W, W, &f))) return rc;
             sc.ew_mid[i] = f16_layer_stream(fs, f.w.data());
             back.emplace_back();
             const int et = f16_layer_stream(back.back(), transpose(f.w.data(), W, W).data());
@@ -593,7 +676,7 @@ extern "C" int dgdm_dynamics_create(DgdmDynamics **out, int kind, const DgdmTens
         Folded64 h0, h2, k1;
         if ((rc = fold_linear64(sd, "gripper_encoder.0", "", W, params_ch, &h0))) return rc;
         if ((rc = fold_linear64(sd, "gripper_encoder.2", "", W, W, &h2))) return rc;
-        if ((rc = fold_linear64(sd, "linears.0", "linears.1", W1, IN1, &k1))) return rc;
+        if ((rc = eq.fold64(sd, 0, W1, IN1, &k1))) return rc;
         q.g0_wt = b6.add(transpose64(h0.w.data(), W, params_ch)); q.g0_b = b6.add(h0.b); q.g0_w = b6.add(h0.w);
         q.g2_wt = b6.add(transpose64(h2.w.data(), W, W)); q.g2_b = b6.add(h2.b); q.g2_w = b6.add(h2.w);
         const std::vector<double> v1o = cols64(k1.w, W1, IN1, 0, W), v1c = cols64(k1.w, W1, IN1, W, W), v1p = cols64(k1.w, W1, IN1, 2 * W, 27),

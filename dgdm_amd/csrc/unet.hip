@@ -311,7 +311,8 @@ __device__ int input_scale_exp(const ConvArgs &a, const lds_f *in, int CPi, int 
     float mm = 0.f;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) mm = fmaxf(mm, red[w]);
     const int e = (int)((__float_as_uint(mm) >> 23) & 0xffu);
-    return __builtin_amdgcn_readfirstlane((mm > 0.f && e < 255) ? 12 + 127 - e : 0);
+    // (clamped: beyond 2^100 pow2_f's own clamp would make the input scale and its inverse disagree; inputs below 2^-88 keep fewer bits)
+    return __builtin_amdgcn_readfirstlane((mm > 0.f && e < 255) ? min(max(12 + 127 - e, -100), 100) : 0);
 }
 
 template <int NT, int MT, int MODE>
@@ -329,6 +330,8 @@ __device__ void conv_mfma_f16x3(const ConvArgs a, const lds_f *in, int CPi, lds_
     const int iters = __builtin_amdgcn_readfirstlane(ntaps * groups);
     const float f = pow2_f(kx), un = pow2_f(-(kx + a.ew));
     const f32x2_u f2 = {f, f};
+    // 2^-e_co per output channel (the image's rows carry their own scale, models_api.hip conv_image_f16x3): right behind the image
+    const float *unw = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.img) + (size_t)4 * a.cout * a.cin * a.ntaps);
     for (int mp0 = 0; mp0 * MT < mtiles; mp0 += nwave) {        // the same trip count for every wave (barriers inside)
         const int mp = mp0 + wave;
         int mt[MT];
@@ -411,7 +414,8 @@ __device__ void conv_mfma_f16x3(const ConvArgs a, const lds_f *in, int CPi, lds_
                 if (l < Lout) {
                     lds_f4 *p = (lds_f4 *)(out + ((l * a.ostride + a.ooff) + 2) * CPo + 4 * q + mt[m] * 16);
                     const f32x4 sum = tot[m][nt];
-                    f32x4 v = {fmaf(sum[0], un, b4.x), fmaf(sum[1], un, b4.y), fmaf(sum[2], un, b4.z), fmaf(sum[3], un, b4.w)};      // (x 2^-k exact: one rounding, the bias add's)
+                    const float4 u4 = *reinterpret_cast<const float4 *>(unw + mt[m] * 16 + 4 * q);
+                    f32x4 v = {fmaf(sum[0], un * u4.x, b4.x), fmaf(sum[1], un * u4.y, b4.y), fmaf(sum[2], un * u4.z, b4.z), fmaf(sum[3], un * u4.w, b4.w)};      // (x 2^-k exact: one rounding, the bias add's)
                     if (MODE == 1) v += *p;
                     *p = v;
                 }

@@ -254,7 +254,8 @@ def test_bench_spawns_ranks_itself(dev):
                         "--no-cpu-baseline", "--no-extra"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     out = r.stdout.strip().splitlines()
-    assert len(out) == 1 and len(out[0]) < 4096, (len(out), [len(o) for o in out])      # only rank 0 writes stdout, and only the headline
+    # only rank 0 writes stdout: ONE JSON line, and it is the last line (gloo itself may print a connection note before it)
+    assert len([o for o in out if o.startswith("{")]) == 1 and out[-1].startswith("{") and len(out[-1]) < 4096, [o[:80] for o in out]
     line = json.loads(out[-1])
     assert line["n_gpus"] == 2 and line["steps"] == 1 and line["value"] > 0 and line["config"]["pairs_per_gpu_per_step"] == 2
     assert "cpu_baseline" not in line and line["roofline"]["frac"] > 0
