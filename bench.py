@@ -692,6 +692,9 @@ def main():
     if a.gpus != world:
         print(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s)", file=sys.stderr)
         sys.exit(2)
+    if rank != 0:
+        # only rank 0 reports: whatever a library on another rank writes to stdout (under torchrun all ranks share it) must not follow the headline
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     dist = None
     if world > 1 or a.force_group:
         import torch.distributed as dist
@@ -743,11 +746,19 @@ def main():
             print(f"bench.py: details in {a.extra_out}", file=sys.stderr)
         except OSError as e:                                 # a read-only tree must not cost the headline
             print(f"bench.py: could not write {a.extra_out}: {e}", file=sys.stderr)
-    # the LAST stdout line is the record the driver parses: compact (< 4 KB), scalars only
-    sys.stdout.flush()
-    print(json.dumps(headline(meas, roof, shares, cpu)), flush=True)
+    # the LAST stdout line is the record the driver parses: compact (< 4 KB), scalars only - printed after the process group is gone, so that
+    # nothing a collective library says at teardown can follow it
     if dist is not None:
         dist.destroy_process_group()
+    # librccl announces itself ("RCCL version ... Librccl path ...") through C stdio, which on a pipe sits in libc's buffer until the process
+    # exits - i.e. it would land BEHIND a line printed from Python: flush libc's buffers first
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(headline(meas, roof, shares, cpu)), flush=True)
 
 
 def headline(m, roof, shares, cpu):

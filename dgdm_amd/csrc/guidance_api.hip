@@ -233,15 +233,23 @@ extern "C" int dgdm_guidance_debug_fps_path(DgdmGuidance *g, int force_per_row, 
     }
     return DGDM_OK;
 }
+// d objective / d (scaled z1) -> d objective / d z1: x 2^e_j per column (the trunk is equilibrated by exact powers of two, models_api.hip TrunkEquil)
+__global__ void partials_true_units_kernel(float *p, const float *unit, size_t n, int W1) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] *= unit[i % W1];
+}
 // Test hook: the per-tile partial sums of d objective / d z1 the last dgdm_dyn{2,3}d_guidance_grad call left behind
 // ([n_chains * B * tiles_per_b][W1], tile = (chain * B + b) * tiles_per_b + cell tile; a tile is 32 consecutive pose cells of one finger).
 extern "C" int dgdm_guidance_debug_partials(DgdmGuidance *g, int n_chains, float *out_dev, int32_t *tiles_per_finger, int32_t *width, void *stream) {
     DGDM_REQUIRE(g && n_chains > 0 && n_chains <= g->cfg.max_chains, DGDM_EINVAL, "dgdm_guidance_debug_partials: bad argument");
     if (tiles_per_finger) *tiles_per_finger = g->tiles_per_b;
     if (width) *width = g->m->W1;
-    if (out_dev)
-        DGDM_HIP_CHECK(hipMemcpyAsync(out_dev, g->partial.p, (size_t)n_chains * g->B * g->tiles_per_b * g->m->W1 * sizeof(float), hipMemcpyDeviceToDevice,
-                                      (hipStream_t)stream));
+    if (out_dev) {
+        const size_t n = (size_t)n_chains * g->B * g->tiles_per_b * g->m->W1;
+        DGDM_HIP_CHECK(hipMemcpyAsync(out_dev, g->partial.p, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        hipLaunchKernelGGL(partials_true_units_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out_dev, g->m->z1_unit.as<float>(), n, g->m->W1);
+        DGDM_HIP_CHECK(hipGetLastError());
+    }
     return DGDM_OK;
 }
 extern "C" int64_t dgdm_guidance_rows(const DgdmGuidance *g) { return g ? g->R : 0; }

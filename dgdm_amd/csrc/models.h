@@ -53,6 +53,7 @@ struct DgdmDynamics {
     dgdm::DevBuf wf16;      // two-way f16 split streams of the trunk (trunk_f16l.hip): forward then backward
     size_t fwdh_bytes = 0, bwdh_bytes = 0;
     dgdm::TrunkF16Scales f16_scales{};
+    dgdm::DevBuf z1_unit;   // [W1] floats 2^e: the library carries unit j of the first trunk layer as (true value) x 2^e_j (models_api.hip TrunkEquil)
 
     void fill_trunk(dgdm::TrunkParams *p) const;
     void fill_trunk_f16(dgdm::TrunkParams *p, dgdm::TrunkF16Scales *sc) const;

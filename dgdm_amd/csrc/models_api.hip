@@ -470,6 +470,11 @@ extern "C" int dgdm_dynamics_create(DgdmDynamics **out, int kind, const DgdmTens
     TrunkEquil eq;
     if ((rc = eq.build(sd, W1, IN1))) return rc;
     if (getenv("DGDM_NO_EQUILIBRATION")) for (int l = 0; l < 8; ++l) { std::fill(eq.e[l].begin(), eq.e[l].end(), 0); std::fill(eq.dead[l].begin(), eq.dead[l].end(), 0); }      // test hook: the trunk as the checkpoint scales it
+    {
+        std::vector<float> u(W1);
+        for (int j = 0; j < W1; ++j) u[j] = std::ldexp(1.0f, eq.e[0][j]);
+        if ((rc = m->z1_unit.upload(u.data(), u.size() * sizeof(float)))) return rc;
+    }
     Folded g0, g2, l1, lout;
     if ((rc = fold_linear(sd, "gripper_encoder.0", "", W, params_ch, &g0))) return rc;
     if ((rc = fold_linear(sd, "gripper_encoder.2", "", W, W, &g2))) return rc;

@@ -95,7 +95,7 @@ def test_bench_rank_body_on_rccl_world_size_1():
                            capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]
         last = r.stdout.strip().splitlines()[-1]                      # what a tail-capturing driver keeps
-        assert len(last) < 4096, len(last)
+        assert last.startswith("{") and len(last) < 4096, (len(last), r.stdout[-600:])
         line = json.loads(last)
         assert line["n_gpus"] == 1 and line["steps"] == 3 and line["roofline"]["frac"] > 0 and line["roofline"]["avg_launch_ms"] > 0
         assert all(not isinstance(v, (dict, list)) for v in line["roofline"].values())
