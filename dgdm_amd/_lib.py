@@ -116,6 +116,12 @@ PROTOTYPES = {
     "dgdm_trainer3d_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_int, _P, C.POINTER(C.c_float), _P]),
     "dgdm_trainer3d_export": (C.c_int, [_P, C.c_int, C.POINTER(Tensor), C.c_int]),
     "dgdm_trainer3d_steps": (C.c_int64, [_P]),
+    "dgdm_trainer3d_forward_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, _P, C.POINTER(C.c_float), _P]),
+    "dgdm_trainer3d_gradient_count": (C.c_int64, [_P]),
+    "dgdm_trainer3d_gradients": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
+    "dgdm_trainer3d_apply": (C.c_int, [_P, C.c_float, _P]),
+    "dgdm_trainer3d_running_stats_count": (C.c_int64, [_P]),
+    "dgdm_trainer3d_running_stats": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
     "dgdm_trainer3d_debug_read": (C.c_int, [_P, C.c_int, _P, C.c_int64, _P]),
 }
 

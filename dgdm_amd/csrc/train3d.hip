@@ -272,11 +272,11 @@ __global__ void mse_kernel(const float *__restrict__ pred, const float *__restri
     dpred[r * 4 + 3] = 0.f;
     part[r] = a;
 }
-__global__ void mse_finish_kernel(const float *__restrict__ part, int64_t R, float *__restrict__ loss) {
+__global__ void mse_finish_kernel(const float *__restrict__ part, int64_t R, int64_t RT, float *__restrict__ loss) {
     if (threadIdx.x || blockIdx.x) return;
     double a = 0.0;
     for (int64_t r = 0; r < R; ++r) a += (double)part[r];
-    *loss = (float)(a / (3.0 * (double)R));
+    *loss = (float)(a / (3.0 * (double)RT));          // RT rows in the batch the mean runs over (R of them here)
 }
 __global__ void copy_cols_kernel(const float *__restrict__ src, int64_t ld_s, float *__restrict__ dst, int64_t ld_d, int64_t M, int C) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -337,7 +337,8 @@ struct DgdmTrainer3d {
     int bn_bwd_finalize(const Bn &b, int64_t T, int64_t M, hipStream_t s);
     int relu_bwd(const Bn *b, float *da, const float *y, int64_t M, int C, hipStream_t s);
     int run_step(const float *ctrl1, const float *noise, const float *sa_, const float *sb_, const float *t, const float *ori, const float *pos, const float *xyz_in,
-                 const int64_t *start1, const int64_t *start2, const float *score, int64_t R, float lr, int train, float *pred_out, float *loss_host, hipStream_t s);
+                 const int64_t *start1, const int64_t *start2, const float *score, int64_t R, float lr, int train, float *pred_out, float *loss_host, hipStream_t s,
+                 int64_t total_rows = 0 /* 0: R - the loss is the mean over this many rows (a data-parallel chunk: the whole batch's) */, bool apply = true);
     int adam(float lr, hipStream_t s);
     int repack(hipStream_t s);
     int copy_state(int which, DgdmTensor *t, int n, bool to_device);
@@ -503,9 +504,10 @@ int DgdmTrainer3d::adam(float lr, hipStream_t s) {
 
 int DgdmTrainer3d::run_step(const float *ctrl1, const float *noise, const float *sa_, const float *sb_, const float *t, const float *ori, const float *pos,
                             const float *xyz_in, const int64_t *start1, const int64_t *start2, const float *score, int64_t R, float lr, int train, float *pred_out,
-                            float *loss_host, hipStream_t s) {
+                            float *loss_host, hipStream_t s, int64_t total_rows, bool apply) {
     int rc = reserve(R);
     if (rc) return rc;
+    const int64_t RT = total_rows > 0 ? total_rows : R;
     const bool tr_ = train != 0;
     const int64_t Mr1 = R * 512, M1r = Mr1 * 32, Mr2 = R * 128, M2r = Mr2 * 64;
     auto grid = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
@@ -559,8 +561,8 @@ int DgdmTrainer3d::run_step(const float *ctrl1, const float *noise, const float 
         DGDM_HIP_CHECK(hipGetLastError());
     }
     if ((rc = rowgemm(ta[7], 256, outl.F, pred, 4, p(outl.b), R, s))) return rc;
-    hipLaunchKernelGGL(mse_kernel, grid(R), dim3(256), 0, s, pred, score, R, (float)(2.0 / (3.0 * (double)R)), dpred, lpart);
-    hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(1), 0, s, lpart, R, loss_dev.as<float>());
+    hipLaunchKernelGGL(mse_kernel, grid(R), dim3(256), 0, s, pred, score, R, (float)(2.0 / (3.0 * (double)RT)), dpred, lpart);
+    hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(1), 0, s, lpart, R, RT, loss_dev.as<float>());
     DGDM_HIP_CHECK(hipGetLastError());
     if (pred_out) {
         hipLaunchKernelGGL(copy_cols_kernel, grid(R * 3), dim3(256), 0, s, pred, (int64_t)4, pred_out, (int64_t)3, R, 3);
@@ -612,7 +614,7 @@ int DgdmTrainer3d::run_step(const float *ctrl1, const float *noise, const float 
         if ((rc = lin_bwd(sa[1], a11, 64, dy12, 128, da11, 64, M1r, s))) return rc;
         if ((rc = relu_bwd(&sabn[0], da11, y11, M1r, 64, s))) return rc;
         if ((rc = lin_bwd(sa[0], feat1, 4, da11, 64, nullptr, 0, M1r, s))) return rc;
-        if ((rc = adam(lr, s))) return rc;
+        if (apply && (rc = adam(lr, s))) return rc;
         ++bn_batches;
     }
     if (loss_host) {
@@ -719,6 +721,37 @@ extern "C" int dgdm_trainer3d_step(DgdmTrainer3d *m, const float *ctrl1_dev, con
                  "holds at most 4096 clouds - 68 MB of activations each - use the sub-batches of --use_sub_batch)", (long long)rows);
     return m->run_step(ctrl1_dev, noise_dev, sqrt_abar_dev, sqrt_1m_abar_dev, t_dev, ori_dev, pos_dev, xyz_dev, start_sa1_host, start_sa2_host, score_dev, rows, lr, train,
                        pred_dev, loss_host, (hipStream_t)stream);
+}
+
+// ---- data-parallel pieces (dgdm_amd/dynamics/trainer.py: nn.DataParallel's semantics, dynamics/trainer.py:41-43, one process per GPU)
+extern "C" int dgdm_trainer3d_forward_backward(DgdmTrainer3d *m, const float *ctrl1_dev, const float *noise_dev, const float *sqrt_abar_dev,
+                                               const float *sqrt_1m_abar_dev, const float *t_dev, const float *ori_dev, const float *pos_dev, const float *xyz_dev,
+                                               const int64_t *start_sa1_host, const int64_t *start_sa2_host, const float *score_dev, int64_t rows, int64_t total_rows,
+                                               float *pred_dev, float *loss_host, void *stream) {
+    DGDM_REQUIRE(m && ctrl1_dev && t_dev && ori_dev && pos_dev && xyz_dev && start_sa1_host && start_sa2_host && score_dev, DGDM_EINVAL,
+                 "dgdm_trainer3d_forward_backward: null argument");
+    DGDM_REQUIRE(!noise_dev || (sqrt_abar_dev && sqrt_1m_abar_dev), DGDM_EINVAL, "dgdm_trainer3d_forward_backward: noise without its two scale vectors");
+    DGDM_REQUIRE(rows >= 2 && rows <= 4096 && total_rows >= rows, DGDM_EINVAL, "dgdm_trainer3d_forward_backward: %lld of %lld rows", (long long)rows, (long long)total_rows);
+    return m->run_step(ctrl1_dev, noise_dev, sqrt_abar_dev, sqrt_1m_abar_dev, t_dev, ori_dev, pos_dev, xyz_dev, start_sa1_host, start_sa2_host, score_dev, rows, 0.f, 1,
+                       pred_dev, loss_host, (hipStream_t)stream, total_rows, false);
+}
+extern "C" int64_t dgdm_trainer3d_gradient_count(const DgdmTrainer3d *m) { return m ? (int64_t)m->n_trainable : -1; }
+extern "C" int dgdm_trainer3d_gradients(DgdmTrainer3d *m, float *flat_dev, int64_t numel, int to_trainer, void *stream) {
+    DGDM_REQUIRE(m && flat_dev && numel == (int64_t)m->n_trainable, DGDM_EINVAL, "dgdm_trainer3d_gradients: expected %lld floats", m ? (long long)m->n_trainable : -1LL);
+    DGDM_HIP_CHECK(hipMemcpyAsync(to_trainer ? m->G.p : (void *)flat_dev, to_trainer ? (const void *)flat_dev : m->G.p, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice,
+                                  (hipStream_t)stream));
+    return DGDM_OK;
+}
+extern "C" int dgdm_trainer3d_apply(DgdmTrainer3d *m, float lr, void *stream) {
+    DGDM_REQUIRE(m, DGDM_EINVAL, "dgdm_trainer3d_apply: null handle");
+    return m->adam(lr, (hipStream_t)stream);
+}
+extern "C" int64_t dgdm_trainer3d_running_stats_count(const DgdmTrainer3d *m) { return m ? (int64_t)m->n_bn * 2 * CW : -1; }
+extern "C" int dgdm_trainer3d_running_stats(DgdmTrainer3d *m, float *flat_dev, int64_t numel, int to_trainer, void *stream) {
+    DGDM_REQUIRE(m && flat_dev && numel == (int64_t)m->n_bn * 2 * CW, DGDM_EINVAL, "dgdm_trainer3d_running_stats: expected %lld floats", m ? (long long)m->n_bn * 2 * CW : -1LL);
+    DGDM_HIP_CHECK(hipMemcpyAsync(to_trainer ? m->run.p : (void *)flat_dev, to_trainer ? (const void *)flat_dev : m->run.p, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice,
+                                  (hipStream_t)stream));
+    return DGDM_OK;
 }
 
 extern "C" int dgdm_trainer3d_export(DgdmTrainer3d *m, int which, DgdmTensor *tensors, int n_tensors) {

@@ -254,8 +254,7 @@ class Trainer(object):
         (rows, 3, L): only channel 1 is noised (trainer.py:68) and read (profile_forward_3d.py:77); object_vertices (rows, 3, N)."""
         if self._h is None:
             raise RuntimeError("Trainer.create_model() has not been called")
-        if _dist.world_rank()[0] != 1:
-            raise NotImplementedError("data-parallel training of the 3-D model is not built (the 2-D Trainer is; one GPU holds a --sub_bs=2048 slice)")
+        world, rank = _dist.world_rank()
         dev = torch.device("cuda", torch.cuda.current_device())
         f = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()       # noqa: E731
         noise, timesteps = drawn
@@ -265,14 +264,56 @@ class Trainer(object):
         # the FPS start draws of this forward: sa1 over the cloud's N points, then sa2 over sa1's 512 centres (pointnet2_utils.py:83)
         s1 = np.ascontiguousarray(torch.randint(0, N, (rows,), dtype=torch.long).numpy())
         s2 = np.ascontiguousarray(torch.randint(0, 512, (rows,), dtype=torch.long).numpy())
-        args = [f(ctrl[:, 1, :]), f(noise), f(ac ** 0.5), f((1 - ac) ** 0.5), f(timesteps.float() / T), f(input_ori), f(input_pos),
-                f(object_vertices.permute(0, 2, 1))]
-        sc = f(score)
-        pred = torch.empty((rows, 3), dtype=torch.float32, device=dev)
+        lr = float(self.optimizer.param_groups[0]["lr"])
         loss = C.c_float()
-        check(lib().dgdm_trainer3d_step(self._h, *[dptr(v) for v in args], s1.ctypes.data, s2.ctypes.data, dptr(sc), rows,
-                                        float(self.optimizer.param_groups[0]["lr"]), 1 if train else 0, dptr(pred), C.byref(loss), stream_ptr()))
-        return float(loss.value), pred
+        if world == 1:
+            args = [f(ctrl[:, 1, :]), f(noise), f(ac ** 0.5), f((1 - ac) ** 0.5), f(timesteps.float() / T), f(input_ori), f(input_pos),
+                    f(object_vertices.permute(0, 2, 1))]
+            sc = f(score)
+            pred = torch.empty((rows, 3), dtype=torch.float32, device=dev)
+            check(lib().dgdm_trainer3d_step(self._h, *[dptr(v) for v in args], s1.ctypes.data, s2.ctypes.data, dptr(sc), rows, lr, 1 if train else 0, dptr(pred),
+                                            C.byref(loss), stream_ptr()))
+            return float(loss.value), pred
+        # Data parallel, one process per GPU, nn.DataParallel's semantics (trainer.py:41-43 wraps the 3-D model too): the rows are cut into
+        # `world` chunks as torch.chunk does for scatter, every replica's BatchNorm layers normalise with ITS chunk's statistics, the loss is
+        # the mean over all rows, the replicas' gradients add up (RCCL all-reduce) and every rank takes the same Adam step; rank 0's
+        # running statistics are the ones that survive (broadcast).  Every rank was handed all rows and made all draws - noise, timesteps
+        # and the FPS starts - from the synchronised CPU generator (dist.init_from_env) and keeps its chunk's: the reference's replicas
+        # draw their FPS starts from that one generator in thread order, which is not defined; chunk order is the single-process order.
+        cs = -(-rows // world)
+        lo, hi = min(rows, rank * cs), min(rows, (rank + 1) * cs)
+        n = hi - lo
+        if train and any(min(rows, (r + 1) * cs) - min(rows, r * cs) == 1 for r in range(world)):
+            raise ValueError("Expected more than 1 value per channel when training (a DataParallel chunk of one row)")
+        args = [f(v[lo:hi]) for v in (ctrl[:, 1, :], noise, ac ** 0.5, (1 - ac) ** 0.5, timesteps.float() / T, input_ori, input_pos)]
+        args.append(f(object_vertices[lo:hi].permute(0, 2, 1)))
+        sc = f(score[lo:hi])
+        a1, a2 = np.ascontiguousarray(s1[lo:hi]), np.ascontiguousarray(s2[lo:hi])
+        pred = torch.zeros((cs, 3), dtype=torch.float32, device=dev)
+        share = 0.0
+        if train:
+            flat = torch.zeros(int(lib().dgdm_trainer3d_gradient_count(self._h)), dtype=torch.float32, device=dev)
+            if n:
+                check(lib().dgdm_trainer3d_forward_backward(self._h, *[dptr(v) for v in args], a1.ctypes.data, a2.ctypes.data, dptr(sc), n, rows, dptr(pred),
+                                                            C.byref(loss), stream_ptr()))
+                check(lib().dgdm_trainer3d_gradients(self._h, dptr(flat), flat.numel(), 0, stream_ptr()))
+                share = float(loss.value)
+            flat = _dist.all_reduce_sum(flat)
+            check(lib().dgdm_trainer3d_gradients(self._h, dptr(flat), flat.numel(), 1, stream_ptr()))
+            check(lib().dgdm_trainer3d_apply(self._h, lr, stream_ptr()))
+            run = torch.empty(int(lib().dgdm_trainer3d_running_stats_count(self._h)), dtype=torch.float32, device=dev)
+            check(lib().dgdm_trainer3d_running_stats(self._h, dptr(run), run.numel(), 0, stream_ptr()))
+            run = _dist.broadcast_from_rank0(run)
+            check(lib().dgdm_trainer3d_running_stats(self._h, dptr(run), run.numel(), 1, stream_ptr()))
+        elif n:
+            check(lib().dgdm_trainer3d_step(self._h, *[dptr(v) for v in args], a1.ctypes.data, a2.ctypes.data, dptr(sc), n, lr, 0, dptr(pred), C.byref(loss),
+                                            stream_ptr()))
+            share = float(loss.value) * n / rows
+        tail = torch.zeros((1, 3), dtype=torch.float32, device=dev)
+        tail[0, 0] = share
+        got = _dist.all_gather_rows(torch.cat([pred, tail]))                            # [world, cs + 1, 3]
+        full = torch.cat([got[r, :max(0, min(rows, (r + 1) * cs) - min(rows, r * cs))] for r in range(world)])
+        return float(got[:, cs, 0].sum()), full
 
     def _draw3d(self, rows: int):
         """trainer.py:68-73 for --fingers_3d: randn for channel 1's noise (the zeros around it draw nothing), then the timesteps."""

@@ -230,11 +230,15 @@ class Guidance:
             lib().dgdm_guidance_destroy(self._h)
             self._h = None
 
-    def set_objects(self, objects: torch.Tensor) -> None:
-        """2-D: (n, V, 2); 3-D: (n, N, 3)."""
+    def set_objects(self, objects: torch.Tensor, wait: bool = True) -> None:
+        """2-D: (n, V, 2); 3-D: (n, N, 3).  The table build (3-D) is enqueued on the current stream and the handle's build streams;
+        `wait=False` returns without waiting for it (the handle keeps the coordinates alive): a caller that knows its next objects can
+        build their tables on a side stream under the current batch's chains (bench.py does)."""
         o = _f32(objects)
         check(lib().dgdm_guidance_set_objects(self._h, dptr(o), o.shape[0], stream_ptr()))
-        torch.cuda.current_stream().synchronize()     # `o` may be a temporary
+        self._objects_ref = o                            # `o` may be a temporary: it is read by kernels still in flight
+        if wait:
+            torch.cuda.current_stream().synchronize()
         self.n_objects = o.shape[0]
 
     def debug_fps_path(self, mode):

@@ -443,6 +443,25 @@ int dgdm_trainer3d_step(DgdmTrainer3d *m, const float *ctrl1_dev, const float *n
                         const float *sqrt_1m_abar_dev, const float *t_dev, const float *ori_dev, const float *pos_dev, const float *xyz_dev,
                         const int64_t *start_sa1_host, const int64_t *start_sa2_host, const float *score_dev, int64_t rows, float lr,
                         int train, float *pred_dev, float *loss_host, void *stream);
+/* Data-parallel training, one process per GPU, with nn.DataParallel's semantics (dynamics/trainer.py:41-43 wraps the 3-D model as well):
+ *   dgdm_trainer3d_forward_backward  this rank's `rows` of a batch (or --use_sub_batch slice) of `total_rows`: forward in training mode on
+ *                                    these rows' batch statistics (running statistics updated), loss share sum / (3 total_rows), backward;
+ *                                    no update
+ *   dgdm_trainer3d_gradients         the flat gradient buffer (dgdm_trainer3d_gradient_count floats, layout private to the library) read
+ *                                    (to_trainer = 0) or written back after the all-reduce (1)
+ *   dgdm_trainer3d_apply             one Adam update from the gradient buffer
+ *   dgdm_trainer3d_running_stats     BatchNorm running means / variances of all 13 layers as one flat buffer
+ *                                    (dgdm_trainer3d_running_stats_count floats): rank 0's are broadcast after every step
+ * dgdm_trainer3d_step(train = 1) == forward_backward(rows, rows) + apply.                                                              */
+int dgdm_trainer3d_forward_backward(DgdmTrainer3d *m, const float *ctrl1_dev, const float *noise_dev, const float *sqrt_abar_dev,
+                                    const float *sqrt_1m_abar_dev, const float *t_dev, const float *ori_dev, const float *pos_dev,
+                                    const float *xyz_dev, const int64_t *start_sa1_host, const int64_t *start_sa2_host, const float *score_dev,
+                                    int64_t rows, int64_t total_rows, float *pred_dev, float *loss_host, void *stream);
+int64_t dgdm_trainer3d_gradient_count(const DgdmTrainer3d *m);
+int dgdm_trainer3d_gradients(DgdmTrainer3d *m, float *flat_dev, int64_t numel, int to_trainer, void *stream);
+int dgdm_trainer3d_apply(DgdmTrainer3d *m, float lr, void *stream);
+int64_t dgdm_trainer3d_running_stats_count(const DgdmTrainer3d *m);
+int dgdm_trainer3d_running_stats(DgdmTrainer3d *m, float *flat_dev, int64_t numel, int to_trainer, void *stream);
 /* which = 0 the state_dict (parameters + running statistics), 1 gradients of the last step, 2 / 3 Adam's exp_avg / exp_avg_sq */
 int dgdm_trainer3d_export(DgdmTrainer3d *m, int which, DgdmTensor *tensors, int n_tensors);
 int64_t dgdm_trainer3d_steps(const DgdmTrainer3d *m);      /* training steps taken = num_batches_tracked increment */

@@ -236,6 +236,19 @@ def _trunk_bf16(sd: SD, x: torch.Tensor, n_embed: int) -> torch.Tensor:
 
 
 TRUNK_CAPTURE: Optional[list] = None     # test hook: when a list, _trunk appends the first layer's pre-activation tensor to it
+TRUNK_MARGIN: Optional[list] = None      # test hook: when a list, _trunk appends per row the smallest RELATIVE distance of any ReLU input from zero
+
+
+def _relu_margin(x_in: torch.Tensor, z: torch.Tensor, sd: SD, i: int) -> torch.Tensor:
+    """Per row: min over the units of layer i of |z_j| / (sum_k |w'_jk| |x_k| + |b'_j|), w' / b' the BatchNorm-folded layer - the size of
+    the sum whose rounding decides the sign of z_j (a float32 evaluation is off by ~1e-7 .. 1e-6 of it)."""
+    with torch.no_grad():
+        n = f"linears.{3 * i + 1}"
+        sc = sd[n + ".weight"].double() / torch.sqrt(sd[n + ".running_var"].double() + 1e-5)
+        w = (sc[:, None] * sd[f"linears.{3 * i}.weight"].double()).abs()
+        b = (sc * (sd[f"linears.{3 * i}.bias"].double() - sd[n + ".running_mean"].double()) + sd[n + ".bias"].double()).abs()
+        size = x_in.detach().double().abs() @ w.t() + b
+        return (z.detach().double().abs() / size.clamp_min(1e-300)).min(dim=1).values
 
 
 def _trunk(sd: SD, x: torch.Tensor, n_embed: int = 0) -> torch.Tensor:
@@ -243,15 +256,22 @@ def _trunk(sd: SD, x: torch.Tensor, n_embed: int = 0) -> torch.Tensor:
     if _CONTRACTION == 'bf16':
         return _trunk_bf16(sd, x, n_embed)
     i = 0
+    margin = None
     while f"linears.{3 * i}.weight" in sd:
+        x_in = x
         x = F.linear(x, sd[f"linears.{3 * i}.weight"], sd[f"linears.{3 * i}.bias"])
         b = f"linears.{3 * i + 1}"
         x = F.batch_norm(x, sd[b + ".running_mean"], sd[b + ".running_var"], sd[b + ".weight"], sd[b + ".bias"],
                          training=False, eps=1e-5)
         if TRUNK_CAPTURE is not None and i == 0:
             TRUNK_CAPTURE.append(x)          # z1: first-layer pre-activation (tests: per-row d objective / d z1, see make_golden.g9_tiles)
+        if TRUNK_MARGIN is not None:
+            m = _relu_margin(x_in, x, sd, i)
+            margin = m if margin is None else torch.minimum(margin, m)
         x = F.relu(x)
         i += 1
+    if TRUNK_MARGIN is not None:
+        TRUNK_MARGIN.append(margin)
     return F.linear(x, sd["output.weight"], sd["output.bias"])
 
 
@@ -818,25 +838,44 @@ class Trainer3D:
         full = torch.cat([torch.zeros_like(noise)[:, None], noise[:, None], torch.zeros_like(noise)[:, None]], dim=1)      # :68
         return self.ddim.add_noise(ctrl, full, timesteps), timesteps.float() / self.ddim.num_train_timesteps
 
-    def _forward(self, sd, noisy, ori, pos, t, object_vertices, training, starts):
+    def _forward(self, sd, noisy, ori, pos, t, object_vertices, training, starts, buffers=None):
+        bufs = self.sd if buffers is None else buffers
         g = _mlp2(sd, "gripper_encoder", noisy[:, 1, :], F.relu)
         pose = torch.cat([nerf_embed(ori), nerf_embed(pos)], dim=1)
-        o = pointnet2_forward(sd, object_vertices, starts, prefix="object_encoder.", training=training, buffers=self.sd)
+        o = pointnet2_forward(sd, object_vertices, starts, prefix="object_encoder.", training=training, buffers=bufs)
         te = timestep_embedding(t, sd["gripper_encoder.2.weight"].shape[0])
         x = torch.cat([o, g, pose, te], dim=1)
         i = 0
         while f"linears.{3 * i}.weight" in sd:
             x = F.linear(x, sd[f"linears.{3 * i}.weight"], sd[f"linears.{3 * i}.bias"])
             b = f"linears.{3 * i + 1}"
-            x = F.relu(F.batch_norm(x, self.sd[b + ".running_mean"], self.sd[b + ".running_var"], sd[b + ".weight"], sd[b + ".bias"],
+            x = F.relu(F.batch_norm(x, bufs[b + ".running_mean"], bufs[b + ".running_var"], sd[b + ".weight"], sd[b + ".bias"],
                                     training=training, momentum=0.1, eps=1e-5))
             i += 1
         return F.linear(x, sd["output.weight"], sd["output.bias"])
 
-    def step(self, ctrl, score, input_ori, input_pos, object_vertices, draws, starts: Optional[StartLog] = None):
+    def step(self, ctrl, score, input_ori, input_pos, object_vertices, draws, starts: Optional[StartLog] = None, replicas: int = 1):
+        """replicas > 1: nn.DataParallel around the model (trainer.py:41-43) as its documentation states it - the rows are cut with
+        torch.chunk, every replica runs the module on its chunk in training mode (so every BatchNorm layer, PointNet++'s included,
+        normalises with ITS chunk's statistics; only replica 0's running-statistics updates survive), the outputs are concatenated for
+        one loss and autograd adds the replicas' gradients.  The replicas' FPS start draws come from the one CPU generator in thread
+        order, which the reference leaves undefined; here: sa1's and sa2's draws for ALL rows first (the single-process order), each
+        replica taking its chunk's.  No multi-GPU host exists to pin this against the real wrapper: parity unpinned for replicas > 1."""
         noisy, t = self._noisy(ctrl, draws)
         leaf = {k: self.sd[k].clone().requires_grad_(True) for k in self.names}
-        pred = self._forward({**self.sd, **leaf}, noisy, input_ori, input_pos, t, object_vertices, True, starts or StartLog())
+        if replicas == 1:
+            pred = self._forward({**self.sd, **leaf}, noisy, input_ori, input_pos, t, object_vertices, True, starts or StartLog())
+        else:
+            rows, N = ctrl.shape[0], object_vertices.shape[2]
+            log = starts or StartLog()
+            s1, s2 = log.draw(N, rows), log.draw(512, rows)
+            outs, first = [], None
+            for part in zip(*[torch.chunk(v, replicas) for v in (noisy, input_ori, input_pos, t, object_vertices, s1, s2)]):
+                bufs = {k: v.clone() for k, v in self.sd.items() if "running_" in k}       # every replica starts from the same buffers
+                outs.append(self._forward({**self.sd, **leaf}, *part[:5], True, StartLog([part[5], part[6]]), buffers=bufs))
+                first = first or bufs
+            self.sd.update(first)
+            pred = torch.cat(outs)
         loss = F.mse_loss(pred, score)
         grads = torch.autograd.grad(loss, [leaf[k] for k in self.names], allow_unused=True)
         self.grads = {k: g for k, g in zip(self.names, grads) if g is not None}

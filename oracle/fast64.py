@@ -117,11 +117,14 @@ def dyn3d_logits(sd: SD, x_ctrl, x_ori, x_pos, timesteps, emb: torch.Tensor) -> 
 
 
 def cond_fn(s: orc.Setup, tab: ObjectTables64, x: torch.Tensor, t: torch.Tensor, opt_obj: str, centers, calls: Sequence[torch.Tensor],
-            tiles: Optional[list] = None) -> torch.Tensor:
+            tiles: Optional[list] = None, risk: Optional[list] = None, risk_level: float = 2.0 ** -20) -> torch.Tensor:
     """``Diffusion.cond_fn`` for 'point_3d' (generator/diffusion.py:473-504) in float64 with the recorded FPS draws of this call
     (`calls` = [sub-batch 0's sa1 draws, its sa2 draws, sub-batch 1's ...], the order dgdm_oracle.StartLog replays them in).
     `tiles`: when a list, receives the [B][tiles][W1] sums of d objective / d z1 over 32 consecutive pose cells per finger - what the
-    HIP trunk leaves behind per 32-row tile (make_golden.g9_tiles)."""
+    HIP trunk leaves behind per 32-row tile (make_golden.g9_tiles).
+    `risk` (with `tiles`): when a list, receives (number of rows holding a ReLU whose float64 input lies within `risk_level` - relative to
+    the size of the sum that produces it, dgdm_oracle._relu_margin - of zero, the sum over those rows of the norm of the row's whole
+    contribution to its finger's gradient): what float32 sign flips can move, from float64 evidence alone (make_golden.g9_ties64)."""
     T = s.sched.num_train_timesteps
     with torch.enable_grad():
         x = x.detach().double().requires_grad_(True)
@@ -131,7 +134,7 @@ def cond_fn(s: orc.Setup, tab: ObjectTables64, x: torch.Tensor, t: torch.Tensor,
         tt = t.repeat(cells).float() / T
         pts = orc._pts3d(s, x).repeat(cells, 1, 1)
         kw = dict(centers=centers, grid_size=s.grid_size, num_pos=s.num_pos)
-        grad, k, zrows = 0.0, 0, []
+        grad, k, zrows, margins = 0.0, 0, [], []
         for i in range(0, B * cells, s.sub_batch_size):
             j = min(i + s.sub_batch_size, B * cells)
             s1, s2 = calls[k], calls[k + 1]
@@ -140,11 +143,16 @@ def cond_fn(s: orc.Setup, tab: ObjectTables64, x: torch.Tensor, t: torch.Tensor,
             emb = tab.embed(s1, s2)
             if tiles is not None:
                 orc.TRUNK_CAPTURE = []
+                if risk is not None:
+                    orc.TRUNK_MARGIN = []
             logits = dyn3d_logits(s.dyn, pts[i:j], ori[i:j], pos[i:j], tt[i:j], emb)
             val = orc.deltas_to_objective(logits, opt_obj, **kw).sum()
             if tiles is not None:
                 z1 = orc.TRUNK_CAPTURE[0]
                 orc.TRUNK_CAPTURE = None
+                if risk is not None:
+                    margins.append(orc.TRUNK_MARGIN[0])
+                    orc.TRUNK_MARGIN = None
                 gx, gz = torch.autograd.grad(val, [x, z1])
                 zrows.append(gz.detach())
             else:
@@ -159,6 +167,17 @@ def cond_fn(s: orc.Setup, tab: ObjectTables64, x: torch.Tensor, t: torch.Tensor,
                 for ti in range(nt):
                     acc[b, ti] = zb[32 * ti:32 * ti + 32].sum(0)
             tiles.append(acc)
+            if risk is not None:
+                mg = torch.cat(margins)
+                rows = torch.nonzero(mg < risk_level).reshape(-1)
+                total = 0.0
+                jac = {}
+                for r in rows.tolist():
+                    b = r % B
+                    if b not in jac:
+                        jac[b] = gripper_jacobian(s.dyn, x.detach()[b, :, 0])
+                    total += float((zg[r] @ jac[b]).norm())
+                risk.append((int(rows.numel()), total))
         return grad
 
 

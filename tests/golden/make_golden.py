@@ -1035,6 +1035,63 @@ def g9_calls64(parts=None):
             np.savez_compressed(path, **out)
 
 
+def g9_ties64(parts=None):
+    """What float32 sign flips of ReLUs can do to every recorded cond_fn call of the full-grid 3-D chains, from FLOAT64 evidence alone
+    (no float32 path, reference's or anyone's, enters): per call the rows that hold a ReLU whose float64 input lies within 2^-20 of
+    zero - relative to the size of the sum that produces it (dgdm_oracle._relu_margin); a float32 evaluation is off by 1e-7 .. 1e-6 of
+    that size, so these are the rows whose masks a float32 implementation may get 'wrong' - and the sum of the norms of those rows' whole
+    contributions to their fingers' gradient, relative to the call's gradient norm.  '<part>/risk' [calls], '<part>/n_risky' [calls],
+    '<part>/grad_norm' [calls] in tests/golden/g9_ties64.npz; tests/test_gpu_fullgrid.py turns them into the end-point budget."""
+    import glob
+    import time
+    from tests import util as tu
+    from oracle import fast64
+    path = os.path.join(OUT, "g9_ties64.npz")
+    out = dict(np.load(path)) if os.path.exists(path) else {}
+    names = [os.path.basename(f)[len("g9_3d_"):-4] for f in sorted(glob.glob(os.path.join(OUT, "g9_3d_*.npz")))]
+    names = [n for n in names if not n.endswith(("_alt", "_eps", "_arith")) and "raw" not in n]
+    names = [n for n in names if n in parts] if parts else [n for n in names if not n.startswith("full_")]
+    todo = [n for n in names if f"{n}/risk" not in out]
+    all_objs = torch.stack([synth.synth_object_3d(50 + i) for i in range(4)])
+    tabs = {}
+    for n in todo:
+        g = np.load(os.path.join(OUT, f"g9_3d_{n}.npz"))
+        objs = [0, 1] if n == "multi" else ([int(v) for v in g["obj"].reshape(-1)] if "obj" in g.files else [0])
+        B, G, P, L, T, S, N = [int(v) for v in g["dims"]]
+        o, gain = str(g["opt_obj"]), float(g["gain"])
+        sd32 = synth.scale_output(synth.synth_state_dict(synth.dyn3d_spec(42), DYN3D_SEED), gain)
+        sd64 = fast64._f64(sd32)
+        for oi in objs:
+            if oi not in tabs:
+                t0 = time.time()
+                tabs[oi] = fast64.ObjectTables64(sd64, all_objs[oi])
+                print("  ties64: tables of object", oi, f"{time.time() - t0:.0f}s", flush=True)
+        sch = orc.DDIM(T)
+        sch.set_timesteps(S)
+        calls = tu.unpack_starts(g["starts"].astype(np.int64), g["start_lens"])
+        centers = None
+        if o == 'convergence':
+            sweep, calls = calls[:2], calls[2:]
+            s32 = orc.Setup('point_3d', None, sd32, sch, L, G, P, 512)
+            centers = orc.get_convergence_centers(s32, torch.from_numpy(g["unguided"]), all_objs[objs[0]], (-1.0, 1.0), orc.StartLog(list(sweep)))
+        s64 = orc.Setup('point_3d', None, sd64, sch, L, G, P, 512)
+        n_sub = 2 * ((B * G * P * P + 511) // 512)
+        risk, cnt, norms, k = [], [], [], 0
+        t0 = time.time()
+        for si, t in enumerate(sch.timesteps):
+            ts = t * torch.ones(B, dtype=torch.int64)
+            for oi in objs:
+                x = torch.from_numpy(g["trace_x"][si]).double()
+                acc, rk = [], []
+                gr = fast64.cond_fn(s64, tabs[oi], x, ts, o, centers, calls[k:k + n_sub], tiles=acc, risk=rk)
+                k += n_sub
+                gn = float(gr.norm())
+                cnt.append(rk[0][0]); risk.append(rk[0][1] / gn); norms.append(gn)
+        out[f"{n}/risk"], out[f"{n}/n_risky"], out[f"{n}/grad_norm"] = np.array(risk), np.array(cnt, np.int64), np.array(norms)
+        print("  ties64", n, o, f"{time.time() - t0:.0f}s | rows at risk per call", cnt, "| their contributions / |grad|", [float("%.1e" % r) for r in risk], flush=True)
+        np.savez_compressed(path, **out)
+
+
 def synth_metrics(seed, n_ori=360):
     """Synthetic stand-in for what the simulator returns per (object, gripper) pair (dynamics/sim_test_mj.py:210-232):
     three-class profiles and the motion statistics metric2objective reads.  Inputs only; the outputs come from the reference."""
@@ -1317,7 +1374,7 @@ if __name__ == "__main__":
     os.makedirs("/tmp/dgdm_golden", exist_ok=True)
     only = sys.argv[1:]
     for name, fn in (("g2", g2_unet), ("g3", g3_dyn2d), ("g4", g4_pointnet), ("g5", g5_dyn3d), ("g6", g6_chains),
-                     ("g7", g7_convergence), ("g8", g8_harness), ("g9_2d", g9_2d), ("g9_3d", g9_3d), ("g9_3d_dist", g9_3d_dist), ("g9_3d_full", g9_3d_full), ("g9_3d_eps", g9_3d_eps), ("g9_3d_arith", g9_3d_arith), ("g9_f64", g9_f64), ("g9_tiles", g9_tiles), ("g9_calls64", g9_calls64), ("g10", g10_train2d), ("g11", g11_dataset), ("g12", g12_unet_train), ("g13", g13_train3d)):
+                     ("g7", g7_convergence), ("g8", g8_harness), ("g9_2d", g9_2d), ("g9_3d", g9_3d), ("g9_3d_dist", g9_3d_dist), ("g9_3d_full", g9_3d_full), ("g9_3d_eps", g9_3d_eps), ("g9_3d_arith", g9_3d_arith), ("g9_f64", g9_f64), ("g9_tiles", g9_tiles), ("g9_calls64", g9_calls64), ("g9_ties64", g9_ties64), ("g10", g10_train2d), ("g11", g11_dataset), ("g12", g12_unet_train), ("g13", g13_train3d)):
         if only and name not in [a.split(":")[0] for a in only]:
             continue
         sub = [a.split(":", 1)[1].split(",") for a in only if a.startswith(name + ":")]

@@ -82,7 +82,9 @@ def test_unet_arithmetic_modes_vs_float64(dev, L):
 def test_ddim_step_and_unguided_chain(dev):
     sd = util.unet_sd(11)
     net = engine.Unet1d(sd)
-    for T, S, B, L in ((15, 5, 3, 14), (1000, 100, 2, 42)):
+    # (1000, 1000, 4, 14) is BASELINE configs[0] itself: 2-D unconditional sampling, B = 4, L = 14, T = S = 1000 (dynamics/parser.py:29,31
+    # defaults; generator/diffusion.py:249-256), teacher-forced along the oracle's trajectory through all 1000 steps
+    for T, S, B, L in ((15, 5, 3, 14), (1000, 100, 2, 42), (1000, 1000, 4, 14)):
         s = sched(T, S)
         so = orc.DDIM(T)
         so.set_timesteps(S)
@@ -92,8 +94,9 @@ def test_ddim_step_and_unguided_chain(dev):
         for t in (int(s.timesteps[0]), int(s.timesteps[-1])):
             got = s.step(e.to(dev), t, x.to(dev)).prev_sample.cpu()
             assert util.rel_l2(got, so.step(e, t, x)) < 1e-6
-        n = s.add_noise(x.to(dev), e.to(dev), torch.full((B,), S, dtype=torch.int64)).cpu()
-        assert util.rel_l2(n, so.add_noise(x, e, torch.full((B,), S, dtype=torch.int64))) < 1e-6
+        tn = min(S, T - 1)
+        n = s.add_noise(x.to(dev), e.to(dev), torch.full((B,), tn, dtype=torch.int64)).cpu()
+        assert util.rel_l2(n, so.add_noise(x, e, torch.full((B,), tn, dtype=torch.int64))) < 1e-6
         # Random-init nets make long chains chaotic: on the CPU oracle itself a 1e-7 relative change of the start noise moves
         # the end of the 100-step chain by 5e-3 (finger L2) but the 5-step chain by 5e-6.  So the shipped 5-step chain is
         # compared end to end, and long chains step by step along the oracle's trajectory (teacher forcing).
@@ -108,6 +111,9 @@ def test_ddim_step_and_unguided_chain(dev):
             got = s.step(net.forward(xo.to(dev), ts.to(dev)), int(t), xo.to(dev)).prev_sample.cpu()
             assert finger_l2(got, nxt) < 2e-5, int(t)
             xo = nxt
+        if S == 1000:       # and the library's own loop over the 1000 steps, free-running: finite, inside the scheduler's clip range
+            out = sampler.unguided_sample(net, s, x.to(dev)).cpu()
+            assert out.shape == (B, L, 1) and bool(torch.isfinite(out).all()) and float(out.abs().max()) <= 1.0
 
 
 # ------------------------------------------------------------------------------------------------ a8 / a4 (2-D)

@@ -20,6 +20,19 @@ def _args(sub, wd):
                               num_train_timesteps=15)
 
 
+def dp3d_data(rows):
+    """Inputs of the data-parallel test (shared with tests/dp_train3d_worker.py): state_dict and one batch of `rows` rows over three clouds."""
+    from dgdm_amd import synth
+    sd = util.dyn3d_sd(58)
+    rs = np.random.RandomState(1000 + rows)
+    ctrl = torch.from_numpy(rs.uniform(-1, 1, (rows, 3, 42)).astype(np.float32))
+    obj = torch.stack([synth.synth_object_3d(90 + i % 3) for i in range(rows)]).permute(0, 2, 1).contiguous()
+    ori = torch.from_numpy(rs.uniform(-1, 1, (rows, 1)).astype(np.float32))
+    pos = torch.from_numpy(rs.uniform(-1, 1, (rows, 2)).astype(np.float32))
+    score = torch.from_numpy(rs.normal(0, 1, (rows, 3)).astype(np.float32))
+    return sd, [ctrl, score, ori, pos, obj]
+
+
 class _HipTrainer3D:
     def __init__(self, sd, T, wd, sub):
         from dgdm_amd.dynamics.trainer import Trainer
@@ -175,3 +188,47 @@ def test_training_driver_3d_end_to_end(tmp_path):
     out = m.to(dev).eval()(torch.zeros(4, 3, 42, device=dev), torch.zeros(4, 1, device=dev), torch.zeros(4, 2, device=dev), torch.zeros(4, device=dev),
                            synth.synth_object_3d(90).t()[None].expand(4, -1, -1).contiguous().to(dev))
     assert out.shape == (4, 3) and bool(torch.isfinite(out).all())
+
+
+def test_trainer3d_data_parallel(tmp_path):
+    """`Trainer.step --fingers_3d` data-parallel (the reference wraps the 3-D model in nn.DataParallel as well, dynamics/trainer.py:41-43): two
+    ranks (sharing this box's GPU; gloo carries the gradient all-reduce) on 9 rows = chunks of 5 + 4 as torch.chunk cuts them, every
+    BatchNorm layer - PointNet++'s included - on its chunk's statistics, one loss over all rows, gradients summed, the same Adam step on
+    every rank, rank 0's running statistics on all.  Against the oracle's statement of those semantics on the same draws (float32 and
+    float64, tolerances of test_trainer3d_vs_oracle), and the ranks' parameters are identical afterwards."""
+    import subprocess
+    import sys
+    from oracle import dgdm_oracle as orc
+    rows = 9
+    sd, (ctrl, score, ori, pos, obj) = dp3d_data(rows)
+    o = orc.Trainer3D(sd, 15, 1e-4, 0.0)
+    torch.manual_seed(4343)
+    draws, log = o.draw(ctrl), orc.StartLog()
+    lo, po = o.step(ctrl, score, ori, pos, obj, draws, log, replicas=2)
+    o64 = orc.Trainer3D({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, 15, 1e-4, 0.0)
+    o64.step(ctrl.double(), score.double(), ori.double(), pos.double(), obj.double(), (draws[0].double(), draws[1]), orc.StartLog(list(log.log)), replicas=2)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DGDM_TORCH_SEED="4343", DGDM_DIST_BACKEND="gloo")
+    out = str(tmp_path / "dp3d.npz")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29543", os.path.join(root, "tests", "dp_train3d_worker.py"), str(rows), out],
+                       capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    g = np.load(out)
+    assert int(g["world"]) == 2
+    assert abs(float(g["loss0"]) / lo - 1) < 2e-5, (float(g["loss0"]), lo)
+    assert util.rel_l2(g["pred0"], po) < 1e-4
+    for k in o.grads:
+        if k in t3.BN_FED_BIAS:
+            continue
+        e_h64, e_o64, e_ho = util.rel_l2(g["grad/" + k], o64.grads[k]), util.rel_l2(o.grads[k], o64.grads[k]), util.rel_l2(g["grad/" + k], o.grads[k])
+        # (BatchNorm over chunks of 5 and 4 rows: the float32 oracle itself is 2e-4 from float64 on the trunk's BatchNorm parameters)
+        assert e_h64 <= max(3e-4, 1.5 * e_o64), (k, e_h64, e_o64)
+        assert e_ho <= max(3e-4, 2 * e_o64), (k, e_ho, e_o64)
+    for k in o.sd:                  # replica 0's running statistics (its chunk of 5 rows), on every rank
+        if "running_" in k:
+            assert float(np.abs(g["sd/" + k] - o.sd[k].numpy()).max()) < 1e-5 * max(1.0, float(o.sd[k].abs().max())), k
+    assert int(g["sd/linears.1.num_batches_tracked"]) == 1
+    assert np.array_equal(g["replica_sums"][0], g["replica_sums"][1])          # the two ranks hold the same parameters
+    assert np.isfinite(g["inf_pred"]).all() and g["inf_pred"].shape == (rows, 3)
