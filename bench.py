@@ -268,7 +268,7 @@ def pmc_traffic(workload, contraction, kernel):
     FETCH_SIZE is the raw counter: on gfx950 it can under-count wide coalesced reads by 2x (MI355X_MICROARCH.md §HBM), so the
     true read traffic lies between 1x and 2x of `fetch_bytes_raw`.  None when no recording exists."""
     tag = workload + ("_bf16" if contraction == "bf16" else "")
-    f = next((c for c in (os.path.join(ROOT, "profiles", f"{r}_{tag}_pmc_hbm.json") for r in ("r04", "r03")) if os.path.exists(c)), None)
+    f = next((c for c in (os.path.join(ROOT, "profiles", f"{r}_{tag}_pmc_hbm.json") for r in ("r05", "r04", "r03")) if os.path.exists(c)), None)
     if f is None:
         return None
     d = json.load(open(f))

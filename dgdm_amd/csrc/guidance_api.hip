@@ -61,7 +61,9 @@ struct DgdmGuidance {
 #ifndef DGDM_NBUILD
 #define DGDM_NBUILD 3
 #endif
-    static constexpr int NBUILD = DGDM_NBUILD;   // objects whose tables are built concurrently (own stream + temporaries each)
+    static constexpr int NBUILD = 16;            // most objects whose tables can be built concurrently (own stream + 0.5 GB of temporaries each)
+    // how many are: DGDM_NBUILD at compile time, the environment variable of that name at run time (experiments: bench.py --extra records them)
+    int nbuild = []() { const char *e = getenv("DGDM_NBUILD"); const int v = e ? atoi(e) : DGDM_NBUILD; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
     DevBuf pool_crowded, pool_clist, pool_off, pool_pairs, pool_rank, pool_F1, pool_U;   // [n_objects] x the light build stages' outputs (built by one launch per stage)
     DevBuf pool_xyz, pool_fps1, pool_fps2, pool_flags, pool_ncr;   // [n_objects] x per-object FPS tables (ObjectTables point into these), crowded-centre counts
     DevBuf tmpY[NBUILD], tmpL2[NBUILD], vlist;      // 3-D table-build temporaries of the heavy stages (per build stream)
@@ -340,7 +342,7 @@ extern "C" int dgdm_guidance_set_objects(DgdmGuidance *g, const float *objects_d
         }
         // objects are independent: build them round-robin on a few side streams so the latency-bound stages (FPS: 512
         // dependent iterations on 128 workgroups) of one object overlap the bandwidth/MFMA-bound stages of the others
-        const int nb = std::min<int>(DgdmGuidance::NBUILD, n_objects);
+        const int nb = std::min<int>(g->nbuild, n_objects);
         if (!g->bstart) DGDM_HIP_CHECK(hipEventCreateWithFlags(&g->bstart, hipEventDisableTiming));
         if (!g->ldone) DGDM_HIP_CHECK(hipEventCreateWithFlags(&g->ldone, hipEventDisableTiming));
         for (int i = 0; i < nb; ++i) {
