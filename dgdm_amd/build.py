@@ -3,9 +3,12 @@
 The library is kept in-tree so that it travels with the source snapshot to the GPU box."""
 from __future__ import annotations
 
+import hashlib
+import json
 import os
 import subprocess
 import sys
+import time
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -18,25 +21,56 @@ PER_FILE_FLAGS = {"unet.hip": ["-mllvm", "-amdgpu-function-calls=false"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("DGDM_EXTRA_FLAGS", "").split()
 
 
-def _stale(target: str, deps) -> bool:
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+INFO = LIB + ".json"      # provenance of the shipped library: content hashes of what it was built from (travels with the .so)
+
+
+def _sha(paths, extra=()) -> str:
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(hashlib.sha256(f.read()).digest())
+    for e in extra:
+        h.update(str(e).encode())
+    return h.hexdigest()
+
+
+def _headers():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(HERE, "..", "include", "dgdm_hip.h")]
+
+
+def source_hashes() -> dict:
+    """Per object file: the hash of its source, every header and its flags - what decides whether it is rebuilt (content, not mtimes: a
+    checkout or a copy to another box changes mtimes, not sources)."""
+    hd = _headers()
+    return {src: _sha([os.path.join(CSRC, src)] + hd, FLAGS + PER_FILE_FLAGS.get(src, [])) for src in SOURCES}
+
+
+def build_info() -> dict:
+    """What the library on disk was built from ({} when there is none) and whether that is what the tree holds now."""
+    if not (os.path.exists(LIB) and os.path.exists(INFO)):
+        return {}
+    with open(INFO) as f:
+        info = json.load(f)
+    info["current"] = info.get("sources") == source_hashes()
+    return info
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    headers.append(os.path.join(HERE, "..", "include", "dgdm_hip.h"))
-    objs, jobs = [], []
+    want = source_hashes()
+    have = {}
+    if os.path.exists(INFO):
+        with open(INFO) as f:
+            have = json.load(f).get("sources", {})
+    objs, jobs, rebuilt = [], [], []
     os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, "build", src.replace(".hip", ".o"))
         objs.append(o)
-        if force or _stale(o, [s] + headers):
+        if force or not os.path.exists(o) or have.get(src) != want[src]:
             jobs.append([hipcc] + FLAGS + PER_FILE_FLAGS.get(src, []) + ["-c", s, "-o", o])
+            rebuilt.append(src)
 
     def run(cmd):
         if verbose:
@@ -50,8 +84,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
         for err in ex.map(run, jobs):
             if verbose and err.strip():
                 print(err)
-    if force or jobs or _stale(LIB, objs):
+    linked = bool(force or jobs or not os.path.exists(LIB))
+    if linked:
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        with open(INFO, "w") as f:
+            json.dump({"sources": want, "flags": FLAGS, "built_at": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()), "recompiled": rebuilt,
+                       "lib_sha256": _sha([LIB])}, f, indent=1)
+    build.last = {"mode": "rebuilt" if linked else "up to date", "recompiled": rebuilt}
     return LIB
 
 

@@ -307,3 +307,16 @@ def test_bench_headline_is_compact_and_parses():
     for w in bench.WORKLOAD_NAME:
         for c in bench.DTYPE_LABEL:
             assert len(json.dumps(bench.headline(dict(m, workload=w, contraction=c), roof, stages, cpu))) < 4096
+
+
+def test_shipped_library_is_built_from_this_tree():
+    """Build provenance: dgdm_amd/csrc/libdgdm_hip.so is git-ignored and travels to the GPU box with the snapshot; its side file records the
+    content hashes of every source / header / flag set it was compiled from, and rebuilds are decided by those hashes (not by mtimes).  The
+    library that the tests load is the one built from the sources in this tree."""
+    import hashlib
+    from dgdm_amd import build as b
+    info = b.build_info()
+    assert info, "no library (or no provenance file) - run `python __graft_entry__.py`"
+    assert info["current"], "libdgdm_hip.so is older than the sources next to it"
+    assert hashlib.sha256(hashlib.sha256(open(b.LIB, "rb").read()).digest()).hexdigest() == info["lib_sha256"]
+    assert set(info["sources"]) == set(b.SOURCES)
