@@ -16,6 +16,10 @@ struct DgdmUnet1d {
     dgdm::DevBuf wf16;      // two-piece f16 images of the MFMA convolutions (unet.hip conv_mfma_f16x3)
     dgdm::DevBuf pf16_dev;  // `p` with those images (bf16 = 2) and their scale exponents
     int mode = 2;           // dgdm_unet1d_set_contraction_dtype: 0 float32 MFMA chain, 1 bf16, 2 f16x3 (the default float32 form)
+    dgdm::UnetParams pf16;  // host copy of what pf16_dev holds (the batched form's launches take their image pointers from it)
+    dgdm::DevBuf bws;       // batched form: activation workspace (halo rows zero), sized for (bws_B, bws_L)
+    int bws_B = 0, bws_L = 0;
+    int batched_min = 256;  // batches of at least this many samples run the batched form (DGDM_UNET_BATCHED_MIN; 0 = never)
 };
 
 namespace dgdm {

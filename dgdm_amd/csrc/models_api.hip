@@ -257,7 +257,9 @@ extern "C" int dgdm_unet1d_create(DgdmUnet1d **out, const DgdmTensor *tensors, i
         q.down_w = ath(o_dwh); q.up_w_even = ath(o_uweh); q.up_w_odd = ath(o_uwoh); q.fin_w = ath(o_fwh);
         q.down_e = e_dw; q.up_e_even = e_uwe; q.up_e_odd = e_uwo; q.fin_e = e_fw;
         if ((rc = m->pf16_dev.upload(&q, sizeof q))) return rc;
+        m->pf16 = q;
     }
+    if (const char *e = getenv("DGDM_UNET_BATCHED_MIN")) m->batched_min = atoi(e);
     *out = m.release();
     return DGDM_OK;
 }
@@ -273,6 +275,20 @@ extern "C" int dgdm_unet1d_forward(DgdmUnet1d *m, const float *sample_dev, const
     prof_begin((hipStream_t)stream, DGDM_STAGE_UNET);
     // the f16x3 form needs 12 KB of LDS beside one sample's activations: where that does not fit (L = 44, 46) the float32 MFMA chain runs
     const int mode = (m->mode == 2 && !unet_f16x3_fits(m->p, L)) ? 0 : m->mode;
+    if (mode == 2 && m->batched_min > 0 && B >= m->batched_min && unet_batched_samples(m->pf16, L) > 0) {
+        // large batches: layer by layer, several samples per workgroup (unet.hip "batched form"; the same bits as the per-sample kernel)
+        int rc = DGDM_OK;
+        if (m->bws_B < B || m->bws_L != L) {
+            const size_t n = unet_batched_ws_floats(m->pf16, B, L);
+            DGDM_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+            if ((rc = m->bws.alloc(n * sizeof(float)))) return rc;
+            DGDM_HIP_CHECK(hipMemsetAsync(m->bws.p, 0, n * sizeof(float), (hipStream_t)stream));      // the halo rows stay zero: no launch writes them
+            m->bws_B = B; m->bws_L = L;
+        }
+        rc = unet_launch_batched(m->pf16, m->pf16_dev.as<UnetParams>(), m->bws.as<float>(), m->bws_B, sample_dev, timestep_dev, eps_dev, B, L, (hipStream_t)stream);
+        prof_end((hipStream_t)stream, DGDM_STAGE_UNET, 2.0 * macs * B);
+        return rc;
+    }
     const int rc = unet_launch(m->p, (mode == 1 ? m->p16_dev : mode == 2 ? m->pf16_dev : m->p_dev).as<UnetParams>(), mode == 2, sample_dev, timestep_dev, eps_dev, B, L, (hipStream_t)stream);
     prof_end((hipStream_t)stream, DGDM_STAGE_UNET, 2.0 * macs * B);
     return rc;

@@ -31,5 +31,10 @@ struct UnetParams {
 // f16x3: p_dev holds the two-piece f16 images (the kernel then needs LDS for the split slabs: unet_f16x3_fits)
 int unet_launch(const UnetParams &p, const UnetParams *p_dev, bool f16x3, const float *sample, const int *timestep, float *eps, int B, int L, hipStream_t s);
 bool unet_f16x3_fits(const UnetParams &p, int L);
+// Batched form for large batches (f16x3 only; unet.hip "batched form"): layer-by-layer launches, several samples per workgroup, activations in a
+// zero-initialised global workspace.  unet_batched_samples: samples per workgroup, 0 when the shape is not supported.
+int unet_batched_samples(const UnetParams &p, int L);
+size_t unet_batched_ws_floats(const UnetParams &p, int B, int L);
+int unet_launch_batched(const UnetParams &q, const UnetParams *q_dev, float *ws, int Bcap, const float *sample, const int *timestep, float *eps, int B, int L, hipStream_t s);
 
 }  // namespace dgdm

@@ -468,45 +468,49 @@ __device__ void zero_halo(lds_f *buf, int CP, int C, int L) {
 }
 
 // GroupNorm(groups, C) -> Mish -> optional FiLM (scale*y + shift), in place on a [pos+2][CP] buffer.  (diffusion_utils.py:65-69,113-116)
-__device__ void gn_mish_film(lds_f *buf, int CP, int C, int L, int groups, const float *__restrict__ gamma, const float *__restrict__ beta,
-                             const lds_f *film /*LDS [2C] or null*/) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = blockDim.x >> 6;
+// One group g, by the calling wave.
+__device__ __forceinline__ void gn_group(lds_f *buf, int CP, int C, int L, int groups, int g, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                         const lds_f *film /*LDS [2C] or null*/) {
+    const int lane = threadIdx.x & 63;
     const int cg = C / groups, cnt = cg * L;
     // lane -> (row offset, channel) without a division per element when the group width divides the wave (16 or 32 here)
     const bool pow2 = cg <= 64 && (64 % cg) == 0;
     const int rstep = pow2 ? 64 / cg : 0, c0 = pow2 ? lane % cg : 0, l0 = pow2 ? lane / cg : 0;
-    for (int g = wave; g < groups; g += nwave) {
-        lds_f *gb = buf + 2 * CP + g * cg;
-        if (pow2) {
-            float s = 0.f;
-            for (int l = l0; l < L; l += rstep) s += gb[l * CP + c0];
-            const float mean = wave_sum(s) / (float)cnt;
-            float q = 0.f;
-            for (int l = l0; l < L; l += rstep) { const float d = gb[l * CP + c0] - mean; q = fmaf(d, d, q); }
-            const float rstd = 1.f / sqrtf(wave_sum(q) / (float)cnt + 1e-5f);
-            const int ch = g * cg + c0;
-            const float ga = gamma[ch] * rstd, be = beta[ch];
-            const float fs = film ? film[ch] : 1.f, fb = film ? film[C + ch] : 0.f;
-            for (int l = l0; l < L; l += rstep) {
-                float y = mish((gb[l * CP + c0] - mean) * ga + be);
-                if (film) y = fs * y + fb;
-                gb[l * CP + c0] = y;
-            }
-        } else {
-            float s = 0.f;
-            for (int i = lane; i < cnt; i += 64) { const int l = i / cg, c = i - l * cg; s += gb[l * CP + c]; }
-            const float mean = wave_sum(s) / (float)cnt;
-            float q = 0.f;
-            for (int i = lane; i < cnt; i += 64) { const int l = i / cg, c = i - l * cg; const float d = gb[l * CP + c] - mean; q = fmaf(d, d, q); }
-            const float rstd = 1.f / sqrtf(wave_sum(q) / (float)cnt + 1e-5f);
-            for (int i = lane; i < cnt; i += 64) {
-                const int l = i / cg, c = i - l * cg, ch = g * cg + c;
-                float y = mish((gb[l * CP + c] - mean) * (gamma[ch] * rstd) + beta[ch]);
-                if (film) y = film[ch] * y + film[C + ch];
-                gb[l * CP + c] = y;
-            }
+    lds_f *gb = buf + 2 * CP + g * cg;
+    if (pow2) {
+        float s = 0.f;
+        for (int l = l0; l < L; l += rstep) s += gb[l * CP + c0];
+        const float mean = wave_sum(s) / (float)cnt;
+        float q = 0.f;
+        for (int l = l0; l < L; l += rstep) { const float d = gb[l * CP + c0] - mean; q = fmaf(d, d, q); }
+        const float rstd = 1.f / sqrtf(wave_sum(q) / (float)cnt + 1e-5f);
+        const int ch = g * cg + c0;
+        const float ga = gamma[ch] * rstd, be = beta[ch];
+        const float fs = film ? film[ch] : 1.f, fb = film ? film[C + ch] : 0.f;
+        for (int l = l0; l < L; l += rstep) {
+            float y = mish((gb[l * CP + c0] - mean) * ga + be);
+            if (film) y = fs * y + fb;
+            gb[l * CP + c0] = y;
+        }
+    } else {
+        float s = 0.f;
+        for (int i = lane; i < cnt; i += 64) { const int l = i / cg, c = i - l * cg; s += gb[l * CP + c]; }
+        const float mean = wave_sum(s) / (float)cnt;
+        float q = 0.f;
+        for (int i = lane; i < cnt; i += 64) { const int l = i / cg, c = i - l * cg; const float d = gb[l * CP + c] - mean; q = fmaf(d, d, q); }
+        const float rstd = 1.f / sqrtf(wave_sum(q) / (float)cnt + 1e-5f);
+        for (int i = lane; i < cnt; i += 64) {
+            const int l = i / cg, c = i - l * cg, ch = g * cg + c;
+            float y = mish((gb[l * CP + c] - mean) * (gamma[ch] * rstd) + beta[ch]);
+            if (film) y = film[ch] * y + film[C + ch];
+            gb[l * CP + c] = y;
         }
     }
+}
+__device__ void gn_mish_film(lds_f *buf, int CP, int C, int L, int groups, const float *__restrict__ gamma, const float *__restrict__ beta,
+                             const lds_f *film /*LDS [2C] or null*/) {
+    const int wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    for (int g = wave; g < groups; g += nwave) gn_group(buf, CP, C, L, groups, g, gamma, beta, film);
 }
 
 // sum_k WT[k][n] x[k] (x in LDS, K a multiple of 8): eight weight loads in flight per step, the same ascending-k fmaf chain
@@ -680,6 +684,445 @@ __global__ __launch_bounds__(UNET_THREADS) void unet_kernel(const UnetParams *__
         eps[(size_t)b * L + l] = acc + p.out_b[0];
     }
     UCLK();          // output conv
+}
+
+// ================================================================================================ batched form (f16x3, large batches)
+// One workgroup per sample streams all 7.8 MB of two-piece weight images through its CU for 3 (L = 42) or 2 (L = 21) position tiles per
+// weight fragment, pays every convolution's fixed costs (first weight fetch, slab split, barriers) on one sample's worth of MFMAs, and
+// pads 21 positions to 32.  For large batches the network runs LAYER BY LAYER instead, UB_S samples per workgroup: activations in global
+// memory ([sample][position + 2 halo rows each side][channels], L2 / MALL resident: 22-52 MB per tensor at 1024 samples), one launch per
+// convolution with everything that follows it fused (GroupNorm + Mish + FiLM, the block's residual - identity, 1x1 convolution or the
+// single-channel input -, Upsample's two phases, the final 1x1 convolution).  A weight fragment now serves UB_S samples' position tiles
+// (S x L positions are tiled contiguously: 168 -> 11 tiles, 84 -> 6, instead of 4 x 3 and 4 x 2), the fixed costs are paid once per
+// UB_S samples.  The arithmetic is the per-sample kernel's, operation for operation (same images, same slab layout and K order, same
+// chunked accumulation, the same per-(sample, convolution input) power-of-two scale - its max now comes from the producing launch's
+// epilogue -, gn_group as it is): the two forms return the same bits (tests/test_gpu_parity.py::test_unet_batched_equals_per_sample).
+constexpr int UB_THREADS = 512;
+typedef const __attribute__((address_space(1))) float glb_f;
+typedef __attribute__((address_space(3))) int lds_i;
+typedef __attribute__((address_space(3))) uint32_t lds_u;
+
+struct UbPass {
+    const float *in;            // [B][Lin + 4][in_ld] (channel offset applied), halo rows zero
+    const float4 *img;          // two-piece f16 image + per-channel factors (models_api.hip conv_image_f16x3)
+    const float *bias;
+    const float *amax0, *amax1; // [B] largest |input| per sample (amax1: the other half of a concatenated input, or null)
+    int in_ld, Lin, cin, ntaps, istride, ioff0, iostep, ostride, ooff, add;
+    int Lpos;                   // positions per sample this pass computes (output row = l * ostride + ooff, l < Lpos)
+};
+struct UbArgs {
+    UbPass pass[2];
+    int n_pass, B, S, Lout, cout, groups;
+    const float *first_x, *first_w, *first_b;   // pass 0 is the single-channel k5 convolution of x [B][Lout] on the VALU (no image)
+    const float *gn_w, *gn_b;                   // GroupNorm + Mish after pass 0 (null: none)
+    const float *film; int film_ld;             // [B][film_ld]: scale [cout] | shift [cout] of this block (null: none); row of sample b: film_idx[b]
+    const int *film_idx;
+    const float *res_id; int res_ld;            // identity residual [B][Lout + 4][res_ld], added last
+    const float *res_x, *res_w, *res_b;         // single-channel residual: + res_w[co] x[b][l] + res_b[co]
+    float *out; int out_ld;                     // [B][Lout + 4][out_ld] (channel offset applied)
+    float *amax_out;                            // [B]
+    const float *fin_w, *fin_b; float *eps;     // final 1x1 convolution -> eps [B][Lout] instead of `out`
+};
+
+__device__ __forceinline__ int scale_exp_of(float mm) {      // input_scale_exp's exponent for a row set whose largest magnitude is mm
+    const int e = (int)((__float_as_uint(mm) >> 23) & 0xffu);
+    return (mm > 0.f && e < 255) ? min(max(12 + 127 - e, -100), 100) : 0;
+}
+
+// One convolution pass of the batched kernel: conv_mfma_f16x3's arithmetic over ns samples.  Waves 0-3 / 4-7 take the lower / upper half
+// of the position tiles, wave & 3 picks MT of the cout / 16 output tiles.
+template <int NT, int MT, bool SPLIT>
+__device__ void ub_conv(const UbPass &a, const int S, const int ns, const int b0, const lds_i *kxs, lds_f *stage, const int CPo, const int LoutS /* stage rows per sample */,
+                        const int cout, lds_u4 *slab) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int groups = __builtin_amdgcn_readfirstlane(a.cin >> 5), ntaps = __builtin_amdgcn_readfirstlane(a.ntaps);
+    const int Rs = a.Lin + 4, R = S * Rs;
+    // SPLIT: waves 0-3 / 4-7 take the lower / upper NT position tiles and wave & 3 picks MT output tiles (both halves fetch the same weight
+    // fragments); otherwise every wave holds all NT position tiles of its own MT output tiles (no fragment is fetched twice)
+    const int half = SPLIT ? __builtin_amdgcn_readfirstlane(wave >> 2) : 0, tg = __builtin_amdgcn_readfirstlane(SPLIT ? (wave & 3) : wave);
+    const int Lp = a.Lpos, npos = ns * Lp;
+    constexpr int GS = 2;
+    int brow[NT], srow[NT];
+    float un[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = (half * NT + nt) * 16 + j, nn = min(n, npos - 1);
+        const int sm = nn / Lp, l = nn - sm * Lp;
+        brow[nt] = q * R + sm * Rs + l * a.istride + a.ioff0 + 2;
+        srow[nt] = n < npos ? sm * LoutS + l * a.ostride + a.ooff : -1;
+        un[nt] = pow2_f(-kxs[sm]);
+    }
+    const int iters = __builtin_amdgcn_readfirstlane(ntaps * groups);
+    const float *unw = reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.img) + (size_t)4 * cout * a.cin * a.ntaps);
+    int mt[MT];
+    glb_f4 *w[MT];
+    f32x4 nh[MT], nl[MT], n2h[MT], n2l[MT];
+    f32x4 acc[MT][NT], tot[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        mt[m] = tg * MT + m;
+        w[m] = (glb_f4 *)a.img + (size_t)mt[m] * iters * 128 + lane;
+        nh[m] = w[m][0]; nl[m] = w[m][64];
+        const size_t o1 = (size_t)min(1, iters - 1) * 128;
+        n2h[m] = w[m][o1]; n2l[m] = w[m][o1 + 64];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { acc[m][nt] = (f32x4)(0.f); tot[m][nt] = (f32x4)(0.f); }
+    }
+    int it = 0;
+    for (int g0 = 0; g0 < groups; g0 += GS) {
+        __syncthreads();                                     // the previous pass' readers of the slab are done
+        // split 64 channels of every row of the ns samples once: lane -> (row, 16-byte piece), eight lanes cover 256 contiguous bytes of a row.
+        // The loads of FU items are issued together: one global round trip per FU items instead of one per item (the activations of the
+        // previous launch come from the MALL, ~1.5 us away - item by item that latency, not the MFMAs, was the launch's time)
+        constexpr int FU = 3;
+        for (int i0 = threadIdx.x; i0 < R * GS * 4; i0 += blockDim.x * FU) {
+            f32x4 lo[FU], hi[FU];
+#pragma unroll
+            for (int u = 0; u < FU; ++u) {
+                const int i = i0 + u * blockDim.x, row = i >> 3, r8 = i & 7, sm = row / Rs;
+                if (i < R * GS * 4 && sm < ns) {
+                    const glb_f *src = (glb_f *)a.in + ((size_t)(b0 + sm) * Rs + (row - sm * Rs)) * a.in_ld + (g0 + (r8 >> 2)) * 32 + 4 * (r8 & 3);
+                    lo[u] = *(glb_f4 *)src; hi[u] = *(glb_f4 *)(src + 16);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < FU; ++u) {
+                const int i = i0 + u * blockDim.x, row = i >> 3, r8 = i & 7, gg = r8 >> 2, qq = r8 & 3, sm = row / Rs;
+                if (i >= R * GS * 4) break;
+                u32x4_u H = {0u, 0u, 0u, 0u}, Lw = {0u, 0u, 0u, 0u};
+                if (sm < ns) {
+                    const float f = pow2_f(kxs[sm]);
+                    const f32x2_u f2 = {f, f};
+                    uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+                    split2_f16(f32x2_u{lo[u][0], lo[u][1]} * f2, h0, l0);
+                    split2_f16(f32x2_u{lo[u][2], lo[u][3]} * f2, h1, l1);
+                    split2_f16(f32x2_u{hi[u][0], hi[u][1]} * f2, h2, l2);
+                    split2_f16(f32x2_u{hi[u][2], hi[u][3]} * f2, h3, l3);
+                    H = u32x4_u{h0, h1, h2, h3}; Lw = u32x4_u{l0, l1, l2, l3};
+                }
+                slab[gg * 8 * R + qq * R + row] = H;
+                slab[gg * 8 * R + 4 * R + qq * R + row] = Lw;
+            }
+        }
+        __syncthreads();
+#ifdef DGDM_UB_EXP_NOMFMA
+        if (S > 0) { it += GS * ntaps; continue; }           // timing experiment (wrong results): everything but the MFMA loop
+#endif
+        for (int gt = 0; gt < GS * ntaps; ++gt, ++it) {
+            const int gg = gt >= ntaps ? 1 : 0, t = gt - gg * ntaps;
+            f16x8_u ah[MT], al[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                ah[m] = __builtin_bit_cast(f16x8_u, nh[m]); al[m] = __builtin_bit_cast(f16x8_u, nl[m]);
+                nh[m] = n2h[m]; nl[m] = n2l[m];
+            }
+            int pre = min(it + 2, iters - 1);
+            asm volatile("" : "+v"(pre));
+#pragma unroll
+            for (int m = 0; m < MT; ++m) { n2h[m] = w[m][(size_t)pre * 128]; n2l[m] = w[m][(size_t)pre * 128 + 64]; }
+            const int ro = gg * 8 * R + t * a.iostep;
+            f16x8_u bh[NT], bl[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                bh[nt] = __builtin_bit_cast(f16x8_u, (u32x4_u)slab[brow[nt] + ro]);
+                bl[nt] = __builtin_bit_cast(f16x8_u, (u32x4_u)slab[4 * R + brow[nt] + ro]);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh[nt], acc[m][nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl[nt], acc[m][nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh[nt], acc[m][nt], 0, 0, 0);
+            if (t == ntaps - 1) {                            // the chain is cut after every channel group
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) { tot[m][nt] += acc[m][nt]; acc[m][nt] = (f32x4)(0.f); }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const float4 b4 = *reinterpret_cast<const float4 *>(a.bias + mt[m] * 16 + 4 * q);
+        const float4 u4 = *reinterpret_cast<const float4 *>(unw + mt[m] * 16 + 4 * q);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (srow[nt] >= 0) {
+                lds_f4 *p = (lds_f4 *)(stage + srow[nt] * CPo + 4 * q + mt[m] * 16);
+                const f32x4 sum = tot[m][nt];
+                const float u = un[nt];
+                f32x4 v = {fmaf(sum[0], u * u4.x, b4.x), fmaf(sum[1], u * u4.y, b4.y), fmaf(sum[2], u * u4.z, b4.z), fmaf(sum[3], u * u4.w, b4.w)};
+                if (a.add) v += *p;
+                *p = v;
+            }
+        }
+    }
+}
+
+__device__ void ub_conv_dispatch(const UbPass &a, int S, int ns, int b0, const lds_i *kxs, lds_f *stage, int CPo, int Lout, int cout, lds_u4 *slab) {
+    const int ntile = (S * a.Lpos + 15) >> 4, nth = (ntile + 1) >> 1;        // position tiles per half of the waves (the host keeps nth <= 6)
+    // (the host keeps ntile <= 6 for the 256-wide convolutions - they all run at the half-length level - and <= 12 for the 128-wide ones)
+    if ((cout >> 4) == 8) {
+        if (nth <= 3) ub_conv<3, 2, true>(a, S, ns, b0, kxs, stage, CPo, Lout, cout, slab);
+        else ub_conv<6, 2, true>(a, S, ns, b0, kxs, stage, CPo, Lout, cout, slab);
+    } else {
+        // 16 output tiles = two per wave with all (<= 6) position tiles: split in halves the 256-wide convolutions pulled 57 B/clk of weight
+        // fragments through the CU's L1 (every fragment twice) - its limit is 64 - and ran at a third of their MFMA rate
+        ub_conv<6, 2, false>(a, S, ns, b0, kxs, stage, CPo, Lout, cout, slab);
+    }
+}
+
+__global__ __launch_bounds__(UB_THREADS) void ub_layer_kernel(const UbArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    lds_f *lds = (lds_f *)lds_raw;
+    const int S = A.S, b0 = blockIdx.x * S, ns = min(S, A.B - b0);
+    const int Lout = A.Lout, cout = A.cout, CPo = cout + UNET_ROW_PAD;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, nwave = blockDim.x >> 6;
+    lds_f *stage = lds;                                           // [S][Lout][CPo]
+    lds_f *filmL = stage + S * Lout * CPo;                        // [S][2 cout]
+    lds_i *kxs = (lds_i *)(filmL + S * 2 * cout);                 // [S] scale exponents, then [S] amax bits
+    lds_u *amx = (lds_u *)(kxs + 8);
+    lds_u4 *slab = (lds_u4 *)(kxs + 16);
+    if (A.film)
+        for (int i = t; i < ns * 2 * cout; i += blockDim.x) { const int sm = i / (2 * cout); filmL[i] = A.film[(size_t)A.film_idx[b0 + sm] * A.film_ld + (i - sm * 2 * cout)]; }
+    if (t < 8) amx[t] = 0u;
+    for (int p = 0; p < A.n_pass; ++p) {
+        const UbPass &a = A.pass[p];
+        if (p == 0 && A.first_x) {
+            // block 0's first convolution: one input channel, on the VALU (unet_kernel's cin == 1 branch)
+            for (int i = t; i < ns * Lout * cout; i += blockDim.x) {
+                const int co = i % cout, r = i / cout, sm = r / Lout, l = r - sm * Lout;
+                const float *x = A.first_x + (size_t)(b0 + sm) * Lout;
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) { const int li = l + k - 2; acc = fmaf(A.first_w[k * cout + co], (li >= 0 && li < Lout) ? x[li] : 0.f, acc); }
+                stage[r * CPo + co] = acc + A.first_b[co];
+            }
+        } else {
+            if (t < S) {
+                float mm = 0.f;
+                if (t < ns) { mm = a.amax0[b0 + t]; if (a.amax1) mm = fmaxf(mm, a.amax1[b0 + t]); }
+                kxs[t] = scale_exp_of(mm);
+            }
+            __syncthreads();
+            ub_conv_dispatch(a, S, ns, b0, kxs, stage, CPo, Lout, cout, slab);
+        }
+        __syncthreads();
+#ifdef DGDM_UB_EXP_NOGN
+        if (false) {                                         // timing experiment (wrong results)
+#else
+        if (p == 0 && A.gn_w) {
+#endif
+            for (int idx = wave; idx < ns * A.groups; idx += nwave) {
+                const int sm = idx / A.groups, g = idx - sm * A.groups;
+                gn_group(stage + sm * Lout * CPo - 2 * CPo, CPo, cout, Lout, A.groups, g, A.gn_w, A.gn_b, A.film ? filmL + sm * 2 * cout : nullptr);
+            }
+            __syncthreads();
+        }
+    }
+    if (A.eps) {                                                  // final_conv.1: Conv1d(d0, 1, 1)
+        for (int r = t; r < ns * Lout; r += blockDim.x) {
+            float acc = 0.f;
+            for (int c = 0; c < cout; ++c) acc = fmaf(A.fin_w[c], stage[r * CPo + c], acc);
+            A.eps[(size_t)b0 * Lout + r] = acc + A.fin_b[0];
+        }
+        return;
+    }
+    // residual, store, and the per-sample magnitude the next launch scales its input by.  One flat loop over all samples' elements, the
+    // residual loads of SU elements in flight together (a residual read is a round trip to the MALL)
+    const int c4n = cout >> 2, per = Lout * c4n, total = ns * per;
+    constexpr int SU = 4;
+    float mx[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i0 = t; i0 < total; i0 += blockDim.x * SU) {
+        f32x4 rv[SU];
+        float xv[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int i = i0 + u * blockDim.x;
+            if (i < total) {
+                const int sm = i / per, r = i - sm * per, l = r / c4n, c = (r - l * c4n) * 4;
+                if (A.res_id) rv[u] = *(glb_f4 *)((glb_f *)A.res_id + ((size_t)(b0 + sm) * (Lout + 4) + l + 2) * A.res_ld + c);
+                if (A.res_x) xv[u] = A.res_x[(size_t)(b0 + sm) * Lout + l];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int i = i0 + u * blockDim.x;
+            if (i >= total) break;
+            const int sm = i / per, r = i - sm * per, l = r / c4n, c = (r - l * c4n) * 4;
+            f32x4 v = *(lds_f4 *)(stage + (sm * Lout + l) * CPo + c);
+            if (A.res_id) v += rv[u];
+            if (A.res_x) {
+                const float x = xv[u];
+                const float4 rw = *reinterpret_cast<const float4 *>(A.res_w + c), rb = *reinterpret_cast<const float4 *>(A.res_b + c);
+                v[0] += fmaf(rw.x, x, rb.x); v[1] += fmaf(rw.y, x, rb.y); v[2] += fmaf(rw.z, x, rb.z); v[3] += fmaf(rw.w, x, rb.w);
+            }
+            *reinterpret_cast<f32x4 *>(A.out + ((size_t)(b0 + sm) * (Lout + 4) + l + 2) * A.out_ld + c) = v;
+            const float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+            mx[0] = sm == 0 ? fmaxf(mx[0], m) : mx[0]; mx[1] = sm == 1 ? fmaxf(mx[1], m) : mx[1];
+            mx[2] = sm == 2 ? fmaxf(mx[2], m) : mx[2]; mx[3] = sm == 3 ? fmaxf(mx[3], m) : mx[3];
+        }
+    }
+#pragma unroll
+    for (int sm = 0; sm < 4; ++sm) {
+        float m = mx[sm];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0 && sm < ns) atomicMax((uint32_t *)(amx + sm), __float_as_uint(m));      // non-negative floats order like their bit patterns
+    }
+    __syncthreads();
+    if (t < ns && A.amax_out) A.amax_out[b0 + t] = __uint_as_float(amx[t]);
+}
+
+// step encoder + the eight FiLM vectors of every sample (unet_kernel's first two phases): film [B][8][2 cmax].  They depend on the sample's
+// timestep only, and a denoise step hands every sample the same one: a sample whose timestep equals sample 0's takes sample 0's row
+// (film_idx) instead of recomputing it (1024 workgroups of dependent L2 round trips -> one: 53 -> 6 us).
+__global__ __launch_bounds__(256) void ub_cond_kernel(const UnetParams *__restrict__ pp, const int *__restrict__ timestep, float *__restrict__ film, int *__restrict__ film_idx) {
+    __shared__ float cond_raw[32 * 5 + 8];
+    const UnetParams &p = *pp;
+    lds_f *cond = (lds_f *)cond_raw, *tmp = cond + p.dsed;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const bool same = b > 0 && timestep[b] == timestep[0];
+    if (t == 0) film_idx[b] = same ? 0 : b;
+    if (same) return;
+    const int half = p.dsed / 2;
+    const float ts = (float)timestep[b];
+    if (t < half) {
+        const float a = ts * p.freqs[t];
+        cond[t] = sinf(a);
+        cond[half + t] = cosf(a);
+    }
+    __syncthreads();
+    matvec(p.se1_wt, p.se1_b, cond, tmp, p.dsed, 4 * p.dsed);
+    __syncthreads();
+    for (int i = t; i < 4 * p.dsed; i += blockDim.x) tmp[i] = mish(tmp[i]);
+    __syncthreads();
+    matvec(p.se3_wt, p.se3_b, tmp, cond, 4 * p.dsed, p.dsed);
+    __syncthreads();
+    for (int i = t; i < p.dsed; i += blockDim.x) cond[i] = mish(cond[i]);
+    __syncthreads();
+    const int stride = 2 * p.cmax;
+    for (int i = t; i < 8 * stride; i += blockDim.x) {
+        const int blk = i / stride, n = i - blk * stride, N = 2 * p.res[blk].cout;
+        if (n < N) film[(size_t)b * 8 * stride + i] = dot_kn(p.res[blk].cond_wt, N, n, cond, p.dsed) + p.res[blk].cond_b[n];
+    }
+}
+
+static size_t ub_lds_bytes(int S, int Lin, int Lout, int cout) {
+    return ((size_t)S * Lout * (cout + UNET_ROW_PAD) + (size_t)S * 2 * cout + 16) * 4 + (size_t)2 * 8 * S * (Lin + 4) * 16;
+}
+
+// samples per workgroup: the most (<= 4) for which every launch fits the LDS and a half of the waves holds at most 6 position tiles
+int unet_batched_samples(const UnetParams &p, int L) {
+    const int L2 = (L - 1) / 2 + 1;
+    if (p.dsed > 32 || p.d0 != 128 || p.d1 != 256) return 0;       // the tilings above are written for the shipped widths (down_dims [128, 256])
+    for (int S = 4; S >= 2; --S) {
+        const bool fits = ub_lds_bytes(S, L, L, p.d0) <= 160 * 1024 && ub_lds_bytes(S, L2, L2, p.d1) <= 160 * 1024 && ub_lds_bytes(S, L2, L, p.d0) <= 160 * 1024 &&
+                          ub_lds_bytes(S, L, L2, p.d0) <= 160 * 1024;
+        if (fits && (S * L + 15) / 16 <= 12 && (S * L2 + 15) / 16 <= 6) return S;
+    }
+    return 0;
+}
+
+size_t unet_batched_ws_floats(const UnetParams &p, int B, int L) {
+    const int L2 = (L - 1) / 2 + 1;
+    return (size_t)B * ((size_t)3 * (L + 4) * p.d0 + (size_t)3 * (L2 + 4) * p.d0 + (size_t)2 * (L2 + 4) * p.d1 + (size_t)(L2 + 4) * 2 * p.d1 + (size_t)8 * 2 * p.cmax + 16);
+}
+
+// q: the host copy of the f16x3 parameter block (images + per-channel factors), q_dev the same in device memory; ws: zero-initialised
+// workspace of unet_batched_ws_floats floats (the halo rows are never written)
+int unet_launch_batched(const UnetParams &q, const UnetParams *q_dev, float *ws, int Bcap, const float *sample, const int *timestep, float *eps, int B, int L, hipStream_t s) {
+    const int L2 = (L - 1) / 2 + 1, S = unet_batched_samples(q, L);
+    DGDM_REQUIRE(S > 0 && 2 * L2 == L && B <= Bcap, DGDM_EINVAL, "unet_launch_batched: unsupported shape (L = %d, B = %d of %d)", L, B, Bcap);
+    const int d0 = q.d0, d1 = q.d1;
+    // the workspace is laid out for Bcap samples whatever this call's B: a sample's halo rows are the same addresses in every call
+    const size_t n1 = (size_t)Bcap * (L + 4) * d0, n2 = (size_t)Bcap * (L2 + 4) * d0, n3 = (size_t)Bcap * (L2 + 4) * d1;
+    float *P = ws, *Q = P + n1, *Rb = Q + n1, *D = Rb + n1, *T6 = D + n2, *O6 = T6 + n2, *T2 = O6 + n2, *O2 = T2 + n3, *CAT = O2 + n3;
+    float *film = CAT + 2 * n3, *am = film + (size_t)Bcap * 8 * 2 * q.cmax;
+    float *aP = am, *aQ = am + Bcap, *aR = am + 2 * Bcap, *aD = am + 3 * Bcap, *aT6 = am + 4 * Bcap, *aO6 = am + 5 * Bcap, *aT2 = am + 6 * Bcap, *aO2 = am + 7 * Bcap,
+          *aC0 = am + 8 * Bcap, *aC1 = am + 9 * Bcap;
+    static bool attr_set = false;
+    if (!attr_set) {
+        DGDM_HIP_CHECK(hipFuncSetAttribute((const void *)ub_layer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    int *fidx = reinterpret_cast<int *>(am + (size_t)10 * Bcap);
+    hipLaunchKernelGGL(ub_cond_kernel, dim3(B), dim3(256), 0, s, q_dev, timestep, film, fidx);
+    const int fl = 8 * 2 * q.cmax;
+    auto conv5 = [&](const float *in, int in_ld, int Lin, int cin, const float *img, const float *bias, const float *a0, const float *a1) {
+        UbPass a{};
+        a.Lpos = Lin;
+        a.in = in; a.img = reinterpret_cast<const float4 *>(img); a.bias = bias; a.amax0 = a0; a.amax1 = a1; a.in_ld = in_ld; a.Lin = Lin; a.cin = cin; a.ntaps = 5;
+        a.istride = 1; a.ioff0 = -2; a.iostep = 1; a.ostride = 1; a.ooff = 0; a.add = 0;
+        return a;
+    };
+    auto launch = [&](UbArgs &A, int Lin) -> int {
+        A.B = B; A.S = S; A.groups = q.groups;
+        const size_t lds = ub_lds_bytes(S, Lin, A.Lout, A.cout);
+        DGDM_REQUIRE(lds <= 160 * 1024, DGDM_EINVAL, "unet_launch_batched: %zu B of LDS", lds);
+        hipLaunchKernelGGL(ub_layer_kernel, dim3((B + S - 1) / S), dim3(UB_THREADS), lds, s, A);
+        DGDM_HIP_CHECK(hipGetLastError());
+        return DGDM_OK;
+    };
+    int rc;
+    // one ConditionalResidualBlock1D (unet_kernel's res_block): conv0 + GN + Mish + FiLM -> t1; conv1 + GN + Mish + residual -> out
+    auto block = [&](int bi, const float *in, int in_ld, const float *ain0, const float *ain1, int Lb, float *t1, float *at1, float *out, int out_ld, float *aout) -> int {
+        const UnetRes &w = q.res[bi];
+        UbArgs A{};
+        A.n_pass = 1; A.Lout = Lb; A.cout = w.cout; A.gn_w = w.g0_w; A.gn_b = w.g0_b; A.film = film + (size_t)bi * 2 * q.cmax; A.film_ld = fl; A.film_idx = fidx;
+        A.out = t1; A.out_ld = w.cout; A.amax_out = at1;
+        if (w.cin == 1) { A.first_x = sample; A.first_w = w.c0_w; A.first_b = w.c0_b; }
+        else A.pass[0] = conv5(in, in_ld, Lb, w.cin, w.c0_w, w.c0_b, ain0, ain1);
+        if ((rc = launch(A, Lb))) return rc;
+        UbArgs C{};
+        C.n_pass = 1; C.Lout = Lb; C.cout = w.cout; C.gn_w = w.g1_w; C.gn_b = w.g1_b; C.out = out; C.out_ld = out_ld; C.amax_out = aout;
+        C.pass[0] = conv5(t1, w.cout, Lb, w.cout, w.c1_w, w.c1_b, at1, nullptr);
+        if (w.cin == 1) { C.res_x = sample; C.res_w = w.res_w; C.res_b = w.res_b; }
+        else if (w.res_w) {
+            C.n_pass = 2;
+            C.pass[1] = conv5(in, in_ld, Lb, w.cin, w.res_w, w.res_b, ain0, ain1);
+            C.pass[1].ntaps = 1; C.pass[1].ioff0 = 0; C.pass[1].add = 1;
+        } else { C.res_id = in; C.res_ld = in_ld; }
+        return launch(C, Lb);
+    };
+    if ((rc = block(0, nullptr, 0, nullptr, nullptr, L, P, aP, Q, d0, aQ))) return rc;                       // down0.0   1 -> d0
+    if ((rc = block(1, Q, d0, aQ, nullptr, L, P, aP, Rb, d0, aR))) return rc;                                // down0.1
+    {   // Downsample1d: Conv1d(d0, d0, 3, 2, 1)
+        UbArgs A{};
+        A.n_pass = 1; A.Lout = L2; A.cout = d0; A.out = D; A.out_ld = d0; A.amax_out = aD;
+        A.pass[0] = conv5(Rb, d0, L, d0, q.down_w, q.down_b, aR, nullptr);
+        A.pass[0].ntaps = 3; A.pass[0].istride = 2; A.pass[0].ioff0 = -1; A.pass[0].Lpos = L2;
+        if ((rc = launch(A, L))) return rc;
+    }
+    if ((rc = block(2, D, d0, aD, nullptr, L2, T2, aT2, O2, d1, aO2))) return rc;                            // down1.0   d0 -> d1
+    if ((rc = block(3, O2, d1, aO2, nullptr, L2, T2, aT2, CAT + d1, 2 * d1, aC1))) return rc;                // down1.1 -> the skip = channels [d1, 2 d1) of the concat buffer
+    if ((rc = block(4, CAT + d1, 2 * d1, aC1, nullptr, L2, T2, aT2, O2, d1, aO2))) return rc;                // mid0
+    if ((rc = block(5, O2, d1, aO2, nullptr, L2, T2, aT2, CAT, 2 * d1, aC0))) return rc;                     // mid1 -> channels [0, d1)
+    if ((rc = block(6, CAT, 2 * d1, aC0, aC1, L2, T6, aT6, O6, d0, aO6))) return rc;                         // up0.0   2 d1 -> d0
+    if ((rc = block(7, O6, d0, aO6, nullptr, L2, T6, aT6, D, d0, aD))) return rc;                            // up0.1
+    {   // Upsample1d: ConvTranspose1d(d0, d0, 4, 2, 1): out[2 li] = W1 in[li] + W3 in[li - 1]; out[2 li + 1] = W2 in[li] + W0 in[li + 1]
+        UbArgs A{};
+        A.n_pass = 2; A.Lout = L; A.cout = d0; A.out = P; A.out_ld = d0; A.amax_out = aP;
+        A.pass[0] = conv5(D, d0, L2, d0, q.up_w_even, q.up_b, aD, nullptr);
+        A.pass[0].ntaps = 2; A.pass[0].ioff0 = 0; A.pass[0].iostep = -1; A.pass[0].ostride = 2; A.pass[0].ooff = 0;
+        A.pass[1] = conv5(D, d0, L2, d0, q.up_w_odd, q.up_b, aD, nullptr);
+        A.pass[1].ntaps = 2; A.pass[1].ioff0 = 0; A.pass[1].iostep = 1; A.pass[1].ostride = 2; A.pass[1].ooff = 1;
+        if ((rc = launch(A, L2))) return rc;
+    }
+    {   // final_conv: Conv1dBlock(d0, d0, 5) then Conv1d(d0, 1, 1)
+        UbArgs A{};
+        A.n_pass = 1; A.Lout = L; A.cout = d0; A.gn_w = q.fin_gw; A.gn_b = q.fin_gb; A.fin_w = q.out_w; A.fin_b = q.out_b; A.eps = eps;
+        A.pass[0] = conv5(P, d0, L, d0, q.fin_w, q.fin_b, aP, nullptr);
+        if ((rc = launch(A, L))) return rc;
+    }
+    return DGDM_OK;
 }
 
 static size_t unet_lds_floats(const UnetParams &p, int L) {

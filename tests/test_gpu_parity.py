@@ -5,6 +5,8 @@ Tolerances (float32 path; north_star asks for finger-profile L2 error < 1e-4):
   * forward passes / gradients: relative L2 <= 2e-5 (summation order and folded BatchNorm differ from torch's)
   * final samples of a chain:   absolute L2 per finger <= 1e-4
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -440,3 +442,33 @@ def test_native_loop_equals_step_by_step(dev):
         a = sampler.guided_multi_object_groups(net, gd, s, mode, noise, groups, objv, predrawn=pre)
         b = sampler.guided_multi_object_groups(net, gd, s, mode, noise, groups, objv, predrawn=pre, python_loop=True)
         assert torch.equal(a, b), mode
+
+
+def test_unet_batched_equals_per_sample(dev):
+    """The eps-net's two execution forms of the default (f16x3) arithmetic - one workgroup per sample with the whole network in LDS, and, for
+    large batches, layer-by-layer launches with four samples per workgroup and the activations in global memory (csrc/unet.hip, "batched
+    form") - are the same arithmetic operation for operation: identical bits, for every batch size (ragged last workgroup included), both
+    finger lengths, mixed timesteps, and when a smaller batch follows a larger one in the same workspace."""
+    sd = util.unet_sd(11)
+    env = os.environ.get("DGDM_UNET_BATCHED_MIN")
+    try:
+        os.environ["DGDM_UNET_BATCHED_MIN"] = "0"
+        per_sample = engine.Unet1d(sd)
+        os.environ["DGDM_UNET_BATCHED_MIN"] = "1"
+        batched = engine.Unet1d(sd)
+    finally:
+        if env is None:
+            os.environ.pop("DGDM_UNET_BATCHED_MIN", None)
+        else:
+            os.environ["DGDM_UNET_BATCHED_MIN"] = env
+    g = torch.Generator().manual_seed(5)
+    for L in (42, 14):
+        for B in (1024, 37, 5, 4, 3, 1, 130):
+            x = torch.randn((B, L, 1), generator=g).to(dev)
+            x[B // 2] *= 1e-3                                   # samples of very different magnitude in one workgroup (the scale is per sample)
+            t = torch.randint(0, 15, (B,), generator=g).to(dev)
+            a, b = per_sample.forward(x, t), batched.forward(x, t)
+            assert bool(torch.isfinite(b).all())
+            assert torch.equal(a, b), (L, B, float((a - b).abs().max()))
+    ref = orc.unet1d_forward(sd, x.cpu(), t.cpu())
+    assert util.rel_l2(b.cpu(), ref) < REL
