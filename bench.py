@@ -245,7 +245,7 @@ def timed_loop(wl, steps, warmup, dist):
 
 
 # ---------------------------------------------------------------------------------------------------------------- roofline
-# what the JSON's `dtype` / roofline.arithmetic say about each contraction mode of the trunk
+# what the JSON's `dtype` / roofline.arithmetic say about each contraction mode of the trunk (DESIGN_HISTORY.md 4.1 / 4.6 / 4.10)
 DEFAULT_F32_FORM = "f32_f16x3"           # what the library's DGDM_DTYPE_F32 selects (csrc/guidance_api.hip DGDM_DEFAULT_F16X3)
 DTYPE_LABEL = {"f32": "f32_split_f16x3", "f32_bf16x6": "f32_split_bf16x6", "f32_f16x3": "f32_split_f16x3", "f32_mfma": "f32", "bf16": "bf16"}
 ARITHMETIC = {"f32_bf16x6": "float32-grade: every float32 product as six bf16 MFMA products on exactly three-way-split operands (products exact, float32 "
@@ -258,7 +258,7 @@ ARITHMETIC = {"f32_bf16x6": "float32-grade: every float32 product as six bf16 MF
 # SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE); recorded, not live
 PIPE_BUSY_RECORDED = {("3d", "f32_f16x3"): 0.54, ("2d", "f32_f16x3"): 0.54, ("3d", "f32_bf16x6"): 0.71, ("2d", "f32_bf16x6"): 0.73, ("3d", "bf16"): 0.54}
 # algorithmic HBM bytes of ONE cond_fn's trunk launch per (pair, object): the xobj rows (1 KiB per replicated row, 3-D) or nothing of size R (2-D:
-# tables only) + the weights once
+# tables only) + the weights once (DESIGN_HISTORY.md 4.1)
 HBM_ALGORITHMIC_BYTES = {"3d": 36000 * 32 / 32 * 1024.0 + 7.2e6 / 32, "2d": 17e6 / 4}
 
 
@@ -295,7 +295,7 @@ def stage_profile(wl, secs_per_step, contraction):
     n, ms, flops = st["trunk"]
     if not n:
         return None, None
-    # The trunk's arithmetic per mode.  'f32' (default): float32 contractions carried by the bf16 matrix
+    # The trunk's arithmetic per mode (DESIGN_HISTORY.md 4.1 / 4.6 / 4.10).  'f32' (default): float32 contractions carried by the bf16 matrix
     # pipe - SIX bf16 MFMA products are issued per algorithmic float32 product - so the kernel is priced against the bf16 dense peak
     # with the ISSUED FLOPs (6 x algorithmic); the algorithmic float32 rate and what that is against the float32-MFMA peak (which the
     # old k-ordered chain was bound by) are reported beside it.  'f32_mfma': that chain.  'bf16': operands rounded to bf16.

@@ -91,7 +91,7 @@ struct Folded {
 int fold_linear(const StateDict &sd, const std::string &lin, const std::string &bn /* "" = none */, int out, int in,
                 Folded *dst);
 // The same fold kept in double precision (nothing rounded to float32): weights of the stages that run in float64 because they are
-// evaluated once per object / per finger instead of once per replicated row
+// evaluated once per object / per finger instead of once per replicated row (DESIGN_HISTORY.md 4.9)
 struct Folded64 {
     int out = 0, in = 0;
     std::vector<double> w;  // [out][in]

@@ -19,7 +19,10 @@ struct DgdmUnet1d {
     dgdm::UnetParams pf16;  // host copy of what pf16_dev holds (the batched form's launches take their image pointers from it)
     dgdm::DevBuf bws;       // batched form: activation workspace (halo rows zero), sized for (bws_B, bws_L)
     int bws_B = 0, bws_L = 0;
-    int batched_min = 256;  // batches of at least this many samples run the batched form (DGDM_UNET_BATCHED_MIN; 0 = never)
+    // batches of at least this many samples run the batched form (DGDM_UNET_BATCHED_MIN; 0 = never).  Four samples per workgroup: below
+    // ~3/4 of the chip's 256 CUs' worth of workgroups the per-sample kernel (one workgroup per sample) is faster - measured at 256
+    // samples, L = 14 (BASELINE configs[1]): 1.5 ms per step per-sample, 3.1 ms batched (64 workgroups x 20 launches)
+    int batched_min = 768;
 };
 
 namespace dgdm {

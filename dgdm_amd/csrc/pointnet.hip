@@ -3,7 +3,7 @@
 // only in the two random FPS start indices (s1 for sa1, s2 for sa2) drawn per row
 // (pointnet2_utils.py:83 via generator/diffusion.py:491-496).
 //
-// Facts used (DESIGN.md §4 derives them; all are exact, no approximation):
+// Facts used (DESIGN_HISTORY.md §4 derives them; all are exact, no approximation):
 //  * sa1 samples npoint = 512 of N points: FPS from start s1 yields an ordering fps1[s1][0..511] of
 //    point ids ("variant" s1).  The sa1 feature of a centre depends on the centre POINT only
 //    (ball query scans the original order), so F1[p] is computed once per cloud.

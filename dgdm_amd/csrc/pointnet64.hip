@@ -2,7 +2,7 @@
 // float64 accumulation.  These stages run once per OBJECT, not once per replicated row, so double precision costs a few per cent of a
 // denoise step - and it takes the object embedding from 1.7e-6 (k-ordered float32 chains, BatchNorm folded into rounded weights) to
 // the float32 rounding of an exact result (~1e-7; torch's own float32 embedding is 3e-7 from exact), which is what decides how many
-// ReLU pre-activations of the trunk land on the wrong side of zero (scripts/exp_ties.py).
+// ReLU pre-activations of the trunk land on the wrong side of zero (DESIGN_HISTORY.md 4.9, scripts/exp_ties.py).
 //
 // Same dataflow, same index decisions (float32 distances in the reference's operation order), same float32 tables out: every
 // table entry is ONE rounding of a float64 accumulation over float32 inputs, with the BatchNorm fold kept in float64 (Folded64).

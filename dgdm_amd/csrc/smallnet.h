@@ -19,7 +19,7 @@ int dyn_post(int W1, const float *partial, int tiles_per_b, const float *w1c, co
              float *grad, int rows, int L, hipStream_t s);
 
 
-// ---- the same small stages in float64.  Everything that is evaluated once per finger, per pose cell or per object
+// ---- the same small stages in float64 (DESIGN_HISTORY.md 4.9).  Everything that is evaluated once per finger, per pose cell or per object
 // instead of once per replicated row costs nothing in double precision, and what it feeds - the first trunk layer's tables - then
 // carries one float32 rounding instead of the error of a 256..795-term float32 dot product.
 // Y = act(X * WT + bias + rowbias[row / rb_div]): X float32 (Xf) or float64 (Xd) rows, WT [K][N] / bias / rowbias float64; the result

@@ -500,7 +500,7 @@ __global__ void transpose_all_kernel(const float *__restrict__ P, float *__restr
     WT[t.wt + e] = P[t.w + (int64_t)m * t.K + k];
 }
 
-// ---- exact de-duplication of the row-invariant encoders (the same idea as the guided path's tables): the time
+// ---- exact de-duplication of the row-invariant encoders (the same idea as the guided path's tables, DESIGN_HISTORY.md 4.1): the time
 // encoder sees num_train_timesteps distinct inputs and the object encoder one input per sample, whatever the number of rows.
 // dst[n][0..256) (row stride ldd) = src[group(n)][0..256),  group(n) = idx[n] or n / run
 __global__ void expand_groups_kernel(const float *__restrict__ src, const int32_t *__restrict__ idx, int run, float *__restrict__ dst, int64_t ldd, int64_t N) {

@@ -272,7 +272,7 @@ static int launch(const TrunkParams &p, hipStream_t s) {
 }
 
 int trunk_launch(int kind, bool rows_mode, bool fwd_only, const TrunkParams &p, hipStream_t s) {
-    // algorithmic FLOPs of what this launch executes: MFMA layers only
+    // algorithmic FLOPs of what this launch executes (DESIGN_HISTORY.md §5): MFMA layers only
     // real rows only (the last cell tile of a finger is padded to 32: 1125 cells -> 36 tiles = 1152 issued rows)
     const double rows = rows_mode ? (double)p.R : (double)(p.ntiles / std::max(1, p.tiles_per_b)) * p.C;
     const double mid = 2.0 * 256 * 256 * p.n_mid;

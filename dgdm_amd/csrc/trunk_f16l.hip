@@ -35,7 +35,7 @@
 // The LDS-DMA loads are issued from inline assembly (LStream::issue says why: hipcc puts s_waitcnt vmcnt(0) in front of every LDS read
 // that follows an LDS-DMA load it knows of).  scripts/micro/mfma_dep.hip: the group of six MFMAs + the splitting + four ds_read_b128
 // runs at 223 cycles on its own (14.3 k per layer); in the kernel a group takes 270-295: what is left is the stream itself (LDS written
-// by the DMA while it is read, barrier skew between the four waves), not the instruction mix.  Measured numbers: DESIGN.md 4.12.
+// by the DMA while it is read, barrier skew between the four waves), not the instruction mix.  Measured numbers: DESIGN_HISTORY.md 4.12.
 #include "common.h"
 #include <algorithm>
 #include "mfma_chain.h"

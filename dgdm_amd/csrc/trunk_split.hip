@@ -473,7 +473,7 @@ int trunk_split_launch(int kind, const TrunkParams &p, hipStream_t s) {
     if (p.n_mid != (kind == 3 ? 6 : 7)) return DGDM_EINVAL;
     const int grid = (p.ntiles + 3) / 4;
     if (grid == 0) return DGDM_OK;
-    // algorithmic FLOPs (float32 contraction FLOPs of the MFMA layers on the real rows) - the matrix pipe issues six bf16
+    // algorithmic FLOPs (float32 contraction FLOPs of the MFMA layers on the real rows, DESIGN_HISTORY.md 5) - the matrix pipe issues six bf16
     // products per float32 product, i.e. 6x this number of bf16 FLOPs
     const double rows = (double)(p.ntiles / std::max(1, p.tiles_per_b)) * p.C;
     const double mid = 2.0 * 256 * 256 * p.n_mid;

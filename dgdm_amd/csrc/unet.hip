@@ -108,7 +108,7 @@ __device__ void conv_mfma(const ConvArgs a, const lds_f *in, int CPi, lds_f *out
         // Chunked accumulation: a k-ordered float32 fma chain over all ntaps * cin terms (up to 2560) carries a rounding error that
         // grows with the chain length; the chain is cut every CHUNK iterations (128 input channels of one tap), each piece starts
         // from zero and is added to the running total - 4x less accumulation error for 12 packed adds per 192 MFMAs.  The eps-net's
-        // error is what perturbs the chain's x between denoise steps.
+        // error is what perturbs the chain's x between denoise steps (DESIGN_HISTORY.md 7.2).
         constexpr int CHUNK = 8;
         f32x4 acc[MT][NT], tot[MT][NT];
 #pragma unroll

@@ -101,7 +101,7 @@ class Diffusion(nn.Module):
         super().__init__()
         if contraction_dtype not in ("f32", "bf16", "f32_mfma", "f32_f16x3", "f32_bf16x6"):
             raise ValueError(f"contraction dtype {contraction_dtype!r} not supported")
-        # not a reference argument: 'bf16' runs the trunk / eps-net / sa3 contractions with bf16 operands
+        # not a reference argument: 'bf16' runs the trunk / eps-net / sa3 contractions with bf16 operands (DESIGN_HISTORY.md 4.6)
         self.contraction_dtype = contraction_dtype
         # not reference arguments either: the simulator callable (sim_test_batch / sim_test_batch_3d signature) that feeds the
         # harness tables, whether the per-step PNGs are drawn (they cost a device->host copy per step, as in the reference), and

@@ -81,7 +81,7 @@ int dgdm_unet1d_forward(DgdmUnet1d *m, const float *sample_dev, const int32_t *t
                         int B, int L, void *stream);
 /* Arithmetic of the convolutions with more than one input and output channel.  DGDM_DTYPE_F32 (default, the parity path):
  * float32-grade on the f16 matrix pipe - every float32 product as three f16 MFMA products on operands scaled by exact powers of two
- * (per convolution's weights, per sample and convolution input) and split in two f16 pieces, float32 accumulation (DESIGN.md 4.2;
+ * (per convolution's weights, per sample and convolution input) and split in two f16 pieces, float32 accumulation (DESIGN_HISTORY.md 4.2;
  * closer to float64 than the float32 MFMA chain).  DGDM_DTYPE_F32_F16X3 / DGDM_DTYPE_F32_BF16X6 select the same form (the eps-net has
  * one split form); DGDM_DTYPE_F32_MFMA the float32 MFMA chain (also used where the split form's LDS slabs do not fit: L = 44, 46);
  * DGDM_DTYPE_BF16: weights and activations entering those convolutions rounded to bf16, float32 accumulation (BASELINE configs[4]).
@@ -174,7 +174,7 @@ void dgdm_guidance_destroy(DgdmGuidance *g);
 /* Arithmetic of the trunk contractions inside dgdm_dyn{2,3}d_guidance_grad.  DGDM_DTYPE_F32 (default, the parity path) =
  * DGDM_DTYPE_F32_F16X3: float32 operands as two f16 pieces each after exact power-of-two scaling (per weight matrix, per tile row),
  * three f16 MFMAs per product with float32 accumulation (csrc/trunk_f16l.hip: 1.9e-7 rms of a 256-term contraction vs float64; half the
- * matrix-pipe instructions of the six-product form).  DGDM_DTYPE_F32_BF16X6: float32 operands split EXACTLY into three
+ * matrix-pipe instructions of the six-product form; DESIGN_HISTORY.md 4.12).  DGDM_DTYPE_F32_BF16X6: float32 operands split EXACTLY into three
  * bf16 pieces each, six bf16 MFMAs per product (csrc/trunk_split.hip, round 3's default; 1.6e-7).  DGDM_DTYPE_F32_MFMA: the k-ordered
  * float32 fma chain itself (v_mfma_f32_32x32x2_f32; 2.0e-7).  DGDM_DTYPE_BF16 (BASELINE configs[4]: "bf16 contractions, f32
  * accumulate"): weights and the activations/gradients entering a contraction rounded to bf16 (nearest even), float32 accumulation;
@@ -183,7 +183,7 @@ void dgdm_guidance_destroy(DgdmGuidance *g);
 int  dgdm_guidance_set_contraction_dtype(DgdmGuidance *g, int dtype);
 /* Objects the chains refer to.  2-D: objects_dev [n][num_vertices][2] (flattened to object_ch as
  * cond_fn does, diffusion.py:485).  3-D: objects_dev [n][N][3]; builds the per-object PointNet++
- * tables on `stream`.                                                            */
+ * tables (DESIGN_HISTORY.md §4) on `stream`.                                                            */
 int  dgdm_guidance_set_objects(DgdmGuidance *g, const float *objects_dev, int n_objects, void *stream);
 /* Rows of the pose grid per chain: R = B * G * P * P (reference row r = cell*B + b). */
 int64_t dgdm_guidance_rows(const DgdmGuidance *g);
@@ -276,7 +276,7 @@ int dgdm_finger_decode_3d(const float *samples_dev, int batch, int num_ctrl, int
  * When enabled, the launches of every stage of the path are bracketed by hipEvents on the stream they are launched on.
  * dgdm_prof_read_stage synchronises those events and returns, for one stage, the number of bracketed regions, their total
  * milliseconds and the algorithmic work they covered (FLOPs for the MFMA-bound stages, 0 where the host cannot know it).
- * dgdm_prof_read = dgdm_prof_read_stage(DGDM_STAGE_TRUNK): the dominant kernel.                               */
+ * dgdm_prof_read = dgdm_prof_read_stage(DGDM_STAGE_TRUNK): the dominant kernel (DESIGN_HISTORY.md §5).                               */
 enum {
     DGDM_STAGE_TRUNK = 0,   /* trunk_kernel / trunk_bf16_kernel: fused dynamics trunk forward + backward (work = FLOPs, real rows only) */
     DGDM_STAGE_UNET,        /* unet_kernel: one eps-net forward (work = useful FLOPs)                                          */
@@ -287,7 +287,7 @@ enum {
     DGDM_STAGE_COUNT
 };
 int dgdm_prof_enable(int on);
-/* Test hook (3-D): where a reference row's PointNet++ embedding comes from - mode 0: default: one workgroup per
+/* Test hook (3-D): where a reference row's PointNet++ embedding comes from (DESIGN_HISTORY.md §4.3) - mode 0: default: one workgroup per
  * (chain, s1) group with the variant's crowded-centre rows staged in LDS, until the objects of the last dgdm_guidance_set_objects have
  * served more than 5 guidance calls; from then on the per-object embedding table X[s1][start point] (built at that moment) and no gather
  * kernel at all; 5: the NEXT set_objects builds the embedding tables right away; 3: always the group kernel; 2: the per-row table kernel;
@@ -317,7 +317,7 @@ int dgdm_debug_chain_layer(const float *W_host, const float *bias_host, const fl
  *   ball2_dev [N][64] + ball2_count_dev [N]: query_ball_point(0.4, 64, ...) for centre point c when the candidates are scanned in the
  *                                             order perm_dev[0..perm_len) (sa2 sees the cloud re-ordered by sa1's FPS); entries past the
  *                                             count are -1 (the reference pads with the first);
- *   crowded_dev [N]: 1 = more than 64 points in that ball.                                                          */
+ *   crowded_dev [N]: 1 = more than 64 points in that ball (DESIGN_HISTORY.md 4.3).                                                          */
 int dgdm_debug_pointnet_indices(DgdmDynamics *m, const float *xyz_dev, int N, const int32_t *perm_dev, int perm_len,
                                 int32_t *fps512_dev, int32_t *fps128_dev, int32_t *fps128_flags_dev, int32_t *ball1_dev,
                                 int32_t *ball2_dev, int32_t *ball2_count_dev, int32_t *crowded_dev, void *stream);

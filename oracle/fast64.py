@@ -5,7 +5,7 @@ leg may import it).
 Why it exists.  ``dgdm_oracle.cond_fn`` in float64 evaluates PointNet++ on every one of the R replicated rows of a ``cond_fn`` call
 (generator/diffusion.py:473-504; dynamics/models/pointnet2.py:21-32) - 25-50 minutes of CPU per full-grid chain - which is why round 3
 had float64 chains for six reference chains only.  In EXACT arithmetic the embedding of a row is a function of the object and of the
-row's two FPS start draws (s1, s2) alone (pointnet2_utils.py:83; DESIGN.md 4.3 states the decomposition):
+row's two FPS start draws (s1, s2) alone (pointnet2_utils.py:83; DESIGN_HISTORY.md 4.3 states the decomposition):
 
   * sa1 (npoint = N = 512): FPS visits every point, so the 512 centre features are the per-point features F1[p] in the order
     fps1[s1]; ball query scans the ORIGINAL order (pointnet2_utils.py:95-115), so F1 does not depend on s1;

@@ -4,7 +4,7 @@ Counts, per trunk layer, the units whose pre-activation has a different SIGN tha
   ref      torch float32 trunk on the torch float32 PointNet++ embedding            (= the reference's arithmetic)
   seq      the HIP trunk's arithmetic emulated (BatchNorm folded in float64 and rounded, one k-ordered float32 fma chain per
            output, layer 1 as chain(W1o xobj) + (Atab + Ptab)) on the float32 embedding
-  seq+e    the same on the embedding perturbed to the table pipeline's measured error (1.7e-6 relative)
+  seq+e    the same on the embedding perturbed to the table pipeline's measured error (1.7e-6 relative, DESIGN_HISTORY.md 7)
   seq+x    the same on the float64 embedding rounded once to float32 (what a float64 table build would deliver)
   blkN     as seq+x with every chain split into N interleaved partial chains summed at the end
 and the disagreements of each variant WITH THE REFERENCE (what the parity tests see).

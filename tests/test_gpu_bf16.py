@@ -49,7 +49,7 @@ def test_bf16_cond_fn_2d_vs_oracle(dev):
         ref32 = orc.cond_fn(s, x[c], ts, o, objs[oi])
         with orc.contraction('bf16'):
             ref16 = orc.cond_fn(s, x[c], ts, o, objs[oi])
-        assert util.rel_l2(f32_before[c].reshape(B, L, 1), ref32) < 2e-3      # float32 path: a single ReLU sign flip is 5e-4 at this R
+        assert util.rel_l2(f32_before[c].reshape(B, L, 1), ref32) < 2e-3      # float32 path: a single ReLU sign flip is 5e-4 at this R (DESIGN_HISTORY.md §7)
         assert util.rel_l2(got[c].reshape(B, L, 1), ref16) < 6e-3, (o, util.rel_l2(got[c].reshape(B, L, 1), ref16))
         assert util.rel_l2(got[c].reshape(B, L, 1), ref32) < 5e-2, o
     with pytest.raises(ValueError):

@@ -33,7 +33,7 @@ it is bit-identical across its own thread counts, so that is arithmetic, not sch
 different summation orders can therefore not agree to the 2e-5 the small golden cases use.  The yardstick is the float64 result:
     first step:  rel(HIP, float64)       <=  max(2e-5, 2 * rel(reference, float64))       (HIP is about as close to exact as the reference)
     every step:  rel(HIP, reference)     <=  max(2e-5, 3 * rel(reference, float64))       (triangle inequality on the above)
-The measured numbers are printed (pytest -s), merged into gpurun_out/fullgrid_parity.json and tabulated in DESIGN.md §7.
+The measured numbers are printed (pytest -s), merged into gpurun_out/fullgrid_parity.json and tabulated in DESIGN_HISTORY.md §7.
 """
 import json
 import os
@@ -156,7 +156,7 @@ def _load3d(part):
 TIE_GRAD = 5e-4          # what a ReLU tie can do to one 3-D gradient (C = 1125 cells per finger); calls without one agree to ~5e-7
 ROUNDING = 2e-6          # a replayed call below this holds no tie
 CHAIN_GAIN = 4.0         # growth of a deviation of x until the end of the 5-step chain: end-point deviation / push measured 0.6 .. 2.3 on the
-                         # four chains whose deviation is explained by replayed ties
+                         # four chains whose deviation is explained by replayed ties (DESIGN_HISTORY.md 7.2)
 FLOOR_CLEAN = 3e-5       # below this the reference's own end point does not move: the chain holds no ReLU within rounding of zero
 
 
@@ -206,7 +206,7 @@ def test_fullgrid_3d(dev, part):
     to ten times that.  Which side a tie falls on depends on every rounding before it - summation order, the eps-net's last bits
     through x - so a chain that contains one is not reproducible to 1e-4 by ANY second float32 implementation, the reference with
     its eps-net or its trunk perturbed at rounding level included (``reference_floor``; scripts/exp_ties.py, scripts/exp_attrib.py,
-    DESIGN.md 7.2).  With objectives that weigh every row (all but 'convergence') about every second call at R = 2250 holds one.
+    DESIGN_HISTORY.md 7.2).  With objectives that weigh every row (all but 'convergence') about every second call at R = 2250 holds one.
     Asserted:
       * every recorded cond_fn call, replayed on the reference's trajectory: gradient within tie level (5e-4) of the reference's
         (without a tie: ~4e-7);

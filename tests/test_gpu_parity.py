@@ -216,7 +216,7 @@ def test_dyn3d_cond_fn_golden(dev):
 def _teacher_forced(net, gd, s, mode, g, key, chains, final, step_starts, dev, n_grad=1, scale=None, multi_obj=None, rowcoef=None, errs=None, rel=None, grads=None):
     """Replays the reference's recorded trajectory (tests/golden: trace*_x/_eps/_grad): at every step the HIP eps-net, cond_fn
     and scheduler step see exactly the inputs the reference saw.  This is the precise check; free-running chains at these
-    tiny R (24-72 rows) can be thrown off by a single ReLU sign flip."""
+    tiny R (24-72 rows) can be thrown off by a single ReLU sign flip (see DESIGN_HISTORY.md §7)."""
     xs, es, gs = g[key + "_x"], g[key + "_eps"], g[key + "_grad"]
     # gradient tolerance: REL, or what a full-grid fixture calibrated against float64 - one value or one per recorded cond_fn call
     rel = REL if rel is None else rel
