@@ -117,6 +117,19 @@ def test_trainer3d_vs_oracle(rows):
         if "running_" in k:
             assert float((sh[k] - o.sd[k]).abs().max()) < 1e-5 * max(1.0, float(o.sd[k].abs().max())), k
     assert int(sh["linears.1.num_batches_tracked"]) == 1
+    if rows >= 32:
+        # a SECOND step, each side on its own updated weights (the generators are in step: both made the same draws).  Adam turns every
+        # gradient entry into a +-lr step, rounding-level entries included, so the two sets of weights differ by lr on a few entries; with
+        # BatchNorm over 33 rows (not the golden fixture's 8) that stays small: the second forward is held to 2e-3 instead of the 1e-2
+        # of tests/train3d_common.py
+        st = torch.get_rng_state()                       # (both sides left the generator in this state after step 1)
+        draws2, log2 = o.draw(ctrl), orc.StartLog()
+        lo2, po2 = o.step(ctrl, score, ori, pos, obj, draws2, log2)
+        torch.set_rng_state(st)
+        lh2, ph2 = t.step(ctrl, score, ori, pos, obj)
+        assert abs(lh2 / lo2 - 1) < 1e-3, (lh2, lo2)
+        assert util.rel_l2(ph2.cpu(), po2) < 2e-3, util.rel_l2(ph2.cpu(), po2)
+        sh = t.state_dict()
     # eval mode (Trainer.inference, trainer.py:108-146) on the HIP path's OWN trained weights against the oracle evaluating those weights
     torch.manual_seed(100 + rows)
     pi, li = t.inference(ctrl, score, ori, pos, obj)
