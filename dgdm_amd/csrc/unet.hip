@@ -470,14 +470,48 @@ __device__ void zero_halo(lds_f *buf, int CP, int C, int L) {
 // GroupNorm(groups, C) -> Mish -> optional FiLM (scale*y + shift), in place on a [pos+2][CP] buffer.  (diffusion_utils.py:65-69,113-116)
 // One group g, by the calling wave.
 __device__ __forceinline__ void gn_group(lds_f *buf, int CP, int C, int L, int groups, int g, const float *__restrict__ gamma, const float *__restrict__ beta,
-                                         const lds_f *film /*LDS [2C] or null*/) {
+                                         const lds_f *film /*LDS [2C] or null*/, __attribute__((address_space(3))) uint32_t *amax = nullptr, bool want_amax = false) {
     const int lane = threadIdx.x & 63;
     const int cg = C / groups, cnt = cg * L;
     // lane -> (row offset, channel) without a division per element when the group width divides the wave (16 or 32 here)
     const bool pow2 = cg <= 64 && (64 % cg) == 0;
     const int rstep = pow2 ? 64 / cg : 0, c0 = pow2 ? lane % cg : 0, l0 = pow2 ? lane / cg : 0;
     lds_f *gb = buf + 2 * CP + g * cg;
-    if (pow2) {
+    if (pow2 && (L + rstep - 1) / rstep <= 16) {
+        // the lane's (at most 16) values in registers: one pipelined LDS read and one write instead of three dependent read passes (each
+        // iteration of those exposed an LDS round trip: 27 k cycles per GroupNorm of 4 x 8 groups on 8 waves, measured).  Same operations in
+        // the same order as the loops below: identical bits.
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const int l = l0 + i * rstep; v[i] = l < L ? gb[l * CP + c0] : 0.f; }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) if (l0 + i * rstep < L) s += v[i];
+        const float mean = wave_sum(s) / (float)cnt;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) if (l0 + i * rstep < L) { const float d = v[i] - mean; q = fmaf(d, d, q); }
+        const float rstd = 1.f / sqrtf(wave_sum(q) / (float)cnt + 1e-5f);
+        const int ch = g * cg + c0;
+        const float ga = gamma[ch] * rstd, be = beta[ch];
+        const float fs = film ? film[ch] : 1.f, fb = film ? film[C + ch] : 0.f;
+        float mx = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int l = l0 + i * rstep;
+            if (l < L) {
+                float y = mish((v[i] - mean) * ga + be);
+                if (film) y = fs * y + fb;
+                gb[l * CP + c0] = y;
+                mx = fmaxf(mx, fabsf(y));
+            }
+        }
+        if (want_amax) {                                   // largest magnitude of what was written (the batched form's fused blocks scale their second convolution by it)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            if (lane == 0) atomicMax((uint32_t *)amax, __float_as_uint(mx));
+        }
+    } else if (pow2) {
         float s = 0.f;
         for (int l = l0; l < L; l += rstep) s += gb[l * CP + c0];
         const float mean = wave_sum(s) / (float)cnt;
@@ -487,10 +521,17 @@ __device__ __forceinline__ void gn_group(lds_f *buf, int CP, int C, int L, int g
         const int ch = g * cg + c0;
         const float ga = gamma[ch] * rstd, be = beta[ch];
         const float fs = film ? film[ch] : 1.f, fb = film ? film[C + ch] : 0.f;
+        float mx = 0.f;
         for (int l = l0; l < L; l += rstep) {
             float y = mish((gb[l * CP + c0] - mean) * ga + be);
             if (film) y = fs * y + fb;
             gb[l * CP + c0] = y;
+            mx = fmaxf(mx, fabsf(y));
+        }
+        if (want_amax) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            if (lane == 0) atomicMax((uint32_t *)amax, __float_as_uint(mx));
         }
     } else {
         float s = 0.f;
@@ -499,11 +540,18 @@ __device__ __forceinline__ void gn_group(lds_f *buf, int CP, int C, int L, int g
         float q = 0.f;
         for (int i = lane; i < cnt; i += 64) { const int l = i / cg, c = i - l * cg; const float d = gb[l * CP + c] - mean; q = fmaf(d, d, q); }
         const float rstd = 1.f / sqrtf(wave_sum(q) / (float)cnt + 1e-5f);
+        float mxg = 0.f;
         for (int i = lane; i < cnt; i += 64) {
             const int l = i / cg, c = i - l * cg, ch = g * cg + c;
             float y = mish((gb[l * CP + c] - mean) * (gamma[ch] * rstd) + beta[ch]);
             if (film) y = film[ch] * y + film[C + ch];
             gb[l * CP + c] = y;
+            mxg = fmaxf(mxg, fabsf(y));
+        }
+        if (want_amax) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mxg = fmaxf(mxg, __shfl_xor(mxg, o));
+            if (lane == 0) atomicMax((uint32_t *)amax, __float_as_uint(mxg));
         }
     }
 }
@@ -698,6 +746,14 @@ __global__ __launch_bounds__(UNET_THREADS) void unet_kernel(const UnetParams *__
 // chunked accumulation, the same per-(sample, convolution input) power-of-two scale - its max now comes from the producing launch's
 // epilogue -, gn_group as it is): the two forms return the same bits (tests/test_gpu_parity.py::test_unet_batched_equals_per_sample).
 constexpr int UB_THREADS = 512;
+#ifdef DGDM_UB_CLOCKS
+// experiment build: workgroup 0's thread 0 stamps the shader clock at phase boundaries of the launch numbered DGDM_UB_CLOCKS (printed by the launcher)
+__device__ long long g_ub_clk[64];
+__device__ int g_ub_clk_n;
+#define UBCLK(A_) do { if ((A_).clk_on && blockIdx.x == 0 && threadIdx.x == 0) { const int i_ = g_ub_clk_n; if (i_ < 64) { g_ub_clk[i_] = (long long)__builtin_readcyclecounter(); g_ub_clk_n = i_ + 1; } } } while (0)
+#else
+#define UBCLK(A_) do { } while (0)
+#endif
 typedef const __attribute__((address_space(1))) float glb_f;
 typedef __attribute__((address_space(3))) int lds_i;
 typedef __attribute__((address_space(3))) uint32_t lds_u;
@@ -715,6 +771,11 @@ struct UbArgs {
     int n_pass, B, S, Lout, cout, groups;
     const float *first_x, *first_w, *first_b;   // pass 0 is the single-channel k5 convolution of x [B][Lout] on the VALU (no image)
     const float *gn_w, *gn_b;                   // GroupNorm + Mish after pass 0 (null: none)
+    // a whole ConditionalResidualBlock1D in one launch: after pass 0's GroupNorm + Mish + FiLM the block's second convolution reads its
+    // input t1 out of the stage (LDS -> slab, as the per-sample kernel does) and overwrites it; then gn1 + Mish, then the residual
+    int fuse;
+    UbPass c1;                                  // (in / amax unused: the stage and its own per-sample max)
+    const float *gn1_w, *gn1_b;
     const float *film; int film_ld;             // [B][film_ld]: scale [cout] | shift [cout] of this block (null: none); row of sample b: film_idx[b]
     const int *film_idx;
     const float *res_id; int res_ld;            // identity residual [B][Lout + 4][res_ld], added last
@@ -722,6 +783,7 @@ struct UbArgs {
     float *out; int out_ld;                     // [B][Lout + 4][out_ld] (channel offset applied)
     float *amax_out;                            // [B]
     const float *fin_w, *fin_b; float *eps;     // final 1x1 convolution -> eps [B][Lout] instead of `out`
+    int clk_on;                                 // experiment build (DGDM_UB_CLOCKS): this launch stamps its phases
 };
 
 __device__ __forceinline__ int scale_exp_of(float mm) {      // input_scale_exp's exponent for a row set whose largest magnitude is mm
@@ -731,9 +793,16 @@ __device__ __forceinline__ int scale_exp_of(float mm) {      // input_scale_exp'
 
 // One convolution pass of the batched kernel: conv_mfma_f16x3's arithmetic over ns samples.  Waves 0-3 / 4-7 take the lower / upper half
 // of the position tiles, wave & 3 picks MT of the cout / 16 output tiles.
+#ifdef DGDM_UB_CLOCKS
+__device__ int g_ub_clk_live;
+#define UBCLK2() do { if (g_ub_clk_live && blockIdx.x == 0 && threadIdx.x == 0) { const int i_ = g_ub_clk_n; if (i_ < 64) { g_ub_clk[i_] = (long long)__builtin_readcyclecounter(); g_ub_clk_n = i_ + 1; } } } while (0)
+#else
+#define UBCLK2() do { } while (0)
+#endif
 template <int NT, int MT, bool SPLIT>
-__device__ void ub_conv(const UbPass &a, const int S, const int ns, const int b0, const lds_i *kxs, lds_f *stage, const int CPo, const int LoutS /* stage rows per sample */,
-                        const int cout, lds_u4 *slab) {
+__device__ void ub_conv(const UbPass &a, const int S, const int ns, const int b0, const lds_i *kxs, lds_f *stage, const int CPo, const int LoutS /* output positions per sample */,
+                        const int cout, lds_u4 *slab, const bool from_lds, const lds_f *lin /* from_lds: the input rows in LDS ([S][Lin + 4][lin_ld], the stage itself); else a.in.  (A flag,
+                        not a null test: the stage sits at LDS offset 0, which compares equal to a null LDS pointer) */, const int lin_ld) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, q = lane >> 4;
     const int groups = __builtin_amdgcn_readfirstlane(a.cin >> 5), ntaps = __builtin_amdgcn_readfirstlane(a.ntaps);
@@ -750,7 +819,7 @@ __device__ void ub_conv(const UbPass &a, const int S, const int ns, const int b0
         const int n = (half * NT + nt) * 16 + j, nn = min(n, npos - 1);
         const int sm = nn / Lp, l = nn - sm * Lp;
         brow[nt] = q * R + sm * Rs + l * a.istride + a.ioff0 + 2;
-        srow[nt] = n < npos ? sm * LoutS + l * a.ostride + a.ooff : -1;
+        srow[nt] = n < npos ? sm * (LoutS + 4) + 2 + l * a.ostride + a.ooff : -1;      // the stage keeps two halo rows around every sample, like the global buffers
         un[nt] = pow2_f(-kxs[sm]);
     }
     const int iters = __builtin_amdgcn_readfirstlane(ntaps * groups);
@@ -782,8 +851,13 @@ __device__ void ub_conv(const UbPass &a, const int S, const int ns, const int b0
             for (int u = 0; u < FU; ++u) {
                 const int i = i0 + u * blockDim.x, row = i >> 3, r8 = i & 7, sm = row / Rs;
                 if (i < R * GS * 4 && sm < ns) {
-                    const glb_f *src = (glb_f *)a.in + ((size_t)(b0 + sm) * Rs + (row - sm * Rs)) * a.in_ld + (g0 + (r8 >> 2)) * 32 + 4 * (r8 & 3);
-                    lo[u] = *(glb_f4 *)src; hi[u] = *(glb_f4 *)(src + 16);
+                    if (from_lds) {
+                        const lds_f *src = lin + row * lin_ld + (g0 + (r8 >> 2)) * 32 + 4 * (r8 & 3);
+                        lo[u] = *(const lds_f4 *)src; hi[u] = *(const lds_f4 *)(src + 16);
+                    } else {
+                        const glb_f *src = (glb_f *)a.in + ((size_t)(b0 + sm) * Rs + (row - sm * Rs)) * a.in_ld + (g0 + (r8 >> 2)) * 32 + 4 * (r8 & 3);
+                        lo[u] = *(glb_f4 *)src; hi[u] = *(glb_f4 *)(src + 16);
+                    }
                 }
             }
 #pragma unroll
@@ -806,6 +880,7 @@ __device__ void ub_conv(const UbPass &a, const int S, const int ns, const int b0
             }
         }
         __syncthreads();
+        UBCLK2();                                            // slab of this pass filled
 #ifdef DGDM_UB_EXP_NOMFMA
         if (S > 0) { it += GS * ntaps; continue; }           // timing experiment (wrong results): everything but the MFMA loop
 #endif
@@ -847,6 +922,7 @@ __device__ void ub_conv(const UbPass &a, const int S, const int ns, const int b0
                     for (int nt = 0; nt < NT; ++nt) { tot[m][nt] += acc[m][nt]; acc[m][nt] = (f32x4)(0.f); }
             }
         }
+        UBCLK2();                                            // this pass' MFMAs issued
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -866,16 +942,17 @@ __device__ void ub_conv(const UbPass &a, const int S, const int ns, const int b0
     }
 }
 
-__device__ void ub_conv_dispatch(const UbPass &a, int S, int ns, int b0, const lds_i *kxs, lds_f *stage, int CPo, int Lout, int cout, lds_u4 *slab) {
+__device__ void ub_conv_dispatch(const UbPass &a, int S, int ns, int b0, const lds_i *kxs, lds_f *stage, int CPo, int Lout, int cout, lds_u4 *slab,
+                                 bool from_lds = false, const lds_f *lin = nullptr, int lin_ld = 0) {
     const int ntile = (S * a.Lpos + 15) >> 4, nth = (ntile + 1) >> 1;        // position tiles per half of the waves (the host keeps nth <= 6)
     // (the host keeps ntile <= 6 for the 256-wide convolutions - they all run at the half-length level - and <= 12 for the 128-wide ones)
     if ((cout >> 4) == 8) {
-        if (nth <= 3) ub_conv<3, 2, true>(a, S, ns, b0, kxs, stage, CPo, Lout, cout, slab);
-        else ub_conv<6, 2, true>(a, S, ns, b0, kxs, stage, CPo, Lout, cout, slab);
+        if (nth <= 3) ub_conv<3, 2, true>(a, S, ns, b0, kxs, stage, CPo, Lout, cout, slab, from_lds, lin, lin_ld);
+        else ub_conv<6, 2, true>(a, S, ns, b0, kxs, stage, CPo, Lout, cout, slab, from_lds, lin, lin_ld);
     } else {
         // 16 output tiles = two per wave with all (<= 6) position tiles: split in halves the 256-wide convolutions pulled 57 B/clk of weight
         // fragments through the CU's L1 (every fragment twice) - its limit is 64 - and ran at a third of their MFMA rate
-        ub_conv<6, 2, false>(a, S, ns, b0, kxs, stage, CPo, Lout, cout, slab);
+        ub_conv<6, 2, false>(a, S, ns, b0, kxs, stage, CPo, Lout, cout, slab, from_lds, lin, lin_ld);
     }
 }
 
@@ -883,16 +960,28 @@ __global__ __launch_bounds__(UB_THREADS) void ub_layer_kernel(const UbArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     lds_f *lds = (lds_f *)lds_raw;
     const int S = A.S, b0 = blockIdx.x * S, ns = min(S, A.B - b0);
-    const int Lout = A.Lout, cout = A.cout, CPo = cout + UNET_ROW_PAD;
+    const int Lout = A.Lout, cout = A.cout, CPo = cout + UNET_ROW_PAD, Rso = Lout + 4;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, nwave = blockDim.x >> 6;
-    lds_f *stage = lds;                                           // [S][Lout][CPo]
-    lds_f *filmL = stage + S * Lout * CPo;                        // [S][2 cout]
-    lds_i *kxs = (lds_i *)(filmL + S * 2 * cout);                 // [S] scale exponents, then [S] amax bits
+    lds_f *stage = lds;                                           // [S][Lout + 4][CPo]: two halo rows around every sample (zero when a fused conv reads them)
+    lds_f *filmL = stage + S * Rso * CPo;                         // [S][2 cout]
+    lds_i *kxs = (lds_i *)(filmL + S * 2 * cout);                 // [8] scale exponents, then [8] amax bits
     lds_u *amx = (lds_u *)(kxs + 8);
     lds_u4 *slab = (lds_u4 *)(kxs + 16);
     if (A.film)
         for (int i = t; i < ns * 2 * cout; i += blockDim.x) { const int sm = i / (2 * cout); filmL[i] = A.film[(size_t)A.film_idx[b0 + sm] * A.film_ld + (i - sm * 2 * cout)]; }
     if (t < 8) amx[t] = 0u;
+#ifdef DGDM_UB_CLOCKS
+    if (blockIdx.x == 0 && t == 0) { g_ub_clk_live = A.clk_on; if (A.clk_on) g_ub_clk_n = 0; }
+#endif
+    UBCLK(A);                                                      // [0] start
+    if (A.fuse)
+        for (int i = t; i < S * 4 * CPo; i += blockDim.x) { const int r = i / CPo, sm = r >> 2, h = r & 3; stage[(sm * Rso + (h < 2 ? h : Lout + h)) * CPo + (i - r * CPo)] = 0.f; }
+    auto gn = [&](const float *gw, const float *gb, bool film, bool want_amax) __attribute__((always_inline)) {
+        for (int idx = wave; idx < ns * A.groups; idx += nwave) {
+            const int sm = idx / A.groups, g = idx - sm * A.groups;
+            gn_group(stage + sm * Rso * CPo, CPo, cout, Lout, A.groups, g, gw, gb, film ? filmL + sm * 2 * cout : nullptr, amx + sm, want_amax);
+        }
+    };
     for (int p = 0; p < A.n_pass; ++p) {
         const UbPass &a = A.pass[p];
         if (p == 0 && A.first_x) {
@@ -903,7 +992,7 @@ __global__ __launch_bounds__(UB_THREADS) void ub_layer_kernel(const UbArgs A) {
                 float acc = 0.f;
 #pragma unroll
                 for (int k = 0; k < 5; ++k) { const int li = l + k - 2; acc = fmaf(A.first_w[k * cout + co], (li >= 0 && li < Lout) ? x[li] : 0.f, acc); }
-                stage[r * CPo + co] = acc + A.first_b[co];
+                stage[(sm * Rso + 2 + l) * CPo + co] = acc + A.first_b[co];
             }
         } else {
             if (t < S) {
@@ -912,25 +1001,38 @@ __global__ __launch_bounds__(UB_THREADS) void ub_layer_kernel(const UbArgs A) {
                 kxs[t] = scale_exp_of(mm);
             }
             __syncthreads();
+            UBCLK(A);                                              // amax -> kxs
             ub_conv_dispatch(a, S, ns, b0, kxs, stage, CPo, Lout, cout, slab);
         }
         __syncthreads();
-#ifdef DGDM_UB_EXP_NOGN
-        if (false) {                                         // timing experiment (wrong results)
-#else
-        if (p == 0 && A.gn_w) {
+        UBCLK(A);                                                  // pass p done (epilogue in the stage)
+        if (p == 0) {
+#ifndef DGDM_UB_EXP_NOGN
+            if (A.gn_w) { gn(A.gn_w, A.gn_b, A.film != nullptr, A.fuse != 0); __syncthreads(); }
 #endif
-            for (int idx = wave; idx < ns * A.groups; idx += nwave) {
-                const int sm = idx / A.groups, g = idx - sm * A.groups;
-                gn_group(stage + sm * Lout * CPo - 2 * CPo, CPo, cout, Lout, A.groups, g, A.gn_w, A.gn_b, A.film ? filmL + sm * 2 * cout : nullptr);
+            UBCLK(A);                                              // GroupNorm + Mish (+ FiLM)
+            if (A.fuse) {
+                // t1 is in the stage, its per-sample magnitude (what the unfused form's producer wrote to amax) came out of the GroupNorm pass
+                if (t < S) { kxs[t] = scale_exp_of(t < ns ? __uint_as_float(amx[t]) : 0.f); }
+                __syncthreads();
+                if (t < 8) amx[t] = 0u;
+                UBCLK(A);                                          // t1's magnitude
+                ub_conv_dispatch(A.c1, S, ns, b0, kxs, stage, CPo, Lout, cout, slab, true, stage, CPo);
+                __syncthreads();
+                UBCLK(A);                                          // second convolution done
+#ifndef DGDM_UB_EXP_NOGN
+                gn(A.gn1_w, A.gn1_b, false, false);
+                __syncthreads();
+#endif
+                UBCLK(A);                                          // GroupNorm + Mish of the block's output
             }
-            __syncthreads();
         }
     }
     if (A.eps) {                                                  // final_conv.1: Conv1d(d0, 1, 1)
         for (int r = t; r < ns * Lout; r += blockDim.x) {
+            const int sm = r / Lout, l = r - sm * Lout;
             float acc = 0.f;
-            for (int c = 0; c < cout; ++c) acc = fmaf(A.fin_w[c], stage[r * CPo + c], acc);
+            for (int c = 0; c < cout; ++c) acc = fmaf(A.fin_w[c], stage[(sm * Rso + 2 + l) * CPo + c], acc);
             A.eps[(size_t)b0 * Lout + r] = acc + A.fin_b[0];
         }
         return;
@@ -948,7 +1050,7 @@ __global__ __launch_bounds__(UB_THREADS) void ub_layer_kernel(const UbArgs A) {
             const int i = i0 + u * blockDim.x;
             if (i < total) {
                 const int sm = i / per, r = i - sm * per, l = r / c4n, c = (r - l * c4n) * 4;
-                if (A.res_id) rv[u] = *(glb_f4 *)((glb_f *)A.res_id + ((size_t)(b0 + sm) * (Lout + 4) + l + 2) * A.res_ld + c);
+                if (A.res_id) rv[u] = *(glb_f4 *)((glb_f *)A.res_id + ((size_t)(b0 + sm) * Rso + l + 2) * A.res_ld + c);
                 if (A.res_x) xv[u] = A.res_x[(size_t)(b0 + sm) * Lout + l];
             }
         }
@@ -957,14 +1059,14 @@ __global__ __launch_bounds__(UB_THREADS) void ub_layer_kernel(const UbArgs A) {
             const int i = i0 + u * blockDim.x;
             if (i >= total) break;
             const int sm = i / per, r = i - sm * per, l = r / c4n, c = (r - l * c4n) * 4;
-            f32x4 v = *(lds_f4 *)(stage + (sm * Lout + l) * CPo + c);
+            f32x4 v = *(lds_f4 *)(stage + (sm * Rso + 2 + l) * CPo + c);
             if (A.res_id) v += rv[u];
             if (A.res_x) {
                 const float x = xv[u];
                 const float4 rw = *reinterpret_cast<const float4 *>(A.res_w + c), rb = *reinterpret_cast<const float4 *>(A.res_b + c);
                 v[0] += fmaf(rw.x, x, rb.x); v[1] += fmaf(rw.y, x, rb.y); v[2] += fmaf(rw.z, x, rb.z); v[3] += fmaf(rw.w, x, rb.w);
             }
-            *reinterpret_cast<f32x4 *>(A.out + ((size_t)(b0 + sm) * (Lout + 4) + l + 2) * A.out_ld + c) = v;
+            *reinterpret_cast<f32x4 *>(A.out + ((size_t)(b0 + sm) * Rso + l + 2) * A.out_ld + c) = v;
             const float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
             mx[0] = sm == 0 ? fmaxf(mx[0], m) : mx[0]; mx[1] = sm == 1 ? fmaxf(mx[1], m) : mx[1];
             mx[2] = sm == 2 ? fmaxf(mx[2], m) : mx[2]; mx[3] = sm == 3 ? fmaxf(mx[3], m) : mx[3];
@@ -979,6 +1081,7 @@ __global__ __launch_bounds__(UB_THREADS) void ub_layer_kernel(const UbArgs A) {
     }
     __syncthreads();
     if (t < ns && A.amax_out) A.amax_out[b0 + t] = __uint_as_float(amx[t]);
+    UBCLK(A);                                                      // residual + store
 }
 
 // step encoder + the eight FiLM vectors of every sample (unet_kernel's first two phases): film [B][8][2 cmax].  They depend on the sample's
@@ -1016,7 +1119,7 @@ __global__ __launch_bounds__(256) void ub_cond_kernel(const UnetParams *__restri
 }
 
 static size_t ub_lds_bytes(int S, int Lin, int Lout, int cout) {
-    return ((size_t)S * Lout * (cout + UNET_ROW_PAD) + (size_t)S * 2 * cout + 16) * 4 + (size_t)2 * 8 * S * (Lin + 4) * 16;
+    return ((size_t)S * (Lout + 4) * (cout + UNET_ROW_PAD) + (size_t)S * 2 * cout + 16) * 4 + (size_t)2 * 8 * S * (std::max(Lin, Lout) + 4) * 16;
 }
 
 // samples per workgroup: the most (<= 4) for which every launch fits the LDS and a half of the waves holds at most 6 position tiles
@@ -1063,34 +1166,52 @@ int unet_launch_batched(const UnetParams &q, const UnetParams *q_dev, float *ws,
         a.istride = 1; a.ioff0 = -2; a.iostep = 1; a.ostride = 1; a.ooff = 0; a.add = 0;
         return a;
     };
+    int launch_no = 0;
     auto launch = [&](UbArgs &A, int Lin) -> int {
         A.B = B; A.S = S; A.groups = q.groups;
+#ifdef DGDM_UB_CLOCKS
+        A.clk_on = (launch_no == DGDM_UB_CLOCKS && B >= 512) ? 1 : 0;
+#endif
+        ++launch_no;
         const size_t lds = ub_lds_bytes(S, Lin, A.Lout, A.cout);
         DGDM_REQUIRE(lds <= 160 * 1024, DGDM_EINVAL, "unet_launch_batched: %zu B of LDS", lds);
         hipLaunchKernelGGL(ub_layer_kernel, dim3((B + S - 1) / S), dim3(UB_THREADS), lds, s, A);
         DGDM_HIP_CHECK(hipGetLastError());
+#ifdef DGDM_UB_CLOCKS
+        if (A.clk_on) {
+            static int printed = 0;
+            long long st[64]; int n = 0;
+            hipStreamSynchronize(s);
+            hipMemcpyFromSymbol(st, HIP_SYMBOL(g_ub_clk), sizeof(st));
+            hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_ub_clk_n), sizeof(n));
+            if (printed++ < 3) {
+                fprintf(stderr, "ub stamps launch %d (Lout %d cout %d passes %d fuse %d): ", launch_no - 1, A.Lout, A.cout, A.n_pass, A.fuse);
+                for (int i = 1; i < n && i < 64; ++i) fprintf(stderr, "%lld ", st[i] - st[i - 1]);
+                fprintf(stderr, "| total %lld\n", n > 0 ? st[n - 1] - st[0] : 0LL);
+            }
+        }
+#endif
         return DGDM_OK;
     };
     int rc;
     // one ConditionalResidualBlock1D (unet_kernel's res_block): conv0 + GN + Mish + FiLM -> t1; conv1 + GN + Mish + residual -> out
     auto block = [&](int bi, const float *in, int in_ld, const float *ain0, const float *ain1, int Lb, float *t1, float *at1, float *out, int out_ld, float *aout) -> int {
+        (void)t1; (void)at1;                              // (the unfused form's intermediate: t1 now stays in the stage)
         const UnetRes &w = q.res[bi];
         UbArgs A{};
         A.n_pass = 1; A.Lout = Lb; A.cout = w.cout; A.gn_w = w.g0_w; A.gn_b = w.g0_b; A.film = film + (size_t)bi * 2 * q.cmax; A.film_ld = fl; A.film_idx = fidx;
-        A.out = t1; A.out_ld = w.cout; A.amax_out = at1;
+        A.out = out; A.out_ld = out_ld; A.amax_out = aout;
         if (w.cin == 1) { A.first_x = sample; A.first_w = w.c0_w; A.first_b = w.c0_b; }
         else A.pass[0] = conv5(in, in_ld, Lb, w.cin, w.c0_w, w.c0_b, ain0, ain1);
-        if ((rc = launch(A, Lb))) return rc;
-        UbArgs C{};
-        C.n_pass = 1; C.Lout = Lb; C.cout = w.cout; C.gn_w = w.g1_w; C.gn_b = w.g1_b; C.out = out; C.out_ld = out_ld; C.amax_out = aout;
-        C.pass[0] = conv5(t1, w.cout, Lb, w.cout, w.c1_w, w.c1_b, at1, nullptr);
-        if (w.cin == 1) { C.res_x = sample; C.res_w = w.res_w; C.res_b = w.res_b; }
+        A.fuse = 1; A.gn1_w = w.g1_w; A.gn1_b = w.g1_b;
+        A.c1 = conv5(nullptr, w.cout + UNET_ROW_PAD, Lb, w.cout, w.c1_w, w.c1_b, nullptr, nullptr);
+        if (w.cin == 1) { A.res_x = sample; A.res_w = w.res_w; A.res_b = w.res_b; }
         else if (w.res_w) {
-            C.n_pass = 2;
-            C.pass[1] = conv5(in, in_ld, Lb, w.cin, w.res_w, w.res_b, ain0, ain1);
-            C.pass[1].ntaps = 1; C.pass[1].ioff0 = 0; C.pass[1].add = 1;
-        } else { C.res_id = in; C.res_ld = in_ld; }
-        return launch(C, Lb);
+            A.n_pass = 2;
+            A.pass[1] = conv5(in, in_ld, Lb, w.cin, w.res_w, w.res_b, ain0, ain1);
+            A.pass[1].ntaps = 1; A.pass[1].ioff0 = 0; A.pass[1].add = 1;
+        } else { A.res_id = in; A.res_ld = in_ld; }
+        return launch(A, Lb);
     };
     if ((rc = block(0, nullptr, 0, nullptr, nullptr, L, P, aP, Q, d0, aQ))) return rc;                       // down0.0   1 -> d0
     if ((rc = block(1, Q, d0, aQ, nullptr, L, P, aP, Rb, d0, aR))) return rc;                                // down0.1
