@@ -729,7 +729,7 @@ def main():
     roof, shares = stage_profile(wl, secs / a.steps, a.contraction)
     meas = {"samples": wl.B * pairs * world * a.steps, "secs": secs, "world": world, "steps": a.steps, "warmup": a.warmup, "contraction": a.contraction,
             "workload": a.workload, "pairs": pairs, "B": wl.B, "S": wl.S, "rows": wl.rows, "n_obj": wl.n_obj, "draw_secs": draw_secs,
-            "gloo": world > 1 and a.backend == "gloo"}
+            "gloo": world > 1 and a.backend == "gloo", "unet_form": "%s%s" % ((lambda f: (f[0], " batched" if f[1] else ""))(wl.net.effective_form(wl.B * pairs, wl.L)))}
     cpu, detail = None, {}
     if world == 1 and a.cpu_baseline != "none":
         cpu, detail["cpu_baseline"] = cpu_baseline(host_view(wl), full=a.cpu_baseline == "full")
@@ -770,7 +770,7 @@ def headline(m, roof, shares, cpu):
             "dtype": DTYPE_LABEL[m["contraction"]], "data": "synthetic",
             "config": {"workload": WORKLOAD_NAME[m["workload"]], "contraction_flag": m["contraction"], "pairs_per_gpu_per_step": m["pairs"],
                        "fingers_per_pair": m["B"], "denoise_steps": m["S"], "rows_per_cond_fn": m["rows"], "cond_fn_per_chain_step": m["n_obj"],
-                       "parallelism": f"pairs-sharded x{m['world']}"},
+                       "eps_net_form": m.get("unet_form"), "parallelism": f"pairs-sharded x{m['world']}"},
             "ms_per_denoise_step": secs / steps / m["S"] * 1e3,
             "ms_per_denoise_step_per_pair": secs / steps / m["S"] / m["pairs"] * 1e3,
             "host_draw_ms_per_step": m["draw_secs"] * 1e3}

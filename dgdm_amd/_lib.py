@@ -67,6 +67,7 @@ PROTOTYPES = {
     "dgdm_guidance_destroy": (None, [_P]),
     "dgdm_debug_chain_layer": (C.c_int, [_P, _P, _P, _P, _P]),
     "dgdm_unet1d_set_contraction_dtype": (C.c_int, [_P, C.c_int]),
+    "dgdm_unet1d_effective_form": (C.c_int, [_P, C.c_int, C.c_int]),
     "dgdm_finger_decode_2d": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P, _P]),
     "dgdm_finger_decode_3d": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P, _P]),
     "dgdm_guidance_set_contraction_dtype": (C.c_int, [_P, C.c_int]),

@@ -294,6 +294,13 @@ extern "C" int dgdm_unet1d_forward(DgdmUnet1d *m, const float *sample_dev, const
     return rc;
 }
 
+extern "C" int dgdm_unet1d_effective_form(const DgdmUnet1d *m, int B, int L) {
+    if (!m || B < 0 || L <= 0) return -1;
+    const int mode = (m->mode == 2 && !unet_f16x3_fits(m->p, L)) ? 0 : m->mode;
+    const bool batched = mode == 2 && m->batched_min > 0 && B >= m->batched_min && unet_batched_samples(m->pf16, L) > 0;
+    return (mode == 1 ? DGDM_DTYPE_BF16 : mode == 2 ? DGDM_DTYPE_F32_F16X3 : DGDM_DTYPE_F32_MFMA) + (batched ? 16 : 0);
+}
+
 extern "C" int dgdm_unet1d_set_contraction_dtype(DgdmUnet1d *m, int dtype) {
     DGDM_REQUIRE(m, DGDM_EINVAL, "dgdm_unet1d_set_contraction_dtype: null handle");
     // DGDM_DTYPE_F32 (the default) and both split forms: float32-grade convolutions as three f16 MFMA products (the eps-net has one split

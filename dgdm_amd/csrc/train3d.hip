@@ -18,6 +18,7 @@
 // per-(cloud, point) ordered sum over the ball lists.  FPS / ball query / gathers are the device functions the guided path's tables are
 // built from (dgdm_farthest_point_sample ...: bit-exact index lists).  No atomics: a step is reproducible bit for bit.
 #include "train_gemm.h"
+#include "pointnet.h"
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -310,6 +311,11 @@ struct DgdmTrainer3d {
     int max_img_elems = 0, L = 42, Lp = 48, N = 512, n_bn = 0;
     float beta1 = 0.9f, beta2 = 0.95f, eps = 1e-8f, wd = 0.f;
     int64_t adam_steps = 0, bn_batches = 0, R_ws = 0, wpart_floats = 0;
+    // the two FPS start vectors of a forward: pinned staging (two slots, alternated per call) -> device, no allocation and no pipeline drain
+    // per step (the index entry point dgdm_farthest_point_sample allocates, uploads and synchronises on every call)
+    int *start_pin = nullptr; DevBuf start_dev; int64_t start_cap = 0; int start_slot = 0;
+    ~DgdmTrainer3d() { if (start_pin) (void)hipHostFree(start_pin); }
+    int upload_starts(const int64_t *s1, const int64_t *s2, int64_t R, hipStream_t s, const int **d1, const int **d2);
     Lin g0, g2, sa[5], tr[8], outl, te0, te2;
     Bn sabn[5], trbn[8];
     // workspace
@@ -502,6 +508,27 @@ int DgdmTrainer3d::adam(float lr, hipStream_t s) {
     return repack(s);
 }
 
+int DgdmTrainer3d::upload_starts(const int64_t *s1, const int64_t *s2, int64_t R, hipStream_t s, const int **d1, const int **d2) {
+    if (R > start_cap) {
+        if (start_pin) { DGDM_HIP_CHECK(hipStreamSynchronize(s)); DGDM_HIP_CHECK(hipHostFree(start_pin)); start_pin = nullptr; }
+        DGDM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&start_pin), (size_t)4 * R * sizeof(int), hipHostMallocDefault));
+        int rc = start_dev.alloc((size_t)4 * R * sizeof(int));
+        if (rc) return rc;
+        start_cap = R;
+    }
+    start_slot ^= 1;
+    int *pin = start_pin + (size_t)start_slot * 2 * start_cap;
+    for (int64_t i = 0; i < R; ++i) {
+        DGDM_REQUIRE(s1[i] >= 0 && s1[i] < N, DGDM_EINVAL, "FPS start %lld outside [0, %d)", (long long)s1[i], N);
+        DGDM_REQUIRE(s2[i] >= 0 && s2[i] < 512, DGDM_EINVAL, "FPS start %lld outside [0, 512)", (long long)s2[i]);
+        pin[i] = (int)s1[i]; pin[start_cap + i] = (int)s2[i];
+    }
+    int *dev = start_dev.as<int>() + (size_t)start_slot * 2 * start_cap;
+    DGDM_HIP_CHECK(hipMemcpyAsync(dev, pin, (size_t)2 * start_cap * sizeof(int), hipMemcpyHostToDevice, s));
+    *d1 = dev; *d2 = dev + start_cap;
+    return DGDM_OK;
+}
+
 int DgdmTrainer3d::run_step(const float *ctrl1, const float *noise, const float *sa_, const float *sb_, const float *t, const float *ori, const float *pos,
                             const float *xyz_in, const int64_t *start1, const int64_t *start2, const float *score, int64_t R, float lr, int train, float *pred_out,
                             float *loss_host, hipStream_t s, int64_t total_rows, bool apply) {
@@ -520,7 +547,9 @@ int DgdmTrainer3d::run_step(const float *ctrl1, const float *noise, const float 
     hipLaunchKernelGGL(bn_relu_kernel, grid(R * 64), dim3(256), 0, s, gh, (const float *)nullptr, ga, R, 256, (int64_t)256);
     if ((rc = lin_fwd(g2, ga, 256, X0 + 256, 800, R, s))) return rc;
     // ---- PointNet++ (pointnet2.py:21-32).  sa1: FPS(512) from the drawn start, ball query r = 0.2 / 32 in the original order
-    if ((rc = dgdm_farthest_point_sample(xyz, start1, (int)R, N, 512, fps1, s))) return rc;
+    const int *st1 = nullptr, *st2 = nullptr;
+    if ((rc = upload_starts(start1, start2, R, s, &st1, &st2))) return rc;
+    if ((rc = pn_fps_rows(xyz, st1, (int)R, N, 512, fps1, s))) return rc;
     if ((rc = dgdm_index_points(xyz, fps1, (int)R, N, 512, 3, nx1, s))) return rc;
     if ((rc = dgdm_query_ball_point((float)(0.2 * 0.2), 32, xyz, nx1, (int)R, N, 512, idx1, s))) return rc;
     hipLaunchKernelGGL(group_kernel, grid(M1r), dim3(256), 0, s, xyz, (const float *)nullptr, fps1, idx1, N, 512, 32, 0, 4, M1r, feat1);
@@ -533,7 +562,7 @@ int DgdmTrainer3d::run_step(const float *ctrl1, const float *noise, const float 
     hipLaunchKernelGGL(maxpool_kernel, grid(Mr1 * 128), dim3(256), 0, s, y12, (const float *)cf(sabn[1].slot), 32, 128, Mr1, l1p, (int64_t)128, arg1);
     DGDM_HIP_CHECK(hipGetLastError());
     // sa2 on the 512 sampled points (order fps1) with their features: FPS(128), ball query r = 0.4 / 64
-    if ((rc = dgdm_farthest_point_sample(nx1, start2, (int)R, 512, 128, fps2, s))) return rc;
+    if ((rc = pn_fps_rows(nx1, st2, (int)R, 512, 128, fps2, s))) return rc;
     if ((rc = dgdm_index_points(nx1, fps2, (int)R, 512, 128, 3, nx2, s))) return rc;
     if ((rc = dgdm_query_ball_point((float)(0.4 * 0.4), 64, nx1, nx2, (int)R, 512, 128, idx2, s))) return rc;
     hipLaunchKernelGGL(group_kernel, grid(M2r * 33), dim3(256), 0, s, nx1, (const float *)l1p, fps2, idx2, 512, 128, 64, 128, 132, M2r, feat2);

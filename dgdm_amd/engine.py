@@ -42,6 +42,15 @@ class Unet1d:
         check(lib().dgdm_unet1d_set_contraction_dtype(self._h, codes[dtype]))
         self.contraction_dtype = dtype
 
+    def effective_form(self, batch: int, num_points: int):
+        """(arithmetic, batched) a forward of `batch` samples of `num_points` control points actually runs: arithmetic is 'f32_f16x3',
+        'f32_mfma' (also what 'f32' falls back to where the split form's slabs do not fit the LDS: L = 44, 46) or 'bf16'; batched says
+        whether the layer-by-layer form for large batches is used (same bits as the per-sample kernel)."""
+        code = int(lib().dgdm_unet1d_effective_form(self._h, int(batch), int(num_points)))
+        if code < 0:
+            raise ValueError("bad batch / num_points")
+        return {1: "bf16", 2: "f32_mfma", 3: "f32_f16x3"}[code & 15], bool(code & 16)
+
     def __del__(self):
         if getattr(self, "_h", None) and lib is not None:      # module globals are None during interpreter shutdown
             lib().dgdm_unet1d_destroy(self._h)

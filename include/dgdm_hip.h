@@ -87,6 +87,10 @@ int dgdm_unet1d_forward(DgdmUnet1d *m, const float *sample_dev, const int32_t *t
  * DGDM_DTYPE_BF16: weights and activations entering those convolutions rounded to bf16, float32 accumulation (BASELINE configs[4]).
  * GroupNorm, Mish, FiLM, residual adds, the Linear layers and the single-channel first/last convolutions are float32 in every mode.   */
 int dgdm_unet1d_set_contraction_dtype(DgdmUnet1d *m, int dtype);
+/* What a dgdm_unet1d_forward call with B samples of L control points actually runs: the DGDM_DTYPE_* of its convolutions
+ * (DGDM_DTYPE_F32_F16X3, DGDM_DTYPE_F32_MFMA - also where the split form's slabs do not fit the LDS - or DGDM_DTYPE_BF16), + 16 when the
+ * layer-by-layer batched form is used (large batches; the same bits as the per-sample kernel).  Negative: bad argument.               */
+int dgdm_unet1d_effective_form(const DgdmUnet1d *m, int B, int L);
 
 /* ------------------------------------------------------------------ a13/a14: scheduler step
  * noise_pred - sqrt(1-abar_t)*grad*scale  (generator/diffusion.py:575,645) followed by

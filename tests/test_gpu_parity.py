@@ -472,3 +472,8 @@ def test_unet_batched_equals_per_sample(dev):
             assert torch.equal(a, b), (L, B, float((a - b).abs().max()))
     ref = orc.unet1d_forward(sd, x.cpu(), t.cpu())
     assert util.rel_l2(b.cpu(), ref) < REL
+    # what runs is reported, not assumed (advisor, round 4): the split form falls back to the float32 chain where its slabs do not fit
+    assert batched.effective_form(1024, 42) == ("f32_f16x3", True) and per_sample.effective_form(1024, 42) == ("f32_f16x3", False)
+    assert batched.effective_form(4, 46) == ("f32_mfma", False)
+    assert engine.Unet1d(sd, contraction_dtype="bf16").effective_form(1024, 42) == ("bf16", False)
+    assert engine.Unet1d(sd).effective_form(767, 42)[1] is False and engine.Unet1d(sd).effective_form(768, 42)[1] is True
