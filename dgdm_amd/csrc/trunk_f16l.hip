@@ -84,7 +84,15 @@ struct Act2 {
 };
 
 // The shared weight stream (see the file header).
-constexpr int CH = 16, NBUF = 4;
+// Chunk = CH stream entries (1 KiB each): 16 (one K-step of all four output-block pairs) in four slots.  -DDGDM_F16_CHUNK=32 (round 5
+// experiment): a whole 32-feature input block (both K-steps) per chunk in THREE slots (96 KiB) - half the barriers and counted waits per
+// MFMA (one per 1 536 cycles of issue); c + 3 goes into c's slot once every wave has passed the barrier behind its last reads of c.
+// Bit-identical results, and 1.5 % SLOWER on the same box (3-D launch 6.92 -> 7.03 ms, three alternating runs each): the barrier count
+// is not what holds the stack at 0.6 of its MFMA rate.
+#ifndef DGDM_F16_CHUNK
+#define DGDM_F16_CHUNK 16
+#endif
+constexpr int CH = DGDM_F16_CHUNK, NBUF = CH == 16 ? 4 : 3, CQ = CH / 4 /* entries a wave fetches per chunk */, CG = CH / 4 /* groups of four entries per chunk */;
 typedef __attribute__((address_space(3))) v4f32 lds_f4_t;      // (a plain vector type: HIP's float4 class has no address-space-qualified copy)
 __device__ void llvm_amdgcn_raw_buffer_load_lds(wrsrc_t rsrc, __attribute__((address_space(3))) void *lds, int size, int voffset, int soffset, int offset, int aux)
     __asm("llvm.amdgcn.raw.buffer.load.lds");
@@ -94,7 +102,7 @@ struct LStream {
     lds_f4_t *buf;           // [NBUF][CH][64 lanes]
     int voff, wave, lane;
     int base;                // byte offset of the stream's chunk 0
-    int cur;                 // chunk whose entries read() addresses (relative to base)
+    int cur, slot;           // chunk whose entries read() addresses (relative to base), and its slot
 #ifdef DGDM_F16_STAMPS
     long long stall_vm = 0, stall_bar = 0;
 #endif
@@ -107,10 +115,11 @@ struct LStream {
 #ifdef DGDM_EXP_NODMA
         if (c > 2) return;         // timing experiment (wrong results): no LDS-DMA traffic beside the reads
 #endif
+        const int sl = c % NBUF;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int e = 4 * wave + j;
-            const uint32_t la = (uint32_t)(uintptr_t)(buf + ((c & (NBUF - 1)) * CH + e) * 64);
+        for (int j = 0; j < CQ; ++j) {
+            const int e = CQ * wave + j;
+            const uint32_t la = (uint32_t)(uintptr_t)(buf + (sl * CH + e) * 64);
             const int so = base + (c * CH + e) * 1024;
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(la), "v"(voff), "s"(rs), "s"(so) : "memory", "m0");
         }
@@ -118,29 +127,34 @@ struct LStream {
     // a new stream: chunks 0 .. 2 on their way, chunk 0 readable on return
     __device__ __forceinline__ void start(const wrsrc_t rs_, int base_) {
         __builtin_amdgcn_s_barrier();                      // nobody reads the previous stream's slots any more
-        rs = rs_; base = base_; cur = 0;
+        rs = rs_; base = base_; cur = 0; slot = 0;
         issue(0); issue(1); issue(2);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (CQ == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
     // chunk cur + 1 becomes readable, chunk cur + 3 is requested; cur moves on
     __device__ __forceinline__ void advance() {
+        // (lgkmcnt(0): this wave's LDS reads of the chunk it leaves have returned - with three slots the chunk requested below lands in that slot)
 #ifdef DGDM_F16_STAMPS
         const long long t0 = clock64();
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (CQ == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         const long long t1 = clock64();
         __builtin_amdgcn_s_barrier();
         const long long t2 = clock64();
         stall_vm += t1 - t0; stall_bar += t2 - t1;
 #else
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (CQ == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 #endif
         issue(cur + 3);
         ++cur;
+        slot = slot == NBUF - 1 ? 0 : slot + 1;
     }
     // entry e (0 .. 15) of chunk cur
-    __device__ __forceinline__ v4f32 read(const int e) const { return buf[((cur & (NBUF - 1)) * CH + e) * 64 + lane]; }
+    __device__ __forceinline__ v4f32 read(const int e) const { return buf[(slot * CH + e) * 64 + lane]; }
 };
 
 // the three terms of one K-step for two accumulators (w: [A.h A.l B.h B.l]); small terms first
@@ -215,9 +229,10 @@ __device__ __forceinline__ void stream_layer(LStream &ls, v4f32 (&wn)[4], const 
                 v4f32 w[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) w[j] = wn[j];
-                if (pp == 3) ls.advance();         // the next chunk (the next layer's first, after the last one)
+                const int gi = (sx * 4 + pp) & (CG - 1);         // this group's place in its chunk
+                if (gi == CG - 1) ls.advance();    // the next chunk (the next layer's first, after the last one)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) wn[j] = ls.read(((pp + 1) & 3) * 4 + j);
+                for (int j = 0; j < 4; ++j) wn[j] = ls.read(((gi + 1) & (CG - 1)) * 4 + j);
                 if (b < 7) {
                     const int q = sx * 4 + pp, nb = b + 1;
                     if (q == 0 && (nb & 1) == 0) mk = FWD ? 0u : smask[slot_in + nb / 2][tid];
@@ -242,8 +257,8 @@ __device__ __forceinline__ f32x16 block_out(LStream &ls, v4f32 (&wn)[4], const A
     for (int ks = 0; ks < 16; ++ks) {
         const int s = (ks & 1) * 2;
         const v4f32 w0 = wn[s], w1 = wn[s + 1];
-        if ((ks & 7) == 6) ls.advance();
-        wn[s] = ls.read(((ks + 2) & 7) * 2); wn[s + 1] = ls.read(((ks + 2) & 7) * 2 + 1);
+        if ((ks & (CH / 2 - 1)) == CH / 2 - 2) ls.advance();
+        wn[s] = ls.read(((ks + 2) & (CH / 2 - 1)) * 2); wn[s + 1] = ls.read(((ks + 2) & (CH / 2 - 1)) * 2 + 1);
         const hu32x4_t xh = X.v[0][ks / 2][ks % 2], xl = X.v[1][ks / 2][ks % 2];
         side(ks);
         za = hmfma(w1, xh, za);
@@ -310,7 +325,7 @@ __global__ __launch_bounds__(256, 1) void trunk_f16l_kernel(const TrunkParams p,
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    __shared__ __attribute__((aligned(16))) v4f32 wbuf[NBUF * CH * 64];      // the shared weight stream: 4 slots of 16 KiB
+    __shared__ __attribute__((aligned(16))) v4f32 wbuf[NBUF * CH * 64];      // the shared weight stream: 3 slots of 32 KiB (4 of 16 KiB with -DDGDM_F16_CHUNK=16)
     // the stack's biases and the output layer's three rows, copied once: read from global memory where they are used, every one of these
     // 32-load bursts is a full memory round trip behind the stream's prefetches (3.5 k cycles per layer prologue, 15 k for the output phase)
     __shared__ __attribute__((aligned(16))) v4f32 small[(8 * 256 + 768) / 4];
@@ -455,9 +470,9 @@ __global__ __launch_bounds__(256, 1) void trunk_f16l_kernel(const TrunkParams p,
                     v4f32 w[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) w[j] = wn[j];
-                    if ((gq & 3) == 3) ls.advance();
+                    if ((gq & (CG - 1)) == CG - 1) ls.advance();
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) wn[j] = ls.read(((gq + 1) & 3) * 4 + j);
+                    for (int j = 0; j < 4; ++j) wn[j] = ls.read(((gq + 1) & (CG - 1)) * 4 + j);
                     F16_STEP(Y[2 * pp], Y[2 * pp + 1], w, ah[sx], al[sx]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
