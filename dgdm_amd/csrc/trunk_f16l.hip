@@ -79,6 +79,24 @@ __device__ __forceinline__ void split2(float lo, float hi, uint32_t &ph, uint32_
     ph = __builtin_bit_cast(uint32_t, h);
     pl = __builtin_bit_cast(uint32_t, __builtin_convertvector(d, hf16x2_t));
 }
+// The same values in three instructions instead of five (round 5): the residual and its conversion are ONE mixed-precision fma per value
+// (v_fma_mixlo/mixhi_f16: (-h) x 1.0 + v evaluated in float32 - exact - and rounded once to f16: bit for bit what convert-back, subtract,
+// convert give).  The work between the MFMAs is NOT free (removing it all: 7.12 -> 6.19 ms per 3-D launch, -DDGDM_EXP_NOITEM), so every
+// instruction there counts.  Inline assembly (hipcc does not form the mix instructions from this pattern), and therefore ONLY where the
+// pieces are consumed many instructions later (the stack layers' items: at least four MFMA groups): the hazard recogniser does not see an
+// asm statement as a VALU write, so an MFMA reading the pieces right behind it gets no wait states - used in the 3-D front that way the
+// results were nondeterministic (scripts/det_bits.sh).  -DDGDM_F16_SPLIT_CVT: the five-instruction form everywhere.
+__device__ __forceinline__ void split2_mix(float lo, float hi, uint32_t &ph, uint32_t &pl) {
+#ifdef DGDM_F16_SPLIT_CVT
+    split2(lo, hi, ph, pl);
+#else
+    uint32_t h, l;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(lo), "v"(hi));
+    asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(lo));
+    asm("v_fma_mixhi_f16 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(hi));
+    ph = h; pl = l;
+#endif
+}
 struct Act2 {
     hu32x4_t v[2][8][2];      // [piece][32-feature block][K-step]
 };
@@ -154,7 +172,12 @@ struct LStream {
         slot = slot == NBUF - 1 ? 0 : slot + 1;
     }
     // entry e (0 .. 15) of chunk cur
+#ifdef DGDM_EXP_NOREAD
+    // timing experiment (wrong results): the operands are read once per stream and reused - what the kernel costs without its LDS operand reads
+    __device__ __forceinline__ v4f32 read(const int e) const { return buf[(e & 3) * 64 + lane]; }
+#else
     __device__ __forceinline__ v4f32 read(const int e) const { return buf[(slot * CH + e) * 64 + lane]; }
+#endif
 };
 
 // the three terms of one K-step for two accumulators (w: [A.h A.l B.h B.l]); small terms first
@@ -199,14 +222,29 @@ __device__ __forceinline__ void stream_layer(LStream &ls, v4f32 (&wn)[4], const 
     hu32x4_t P[2][2][2];                           // [block parity][piece][K-step]
     HSTAMP(FWD ? 23 : 26);
     uint32_t mk = FWD ? 0u : smask[slot_in][tid];
-    auto item = [&](const f32x16 &y, const int blk, const int d) __attribute__((always_inline)) {
+    auto item = [&](const f32x16 &y, const int blk, const int d, const bool far) __attribute__((always_inline)) {
+#ifdef DGDM_EXP_NOITEM
+        // timing experiment (wrong results): no scaling / ReLU / mask / split work between the MFMAs
+        P[blk & 1][0][d / 4][d % 4] = __float_as_uint(y[2 * d]); P[blk & 1][1][d / 4][d % 4] = __float_as_uint(y[2 * d + 1]);
+        return;
+#endif
         // scale first (one packed multiply; exact, f is a power of two), then ReLU / mask: the same values as the other way round
         const hf32x2_t v = hf32x2_t{y[2 * d], y[2 * d + 1]} * hf32x2_t{f, f};
         float lo = v.x, hi = v.y;
         const int sh = 2 * d + 16 * (blk & 1);
         if (FWD) {
+#ifdef DGDM_F16_MASK_CMP
             mk |= (y[2 * d] > 0.f ? 1u : 0u) << sh;
             mk |= (y[2 * d + 1] > 0.f ? 1u : 0u) << (sh + 1);
+#else
+            // (y > 0) as the SIGN of 0 - y (one packed subtract for the pair; +0 - +-0 = +0, so zeros of either sign and negative values give
+            // 0, positive values 1: exactly the comparison), pushed through a shift register - one v_alignbit_b32 per value (mk = mk << 1 |
+            // sign) instead of compare + select + or.  The 32 values of two blocks arrive in the order of their bit numbers, so the finished
+            // word is bitreverse(mk) (where it is stored).
+            const hf32x2_t ny = hf32x2_t{0.f, 0.f} - hf32x2_t{y[2 * d], y[2 * d + 1]};
+            mk = __builtin_amdgcn_alignbit(mk, __float_as_uint(ny.x), 31);
+            mk = __builtin_amdgcn_alignbit(mk, __float_as_uint(ny.y), 31);
+#endif
             asm("v_max_f32 %0, 0, %1" : "=v"(lo) : "v"(lo));
             asm("v_max_f32 %0, 0, %1" : "=v"(hi) : "v"(hi));
         } else {
@@ -214,11 +252,12 @@ __device__ __forceinline__ void stream_layer(LStream &ls, v4f32 (&wn)[4], const 
             hi = apply_bit(hi, mk, sh + 1);
         }
         uint32_t a, b;
-        split2(lo, hi, a, b);
+        if (far) split2_mix(lo, hi, a, b);         // consumed at least four MFMA groups later (see split2_mix)
+        else split2(lo, hi, a, b);
         P[blk & 1][0][d / 4][d % 4] = a; P[blk & 1][1][d / 4][d % 4] = b;
     };
 #pragma unroll
-    for (int d = 0; d < 8; ++d) item(Yp[0], 0, d);
+    for (int d = 0; d < 8; ++d) item(Yp[0], 0, d, false);        // block 0's pieces feed the first MFMAs
     HSTAMP(FWD ? 24 : 27);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
@@ -236,8 +275,12 @@ __device__ __forceinline__ void stream_layer(LStream &ls, v4f32 (&wn)[4], const 
                 if (b < 7) {
                     const int q = sx * 4 + pp, nb = b + 1;
                     if (q == 0 && (nb & 1) == 0) mk = FWD ? 0u : smask[slot_in + nb / 2][tid];
-                    item(Yp[nb], nb, q);
+                    item(Yp[nb], nb, q, true);
+#ifdef DGDM_F16_MASK_CMP
                     if (FWD && q == 7 && (nb & 1) == 1) smask[slot_in + nb / 2][tid] = mk;
+#else
+                    if (FWD && q == 7 && (nb & 1) == 1) smask[slot_in + nb / 2][tid] = __builtin_bitreverse32(mk);
+#endif
                 }
                 F16_STEP(Y[2 * pp], Y[2 * pp + 1], w, P[b & 1][0][sx], P[b & 1][1][sx]);
                 __builtin_amdgcn_sched_barrier(0);
