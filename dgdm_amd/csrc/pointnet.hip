@@ -447,29 +447,37 @@ __device__ __forceinline__ void l2c_reduce(const uint32_t *ych, const unsigned c
     if (sg == 0) *reinterpret_cast<u4 *>(dst + fl * 4) = best;
 }
 
+// one crowded centre c, the variants of share blockIdx.y
 template <bool BF16>
-__global__ __launch_bounds__(L2C_THREADS, 1) void l2c_kernel(int N, const int *__restrict__ fps1 /*[N][512]*/, int nv, const uint32_t *__restrict__ Y,
-                                                             uint32_t *__restrict__ L2 /*[nv][N][W]*/, const int *__restrict__ clist,
-                                                             const int *__restrict__ ncr, const int *__restrict__ off,
-                                                             const short *__restrict__ rank) {
+__device__ __forceinline__ void l2c_centre(int c, int N, const int *__restrict__ fps1 /*[N][512]*/, int nv, const uint32_t *__restrict__ Y,
+                                           uint32_t *__restrict__ L2 /*[nv][N][W]*/, const int *__restrict__ off, const short *__restrict__ rank,
+                                           int (*selw)[64]) {
     constexpr int W = BF16 ? 128 : 256;                           // dwords per row of Y / L2
     extern __shared__ uint32_t l2c_lds[];
     short *rks = reinterpret_cast<short *>(l2c_lds);              // [1024]
     unsigned char *sel = reinterpret_cast<unsigned char *>(l2c_lds + 512);        // [512][64]
     unsigned char *cnts = sel + 512 * 64;                         // [512]
     uint32_t *ych = l2c_lds + 512 + 512 * 16 + 128;               // [K][F]
-    if ((int)blockIdx.x >= *ncr) return;
-    const int c = clist[blockIdx.x];
     const int K = off[c + 1] - off[c];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = L2C_THREADS / 64;
+    // blockIdx.y: this workgroup's share of the variants (an object has ~40 crowded centres: one workgroup per centre leaves five CUs
+    // of six idle, and the reduction is bound by the LDS bandwidth of the CU it runs on; staging the block of Y once per share is cheap)
+    const int vlo = 1 + (int)(((int64_t)(nv - 1) * blockIdx.y) / gridDim.y), vhi = 1 + (int)(((int64_t)(nv - 1) * (blockIdx.y + 1)) / gridDim.y);
+#ifdef DGDM_L2C_CLOCKS
+    long long tk[8]; int nk = 0;
+#define L2C_STAMP() do { if (nk < 8) tk[nk++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define L2C_STAMP() do {} while (0)
+#endif
+    L2C_STAMP();
     for (int i = threadIdx.x; i < N; i += L2C_THREADS) rks[i] = rank[(size_t)c * N + i];
     __syncthreads();
-    __shared__ int selw[L2C_THREADS / 64][64];
+    L2C_STAMP();
     if (K > 255) {
         // a ball with more points than a byte can index (never on the shipped 512-point clouds): gather from global memory as
         // l2_kernel does, W / 64 dwords per lane
         constexpr int D = W / 64;
-        for (int v = 1 + wave; v < nv; v += nwave) {
+        for (int v = vlo + wave; v < vhi; v += nwave) {
             const int cnt = l2_select(rks, fps1 + (size_t)v * 512, 512, selw[wave], lane);
             uint32_t best[D];
 #pragma unroll
@@ -492,14 +500,14 @@ __global__ __launch_bounds__(L2C_THREADS, 1) void l2c_kernel(int N, const int *_
     //  has only its own 8 waves to hide the L2 latency of those loads)
     {
         int pv[8], pn[8];
-        const int v0 = 1 + wave;
+        const int v0 = vlo + wave;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) pn[i] = v0 < nv ? fps1[(size_t)v0 * 512 + 64 * i + lane] : 0;
-        for (int v = v0; v < nv; v += nwave) {
+        for (int i = 0; i < 8; ++i) pn[i] = v0 < vhi ? fps1[(size_t)v0 * 512 + 64 * i + lane] : 0;
+        for (int v = v0; v < vhi; v += nwave) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) pv[i] = pn[i];
             const int vn = v + nwave;
-            if (vn < nv) {
+            if (vn < vhi) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) pn[i] = fps1[(size_t)vn * 512 + 64 * i + lane];
             }
@@ -527,11 +535,13 @@ __global__ __launch_bounds__(L2C_THREADS, 1) void l2c_kernel(int N, const int *_
     const uint32_t *Yc = Y + (size_t)off[c] * W;
     for (int f0 = 0; f0 < W; f0 += 4 * lpr) {
         __syncthreads();                                          // selections written / previous chunk consumed
+        L2C_STAMP();
         const int pieces = K * lpr;
         for (int i = threadIdx.x; i < pieces; i += L2C_THREADS)
             *reinterpret_cast<uint4 *>(ych + (size_t)i * 4) = *reinterpret_cast<const uint4 *>(Yc + (size_t)(i / lpr) * W + f0 + (i % lpr) * 4);
         __syncthreads();
-        for (int v = 1 + wave; v < nv; v += nwave) {
+        L2C_STAMP();
+        for (int v = vlo + wave; v < vhi; v += nwave) {
             uint32_t *dst = L2 + ((size_t)v * N + c) * W + f0;
             const unsigned char *sv = sel + (size_t)v * 64;
             const int cnt = cnts[v];
@@ -542,6 +552,34 @@ __global__ __launch_bounds__(L2C_THREADS, 1) void l2c_kernel(int N, const int *_
                 default: l2c_reduce<BF16, 8>(ych, sv, cnt, dst, lane); break;
             }
         }
+    }
+#ifdef DGDM_L2C_CLOCKS
+    __syncthreads();
+    L2C_STAMP();
+    if (threadIdx.x == 0 && blockIdx.x == 3 && blockIdx.y == 0) {
+        printf("l2c c %d K %d lpr %d share %d..%d:", c, K, lpr, vlo, vhi);
+        for (int i = 1; i < nk; ++i) printf(" %lld", tk[i] - tk[i - 1]);
+        printf("\n");
+    }
+#endif
+}
+
+// Grid (centres' stride, variant shares): a workgroup takes the crowded centres blockIdx.x, blockIdx.x + gridDim.x, ...  The count is
+// device data; a grid sized for the worst case (N centres) is N workgroups of 16 waves and 150 KB of LDS each that have to be placed on
+// a whole free CU to find out that they have nothing to do - with 40 crowded centres that churn, not the reduction, was the launch's time.
+template <bool BF16>
+__global__ __launch_bounds__(L2C_THREADS, 1) void l2c_kernel(int N, const int *__restrict__ fps1 /*[N][512]*/, int nv, const uint32_t *__restrict__ Y,
+                                                             uint32_t *__restrict__ L2 /*[nv][N][W]*/, const int *__restrict__ clist,
+                                                             const int *__restrict__ ncr, const int *__restrict__ off,
+                                                             const short *__restrict__ rank) {
+    __shared__ int selw[L2C_THREADS / 64][64];
+    const int n = *ncr;
+#ifdef DGDM_L2C_CLOCKS
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) printf("l2c ncr %d pairs %d\n", n, off[N]);
+#endif
+    for (int ci = blockIdx.x; ci < n; ci += gridDim.x) {
+        l2c_centre<BF16>(clist[ci], N, fps1, nv, Y, L2, off, rank, selw);
+        __syncthreads();                                          // the LDS areas are reused by the next centre
     }
 }
 
@@ -1391,9 +1429,14 @@ int pn_l2c(int N, const int *fps1, int nv, const float *Y, float *L2, const int 
         DGDM_HIP_CHECK(hipFuncSetAttribute((const void *)l2c_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    if (bf16) hipLaunchKernelGGL(l2c_kernel<true>, dim3(N), dim3(L2C_THREADS), lds, s, N, fps1, nv, reinterpret_cast<const uint32_t *>(Y),
+    // 64 x 4 = 256 workgroups, one per CU (150 KB of LDS each): ONE round whatever the number of crowded centres is (0 .. N: a few
+    // objects of a batch have every centre crowded and carry most of the build's work), and 160 busy CUs at the typical 40
+    static const int split = []() { const char *e = getenv("DGDM_L2C_SPLIT"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 32 ? 32 : v); }();
+    static const int gx = []() { const char *e = getenv("DGDM_L2C_GRID"); const int v = e ? atoi(e) : 64; return v < 1 ? 1 : v; }();
+    const dim3 grid(std::min(N, gx), std::min(split, std::max(nv - 1, 1)));
+    if (bf16) hipLaunchKernelGGL(l2c_kernel<true>, grid, dim3(L2C_THREADS), lds, s, N, fps1, nv, reinterpret_cast<const uint32_t *>(Y),
                                  reinterpret_cast<uint32_t *>(L2), clist, ncr, off, rank);
-    else hipLaunchKernelGGL(l2c_kernel<false>, dim3(N), dim3(L2C_THREADS), lds, s, N, fps1, nv, reinterpret_cast<const uint32_t *>(Y),
+    else hipLaunchKernelGGL(l2c_kernel<false>, grid, dim3(L2C_THREADS), lds, s, N, fps1, nv, reinterpret_cast<const uint32_t *>(Y),
                             reinterpret_cast<uint32_t *>(L2), clist, ncr, off, rank);
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;

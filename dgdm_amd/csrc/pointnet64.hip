@@ -13,6 +13,7 @@
 //   C/D: lane (n, rb = l >> 4), register i = output feature f(mt, rb + 4 i) = 16 mt + 4 rb + i of row n  (four consecutive features)
 #include "common.h"
 #include <algorithm>
+#include <cstdlib>
 #include "mfma_chain.h"
 #include "pointnet.h"
 #include "pointnet_dev.h"
@@ -44,6 +45,7 @@ __device__ __forceinline__ void ring64_stream(wrsrc_t rs, int voff, int base_off
 }
 
 constexpr int RING64 = 8;
+constexpr int PN64_GRID = 1024;       // workgroups of the launches whose item count is device data (two per CU resident, two rounds)
 
 // ------------------------------------------------------------------------------------------------ T2
 // sa1 feature of every point as a centre (pointnet.hip sa1_kernel) -> F1 [N][128] doubles
@@ -89,109 +91,120 @@ __global__ __launch_bounds__(256, 2) void pair64_kernel(const float *__restrict_
     const int lane = threadIdx.x & 63, n = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int total = off[N];
-    const int tile = blockIdx.x * 4 + wave;
-    if (tile * 16 >= total) return;
-    const int p = min(tile * 16 + n, total - 1);
-    const int ck = pairs[p], c = ck >> 16, k = ck & 0xffff;
-    const double dx = (double)xyz[3 * k] - (double)xyz[3 * c], dy = (double)xyz[3 * k + 1] - (double)xyz[3 * c + 1],
-                 dz = (double)xyz[3 * k + 2] - (double)xyz[3 * c + 2];
-    const double *urow = U + (size_t)k * 128 + kq * 32, *v = vx + kq * 32;
-    f64x4 acc[16];
-#pragma unroll
-    for (int mt = 0; mt < 16; ++mt) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[mt][i] = bias[16 * mt + 4 * kq + i];
-    }
-    // K = 128 in two chunks of 16 K-steps (a rolled loop): the lane's 16 inputs of a chunk are made just before it runs, the weight
-    // ring is carried across - keeps the kernel inside 256 registers, i.e. two waves per SIMD
     struct D2 { double lo, hi; };
     const wrsrc_t rs = weight_rsrc(reinterpret_cast<const float4 *>(img), 256 * 1024);
-    float4 ring[RING64];
-    ring64_fill<RING64>(rs, lane * 16, 0, ring);
+    const double *v = vx + kq * 32;
+    // the pair count is device data: a bounded grid whose waves stride over the 16-pair tiles
 #pragma nounroll
-    for (int ch = 0; ch < 2; ++ch) {
-        double in[16];
+    for (int tile = blockIdx.x * 4 + wave; tile * 16 < total; tile += gridDim.x * 4) {
+        asm volatile("" ::: "memory");                     // keeps the loop-invariant bias loads inside (hoisted they spill)
+        const int p = min(tile * 16 + n, total - 1);
+        const int ck = pairs[p], c = ck >> 16, k = ck & 0xffff;
+        const double dx = (double)xyz[3 * k] - (double)xyz[3 * c], dy = (double)xyz[3 * k + 1] - (double)xyz[3 * c + 1],
+                     dz = (double)xyz[3 * k + 2] - (double)xyz[3 * c + 2];
+        const double *urow = U + (size_t)k * 128 + kq * 32;
+        f64x4 acc[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int f = 16 * ch + j;
-            in[j] = fmax(fma(v[256 + f], dz, fma(v[128 + f], dy, fma(v[f], dx, urow[f]))), 0.0);
+        for (int mt = 0; mt < 16; ++mt) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[mt][i] = bias[16 * mt + 4 * kq + i];
         }
-        ring64_stream<128, RING64>(rs, lane * 16, ch * 128 * 1024, ring, [&](int e, const float4 a) {
-            const int ks = e / 8, mp = e % 8;
-            const D2 w = __builtin_bit_cast(D2, a);
-            const double b = in[ks];
-            acc[2 * mp] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.lo, b, acc[2 * mp], 0, 0, 0);
-            acc[2 * mp + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.hi, b, acc[2 * mp + 1], 0, 0, 0);
-        });
-    }
-    if (tile * 16 + n < total) {
-        float *dst = Y + (size_t)p * 256 + 4 * kq;
+        // K = 128 in two chunks of 16 K-steps (a rolled loop): the lane's 16 inputs of a chunk are made just before it runs, the weight
+        // ring is carried across - keeps the kernel inside 256 registers, i.e. two waves per SIMD
+        float4 ring[RING64];
+        ring64_fill<RING64>(rs, lane * 16, 0, ring);
+#pragma nounroll
+        for (int ch = 0; ch < 2; ++ch) {
+            double in[16];
 #pragma unroll
-        for (int mt = 0; mt < 16; ++mt)
-            *reinterpret_cast<float4 *>(dst + 16 * mt) = make_float4(fmaxf((float)acc[mt][0], 0.f), fmaxf((float)acc[mt][1], 0.f),
-                                                                      fmaxf((float)acc[mt][2], 0.f), fmaxf((float)acc[mt][3], 0.f));
+            for (int j = 0; j < 16; ++j) {
+                const int f = 16 * ch + j;
+                in[j] = fmax(fma(v[256 + f], dz, fma(v[128 + f], dy, fma(v[f], dx, urow[f]))), 0.0);
+            }
+            ring64_stream<128, RING64>(rs, lane * 16, ch * 128 * 1024, ring, [&](int e, const float4 a) {
+                const int ks = e / 8, mp = e % 8;
+                const D2 w = __builtin_bit_cast(D2, a);
+                const double b = in[ks];
+                acc[2 * mp] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.lo, b, acc[2 * mp], 0, 0, 0);
+                acc[2 * mp + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.hi, b, acc[2 * mp + 1], 0, 0, 0);
+            });
+        }
+        if (tile * 16 + n < total) {
+            float *dst = Y + (size_t)p * 256 + 4 * kq;
+#pragma unroll
+            for (int mt = 0; mt < 16; ++mt)
+                *reinterpret_cast<float4 *>(dst + 16 * mt) = make_float4(fmaxf((float)acc[mt][0], 0.f), fmaxf((float)acc[mt][1], 0.f),
+                                                                          fmaxf((float)acc[mt][2], 0.f), fmaxf((float)acc[mt][3], 0.f));
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ T6
-// Z[row][256] = float32( ReLU(W3'[:,3:] L2[row] + W3'[:,0:3] xyz_c + b3') ),  rows / modes as pointnet.hip z_kernel
+// Z[row][256] = float32( ReLU(W3'[:,3:] L2[row] + W3'[:,0:3] xyz_c + b3') ),  rows as pointnet.hip z_kernel's two modes in ONE launch:
+// items 0 .. N-1 are slot 0's rows (every centre), item N + j is (variant 1 + j / ncr, crowded centre clist[j % ncr]).  The item count
+// is device data: a bounded grid whose waves stride over the 16-row tiles (a worst-case grid is 4096 workgroups of which ~330 find work).
+// (Round 5, tried: two tiles per wave against one pass over the weight image - half the L2 traffic per FLOP, one wave per SIMD with
+//  256 accumulator registers: 232 us per object instead of 143, a single wave does not hide the latency of the stream.)
 __global__ __launch_bounds__(256, 2) void z64_kernel(const float *__restrict__ xyz, int N, int nv, const float *__restrict__ L2,
                                                   const double *__restrict__ img, const double *__restrict__ w3x /*[3][256]*/,
-                                                  const double *__restrict__ bias, float *__restrict__ Z, int mode,
+                                                  const double *__restrict__ bias, float *__restrict__ Z,
                                                   const int *__restrict__ clist, const int *__restrict__ ncr) {
     const int lane = threadIdx.x & 63, n = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-    const int ncrv = mode ? *ncr : N;
-    const int64_t items = mode ? (int64_t)(nv - 1) * ncrv : N;
-    if (tile * 16 >= items) return;
-    const int64_t item = min(tile * 16 + n, items - 1);
-    const int c = mode ? clist[item % ncrv] : (int)item;
-    const int64_t row = mode ? (1 + item / ncrv) * N + c : c;
-    const double x = xyz[3 * c], y = xyz[3 * c + 1], z = xyz[3 * c + 2];
-    const float4 *src = reinterpret_cast<const float4 *>(L2 + (size_t)row * 256 + kq * 64);
-    f64x4 acc[16];
-#pragma unroll
-    for (int mt = 0; mt < 16; ++mt) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int f = 16 * mt + 4 * kq + i;
-            acc[mt][i] = fma(w3x[512 + f], z, fma(w3x[256 + f], y, fma(w3x[f], x, bias[f])));
-        }
-    }
-    // K = 256 in four chunks of 16 K-steps (a rolled loop: 1024 MFMAs in one basic block is more than hipcc unrolls); the lane's 16
-    // inputs of the next chunk are loaded while the current one runs, the weight ring is carried across the chunks
+    const int ncrv = nv > 1 ? *ncr : 0;
+    const int items = N + (nv - 1) * ncrv;                 // <= nv * N
     struct D2 { double lo, hi; };
     const wrsrc_t rs = weight_rsrc(reinterpret_cast<const float4 *>(img), 512 * 1024);
-    float4 ring[RING64];
-    ring64_fill<RING64>(rs, lane * 16, 0, ring);
-    float4 cur[4], nxt[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) cur[j] = src[j];
 #pragma nounroll
-    for (int ch = 0; ch < 4; ++ch) {
-        const int cn = min(ch + 1, 3);
+    for (int tile = blockIdx.x * 4 + wave; tile * 16 < items; tile += gridDim.x * 4) {
+        asm volatile("" ::: "memory");                     // keeps the loop-invariant bias / coordinate-weight loads inside (hoisted they spill)
+        const int item = min(tile * 16 + n, items - 1);
+        const int j = item - N;
+        const int c = j < 0 ? item : clist[j % ncrv];
+        const int row = j < 0 ? c : (1 + j / ncrv) * N + c;
+        const double x = xyz[3 * c], y = xyz[3 * c + 1], z = xyz[3 * c + 2];
+        const float4 *src = reinterpret_cast<const float4 *>(L2 + (size_t)row * 256 + kq * 64);
+        f64x4 acc[16];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) nxt[j] = src[4 * cn + j];
-        float in[16];
+        for (int mt = 0; mt < 16; ++mt) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { in[4 * j] = cur[j].x; in[4 * j + 1] = cur[j].y; in[4 * j + 2] = cur[j].z; in[4 * j + 3] = cur[j].w; }
-        ring64_stream<128, RING64>(rs, lane * 16, ch * 128 * 1024, ring, [&](int e, const float4 a) {
-            const int ks = e / 8, mp = e % 8;
-            const D2 w = __builtin_bit_cast(D2, a);
-            const double b = (double)in[ks];
-            acc[2 * mp] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.lo, b, acc[2 * mp], 0, 0, 0);
-            acc[2 * mp + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.hi, b, acc[2 * mp + 1], 0, 0, 0);
-        });
+            for (int i = 0; i < 4; ++i) {
+                const int f = 16 * mt + 4 * kq + i;
+                acc[mt][i] = fma(w3x[512 + f], z, fma(w3x[256 + f], y, fma(w3x[f], x, bias[f])));
+            }
+        }
+        // K = 256 in four chunks of 16 K-steps (a rolled loop: 1024 MFMAs in one basic block is more than hipcc unrolls); the lane's 16
+        // inputs of the next chunk are loaded while the current one runs, the weight ring is carried across the chunks
+        float4 ring[RING64];
+        ring64_fill<RING64>(rs, lane * 16, 0, ring);
+        float4 cur[4], nxt[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
-    }
-    if (tile * 16 + n < items) {
-        float *dst = Z + (size_t)row * 256 + 4 * kq;       // rows of one tile are distinct (item -> row is injective)
+        for (int j4 = 0; j4 < 4; ++j4) cur[j4] = src[j4];
+#pragma nounroll
+        for (int ch = 0; ch < 4; ++ch) {
+            const int cn = min(ch + 1, 3);
 #pragma unroll
-        for (int mt = 0; mt < 16; ++mt)
-            *reinterpret_cast<float4 *>(dst + 16 * mt) = make_float4(fmaxf((float)acc[mt][0], 0.f), fmaxf((float)acc[mt][1], 0.f),
-                                                                      fmaxf((float)acc[mt][2], 0.f), fmaxf((float)acc[mt][3], 0.f));
+            for (int j4 = 0; j4 < 4; ++j4) nxt[j4] = src[4 * cn + j4];
+            float in[16];
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4) { in[4 * j4] = cur[j4].x; in[4 * j4 + 1] = cur[j4].y; in[4 * j4 + 2] = cur[j4].z; in[4 * j4 + 3] = cur[j4].w; }
+            ring64_stream<128, RING64>(rs, lane * 16, ch * 128 * 1024, ring, [&](int e, const float4 a) {
+                const int ks = e / 8, mp = e % 8;
+                const D2 w = __builtin_bit_cast(D2, a);
+                const double b = (double)in[ks];
+                acc[2 * mp] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.lo, b, acc[2 * mp], 0, 0, 0);
+                acc[2 * mp + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w.hi, b, acc[2 * mp + 1], 0, 0, 0);
+            });
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4) cur[j4] = nxt[j4];
+        }
+        if (tile * 16 + n < items) {
+            float *dst = Z + (size_t)row * 256 + 4 * kq;       // rows of one launch are distinct (item -> row is injective)
+#pragma unroll
+            for (int mt = 0; mt < 16; ++mt)
+                *reinterpret_cast<float4 *>(dst + 16 * mt) = make_float4(fmaxf((float)acc[mt][0], 0.f), fmaxf((float)acc[mt][1], 0.f),
+                                                                          fmaxf((float)acc[mt][2], 0.f), fmaxf((float)acc[mt][3], 0.f));
+        }
     }
 }
 
@@ -204,18 +217,15 @@ int pn_sa1_64(const float *xyz, int N, float r1sq, const PnWeights64 &w, double 
 
 int pn_pairs64(const float *xyz, int N, const double *U64, const PnWeights64 &w, const int *pairs, const int *off, float *Y, hipStream_t s) {
     const int tiles = N * ((N + 15) / 16);     // worst case (every point inside every ball); surplus workgroups leave at once
-    hipLaunchKernelGGL(pair64_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, xyz, N, U64, w.sa2_vx, w.sa2_w1_img, w.sa2_b1, pairs, off, Y);
+    hipLaunchKernelGGL(pair64_kernel, dim3(std::min((tiles + 3) / 4, PN64_GRID)), dim3(256), 0, s, xyz, N, U64, w.sa2_vx, w.sa2_w1_img, w.sa2_b1, pairs, off, Y);
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
 }
 
 int pn_z64(const float *xyz, int N, int nv, const PnWeights64 &w, const float *L2, float *Z, const int *clist, const int *ncr, hipStream_t s) {
-    const int64_t t0 = (N + 15) / 16;
-    hipLaunchKernelGGL(z64_kernel, dim3((unsigned)((t0 + 3) / 4)), dim3(256), 0, s, xyz, N, nv, L2, w.sa3_w_img, w.sa3_wx, w.sa3_b, Z, 0, clist, ncr);
-    if (nv > 1) {      // sized for the worst case (every centre crowded); surplus workgroups leave at once
-        const int64_t t1 = ((int64_t)(nv - 1) * N + 15) / 16;
-        hipLaunchKernelGGL(z64_kernel, dim3((unsigned)((t1 + 3) / 4)), dim3(256), 0, s, xyz, N, nv, L2, w.sa3_w_img, w.sa3_wx, w.sa3_b, Z, 1, clist, ncr);
-    }
+    const int64_t tiles = ((int64_t)nv * N + 15) / 16;     // worst case (every centre crowded)
+    hipLaunchKernelGGL(z64_kernel, dim3((unsigned)std::min<int64_t>((tiles + 3) / 4, PN64_GRID)), dim3(256), 0, s, xyz, N, nv, L2, w.sa3_w_img, w.sa3_wx,
+                       w.sa3_b, Z, clist, ncr);
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
 }
