@@ -56,20 +56,30 @@ __global__ __launch_bounds__(128) void sa1_64_kernel(const float *xyz, int N, fl
     __shared__ double h1[32][64];
     const int t = threadIdx.x, lane = t & 63;
     xyz += (size_t)blockIdx.y * 3 * N; F1 += (size_t)blockIdx.y * N * 128;      // object of a batched launch
+#ifdef DGDM_SA1_CLOCKS
+    long long tk[6]; int nk = 0;
+#define SA1_STAMP() do { if (nk < 6) tk[nk++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SA1_STAMP() do {} while (0)
+#endif
+    SA1_STAMP();
     double wrow[64];
 #pragma unroll
     for (int k = 0; k < 64; ++k) wrow[k] = w1[t * 64 + k];
     const double bias1 = b1[t];
     for (int p = blockIdx.x; p < N; p += gridDim.x) {
         const float cx = xyz[3 * p], cy = xyz[3 * p + 1], cz = xyz[3 * p + 2];
+        SA1_STAMP();
         if (t < 64) ball_first32(xyz, N, p, cx, cy, cz, sq3(cx, cy, cz), r2, nbr, lane);      // wave 0; float32 distances (index decision)
         __syncthreads();
+        SA1_STAMP();
         for (int i = t; i < 32 * 64; i += 128) {          // layer 0 on the relative coordinates (exact differences of float32 values)
             const int s = i >> 6, c = i & 63, k = nbr[s];
             const double dx = (double)xyz[3 * k] - (double)cx, dy = (double)xyz[3 * k + 1] - (double)cy, dz = (double)xyz[3 * k + 2] - (double)cz;
             h1[s][c] = fmax(fma(w0t[128 + c], dz, fma(w0t[64 + c], dy, fma(w0t[c], dx, b0[c]))), 0.0);
         }
         __syncthreads();
+        SA1_STAMP();
         double best = 0.0;                                 // ReLU outputs are >= 0 and the group is never empty
         for (int s = 0; s < 32; ++s) {
             double acc = bias1;
@@ -79,6 +89,10 @@ __global__ __launch_bounds__(128) void sa1_64_kernel(const float *xyz, int N, fl
         }
         F1[(size_t)p * 128 + t] = best;
         __syncthreads();
+        SA1_STAMP();
+#ifdef DGDM_SA1_CLOCKS
+        if (t == 0 && blockIdx.x == 100 && blockIdx.y == 3) printf("sa1: weights %lld ball %lld layer0 %lld layer1 %lld\n", tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2], tk[4] - tk[3]);
+#endif
     }
 }
 

@@ -109,6 +109,10 @@ def fit(model: Diffusion, pts: np.ndarray, args, bounds, dev) -> Diffusion:
     val_loader = DataLoader(val_set, batch_size=args.batch_size, shuffle=False, num_workers=0, drop_last=False)
 
     def validate(limit=None):
+        # Every rank walks the WHOLE validation set, batch by batch, and that is deliberate: validation_step's guided chains are sharded
+        # over the ranks inside each batch (objectives / objects over ranks, results all-gathered: diffusion.py guided_* ->
+        # dist.guided_chains_sharded), so all ranks must enter the same batches.  A DistributedSampler on top (the reference's Lightning
+        # default) would hand the ranks different batches under those collectives.
         model.eval()
         out = []
         with torch.no_grad():
