@@ -139,6 +139,74 @@ def test_trainer3d_vs_oracle(rows):
     assert abs(li / le - 1) < 2e-5 and util.rel_l2(pi.cpu(), pe) < 2e-5, (li, le, util.rel_l2(pi.cpu(), pe))
 
 
+@pytest.mark.parametrize("rows", [64])
+def test_trainer3d_later_steps_teacher_forced(rows):
+    """Steps 1 .. 3 at 64 rows, each held to float64 instead of the loose later-step bounds of the golden fixture: before every step
+    the HIP trainer's CURRENT weights go into a float64 oracle, which evaluates the step's loss, prediction and gradients on the same
+    noise / timestep / FPS start draws.  Asserted per step:
+      * loss 2e-5 and prediction 1e-4 against float64 (the forward pass of every step, on identical weights);
+      * the optimizer exactly: torch.optim.Adam(betas=(0.9, 0.95)) replayed in float64 on the HIP path's OWN gradients must land on
+        the HIP path's new weights (1e-3 of a learning-rate step), so Adam's +-lr steps on rounding-level gradient entries cannot
+        hide an error (dynamics/trainer.py:41-103);
+      * every gradient tensor within 4e-2 of float64.  That bound is what DISCRETE events cost, not rounding: training-mode
+        BatchNorm + ReLU puts the sign of (x - batch mean) in charge of a unit's derivative and the max-pools route a gradient to
+        their arg-max sample; where such a decision falls within float32 rounding of a tie, float32 and float64 take different
+        branches, and one re-routed entry of 64 x 256 moves every tensor below it by ~1/sqrt(16384) = 8e-3 at once.  On this test's
+        first step the reference's own float32 autograd is 2e-2 from float64 on every tensor below the trunk's third BatchNorm -
+        and within 1e-5 of the HIP gradients (scripts/debug_train3d.py 64 7 58 90 1064); at 33 rows, where no event falls, the
+        HIP gradients are 1e-5 from float64 (test_trainer3d_vs_oracle)."""
+    from dgdm_amd.dynamics.trainer import Trainer
+    from dgdm_amd import synth
+    from oracle import dgdm_oracle as orc
+    sd = util.dyn3d_sd(58)
+    rs = np.random.RandomState(1000 + rows)
+    ctrl = torch.from_numpy(rs.uniform(-1, 1, (rows, 3, 42)).astype(np.float32))
+    obj = torch.stack([synth.synth_object_3d(90 + i % 7) for i in range(rows)]).permute(0, 2, 1).contiguous()
+    ori = torch.from_numpy(rs.uniform(-1, 1, (rows, 1)).astype(np.float32))
+    pos = torch.from_numpy(rs.uniform(-1, 1, (rows, 2)).astype(np.float32))
+    score = torch.from_numpy(rs.normal(0, 1, (rows, 3)).astype(np.float32))
+    t = Trainer(_args(False, 0.0))
+    t.create_model(sd)
+    lr, (b1, b2), eps = t.optimizer.param_groups[0]["lr"], t.optimizer.param_groups[0]["betas"], t.optimizer.param_groups[0]["eps"]
+    m, v = {}, {}
+    torch.manual_seed(rows)
+    for step in range(1, 4):
+        before = {k: x.clone() for k, x in t.state_dict().items()}
+        st = torch.get_rng_state()
+        o64 = orc.Trainer3D({k: (x.double() if x.is_floating_point() else x.clone()) for k, x in before.items()}, 15, lr, 0.0)
+        draws = orc.Trainer3D(before, 15, lr, 0.0).draw(ctrl)                # float32 noise, as the trainer draws it
+        l64, p64 = o64.step(ctrl.double(), score.double(), ori.double(), pos.double(), obj.double(), (draws[0].double(), draws[1]), orc.StartLog())
+        torch.set_rng_state(st)
+        lh, ph = t.step(ctrl, score, ori, pos, obj)
+        assert abs(lh / float(l64) - 1) < 2e-5, (step, lh, float(l64))
+        assert util.rel_l2(ph.cpu().double(), p64) < 1e-4, (step, util.rel_l2(ph.cpu().double(), p64))
+        gh, worst, errs = t.gradients(), (0.0, ""), []
+        for k in o64.grads:
+            if k in t3.BN_FED_BIAS:
+                continue
+            e = util.rel_l2(gh[k].double(), o64.grads[k])
+            worst = max(worst, (e, k))
+            errs.append(e)
+            assert e <= 4e-2, (step, k, e)
+        if step > 1:
+            # the synthetic checkpoint's BatchNorm biases are exactly 0, so on the FIRST step sign(x - batch mean) alone decides every
+            # ReLU and ties are as likely as they get (this data: a handful, shared with the reference's float32); one Adam step
+            # moves every bias by lr = 1e-4, far outside rounding, and the later steps are free of such events: held to float64
+            assert float(np.median(errs)) <= 2e-4 and worst[0] <= 5e-3, (step, float(np.median(errs)), worst)
+        after = t.state_dict()
+        for k in gh:                                                         # Adam on the HIP gradients, in float64
+            g = gh[k].double()
+            m[k] = (m[k] if k in m else torch.zeros_like(g)) * b1 + (1 - b1) * g
+            v[k] = (v[k] if k in v else torch.zeros_like(g)) * b2 + (1 - b2) * g * g
+            want = before[k].double() - lr / (1 - b1 ** step) * m[k] / ((v[k] / (1 - b2 ** step)).sqrt() + eps)
+            err = float((after[k].double() - want).abs().max())
+            assert err <= 1e-3 * lr + 2e-7 * float(before[k].abs().max()), (step, k, err)
+        for k in before:                                                     # parameters without a gradient do not move
+            if k not in gh and before[k].is_floating_point() and "running_" not in k:
+                assert torch.equal(before[k], after[k]), (step, k)
+        print(f"step {step}: loss {lh:.6f} (float64 on the same weights {float(l64):.6f}); gradient tensors vs float64: median {float(np.median(errs)):.1e}, worst {worst[1]} {worst[0]:.1e}")
+
+
 def test_trainer3d_deterministic():
     from dgdm_amd.dynamics.trainer import Trainer
     data = util.train3d_data(3, 2, 3)
