@@ -110,7 +110,14 @@ struct Act2 {
 #ifndef DGDM_F16_CHUNK
 #define DGDM_F16_CHUNK 16
 #endif
-constexpr int CH = DGDM_F16_CHUNK, NBUF = CH == 16 ? 4 : 3, CQ = CH / 4 /* entries a wave fetches per chunk */, CG = CH / 4 /* groups of four entries per chunk */;
+#ifndef DGDM_F16_SLOTS
+#define DGDM_F16_SLOTS 4
+#endif
+// LDS slots of the stream and chunks requested ahead of the one being consumed (AHEAD = NBUF - 2 with 16 KiB chunks: the slot a request
+// lands in is the one the PREVIOUS chunk left, proven free by the barrier; 32 KiB chunks keep their three slots and two chunks ahead)
+constexpr int CH = DGDM_F16_CHUNK, NBUF = CH == 16 ? DGDM_F16_SLOTS : 3, AHEAD = CH == 16 ? NBUF - 2 : 2;
+constexpr int CQ = CH / 4 /* entries a wave fetches per chunk */, CG = CH / 4 /* groups of four entries per chunk */;
+static_assert(NBUF >= 3 && NBUF <= 6 && CQ * AHEAD <= 48, "stream slots: 3 .. 6 (LDS), at most 48 DMA loads in flight per wave (vmcnt)");
 typedef __attribute__((address_space(3))) v4f32 lds_f4_t;      // (a plain vector type: HIP's float4 class has no address-space-qualified copy)
 __device__ void llvm_amdgcn_raw_buffer_load_lds(wrsrc_t rsrc, __attribute__((address_space(3))) void *lds, int size, int voffset, int soffset, int offset, int aux)
     __asm("llvm.amdgcn.raw.buffer.load.lds");
@@ -142,32 +149,30 @@ struct LStream {
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(la), "v"(voff), "s"(rs), "s"(so) : "memory", "m0");
         }
     }
-    // a new stream: chunks 0 .. 2 on their way, chunk 0 readable on return
+    // a new stream: chunks 0 .. AHEAD on their way, chunk 0 readable on return
     __device__ __forceinline__ void start(const wrsrc_t rs_, int base_) {
         __builtin_amdgcn_s_barrier();                      // nobody reads the previous stream's slots any more
         rs = rs_; base = base_; cur = 0; slot = 0;
-        issue(0); issue(1); issue(2);
-        if (CQ == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+#pragma unroll
+        for (int c = 0; c <= AHEAD; ++c) issue(c);
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"(CQ * AHEAD) : "memory");
         __builtin_amdgcn_s_barrier();
     }
-    // chunk cur + 1 becomes readable, chunk cur + 3 is requested; cur moves on
+    // chunk cur + 1 becomes readable, chunk cur + AHEAD + 1 is requested; cur moves on
     __device__ __forceinline__ void advance() {
         // (lgkmcnt(0): this wave's LDS reads of the chunk it leaves have returned - with three slots the chunk requested below lands in that slot)
 #ifdef DGDM_F16_STAMPS
         const long long t0 = clock64();
-        if (CQ == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(CQ * (AHEAD - 1)) : "memory");
         const long long t1 = clock64();
         __builtin_amdgcn_s_barrier();
         const long long t2 = clock64();
         stall_vm += t1 - t0; stall_bar += t2 - t1;
 #else
-        if (CQ == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(CQ * (AHEAD - 1)) : "memory");
         __builtin_amdgcn_s_barrier();
 #endif
-        issue(cur + 3);
+        issue(cur + AHEAD + 1);
         ++cur;
         slot = slot == NBUF - 1 ? 0 : slot + 1;
     }
