@@ -187,6 +187,23 @@ def test_pointnet_golden(dev):
     assert util.rel_l2(emb.cpu(), g["emb"]) < REL
 
 
+def test_pointnet_heavy_object_vs_oracle(dev):
+    """An object whose EVERY centre is crowded (506 of 512: the clouds that carry the table build), 160 variants of it:
+    the launches sized by device data run their stride loops (l2c: eight centres per workgroup; sa3's table: 80 k rows on a bounded
+    grid) - embeddings against the oracle's PointNet++ on the same FPS starts."""
+    sd = util.dyn3d_sd(44)
+    dyn = engine.Dynamics(3, sd, 42)
+    rows = 160
+    cloud = synth.synth_object_3d(2)
+    xyz = cloud.t().contiguous()[None].repeat(rows, 1, 1)
+    s1 = torch.arange(rows, dtype=torch.int64) * 3
+    s2 = torch.from_numpy(np.random.RandomState(3).randint(0, 512, rows).astype(np.int64))
+    emb = dyn.pointnet2(xyz.to(dev), s1, s2)
+    want = orc.pointnet2_forward(sd, xyz, orc.StartLog([s1, s2]), prefix="object_encoder.")
+    assert util.rel_l2(emb.cpu(), want) < REL, util.rel_l2(emb.cpu(), want)
+    assert float((emb.cpu() - want).abs().max()) < 1e-4 * float(want.abs().max())
+
+
 def test_dyn3d_forward_golden(dev):
     g = util.load("g5_dyn3d.npz")
     dyn = engine.Dynamics(3, util.dyn3d_sd(g["seed"]), 42)
