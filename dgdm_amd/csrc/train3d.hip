@@ -411,7 +411,7 @@ int DgdmTrainer3d::bias_grad(const float *D, int64_t rs, int64_t M, int C, size_
     const int64_t blocks = stat_blocks(M, rpb);
     hipLaunchKernelGGL(colstat_kernel, dim3((unsigned)blocks, (C + 63) / 64), dim3(256), 0, s, D, rs, M, C, rpb, (const float *)nullptr, cpart);
     DGDM_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(rows_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, s, cpart, blocks, C, gr(b_off));
+    hipLaunchKernelGGL(rows_sum_kernel, rows_sum_grid(C), dim3(256), 0, s, cpart, blocks, C, gr(b_off));
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
 }
@@ -433,10 +433,10 @@ int DgdmTrainer3d::bn_fwd(const Bn &b, const float *y, int64_t M, bool train, hi
     int64_t rpb;
     const int64_t blocks = stat_blocks(M, rpb);
     hipLaunchKernelGGL(colstat_kernel, dim3((unsigned)blocks, (C + 63) / 64), dim3(256), 0, s, y, (int64_t)C, M, C, rpb, (const float *)nullptr, cpart);
-    hipLaunchKernelGGL(rows_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, s, cpart, blocks, C, sums);
+    hipLaunchKernelGGL(rows_sum_kernel, rows_sum_grid(C), dim3(256), 0, s, cpart, blocks, C, sums);
     hipLaunchKernelGGL(bn_mean_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums, (double)M, C, cf(b.slot));
     hipLaunchKernelGGL(colstat_kernel, dim3((unsigned)blocks, (C + 63) / 64), dim3(256), 0, s, y, (int64_t)C, M, C, rpb, (const float *)(cf(b.slot) + 2 * CW), cpart);
-    hipLaunchKernelGGL(rows_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, s, cpart, blocks, C, sums);
+    hipLaunchKernelGGL(rows_sum_kernel, rows_sum_grid(C), dim3(256), 0, s, cpart, blocks, C, sums);
     hipLaunchKernelGGL(bn_var_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums, (double)M, C, p(b.g), p(b.g) + C, 1e-5f, 0.1f, rn(b.slot, 0), rn(b.slot, 1), cf(b.slot));
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;

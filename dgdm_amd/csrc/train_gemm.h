@@ -233,18 +233,30 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ D
     __syncthreads();
     if (rl == 0 && c < N) part[(int64_t)blockIdx.x * N + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-// out[c] = sum_t in[t][c]  (float64, fixed order)
-__global__ void rows_sum_kernel(const float *__restrict__ in, int64_t T, int W, float *__restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= W) return;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int64_t t = 0;
-    for (; t + 3 < T; t += 4) {
-        a0 += (double)in[t * W + c]; a1 += (double)in[(t + 1) * W + c]; a2 += (double)in[(t + 2) * W + c]; a3 += (double)in[(t + 3) * W + c];
+// out[c] = sum_t in[t][c]  (float64, fixed order): four interleaved partial sums per column - t = 0, 4, 8, ..., t = 1, 5, ..., ... over the
+// first 4 floor(T / 4) rows, the remaining rows onto the first - folded as (a0 + a1) + (a2 + a3).  One thread per (column, partial sum):
+// a workgroup covers 64 columns (the four sums of a column were one thread's four accumulators until round 5 - the same additions in
+// the same order, bit for bit, on four times the threads and a grid of W / 64 instead of W / 256 workgroups: the serial walk over up
+// to 2048 partial rows made this reduction 16 % of an eps-net training step).
+__global__ __launch_bounds__(256) void rows_sum_kernel(const float *__restrict__ in, int64_t T, int W, float *__restrict__ out) {
+    __shared__ double red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    double a = 0.0;
+    if (c < W) {
+        const int64_t T4 = T & ~(int64_t)3;
+        int64_t t = q;
+        for (; t + 12 < T4; t += 16) {                       // four loads in flight, added in order
+            const float x0 = in[t * W + c], x1 = in[(t + 4) * W + c], x2 = in[(t + 8) * W + c], x3 = in[(t + 12) * W + c];
+            a += (double)x0; a += (double)x1; a += (double)x2; a += (double)x3;
+        }
+        for (; t < T4; t += 4) a += (double)in[t * W + c];
+        if (q == 0) for (t = T4; t < T; ++t) a += (double)in[t * W + c];
     }
-    for (; t < T; ++t) a0 += (double)in[t * W + c];
-    out[c] = (float)((a0 + a1) + (a2 + a3));
+    red[q][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (q == 0 && c < W) out[c] = (float)((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
+inline dim3 rows_sum_grid(int W) { return dim3((unsigned)((W + 63) / 64)); }
 
 
 // torch.optim.Adam (single-tensor form: lerp first moment, bias corrections on the host), as train2d.hip

@@ -379,7 +379,7 @@ int DgdmUnetTrainer::bias_grad(const float *D, int64_t rs, int64_t Mrows, int N,
     const int64_t blocks = (Mrows + CS_ROWS - 1) / CS_ROWS;
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks, (N + 63) / 64), dim3(256), 0, s, D, rs, Mrows, N, (int64_t)CS_ROWS, cpart);
     DGDM_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(rows_sum_kernel, dim3((N + 255) / 256), dim3(256), 0, s, cpart, blocks, N, gr(b_off));
+    hipLaunchKernelGGL(rows_sum_kernel, rows_sum_grid(N), dim3(256), 0, s, cpart, blocks, N, gr(b_off));
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
 }
@@ -450,7 +450,7 @@ int DgdmUnetTrainer::gn_bwd(T &x, const T &y, size_t gb, const T *film, T *dfilm
     DGDM_HIP_CHECK(hipGetLastError());
     x.gw = true;
     if (dfilm) dfilm->gw = true;
-    hipLaunchKernelGGL(rows_sum_kernel, dim3((2 * x.C + 255) / 256), dim3(256), 0, s, spart, (int64_t)S, 2 * x.C, gr(gb));       // dgamma | dbeta
+    hipLaunchKernelGGL(rows_sum_kernel, rows_sum_grid(2 * x.C), dim3(256), 0, s, spart, (int64_t)S, 2 * x.C, gr(gb));       // dgamma | dbeta
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
 }
