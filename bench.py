@@ -50,8 +50,8 @@ STREAM_SEED = 1234
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=4)
-    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--workload", choices=["3d", "2d", "3d_ensemble"], default="3d")
     p.add_argument("--pairs", type=int, default=0, help="(object x objective) pairs per GPU per step (default 32 for 3d, 4 for 2d; "
                                                         "3d_ensemble: chains per GPU per step, default 8, each averaging 4 objects' gradients)")
