@@ -204,6 +204,32 @@ def test_pointnet_heavy_object_vs_oracle(dev):
     assert float((emb.cpu() - want).abs().max()) < 1e-4 * float(want.abs().max())
 
 
+def test_guidance_grad_bit_reproducible(dev):
+    """The same 3-D (full grid, 36 000 rows) and 2-D guidance gradient three times over, each from a fresh Guidance handle: bit-identical.
+    (A hand-scheduled kernel with inline assembly between MFMAs can lose that without failing a tolerance: round 5's first mix-fma
+    split fed an MFMA straight from an asm statement the hazard recogniser does not see as a VALU write - DESIGN.md 4.1.)"""
+    g = util.load("g9_3d_rotate.npz")
+    B, G, P, L, T, S, N = [int(v) for v in g["dims"]]
+    dyn = engine.Dynamics(3, synth.scale_output(util.dyn3d_sd(g["dyn3d_seed"]), float(g["gain"])), L)
+    x = torch.from_numpy(g["trace_x"][0]).to(dev).reshape(1, B, L)
+    outs = []
+    for _ in range(3):
+        gd = engine.Guidance(dyn, B, G, P, (-1.0, 1.0), 2, T, N, 512, max_objects=2)
+        gd.set_objects(torch.from_numpy(g["objs"]).to(dev))
+        st = sampler.StartStream(N, 512, util.unpack_starts(g["starts"].astype(np.int64), g["start_lens"]))
+        outs.append(gd.grad(x, 12, [engine.make_objective("rotate", 0)], None, st.call(gd.rows)).cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    nv = 100
+    dyn2 = engine.Dynamics(2, util.dyn2d_sd(77, nv), 14, 2 * nv)
+    x2 = synth.synth_noise(50, 5, 14).clamp(-1, 1).reshape(1, 5, 14).to(dev)
+    outs = []
+    for _ in range(3):
+        gd2 = engine.Guidance(dyn2, 5, 360, 5, (-1.0, 1.0), 1, 15, nv, 0, max_objects=1)
+        gd2.set_objects(synth.synth_object_2d(1, nv)[None].to(dev))
+        outs.append(gd2.grad(x2, 6, [engine.make_objective("rotate", 0)], None).cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 def test_dyn3d_forward_golden(dev):
     g = util.load("g5_dyn3d.npz")
     dyn = engine.Dynamics(3, util.dyn3d_sd(g["seed"]), 42)
