@@ -564,9 +564,10 @@ __device__ __forceinline__ void l2c_centre(int c, int N, const int *__restrict__
 #endif
 }
 
-// Grid (centres' stride, variant shares): a workgroup takes the crowded centres blockIdx.x, blockIdx.x + gridDim.x, ...  The count is
-// device data; a grid sized for the worst case (N centres) is N workgroups of 16 waves and 150 KB of LDS each that have to be placed on
-// a whole free CU to find out that they have nothing to do - with 40 crowded centres that churn, not the reduction, was the launch's time.
+// Grid (centres' stride, variant shares): a workgroup takes the crowded centres blockIdx.x, blockIdx.x + gridDim.x, ... and of each the
+// variants of share blockIdx.y.  The number of crowded centres is device data (0 .. N): the host launches 64 x 4 workgroups - one per
+// CU, ONE round for any count - instead of one workgroup per possible centre (N x shares workgroups of 16 waves and 150 KB of LDS,
+// each of which needs a whole free CU to find out that it has nothing to do: 3072 of them cost more than the 240 that had work).
 template <bool BF16>
 __global__ __launch_bounds__(L2C_THREADS, 1) void l2c_kernel(int N, const int *__restrict__ fps1 /*[N][512]*/, int nv, const uint32_t *__restrict__ Y,
                                                              uint32_t *__restrict__ L2 /*[nv][N][W]*/, const int *__restrict__ clist,
