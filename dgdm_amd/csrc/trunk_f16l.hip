@@ -234,9 +234,26 @@ __device__ __forceinline__ void stream_layer(LStream &ls, v4f32 (&wn)[4], const 
         return;
 #endif
         // scale first (one packed multiply; exact, f is a power of two), then ReLU / mask: the same values as the other way round
-        const hf32x2_t v = hf32x2_t{y[2 * d], y[2 * d + 1]} * hf32x2_t{f, f};
-        float lo = v.x, hi = v.y;
         const int sh = 2 * d + 16 * (blk & 1);
+        float lo, hi;
+#if !defined(DGDM_F16_MASK_CMP) && !defined(DGDM_F16_NO_NEGSCALE)
+        if (FWD) {
+            // forward: ONE packed fma makes -(y f) (+0 for a zero of either sign: y x (-f) + (+0)); its sign bit is (y > 0) - the mask bit,
+            // pushed through the alignbit shift register (see below) - and max(0, -that) is the scaled ReLU: the packed multiply and the
+            // packed 0 - y of the form below in one instruction, the same values bit for bit
+            const hf32x2_t nv = __builtin_elementwise_fma(hf32x2_t{y[2 * d], y[2 * d + 1]}, hf32x2_t{-f, -f}, hf32x2_t{0.f, 0.f});
+            mk = __builtin_amdgcn_alignbit(mk, __float_as_uint(nv.x), 31);
+            mk = __builtin_amdgcn_alignbit(mk, __float_as_uint(nv.y), 31);
+            asm("v_max_f32 %0, 0, -%1" : "=v"(lo) : "v"(nv.x));
+            asm("v_max_f32 %0, 0, -%1" : "=v"(hi) : "v"(nv.y));
+        } else {
+            const hf32x2_t v = hf32x2_t{y[2 * d], y[2 * d + 1]} * hf32x2_t{f, f};
+            lo = apply_bit(v.x, mk, sh);
+            hi = apply_bit(v.y, mk, sh + 1);
+        }
+#else
+        const hf32x2_t v = hf32x2_t{y[2 * d], y[2 * d + 1]} * hf32x2_t{f, f};
+        lo = v.x; hi = v.y;
         if (FWD) {
 #ifdef DGDM_F16_MASK_CMP
             mk |= (y[2 * d] > 0.f ? 1u : 0u) << sh;
@@ -256,6 +273,7 @@ __device__ __forceinline__ void stream_layer(LStream &ls, v4f32 (&wn)[4], const 
             lo = apply_bit(lo, mk, sh);
             hi = apply_bit(hi, mk, sh + 1);
         }
+#endif
         uint32_t a, b;
         if (far) split2_mix(lo, hi, a, b);         // consumed at least four MFMA groups later (see split2_mix)
         else split2(lo, hi, a, b);
