@@ -35,7 +35,8 @@ struct ObjectTables {       // 3-D, per object
     bool   fast_ok = false; // no flag set: rows can take their centres from fps2 instead of running FPS
     int *crowded = nullptr, *clist = nullptr;   // [N] int, [N + 1] int (clist[N] = count): centres whose ball query truncates (pointnet.hip crowd_kernel); pool slices
     DevBuf M0, cl2, cnt2;   // [N][256] float, [N][128] int, [N] int: variant-independent part of the sa3 max (pointnet.hip m0_kernel)
-    DevBuf cl2s;            // [N][128] cl2 as positions in clist (xobj_group_kernel)
+    DevBuf cl2s;            // [N][128] cl2 as positions in clist (xtab_kernel)
+    DevBuf cl2o;            // [N][128] u16: cl2 as byte offsets into xobj_rows_kernel's LDS slab (scaled for the build's mode: has16)
     DevBuf X, X16;          // [N][N][256] float32 / [N][N][128] bf16 dwords: the finished embedding per (s1, start point) (pointnet.hip xtab_kernel)
     bool   has_x = false, has_x16 = false;
     int    ncr = 0;         // number of crowded centres (read back by set_objects)
@@ -265,7 +266,7 @@ int DgdmGuidance::build_object(int oi, int slot, hipStream_t s) {
     int rc;
     if ((rc = t.Z.alloc((size_t)N * N * 256 * 4)) ||
         (rc = t.M0.alloc((size_t)N * 256 * 4)) || (rc = t.cl2.alloc((size_t)N * 128 * sizeof(int))) || (rc = t.cnt2.alloc((size_t)N * sizeof(int))) ||
-        (rc = t.cl2s.alloc((size_t)N * 128 * sizeof(int))))
+        (rc = t.cl2s.alloc((size_t)N * 128 * sizeof(int))) || (rc = t.cl2o.alloc((size_t)N * 128 * sizeof(unsigned short))))
         return rc;
     t.has16 = bf16;
     if (bf16 && ((rc = t.Z16.alloc((size_t)N * N * 128 * 4)) || (rc = t.M0_16.alloc((size_t)N * 128 * 4)))) return rc;
@@ -295,7 +296,7 @@ int DgdmGuidance::build_object(int oi, int slot, hipStream_t s) {
     }
     DGDM_HIP_CHECK(hipStreamWaitEvent(s, fdone, 0));          // fps2 (sa2's FPS table) is built beside the other stages, on its own stream
     if ((rc = pn_m0(t.fps2, t.crowded, N, t.Z.as<float>(), t.M0.as<float>(), t.cl2.as<int>(), t.cnt2.as<int>(), z16,
-                    bf16 ? t.M0_16.as<uint32_t>() : nullptr, t.clist, t.clist + N, t.cl2s.as<int>(), s))) return rc;          // T7
+                    bf16 ? t.M0_16.as<uint32_t>() : nullptr, t.clist, t.clist + N, t.cl2s.as<int>(), t.cl2o.as<unsigned short>(), s))) return rc;          // T7
     t.has_x = t.has_x16 = false;
     return xtab_policy == 1 ? build_xtab(oi, s) : DGDM_OK;       // eager only on request: see guidance_grad for when it pays
 }
@@ -499,7 +500,7 @@ int DgdmGuidance::upload_starts(const int64_t *starts_host, int n_chains, int64_
     // variant gather from the same Z slab; group offsets.  Chains are independent: a few host threads share them.
     std::atomic<int> bad{0};
     auto work = [&](int c0, int c1) {
-        std::vector<int> cnt(N + 1);
+        std::vector<int> cnt(N + 1), cnt2(513), tmp;
         for (int c = c0; c < c1; ++c) {
             int *d = dst + (size_t)c * 2 * rt;
             for (int k = 0; k < n_calls; ++k) {
@@ -516,12 +517,19 @@ int DgdmGuidance::upload_starts(const int64_t *starts_host, int n_chains, int64_
                 }
             }
             if (!need_order) continue;                      // embedding-table path: rows are looked up where they are
+            // rows sorted by (s1, s2): two stable counting sorts, s2 first.  Rows of one variant s1 gather from the same Z slab, and
+            // rows that share both draws are the same row (xobj_rows_kernel computes a run of them once)
             int *o = ord + (size_t)c * rt;
+            tmp.resize((size_t)rt);
+            std::fill(cnt2.begin(), cnt2.end(), 0);
+            for (int64_t r = 0; r < rt; ++r) ++cnt2[d[2 * r + 1] + 1];
+            for (int k = 0; k < 512; ++k) cnt2[k + 1] += cnt2[k];
+            for (int64_t r = 0; r < rt; ++r) tmp[cnt2[d[2 * r + 1]]++] = (int)r;
             std::fill(cnt.begin(), cnt.end(), 0);
             for (int64_t r = 0; r < rt; ++r) ++cnt[d[2 * r] + 1];
             for (int k = 0; k < N; ++k) cnt[k + 1] += cnt[k];
             memcpy(goff + (size_t)c * (N + 1), cnt.data(), sizeof(int) * (N + 1));
-            for (int64_t r = 0; r < rt; ++r) o[cnt[d[2 * r]]++] = (int)r;
+            for (int64_t i = 0; i < rt; ++i) { const int r = tmp[i]; o[cnt[d[2 * r]]++] = r; }
         }
     };
     const int hw = (int)std::max(2u, std::thread::hardware_concurrency());
@@ -607,9 +615,9 @@ int DgdmGuidance::run_xobj(const int *objidx_host, int n_chains, int64_t rows, b
     int items = 0;
     for (int i = 0; i < n_chains && groups; ++i) {
         const ObjectTables &t = *tables[objidx_host[i]];
-        const int lpr = xobj_group_lpr(t.ncr, want16);
-        groups = lpr > 0 && cfg.num_object_points >= 128;
-        ch[i].clist = t.clist; ch[i].cl2s = t.cl2s.as<int>(); ch[i].ncr = t.ncr; ch[i].lpr = lpr; ch[i].item_base = items;
+        const int lpr = xobj_rows_lpr(t.ncr, want16);
+        groups = lpr > 0 && cfg.num_object_points >= 128 && want16 == t.has16;     // the slot offsets are scaled for the build's mode
+        ch[i].clist = t.clist; ch[i].cl2s = t.cl2s.as<int>(); ch[i].cl2o = t.cl2o.as<unsigned short>(); ch[i].ncr = t.ncr; ch[i].lpr = lpr; ch[i].item_base = items;
         items += cfg.num_object_points * ((want16 ? 32 : 64) / std::max(1, lpr));
     }
     DGDM_HIP_CHECK(hipMemcpyAsync(xchains.p, ch.data(), sizeof(XobjChain) * n_chains, hipMemcpyHostToDevice, s));     // pageable: staged before return

@@ -45,6 +45,7 @@ struct XobjChain {
     // (chain, s1)-group kernel (xobj_group_kernel): the object's crowded centres, their slot in that list per fps2 sequence
     const int   *clist;           // [ncr] crowded centre point ids (crowd_kernel)
     const int   *cl2s;            // [N][128] cl2 as positions in clist (m0_kernel), padded like cl2
+    const unsigned short *cl2o;   // [N][128] the same as byte offsets into xobj_rows_kernel's LDS slab (position * lpr * 16)
     int          ncr;             // number of crowded centres (host copy)
     int          lpr;             // lanes per row of the group kernel: 64 / 32 / 16 / 8  <=>  1 / 2 / 4 / 8 feature chunks
     int          item_base;       // first work item of this chain: items = (s1, chunk) pairs, chunk fastest
@@ -113,9 +114,14 @@ int pn_sa1_64(const float *xyz, int N, float r1sq, const PnWeights64 &w, double 
 int pn_pairs64(const float *xyz, int N, const double *U64, const PnWeights64 &w, const int *pairs, const int *off, float *Y, hipStream_t s);
 int pn_z64(const float *xyz, int N, int nv, const PnWeights64 &w, const float *L2, float *Z, const int *clist, const int *ncr, hipStream_t s);
 int pn_m0(const int *fps2, const int *crowded, int N, const float *Z0, float *M0, int *cl2, int *cnt2, const uint32_t *Z0_16, uint32_t *M0_16,
-          const int *clist, const int *ncr, int *cl2s, hipStream_t s);
-// lanes per row for an object with `ncr` crowded centres (0 = the group kernel cannot hold its slab: use the per-row kernels)
-int xobj_group_lpr(int ncr, bool bf16);
+          const int *clist, const int *ncr, int *cl2s, unsigned short *cl2o, hipStream_t s);
+// lanes per row for an object with `ncr` crowded centres (0 = the group kernel cannot hold its slab: use the per-row kernels):
+// the largest feature chunk (lpr * 16 B per centre) whose slab fits 64 KiB, so that a slab offset is a 16-bit number
+__host__ __device__ inline int xobj_rows_lpr(int ncr, bool bf16) {
+    for (int lpr = bf16 ? 32 : 64; lpr >= 8; lpr >>= 1)
+        if (ncr * lpr * 16 <= 65536) return lpr;
+    return 0;
+}
 // one workgroup per (chain, s1, feature chunk): the variant's crowded Z rows staged once in LDS, all rows of the group reduced from there
 int pn_xobj_groups(const XobjParams &p, hipStream_t s);
 // index test hook (dgdm_debug_pointnet_indices): sa1's 32-neighbour lists [N][32], sa2's first-64 lists [N][64] + counts for the

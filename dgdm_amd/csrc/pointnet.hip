@@ -735,7 +735,8 @@ __global__ __launch_bounds__(256, 1) void z16_kernel(const float *__restrict__ x
 __global__ __launch_bounds__(256) void m0_kernel(const int *__restrict__ fps2 /*[N][128]*/, const int *__restrict__ crowded, int N,
                                                  const float *__restrict__ Z0 /*[N][256]*/, float *__restrict__ M0, int *__restrict__ cl2,
                                                  int *__restrict__ cnt2, const uint32_t *__restrict__ Z0_16, uint32_t *__restrict__ M0_16,
-                                                 const int *__restrict__ clist, const int *__restrict__ ncr, int *__restrict__ cl2s) {
+                                                 const int *__restrict__ clist, const int *__restrict__ ncr, int *__restrict__ cl2s,
+                                                 unsigned short *__restrict__ cl2o, int bf16) {
     // position of every crowded centre in clist (ascending point ids, crowd_kernel): cl2s = cl2 in those terms
     __shared__ short slot_of[1024];
     for (int i = threadIdx.x; i < *ncr; i += blockDim.x) slot_of[clist[i]] = (short)i;
@@ -761,6 +762,12 @@ __global__ __launch_bounds__(256) void m0_kernel(const int *__restrict__ fps2 /*
         if (crB) ds[nA + __popcll(mB & below)] = slot_of[idB];
         const int ls = cnt > 0 ? slot_of[last] : 0;
         for (int j = cnt + lane; j < 128; j += 64) ds[j] = ls;
+        // the same list as byte offsets into xobj_rows_kernel's LDS slab (slot * lanes-per-row * 16 B; 0 when the slab does not fit)
+        const int sc = xobj_rows_lpr(*ncr, bf16 != 0) * 16;
+        unsigned short *dz = cl2o + (size_t)q * 128;
+        if (crA) dz[__popcll(mA & below)] = (unsigned short)(slot_of[idA] * sc);
+        if (crB) dz[nA + __popcll(mB & below)] = (unsigned short)(slot_of[idB] * sc);
+        for (int j = cnt + lane; j < 128; j += 64) dz[j] = (unsigned short)(ls * sc);
     }
     const float *zt = Z0 + lane * 4;
     float4 best = make_float4(0.f, 0.f, 0.f, 0.f);      // Z >= 0 (ReLU)
@@ -934,129 +941,153 @@ __global__ __launch_bounds__(256) void xobj_kernel(const XobjParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------ per (chain, s1) group
-// All rows of a chain that drew the same sa1 start s1 reduce rows of the SAME slab Z[s1][crowded centres].  One workgroup per
-// (chain, s1, feature chunk): the slab chunk [ncr][F] goes from HBM/L2 to LDS once (<= 78 KB, two workgroups per CU so one
-// loads while the other reduces), then every row of the group takes max(M0[q], its crowded centres' rows) out of LDS -
-// ~38 KB of LDS reads per row instead of ~38 KB of L2 gathers.  LPR lanes (16 B each) cover one row's chunk: 64/LPR rows per
-// wave at a time; a row's slot list (cl2s[q], padded with its last entry, so over-reading is idempotent) sits in registers and
-// is broadcast inside the row's lane group.  Same max, same operands: bit-identical to xobj_fast_kernel.
-constexpr int XG_LDS_BYTES = 78 * 1024;
-#ifndef DGDM_XG_WAVES
-#define DGDM_XG_WAVES 8
-#endif
-constexpr int XG_WAVES = DGDM_XG_WAVES;      // waves per workgroup: two workgroups per CU (LDS), so 16 waves per CU hide the per-row LDS round trips (4: 8 waves)
-
-int xobj_group_lpr(int ncr, bool bf16) {
-    const int W = bf16 ? 128 : 256;                                   // dwords per table row
-    for (int lpr = W / 4; lpr >= 8; lpr >>= 1)                         // F = 4 * lpr dwords per centre and chunk
-        if ((size_t)ncr * lpr * 16 <= (size_t)XG_LDS_BYTES) return lpr;
-    return 0;
+// All rows of a chain that drew the same sa1 start s1 reduce rows of the SAME slab Z[s1][crowded centres], and rows that also drew
+// the same s2 are the same row (q = fps1[s1][s2] is all a row's embedding depends on).  One workgroup per (chain, s1, feature
+// chunk): the slab chunk [ncr][F] goes from HBM/L2 to LDS once (<= 64 KiB: two workgroups per CU), the group's rows - the host
+// sorts a chain's rows by (s1, s2), so equal rows are neighbours - are cut into runs of equal s2, and every lane group of LPR
+// lanes (16 B per lane = one row's chunk) walks the slot list of ITS run's row on its own: 64 / LPR rows in flight per wave, no
+// cross-lane traffic, the result stored to every row of the run.  The slot list cl2o[q] holds slab byte offsets (16 bits, eight
+// per 16-byte load); a slab read is one `ds_read_b128` per lane group and member, two members per `v_max3_u32` (features are
+// >= 0, so the unsigned maximum IS the float maximum: bit-identical to xobj_fast_kernel's fmaxf).
+// What bounds it: 4 LDS cycles and ~3.5 vector instructions per member KiB and CU.
+// a pointer that came out of a struct in memory is a generic one to the compiler (flat loads, which also count as LDS traffic in
+// the wait counters): say that it points to global memory
+template <class T> __device__ __forceinline__ __attribute__((address_space(1))) T *as_global(T *p) {
+    return (__attribute__((address_space(1))) T *)p;
 }
 
+constexpr int XR_WAVES = 8;
+constexpr int XR_PASS = 1024;                                  // rows of a group taken per pass (a group of the 5-call bench launch holds ~350)
+constexpr int XR_SLAB_BYTES = 64 * 1024;
+constexpr int XR_LDS_BYTES = XR_SLAB_BYTES + XR_PASS * 10 + 16; // slab + per row: id (int), start point, list length | flag, run heads (u16 each) + their count
+
 template <bool BF16, int LPR>
-__device__ __forceinline__ void xobj_group_body(const XobjParams &p, const XobjChain &ch, int chain, int s1, int chunk, uint32_t *slab) {
+__device__ __forceinline__ void xobj_rows_body(const XobjParams &p, const XobjChain &ch, int chain, int s1, int chunk, unsigned char *lds) {
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    constexpr int W = BF16 ? 128 : 256, F = 4 * LPR, RPW = 64 / LPR;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    typedef const __attribute__((address_space(1))) u4 *gu4;
+    constexpr int W = BF16 ? 128 : 256, F = 4 * LPR, RPW = 64 / LPR, NG = XR_WAVES * RPW, NT = 64 * XR_WAVES, RPT = XR_PASS / NT;
+    int *rid = reinterpret_cast<int *>(lds + XR_SLAB_BYTES);                     // [XR_PASS] row ids of the pass
+    unsigned short *qs = reinterpret_cast<unsigned short *>(rid + XR_PASS);      // [XR_PASS] their sa2 start points q = fps1[s1][s2]
+    unsigned short *cfs = qs + XR_PASS, *lead = cfs + XR_PASS;                   // [XR_PASS] cnt2[q] | flags[q] << 8 | run head << 9;  [XR_PASS] first rows of the runs
+    int *nlead = reinterpret_cast<int *>(lead + XR_PASS);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f0 = chunk * F;
     const int *goff = p.group_off + (size_t)chain * (ch.N + 1);
     const int g0 = goff[s1], gn = goff[s1 + 1] - g0;
     if (gn == 0) return;                                               // no row of this chain drew s1 (workgroup-uniform)
-    const uint32_t *Zs = (BF16 ? ch.Z16 : reinterpret_cast<const uint32_t *>(ch.Z)) + ((size_t)(ch.slot_of_start ? ch.slot_of_start[s1] : s1) * ch.N) * W + f0;
-    // ---- row metadata of this wave's rows, one row per lane (row k = kb + wave + XG_WAVES * lane, 64 * XG_WAVES rows of the group per pass): the first
-    //      pass issues them before the slab loads so that the chain of dependent lookups (row id -> s2 -> start point q -> flag, count)
-    //      overlaps them.  A group holds ~70 rows when the launch covers one denoise step and ~350 when it covers all five.
-    const int *ord = p.order + (size_t)chain * p.R + g0;
-    const int *st = p.starts + (size_t)chain * 2 * p.R;
+    const auto *Zg = as_global((BF16 ? ch.Z16 : reinterpret_cast<const uint32_t *>(ch.Z)) + ((size_t)(ch.slot_of_start ? ch.slot_of_start[s1] : s1) * ch.N) * W + f0);
+    const auto *clist = as_global(ch.clist);
+    const auto *ord = as_global(p.order + (size_t)chain * p.R + g0);
+    const auto *st = as_global(p.starts + (size_t)chain * 2 * p.R);
     const int sg = lane / LPR, fl = lane % LPR;
-    const uint32_t *M0 = (BF16 ? ch.M0_16 : reinterpret_cast<const uint32_t *>(ch.M0)) + f0 + fl * 4;
-    uint32_t *out = (BF16 ? p.xobj16 : reinterpret_cast<uint32_t *>(p.xobj)) + (size_t)chain * p.R * W + f0 + fl * 4;
-    auto vmax4 = [](u4 a, u4 b) {
+    const auto *M0 = as_global((BF16 ? ch.M0_16 : reinterpret_cast<const uint32_t *>(ch.M0)) + f0 + fl * 4);
+    auto *out = as_global((BF16 ? p.xobj16 : reinterpret_cast<uint32_t *>(p.xobj)) + (size_t)chain * p.R * W + f0 + fl * 4);
+    const unsigned char *mine = lds + fl * 16;                         // this lane's 16 bytes of a slab entry
+    const auto *perm = as_global(ch.fps1 + (size_t)s1 * 512);
+    const auto *cnt2 = as_global(ch.cnt2), *flags = as_global(ch.flags);
+    const gu4 lists = reinterpret_cast<gu4>(as_global(ch.cl2o));      // 16 x (8 offsets) per start point
+    auto mx3 = [](u4 a, u4 b, u4 c) {
         u4 o;
-        if (BF16) { o.x = pkmax_u16(a.x, b.x); o.y = pkmax_u16(a.y, b.y); o.z = pkmax_u16(a.z, b.z); o.w = pkmax_u16(a.w, b.w); }
-        else {
-            o.x = __float_as_uint(fmaxf(__uint_as_float(a.x), __uint_as_float(b.x))); o.y = __float_as_uint(fmaxf(__uint_as_float(a.y), __uint_as_float(b.y)));
-            o.z = __float_as_uint(fmaxf(__uint_as_float(a.z), __uint_as_float(b.z))); o.w = __float_as_uint(fmaxf(__uint_as_float(a.w), __uint_as_float(b.w)));
-        }
+        if (BF16) { o.x = pkmax_u16(pkmax_u16(a.x, b.x), c.x); o.y = pkmax_u16(pkmax_u16(a.y, b.y), c.y); o.z = pkmax_u16(pkmax_u16(a.z, b.z), c.z); o.w = pkmax_u16(pkmax_u16(a.w, b.w), c.w); }
+        else { o.x = max(max(a.x, b.x), c.x); o.y = max(max(a.y, b.y), c.y); o.z = max(max(a.z, b.z), c.z); o.w = max(max(a.w, b.w), c.w); }
         return o;
     };
-    for (int kb = 0; kb < gn; kb += 64 * XG_WAVES) {
-        const int myk = kb + wave + XG_WAVES * lane;
-        const bool have = myk < gn;
-        const int r_v = have ? ord[myk] : 0;
-        const int q_v = have ? ch.fps1[(size_t)s1 * 512 + st[2 * r_v + 1]] : 0;      // start point of sa2's FPS
-        const int slow_v = have ? ch.flags[q_v] : 1;                       // order-dependent sequence: xobj_kernel's row
-        const int cnt_v = have ? ch.cnt2[q_v] : 0;
+    for (int kb = 0; kb < gn; kb += XR_PASS) {
+        const int np = min(XR_PASS, gn - kb);
+        // ---- this pass's rows, RPT per thread: row id, start point, its list length and tie flag; the previous row's s2 (a run
+        //      starts where the draws differ)
+        int r_v[RPT], q_v[RPT], cf_v[RPT];
+        bool head_v[RPT];
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            const int k = tid + NT * u;
+            r_v[u] = q_v[u] = cf_v[u] = 0; head_v[u] = false;
+            if (k < np) {
+                r_v[u] = ord[kb + k];
+                const int s2 = st[2 * r_v[u] + 1], s2p = k ? st[2 * ord[kb + k - 1] + 1] : -1;
+                head_v[u] = s2 != s2p;
+                q_v[u] = perm[s2];                                         // start point of sa2's FPS
+                cf_v[u] = cnt2[q_v[u]] | (flags[q_v[u]] ? 256 : 0) | (head_v[u] ? 512 : 0);        // 256: order-dependent sequence, xobj_kernel's row; 512: first row of a run
+            }
+        }
+        if (kb) __syncthreads();                                        // the previous pass's readers are through
+        if (tid == 0) *nlead = 0;
         if (kb == 0) {
-            // ---- stage the slab chunk: piece i = (centre i / LPR, 16-byte part i % LPR)
+            // ---- stage the slab chunk: piece i = (centre i / LPR, 16-byte part i % LPR) at byte 16 i
             const int pieces = ch.ncr * LPR;
-            for (int i0 = threadIdx.x; i0 < pieces; i0 += 64 * XG_WAVES * 8) {
+            for (int i0 = tid; i0 < pieces; i0 += NT * 8) {
                 u4 v[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const int i = i0 + 64 * XG_WAVES * k;
-                    if (i < pieces) v[k] = *reinterpret_cast<const u4 *>(Zs + (size_t)ch.clist[i / LPR] * W + (i % LPR) * 4);
+                    const int i = i0 + NT * k;
+                    if (i < pieces) v[k] = *reinterpret_cast<gu4>(Zg + (size_t)clist[i / LPR] * W + (i % LPR) * 4);
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const int i = i0 + 64 * XG_WAVES * k;
-                    if (i < pieces) *reinterpret_cast<u4 *>(slab + (size_t)i * 4) = v[k];
+                    const int i = i0 + NT * k;
+                    if (i < pieces) *reinterpret_cast<u4 *>(lds + (size_t)i * 16) = v[k];
                 }
             }
         }
-        if (chunk == 0 && have && slow_v) p.todo[atomicAdd(p.todo_count, 1)] = (int)((int64_t)chain * p.R + r_v);
-        if (kb == 0) __syncthreads();
-        // ---- one row at a time per wave (uniform control flow); the wave's 64 lanes read RPW slots' pieces per ds_read_b128
-        const int nmine = min(64, (gn - kb - wave + XG_WAVES - 1) / XG_WAVES);               // rows of this wave held in lanes
-        // rows in batches of four: the four slot lists and M0 pieces are requested together (the per-row lookups are L2-latency bound)
-        for (int i0 = 0; i0 < nmine; i0 += 4) {
-            int SA[4], SB[4];
-            u4 m0[4];
+        __syncthreads();
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int qn = __builtin_amdgcn_readlane(q_v, min(i0 + u, nmine - 1));
-                SA[u] = ch.cl2s[(size_t)qn * 128 + lane]; SB[u] = ch.cl2s[(size_t)qn * 128 + 64 + lane];
-                m0[u] = *reinterpret_cast<const u4 *>(M0 + (size_t)qn * W);
+        for (int u = 0; u < RPT; ++u) {
+            const int k = tid + NT * u;
+            if (k < np) {
+                rid[k] = r_v[u]; qs[k] = (unsigned short)q_v[u]; cfs[k] = (unsigned short)cf_v[u];
+                if (head_v[u]) lead[atomicAdd(nlead, 1)] = (unsigned short)k;
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u;
-                if (i >= nmine) break;
-                const int r = __builtin_amdgcn_readlane(r_v, i), cnt = __builtin_amdgcn_readlane(cnt_v, i), slow = __builtin_amdgcn_readlane(slow_v, i);
-                const int sa = SA[u], sb = SB[u];
-                u4 best = m0[u];
-                if (slow) continue;
-                // slot j + sg for lane group sg; the list is padded with its last entry to 128, so reading past cnt repeats a member
-                for (int j = 0; j < cnt; j += 4 * RPW) {
-                    u4 v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int jj = j + e * RPW;                              // uniform; jj + sg stays inside one 64-entry half (64 % RPW == 0)
-                        int slot;
-                        if (RPW == 1) slot = jj < 64 ? __builtin_amdgcn_readlane(sa, jj & 63) : __builtin_amdgcn_readlane(sb, jj & 63);
-                        else slot = __shfl(jj < 64 ? sa : sb, (jj & 63) + sg);
-                        v[e] = *reinterpret_cast<const u4 *>(slab + ((size_t)slot * LPR + fl) * 4);
+        }
+        __syncthreads();
+        const int n = *nlead;
+        // ---- one run per lane group at a time; the next run's M0 piece and first eight offsets are requested a run ahead
+        int li = wave * RPW + sg;
+        bool have = li < n;
+        int kk = have ? lead[li] : 0;
+        int q = qs[kk], cf = cfs[kk];
+        u4 m0 = *reinterpret_cast<gu4>(M0 + (size_t)q * W);
+        u4 cur = lists[q * 16];
+        while (have) {
+            const int li2 = li + NG;
+            const bool have2 = li2 < n;
+            const int kk2 = have2 ? lead[li2] : kk;
+            const int q2 = qs[kk2], cf2 = cfs[kk2];
+            const u4 m02 = *reinterpret_cast<gu4>(M0 + (size_t)q2 * W);
+            const u4 cur2 = lists[q2 * 16];
+            const int cnt = cf & 255, slow = cf & 256;
+            u4 best = m0;
+            if (!slow) {
+                const gu4 lp = lists + q * 16;
+                // the list is padded with its last entry to 128: reading past cnt repeats a member
+                for (int j = 0; j < cnt; j += 8) {
+                    u4 nxt = cur;
+                    if (j + 8 < cnt) nxt = lp[(j >> 3) + 1];
+                    const u4 a0 = *reinterpret_cast<const u4 *>(mine + (cur.x & 0xffffu)), a1 = *reinterpret_cast<const u4 *>(mine + (cur.x >> 16));
+                    const u4 a2 = *reinterpret_cast<const u4 *>(mine + (cur.y & 0xffffu)), a3 = *reinterpret_cast<const u4 *>(mine + (cur.y >> 16));
+                    if (j + 4 < cnt) {
+                        const u4 b0 = *reinterpret_cast<const u4 *>(mine + (cur.z & 0xffffu)), b1 = *reinterpret_cast<const u4 *>(mine + (cur.z >> 16));
+                        const u4 b2 = *reinterpret_cast<const u4 *>(mine + (cur.w & 0xffffu)), b3 = *reinterpret_cast<const u4 *>(mine + (cur.w >> 16));
+                        best = mx3(best, b0, b1); best = mx3(best, b2, b3);
                     }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) best = vmax4(best, v[e]);
+                    best = mx3(best, a0, a1); best = mx3(best, a2, a3);
+                    cur = nxt;
                 }
-                if (RPW > 1 && cnt > 0) {                                       // fold the lane groups (each saw every RPW-th slot)
-#pragma unroll
-                    for (int o = 32; o >= LPR; o >>= 1) {
-                        u4 t;
-                        t.x = __shfl_xor(best.x, o); t.y = __shfl_xor(best.y, o); t.z = __shfl_xor(best.z, o); t.w = __shfl_xor(best.w, o);
-                        best = vmax4(best, t);
-                    }
-                }
-                if (sg == 0) *reinterpret_cast<u4 *>(out + (size_t)r * W) = best;
             }
+            int k2 = kk;
+            do {                                                           // every row of the run
+                const int r = rid[k2];
+                if (!slow) *reinterpret_cast<__attribute__((address_space(1))) u4 *>(out + (size_t)r * W) = best;
+                else if (chunk == 0 && fl == 0) p.todo[atomicAdd(p.todo_count, 1)] = (int)((int64_t)chain * p.R + r);
+                ++k2;
+            } while (k2 < np && !(cfs[k2] & 512));
+            li = li2; have = have2; kk = kk2; q = q2; cf = cf2; m0 = m02; cur = cur2;
         }
     }
 }
 
 template <bool BF16>
-__global__ __launch_bounds__(64 * XG_WAVES, 2) void xobj_group_kernel(const XobjParams p) {
-    extern __shared__ uint32_t xg_slab[];
+__global__ __launch_bounds__(64 * XR_WAVES, 2) void xobj_rows_kernel(const XobjParams p) {
+    extern __shared__ unsigned char xr_lds[];
     // work item -> (chain, s1, chunk): chains own contiguous item ranges (item_base ascending)
     const int item = blockIdx.x;
     int lo = 0, hi = p.nchain - 1;
@@ -1069,10 +1100,10 @@ __global__ __launch_bounds__(64 * XG_WAVES, 2) void xobj_group_kernel(const Xobj
     const int nchunk = (BF16 ? 32 : 64) / ch.lpr;
     const int rel = item - ch.item_base, s1 = rel / nchunk, chunk = rel % nchunk;
     switch (ch.lpr) {
-        case 64: if (!BF16) xobj_group_body<BF16, (BF16 ? 32 : 64)>(p, ch, chain, s1, chunk, xg_slab); break;
-        case 32: xobj_group_body<BF16, 32>(p, ch, chain, s1, chunk, xg_slab); break;
-        case 16: xobj_group_body<BF16, 16>(p, ch, chain, s1, chunk, xg_slab); break;
-        default: xobj_group_body<BF16, 8>(p, ch, chain, s1, chunk, xg_slab); break;
+        case 64: if (!BF16) xobj_rows_body<BF16, (BF16 ? 32 : 64)>(p, ch, chain, s1, chunk, xr_lds); break;
+        case 32: xobj_rows_body<BF16, 32>(p, ch, chain, s1, chunk, xr_lds); break;
+        case 16: xobj_rows_body<BF16, 16>(p, ch, chain, s1, chunk, xr_lds); break;
+        default: xobj_rows_body<BF16, 8>(p, ch, chain, s1, chunk, xr_lds); break;
     }
 }
 
@@ -1080,13 +1111,13 @@ int pn_xobj_groups(const XobjParams &p, hipStream_t s) {
     if (p.total_items <= 0) return DGDM_OK;
     static bool attr_set = false;
     if (!attr_set) {
-        DGDM_HIP_CHECK(hipFuncSetAttribute((const void *)xobj_group_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, XG_LDS_BYTES));
-        DGDM_HIP_CHECK(hipFuncSetAttribute((const void *)xobj_group_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, XG_LDS_BYTES));
+        DGDM_HIP_CHECK(hipFuncSetAttribute((const void *)xobj_rows_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, XR_LDS_BYTES));
+        DGDM_HIP_CHECK(hipFuncSetAttribute((const void *)xobj_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, XR_LDS_BYTES));
         attr_set = true;
     }
     DGDM_HIP_CHECK(hipMemsetAsync(p.todo_count, 0, sizeof(int), s));
-    if (p.xobj16) hipLaunchKernelGGL(xobj_group_kernel<true>, dim3((unsigned)p.total_items), dim3(64 * XG_WAVES), XG_LDS_BYTES, s, p);
-    else hipLaunchKernelGGL(xobj_group_kernel<false>, dim3((unsigned)p.total_items), dim3(64 * XG_WAVES), XG_LDS_BYTES, s, p);
+    if (p.xobj16) hipLaunchKernelGGL(xobj_rows_kernel<true>, dim3((unsigned)p.total_items), dim3(64 * XR_WAVES), XR_LDS_BYTES, s, p);
+    else hipLaunchKernelGGL(xobj_rows_kernel<false>, dim3((unsigned)p.total_items), dim3(64 * XR_WAVES), XR_LDS_BYTES, s, p);
     DGDM_HIP_CHECK(hipGetLastError());
     // the rows it recorded (tie-flagged start points) run their own FPS
     XobjParams q = p;
@@ -1106,6 +1137,8 @@ int pn_xobj_groups(const XobjParams &p, hipStream_t s) {
 // afterwards a cond_fn call needs no gather at all - the trunk reads row X[s1 * N + q] directly.  One chain uses 36 000 rows per
 // step, 180 000 over the 5 steps, of these 262 144 - so the table costs about what 1.5 chains' worth of per-step gathers did, and
 // an object usually serves 12 objectives.  Objects without crowded centres need no table: X[s1][q] = M0[q].
+constexpr int XG_LDS_BYTES = 78 * 1024;
+
 template <bool BF16, int LPR>
 __device__ __forceinline__ void xtab_body(const XtabObj &o, int ncr, int s1, int chunk, uint32_t *slab) {
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
@@ -1488,8 +1521,9 @@ int pn_z16(const float *xyz, int N, int nv, const PnWeights &w, const uint32_t *
 }
 
 int pn_m0(const int *fps2, const int *crowded, int N, const float *Z0, float *M0, int *cl2, int *cnt2, const uint32_t *Z0_16, uint32_t *M0_16,
-          const int *clist, const int *ncr, int *cl2s, hipStream_t s) {
-    hipLaunchKernelGGL(m0_kernel, dim3((N + 3) / 4), dim3(256), 0, s, fps2, crowded, N, Z0, M0, cl2, cnt2, Z0_16, M0_16, clist, ncr, cl2s);
+          const int *clist, const int *ncr, int *cl2s, unsigned short *cl2o, hipStream_t s) {
+    hipLaunchKernelGGL(m0_kernel, dim3((N + 3) / 4), dim3(256), 0, s, fps2, crowded, N, Z0, M0, cl2, cnt2, Z0_16, M0_16, clist, ncr, cl2s, cl2o,
+                       M0_16 ? 1 : 0);
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
 }
