@@ -9,6 +9,7 @@
 #include <cstring>
 #include <unordered_map>
 #include <atomic>
+#include <chrono>
 #include <thread>
 
 using namespace dgdm;
@@ -25,6 +26,14 @@ std::vector<float> linspace_f32(float start, float end, int steps) {
     return v;
 }
 
+// experiment hook (DGDM_HOST_TIMING): host wall-clock stamps of the calls' phases on stderr
+static inline void host_stamp(const char *tag) {
+    static const bool on = getenv("DGDM_HOST_TIMING") != nullptr;
+    if (!on) return;
+    static const auto t0 = std::chrono::steady_clock::now();
+    fprintf(stderr, "host %9.3f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), tag);
+}
+
 struct ObjectTables {       // 3-D, per object
     // slices of the guidance handle's pools (the FPS tables of all objects are built by one launch each)
     const float *xyz = nullptr;   // [N][3]
@@ -37,6 +46,7 @@ struct ObjectTables {       // 3-D, per object
     DevBuf M0, cl2, cnt2;   // [N][256] float, [N][128] int, [N] int: variant-independent part of the sa3 max (pointnet.hip m0_kernel)
     DevBuf cl2s;            // [N][128] cl2 as positions in clist (xtab_kernel)
     DevBuf cl2o;            // [N][128] u16: cl2 as byte offsets into xobj_rows_kernel's LDS slab (scaled for the build's mode: has16)
+    DevBuf pcf;             // [N][512] per (s1, s2): sa2's start point, its list length, its tie flag (pointnet.hip pcf_kernel)
     DevBuf X, X16;          // [N][N][256] float32 / [N][N][128] bf16 dwords: the finished embedding per (s1, start point) (pointnet.hip xtab_kernel)
     bool   has_x = false, has_x16 = false;
     int    ncr = 0;         // number of crowded centres (read back by set_objects)
@@ -266,7 +276,8 @@ int DgdmGuidance::build_object(int oi, int slot, hipStream_t s) {
     int rc;
     if ((rc = t.Z.alloc((size_t)N * N * 256 * 4)) ||
         (rc = t.M0.alloc((size_t)N * 256 * 4)) || (rc = t.cl2.alloc((size_t)N * 128 * sizeof(int))) || (rc = t.cnt2.alloc((size_t)N * sizeof(int))) ||
-        (rc = t.cl2s.alloc((size_t)N * 128 * sizeof(int))) || (rc = t.cl2o.alloc((size_t)N * 128 * sizeof(unsigned short))))
+        (rc = t.cl2s.alloc((size_t)N * 128 * sizeof(int))) || (rc = t.cl2o.alloc((size_t)N * 128 * sizeof(unsigned short))) ||
+        (rc = t.pcf.alloc((size_t)N * 512 * sizeof(int))))
         return rc;
     t.has16 = bf16;
     if (bf16 && ((rc = t.Z16.alloc((size_t)N * N * 128 * 4)) || (rc = t.M0_16.alloc((size_t)N * 128 * 4)))) return rc;
@@ -297,6 +308,7 @@ int DgdmGuidance::build_object(int oi, int slot, hipStream_t s) {
     DGDM_HIP_CHECK(hipStreamWaitEvent(s, fdone, 0));          // fps2 (sa2's FPS table) is built beside the other stages, on its own stream
     if ((rc = pn_m0(t.fps2, t.crowded, N, t.Z.as<float>(), t.M0.as<float>(), t.cl2.as<int>(), t.cnt2.as<int>(), z16,
                     bf16 ? t.M0_16.as<uint32_t>() : nullptr, t.clist, t.clist + N, t.cl2s.as<int>(), t.cl2o.as<unsigned short>(), s))) return rc;          // T7
+    if ((rc = pn_pcf(t.fps1, t.cnt2.as<int>(), t.flags, N, t.pcf.as<int>(), s))) return rc;
     t.has_x = t.has_x16 = false;
     return xtab_policy == 1 ? build_xtab(oi, s) : DGDM_OK;       // eager only on request: see guidance_grad for when it pays
 }
@@ -326,6 +338,7 @@ extern "C" int dgdm_guidance_set_objects(DgdmGuidance *g, const float *objects_d
     DGDM_REQUIRE(n_objects <= std::max(1, g->cfg.max_objects), DGDM_EINVAL, "%d objects > max_objects %d", n_objects, g->cfg.max_objects);
     hipStream_t s = (hipStream_t)stream;
     int rc;
+    host_stamp("set_objects: enter");
     prof_begin(s, DGDM_STAGE_TABLES);
     if (g->m->kind == 2) {
         DevBuf tmp;
@@ -429,6 +442,7 @@ extern "C" int dgdm_guidance_set_objects(DgdmGuidance *g, const float *objects_d
     }
     g->n_objects = n_objects;
     g->grads_since_set = 0;
+    host_stamp("set_objects: return");
     return DGDM_OK;
 }
 
@@ -491,6 +505,7 @@ int DgdmGuidance::upload_starts(const int64_t *starts_host, int n_chains, int64_
     const int64_t sb = cfg.sub_batch_size;
     const int64_t rt = rows * n_calls;                         // rows per chain on the device
     int rc;
+    DGDM_REQUIRE(!need_order || rt < ((int64_t)1 << 22), DGDM_EINVAL, "%lld rows per chain in one gather launch (limit 4194303)", (long long)rt);
     if ((rc = ensure_rows(n_chains, rt))) return rc;
     DGDM_HIP_CHECK(hipEventSynchronize(pinned_ev));            // previous copy out of the staging buffer has finished
     int *dst = static_cast<int *>(pinned);
@@ -529,9 +544,11 @@ int DgdmGuidance::upload_starts(const int64_t *starts_host, int n_chains, int64_
             for (int64_t r = 0; r < rt; ++r) ++cnt[d[2 * r] + 1];
             for (int k = 0; k < N; ++k) cnt[k + 1] += cnt[k];
             memcpy(goff + (size_t)c * (N + 1), cnt.data(), sizeof(int) * (N + 1));
-            for (int64_t i = 0; i < rt; ++i) { const int r = tmp[i]; o[cnt[d[2 * r]]++] = r; }
+            for (int64_t i = 0; i < rt; ++i) { const int r = tmp[i]; o[cnt[d[2 * r]]++] = r | (d[2 * r + 1] << 22); }      // row id | s2 << 22
         }
     };
+    static const bool host_timing = getenv("DGDM_HOST_TIMING") != nullptr;      // experiment hook: the host's conversion + sort time per call
+    const auto ht0 = std::chrono::steady_clock::now();
     const int hw = (int)std::max(2u, std::thread::hardware_concurrency());
     const int nthreads = (int)std::min<int64_t>(std::min(16, hw / 2), std::max<int64_t>(1, std::min<int64_t>(n_chains, (int64_t)n_chains * rt / 65536)));
     if (nthreads <= 1) {
@@ -541,6 +558,9 @@ int DgdmGuidance::upload_starts(const int64_t *starts_host, int n_chains, int64_
         for (int t = 0; t < nthreads; ++t) pool.emplace_back(work, (int)((int64_t)n_chains * t / nthreads), (int)((int64_t)n_chains * (t + 1) / nthreads));
         for (auto &th : pool) th.join();
     }
+    if (host_timing)
+        fprintf(stderr, "upload_starts: %d chains x %lld rows, %d threads, need_order %d: host %.2f ms\n", n_chains, (long long)rt, nthreads, (int)need_order,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ht0).count());
     DGDM_REQUIRE(!bad.load(), DGDM_EINVAL, "FPS start out of range (sa1 must be in [0, %d), sa2 in [0, 512))", N);
     if (!cstream) {
         DGDM_HIP_CHECK(hipStreamCreateWithFlags(&cstream, hipStreamNonBlocking));
@@ -611,18 +631,20 @@ int DgdmGuidance::run_xobj(const int *objidx_host, int n_chains, int64_t rows, b
     bool all_fast = true;
     for (int i = 0; i < n_chains; ++i) all_fast = all_fast && tables[objidx_host[i]]->fast_ok;
     // group kernel: every chain needs its tables and a slab chunk that fits LDS (it handles tie-flagged start points itself)
-    bool groups = !force_slow_xobj && xobj_mode == 0;
-    int items = 0;
+    bool groups = !force_slow_xobj && xobj_mode == 0 && cfg.num_object_points >= 128;
     for (int i = 0; i < n_chains && groups; ++i) {
         const ObjectTables &t = *tables[objidx_host[i]];
         const int lpr = xobj_rows_lpr(t.ncr, want16);
-        groups = lpr > 0 && cfg.num_object_points >= 128 && want16 == t.has16;     // the slot offsets are scaled for the build's mode
-        ch[i].clist = t.clist; ch[i].cl2s = t.cl2s.as<int>(); ch[i].cl2o = t.cl2o.as<unsigned short>(); ch[i].ncr = t.ncr; ch[i].lpr = lpr; ch[i].item_base = items;
-        items += cfg.num_object_points * ((want16 ? 32 : 64) / std::max(1, lpr));
+        groups = lpr > 0 && want16 == t.has16;     // the slot offsets are scaled for the build's mode
+        ch[i].clist = t.clist; ch[i].cl2s = t.cl2s.as<int>(); ch[i].cl2o = t.cl2o.as<unsigned short>(); ch[i].pcf = t.pcf.as<int>(); ch[i].ncr = t.ncr; ch[i].lpr = lpr;
     }
     DGDM_HIP_CHECK(hipMemcpyAsync(xchains.p, ch.data(), sizeof(XobjChain) * n_chains, hipMemcpyHostToDevice, s));     // pageable: staged before return
     if (groups) {
-        xp.group_off = groupoff.as<int>(); xp.nchain = n_chains; xp.total_items = items; xp.use_table = 1;
+        xp.group_off = groupoff.as<int>(); xp.nchain = n_chains; xp.group_N = cfg.num_object_points; xp.total_items = n_chains * xp.group_N; xp.use_table = 1;
+        std::vector<int> rank(n_chains);
+        for (int i = 0; i < n_chains; ++i) rank[i] = i;
+        std::stable_sort(rank.begin(), rank.end(), [&](int a, int b) { return ch[a].ncr > ch[b].ncr; });
+        for (int i = 0; i < n_chains; ++i) xp.chain_of_rank[i] = (unsigned char)rank[i];
         return pn_xobj_groups(xp, s);
     }
     return pn_xobj(xp, all_fast, s);
@@ -656,8 +678,11 @@ int DgdmGuidance::embed(const int *oidx, int n_chains, const int64_t *starts_hos
         tab = bf16 ? tables[oidx[i]]->has_x16 : tables[oidx[i]]->has_x;
     }
     const int64_t rt = R * n_calls;
+    host_stamp("embed: enter");
     if ((rc = upload_starts(starts_host, n_chains, R, s, !tab, n_calls, call_stride))) return rc;     // host work: overlaps a table build still in flight
+    host_stamp("embed: starts converted, sorted, copy queued");
     if ((rc = finish_objects())) return rc;
+    host_stamp("embed: tables finished");
     TrunkParams scratch{};
     if (tab && (rc = use_xtab(oidx, n_chains, rt, bf16, &scratch, &tab, s))) return rc;
     e->used16 = false;
@@ -796,16 +821,16 @@ extern "C" int dgdm_guided_chains_run(DgdmUnet1d *unet, DgdmGuidance *g, const f
     bool same_scale = true;
     for (int c = 1; c < n_chains; ++c) same_scale = same_scale && scales[c] == scales[0];
     const int64_t spc = kind == 3 ? 2 * g->R : 0;
-    // 3-D: the embeddings of the rows depend on the draws and the objects, not on x, so they are made ahead of the steps that use them:
-    // step 0's first (the GPU waits for nothing else), then - once step 0's kernels are in the queue and keep the GPU busy while the
-    // host converts and sorts four times as many draws - those of ALL the remaining steps in one upload and one gather launch.
+    // 3-D: the embeddings of the rows depend on the draws and the objects, not on x, so those of ALL the steps are made before the
+    // first one, in one upload and one gather launch: the (chain, s1) groups then hold n_steps times the rows per slab staged (and
+    // per slab read from HBM), and more of them are equal rows computed once.  The host's conversion and sort of the draws runs
+    // while the objects' tables are still being built (embed() waits for them only after the host work).
     DgdmGuidance::Embedded emb;
     std::vector<int> oidx(n_chains * n_grad);
     const int64_t call_stride = (int64_t)n_chains * n_grad * spc;
     if (kind == 3) {
         for (int i = 0; i < n_chains * n_grad; ++i) oidx[i] = objectives[i].object;
-        g->xobj_reserve_rows = (size_t)n_chains * n_grad * g->R * (size_t)std::max(1, n_steps - 1);
-        if ((rc = g->embed(oidx.data(), n_chains * n_grad, starts_host, 1, call_stride, &emb, s))) return rc;
+        if ((rc = g->embed(oidx.data(), n_chains * n_grad, starts_host, n_steps, call_stride, &emb, s))) return rc;
     }
     for (int si = 0; si < n_steps; ++si) {
         float *x = g->loopx[si & 1].as<float>(), *xn = (si + 1 == n_steps) ? x_out_dev : g->loopx[(si + 1) & 1].as<float>();
@@ -826,7 +851,7 @@ extern "C" int dgdm_guided_chains_run(DgdmUnet1d *unet, DgdmGuidance *g, const f
             xg = g->loopxrep.as<float>();
         }
         if ((rc = guidance_grad(g, kind, xg, t, objectives, rowcoef_dev, nullptr, n_chains * n_grad, g->loopgrad.as<float>(), s,
-                                kind == 3 ? &emb : nullptr, si == 0 ? 0 : si - 1))) return rc;
+                                kind == 3 ? &emb : nullptr, si))) return rc;
         const float *cf = coef + 4 * si;
         if (same_scale) {
             if ((rc = dgdm_ddim_guided_step(x, g->loopeps.as<float>(), g->loopgrad.as<float>(), n_grad, xn, (int64_t)nx, cf[0], cf[1], cf[2], cf[3], scales[0], s))) return rc;
@@ -836,10 +861,9 @@ extern "C" int dgdm_guided_chains_run(DgdmUnet1d *unet, DgdmGuidance *g, const f
                 if ((rc = dgdm_ddim_guided_step(x + c * per_chain, g->loopeps.as<float>() + c * per_chain, g->loopgrad.as<float>() + c * per_chain, 1,
                                                 xn + c * per_chain, (int64_t)per_chain, cf[0], cf[1], cf[2], cf[3], scales[c], s))) return rc;
         }
-        if (kind == 3 && si == 0 && n_steps > 1 &&
-            (rc = g->embed(oidx.data(), n_chains * n_grad, starts_host + call_stride, n_steps - 1, call_stride, &emb, s))) return rc;
     }
     DGDM_HIP_CHECK(hipGetLastError());
+    host_stamp("chains_run: all steps queued");
     return DGDM_OK;
 }
 

@@ -47,14 +47,14 @@ struct XobjChain {
     const int   *cl2s;            // [N][128] cl2 as positions in clist (m0_kernel), padded like cl2
     const unsigned short *cl2o;   // [N][128] the same as byte offsets into xobj_rows_kernel's LDS slab (position * lpr * 16)
     int          ncr;             // number of crowded centres (host copy)
+    const int   *pcf;             // [N][512] q | cnt2[q] << 10 | (flags[q] != 0) << 18 with q = fps1[s1][s2] (pcf_kernel)
     int          lpr;             // lanes per row of the group kernel: 64 / 32 / 16 / 8  <=>  1 / 2 / 4 / 8 feature chunks
-    int          item_base;       // first work item of this chain: items = (s1, chunk) pairs, chunk fastest
 };
 
 struct XobjParams {
     const XobjChain *chains;      // device array [nchain]
     const int       *starts;      // [nchain][R][2]  (s1, s2) per reference row
-    const int       *order;       // [nchain][R] row ids of each chain sorted by s1, or null (natural order)
+    const int       *order;       // [nchain][R] row ids of each chain sorted by (s1, s2), each with its s2 in bits 22.., or null (natural order)
     float           *xobj;        // [nchain][R][256]
     uint32_t        *xobj16;      // when set: gather from Z16 / M0_16 and write bf16 operand-order rows [nchain][R][128] here instead
     int64_t          R, total_rows;
@@ -64,7 +64,9 @@ struct XobjParams {
     int             *todo_count;  // device counter of that list
     int64_t          todo_capacity;
     const int       *group_off;   // [nchain][N+1] offsets of the s1-groups in `order` (rows of a chain sorted by s1), or null
-    int              nchain, total_items;
+    int              nchain, total_items;      // group kernel: total_items = nchain * group_N work items (chain rank, s1)
+    int              group_N;                   // points per object = sa1 start values
+    unsigned char    chain_of_rank[DGDM_MAX_CHAINS];   // the chains by descending number of crowded centres
 };
 
 // Per-object table of finished embeddings (xtab_kernel): X[s1][q] = max(M0[q], max over the crowded centres of fps2[q] of Z[s1][centre]) -
@@ -122,8 +124,10 @@ __host__ __device__ inline int xobj_rows_lpr(int ncr, bool bf16) {
         if (ncr * lpr * 16 <= 65536) return lpr;
     return 0;
 }
-// one workgroup per (chain, s1, feature chunk): the variant's crowded Z rows staged once in LDS, all rows of the group reduced from there
+// one workgroup per (chain, s1): per feature chunk the variant's crowded Z rows staged once in LDS, all rows of the group reduced from there
 int pn_xobj_groups(const XobjParams &p, hipStream_t s);
+// the row-metadata table of xobj_rows_kernel: pcf [N][512]
+int pn_pcf(const int *fps1, const int *cnt2, const int *flags, int N, int *pcf, hipStream_t s);
 // index test hook (dgdm_debug_pointnet_indices): sa1's 32-neighbour lists [N][32], sa2's first-64 lists [N][64] + counts for the
 // candidate order perm[0..M), crowded flags [N]; synchronises
 int pn_debug_indices(const float *xyz, int N, const PnWeights &w, const int *perm, int M, int *ball1, int *ball2, int *ball2_cnt, int *crowded,

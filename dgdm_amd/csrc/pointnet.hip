@@ -842,7 +842,7 @@ __global__ __launch_bounds__(256) void xobj_fast_kernel(const XobjParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int64_t w = xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wave;
     if (w >= p.total_rows) return;
-    if (p.order) w = (w / p.R) * p.R + p.order[w];
+    if (p.order) w = (w / p.R) * p.R + (p.order[w] & 0x3fffff);      // row id (its s2 sits in bits 22..)
     const int chain = (int)(w / p.R);
     const int64_t r = w - (int64_t)chain * p.R;
     const XobjChain ch = p.chains[chain];
@@ -870,21 +870,8 @@ __global__ __launch_bounds__(256) void xobj_fast_kernel(const XobjParams p) {
 }
 
 template <bool BF16>
-__global__ __launch_bounds__(256) void xobj_kernel(const XobjParams p) {
+__device__ __forceinline__ void xobj_row(const XobjParams &p, int64_t w, float (*coords)[3][512], int (*centres)[128], int lane, int wave) {
     typedef RowOps<BF16> R;
-    __shared__ float coords[4][3][512];
-    __shared__ int centres[4][128];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int64_t w;
-    if (p.skip_fast) {                                  // only the rows xobj_fast_kernel left out
-        const int i = blockIdx.x * 4 + wave;
-        if (i >= *p.todo_count) return;
-        w = p.todo[i];
-    } else {
-        w = xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wave;
-        if (w >= p.total_rows) return;
-        if (p.order) w = (w / p.R) * p.R + p.order[w];
-    }
     const int chain = (int)(w / p.R);
     const int64_t r = w - (int64_t)chain * p.R;
     const XobjChain ch = p.chains[chain];
@@ -940,16 +927,35 @@ __global__ __launch_bounds__(256) void xobj_kernel(const XobjParams p) {
     R::store(p, (size_t)w, lane, best);
 }
 
+template <bool BF16>
+__global__ __launch_bounds__(256) void xobj_kernel(const XobjParams p) {
+    __shared__ float coords[4][3][512];
+    __shared__ int centres[4][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (p.skip_fast) {                                  // only the rows the table kernels left out (few: a bounded grid walks the list)
+        const int n = *p.todo_count;
+        for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) xobj_row<BF16>(p, p.todo[i], coords, centres, lane, wave);
+        return;
+    }
+    int64_t w = xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wave;
+    if (w >= p.total_rows) return;
+    if (p.order) w = (w / p.R) * p.R + (p.order[w] & 0x3fffff);      // row id (its s2 sits in bits 22..)
+    xobj_row<BF16>(p, w, coords, centres, lane, wave);
+}
+
 // ------------------------------------------------------------------------------------------------ per (chain, s1) group
 // All rows of a chain that drew the same sa1 start s1 reduce rows of the SAME slab Z[s1][crowded centres], and rows that also drew
-// the same s2 are the same row (q = fps1[s1][s2] is all a row's embedding depends on).  One workgroup per (chain, s1, feature
-// chunk): the slab chunk [ncr][F] goes from HBM/L2 to LDS once (<= 64 KiB: two workgroups per CU), the group's rows - the host
-// sorts a chain's rows by (s1, s2), so equal rows are neighbours - are cut into runs of equal s2, and every lane group of LPR
-// lanes (16 B per lane = one row's chunk) walks the slot list of ITS run's row on its own: 64 / LPR rows in flight per wave, no
-// cross-lane traffic, the result stored to every row of the run.  The slot list cl2o[q] holds slab byte offsets (16 bits, eight
-// per 16-byte load); a slab read is one `ds_read_b128` per lane group and member, two members per `v_max3_u32` (features are
-// >= 0, so the unsigned maximum IS the float maximum: bit-identical to xobj_fast_kernel's fmaxf).
-// What bounds it: 4 LDS cycles and ~3.5 vector instructions per member KiB and CU.
+// the same s2 are the same row (q = fps1[s1][s2] is all a row's embedding depends on).  One workgroup per (chain, s1): the host
+// sorts a chain's rows by (s1, s2), so equal rows are neighbours; the group's rows are cut into runs of equal s2 once, then for
+// each feature chunk (lpr * 16 B per centre, 1 .. 8 of them) the slab chunk [ncr][F] goes from HBM/L2 to LDS (<= 64 KiB: two
+// workgroups per CU) and every lane group of LPR lanes (16 B per lane = one row's chunk) walks the slot list of ITS run's row on
+// its own: 64 / LPR rows in flight per wave, no cross-lane traffic, the result stored to every row of the run.  The slot list
+// cl2o[q] holds slab byte offsets (16 bits, eight per 16-byte load); a slab read is one `ds_read_b128` per lane group and member,
+// two members per `v_max3_u32` (features are >= 0, so the unsigned maximum IS the float maximum: bit-identical to
+// xobj_fast_kernel's fmaxf).  Row metadata comes from two loads: the sorted row list carries s2 beside the row id, and
+// pcf[s1][s2] = (start point q, list length, tie flag) is a per-object table.
+// What bounds it: 4 LDS cycles and ~3.5 vector instructions per member KiB and CU; the slab reads from HBM (every Z row of a
+// crowded centre once per launch); a workgroup's set-up round trips.
 // a pointer that came out of a struct in memory is a generic one to the compiler (flat loads, which also count as LDS traffic in
 // the wait counters): say that it points to global memory
 template <class T> __device__ __forceinline__ __attribute__((address_space(1))) T *as_global(T *p) {
@@ -957,35 +963,42 @@ template <class T> __device__ __forceinline__ __attribute__((address_space(1))) 
 }
 
 constexpr int XR_WAVES = 8;
-constexpr int XR_PASS = 1024;                                  // rows of a group taken per pass (a group of the 5-call bench launch holds ~350)
+constexpr int XR_PASS = 1024;                                  // rows of a group taken per pass (a group of the 4-call bench launch holds ~280)
 constexpr int XR_SLAB_BYTES = 64 * 1024;
-constexpr int XR_LDS_BYTES = XR_SLAB_BYTES + XR_PASS * 10 + 16; // slab + per row: id (int), start point, list length | flag, run heads (u16 each) + their count
+constexpr int XR_LDS_BYTES = XR_SLAB_BYTES + XR_PASS * 10 + 16; // slab + per row: id (int), start point, list length | flags, run heads (u16 each) + their count
+
+// pcf[s1][s2] = q | cnt2[q] << 10 | (flags[q] != 0) << 18 with q = fps1[s1][s2]: what xobj_rows_kernel needs to know about a row
+__global__ __launch_bounds__(256) void pcf_kernel(const int *__restrict__ fps1, const int *__restrict__ cnt2, const int *__restrict__ flags, int N,
+                                                  int *__restrict__ pcf) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * 512) return;
+    const int q = fps1[i];
+    pcf[i] = q | (cnt2[q] << 10) | (flags[q] ? 1 << 18 : 0);
+}
 
 template <bool BF16, int LPR>
-__device__ __forceinline__ void xobj_rows_body(const XobjParams &p, const XobjChain &ch, int chain, int s1, int chunk, unsigned char *lds) {
+__device__ __forceinline__ void xobj_rows_body(const XobjParams &p, const XobjChain &ch, int chain, int s1, unsigned char *lds) {
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(1))) u4 *gu4;
-    constexpr int W = BF16 ? 128 : 256, F = 4 * LPR, RPW = 64 / LPR, NG = XR_WAVES * RPW, NT = 64 * XR_WAVES, RPT = XR_PASS / NT;
+    constexpr int W = BF16 ? 128 : 256, F = 4 * LPR, RPW = 64 / LPR, NG = XR_WAVES * RPW, NT = 64 * XR_WAVES, RPT = XR_PASS / NT, NCHUNK = W / F;
     int *rid = reinterpret_cast<int *>(lds + XR_SLAB_BYTES);                     // [XR_PASS] row ids of the pass
     unsigned short *qs = reinterpret_cast<unsigned short *>(rid + XR_PASS);      // [XR_PASS] their sa2 start points q = fps1[s1][s2]
     unsigned short *cfs = qs + XR_PASS, *lead = cfs + XR_PASS;                   // [XR_PASS] cnt2[q] | flags[q] << 8 | run head << 9;  [XR_PASS] first rows of the runs
     int *nlead = reinterpret_cast<int *>(lead + XR_PASS);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int f0 = chunk * F;
     const int *goff = p.group_off + (size_t)chain * (ch.N + 1);
     const int g0 = goff[s1], gn = goff[s1 + 1] - g0;
     if (gn == 0) return;                                               // no row of this chain drew s1 (workgroup-uniform)
-    const auto *Zg = as_global((BF16 ? ch.Z16 : reinterpret_cast<const uint32_t *>(ch.Z)) + ((size_t)(ch.slot_of_start ? ch.slot_of_start[s1] : s1) * ch.N) * W + f0);
+    const auto *Zg = as_global((BF16 ? ch.Z16 : reinterpret_cast<const uint32_t *>(ch.Z)) + ((size_t)(ch.slot_of_start ? ch.slot_of_start[s1] : s1) * ch.N) * W);
     const auto *clist = as_global(ch.clist);
     const auto *ord = as_global(p.order + (size_t)chain * p.R + g0);
-    const auto *st = as_global(p.starts + (size_t)chain * 2 * p.R);
     const int sg = lane / LPR, fl = lane % LPR;
-    const auto *M0 = as_global((BF16 ? ch.M0_16 : reinterpret_cast<const uint32_t *>(ch.M0)) + f0 + fl * 4);
-    auto *out = as_global((BF16 ? p.xobj16 : reinterpret_cast<uint32_t *>(p.xobj)) + (size_t)chain * p.R * W + f0 + fl * 4);
+    const auto *M0 = as_global((BF16 ? ch.M0_16 : reinterpret_cast<const uint32_t *>(ch.M0)) + fl * 4);
+    auto *out = as_global((BF16 ? p.xobj16 : reinterpret_cast<uint32_t *>(p.xobj)) + (size_t)chain * p.R * W + fl * 4);
     const unsigned char *mine = lds + fl * 16;                         // this lane's 16 bytes of a slab entry
-    const auto *perm = as_global(ch.fps1 + (size_t)s1 * 512);
-    const auto *cnt2 = as_global(ch.cnt2), *flags = as_global(ch.flags);
+    const auto *pcf = as_global(ch.pcf + (size_t)s1 * 512);
     const gu4 lists = reinterpret_cast<gu4>(as_global(ch.cl2o));      // 16 x (8 offsets) per start point
+    const int pieces = ch.ncr * LPR;
     auto mx3 = [](u4 a, u4 b, u4 c) {
         u4 o;
         if (BF16) { o.x = pkmax_u16(pkmax_u16(a.x, b.x), c.x); o.y = pkmax_u16(pkmax_u16(a.y, b.y), c.y); o.z = pkmax_u16(pkmax_u16(a.z, b.z), c.z); o.w = pkmax_u16(pkmax_u16(a.w, b.w), c.w); }
@@ -994,117 +1007,129 @@ __device__ __forceinline__ void xobj_rows_body(const XobjParams &p, const XobjCh
     };
     for (int kb = 0; kb < gn; kb += XR_PASS) {
         const int np = min(XR_PASS, gn - kb);
-        // ---- this pass's rows, RPT per thread: row id, start point, its list length and tie flag; the previous row's s2 (a run
-        //      starts where the draws differ)
-        int r_v[RPT], q_v[RPT], cf_v[RPT];
-        bool head_v[RPT];
+        // ---- this pass's rows, RPT per thread: (row id | s2 << 22) of the row and of the one before it (a run starts where the
+        //      draws differ); requested together with chunk 0's centre ids
+        int o_v[RPT], op_v[RPT];
 #pragma unroll
         for (int u = 0; u < RPT; ++u) {
             const int k = tid + NT * u;
-            r_v[u] = q_v[u] = cf_v[u] = 0; head_v[u] = false;
-            if (k < np) {
-                r_v[u] = ord[kb + k];
-                const int s2 = st[2 * r_v[u] + 1], s2p = k ? st[2 * ord[kb + k - 1] + 1] : -1;
-                head_v[u] = s2 != s2p;
-                q_v[u] = perm[s2];                                         // start point of sa2's FPS
-                cf_v[u] = cnt2[q_v[u]] | (flags[q_v[u]] ? 256 : 0) | (head_v[u] ? 512 : 0);        // 256: order-dependent sequence, xobj_kernel's row; 512: first row of a run
-            }
+            o_v[u] = 0; op_v[u] = -1;
+            if (k < np) { o_v[u] = ord[kb + k]; if (k) op_v[u] = ord[kb + k - 1]; }
         }
-        if (kb) __syncthreads();                                        // the previous pass's readers are through
-        if (tid == 0) *nlead = 0;
-        if (kb == 0) {
-            // ---- stage the slab chunk: piece i = (centre i / LPR, 16-byte part i % LPR) at byte 16 i
-            const int pieces = ch.ncr * LPR;
-            for (int i0 = tid; i0 < pieces; i0 += NT * 8) {
-                u4 v[8];
+        int n = 0;
+        for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+            const int f0 = chunk * F;
+            // ---- stage the slab chunk: piece i = (centre i / LPR, 16-byte part i % LPR) at byte 16 i; 64 KiB = NT * 8 pieces at most
+            int ci[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int i = i0 + NT * k;
-                    if (i < pieces) v[k] = *reinterpret_cast<gu4>(Zg + (size_t)clist[i / LPR] * W + (i % LPR) * 4);
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int i = i0 + NT * k;
-                    if (i < pieces) *reinterpret_cast<u4 *>(lds + (size_t)i * 16) = v[k];
-                }
+            for (int k = 0; k < 8; ++k) {
+                const int i = tid + NT * k;
+                ci[k] = i < pieces ? clist[i / LPR] : 0;
             }
-        }
-        __syncthreads();
+            int pc_v[RPT];
 #pragma unroll
-        for (int u = 0; u < RPT; ++u) {
-            const int k = tid + NT * u;
-            if (k < np) {
-                rid[k] = r_v[u]; qs[k] = (unsigned short)q_v[u]; cfs[k] = (unsigned short)cf_v[u];
-                if (head_v[u]) lead[atomicAdd(nlead, 1)] = (unsigned short)k;
+            for (int u = 0; u < RPT; ++u) pc_v[u] = chunk == 0 ? pcf[(unsigned)o_v[u] >> 22] : 0;      // start point, list length, tie flag
+            u4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = tid + NT * k;
+                if (i < pieces) v[k] = *reinterpret_cast<gu4>(Zg + (size_t)ci[k] * W + f0 + (i % LPR) * 4);
             }
-        }
-        __syncthreads();
-        const int n = *nlead;
-        // ---- one run per lane group at a time; the next run's M0 piece and first eight offsets are requested a run ahead
-        int li = wave * RPW + sg;
-        bool have = li < n;
-        int kk = have ? lead[li] : 0;
-        int q = qs[kk], cf = cfs[kk];
-        u4 m0 = *reinterpret_cast<gu4>(M0 + (size_t)q * W);
-        u4 cur = lists[q * 16];
-        while (have) {
-            const int li2 = li + NG;
-            const bool have2 = li2 < n;
-            const int kk2 = have2 ? lead[li2] : kk;
-            const int q2 = qs[kk2], cf2 = cfs[kk2];
-            const u4 m02 = *reinterpret_cast<gu4>(M0 + (size_t)q2 * W);
-            const u4 cur2 = lists[q2 * 16];
-            const int cnt = cf & 255, slow = cf & 256;
-            u4 best = m0;
-            if (!slow) {
-                const gu4 lp = lists + q * 16;
-                // the list is padded with its last entry to 128: reading past cnt repeats a member
-                for (int j = 0; j < cnt; j += 8) {
-                    u4 nxt = cur;
-                    if (j + 8 < cnt) nxt = lp[(j >> 3) + 1];
-                    const u4 a0 = *reinterpret_cast<const u4 *>(mine + (cur.x & 0xffffu)), a1 = *reinterpret_cast<const u4 *>(mine + (cur.x >> 16));
-                    const u4 a2 = *reinterpret_cast<const u4 *>(mine + (cur.y & 0xffffu)), a3 = *reinterpret_cast<const u4 *>(mine + (cur.y >> 16));
-                    if (j + 4 < cnt) {
-                        const u4 b0 = *reinterpret_cast<const u4 *>(mine + (cur.z & 0xffffu)), b1 = *reinterpret_cast<const u4 *>(mine + (cur.z >> 16));
-                        const u4 b2 = *reinterpret_cast<const u4 *>(mine + (cur.w & 0xffffu)), b3 = *reinterpret_cast<const u4 *>(mine + (cur.w >> 16));
-                        best = mx3(best, b0, b1); best = mx3(best, b2, b3);
+            __syncthreads();                                    // the slab's and the row arrays' previous readers are through
+            if (chunk == 0) {
+                if (tid == 0) *nlead = 0;
+#pragma unroll
+                for (int u = 0; u < RPT; ++u) {
+                    const int k = tid + NT * u;
+                    if (k < np) {
+                        const bool head = ((unsigned)o_v[u] >> 22) != ((unsigned)op_v[u] >> 22);       // op = -1 for the pass's first row
+                        rid[k] = o_v[u] & 0x3fffff; qs[k] = (unsigned short)(pc_v[u] & 1023);
+                        cfs[k] = (unsigned short)(((pc_v[u] >> 10) & 511) | (head ? 512 : 0));          // 256: order-dependent sequence, xobj_kernel's row
                     }
-                    best = mx3(best, a0, a1); best = mx3(best, a2, a3);
-                    cur = nxt;
                 }
             }
-            int k2 = kk;
-            do {                                                           // every row of the run
-                const int r = rid[k2];
-                if (!slow) *reinterpret_cast<__attribute__((address_space(1))) u4 *>(out + (size_t)r * W) = best;
-                else if (chunk == 0 && fl == 0) p.todo[atomicAdd(p.todo_count, 1)] = (int)((int64_t)chain * p.R + r);
-                ++k2;
-            } while (k2 < np && !(cfs[k2] & 512));
-            li = li2; have = have2; kk = kk2; q = q2; cf = cf2; m0 = m02; cur = cur2;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = tid + NT * k;
+                if (i < pieces) *reinterpret_cast<u4 *>(lds + (size_t)i * 16) = v[k];
+            }
+            __syncthreads();
+            if (chunk == 0) {
+#pragma unroll
+                for (int u = 0; u < RPT; ++u) {
+                    const int k = tid + NT * u;
+                    if (k < np && (cfs[k] & 512)) lead[atomicAdd(nlead, 1)] = (unsigned short)k;
+                }
+                __syncthreads();
+                n = *nlead;
+            }
+            // ---- one run per lane group at a time; the next run's M0 piece and first sixteen offsets are requested a run ahead, a
+            //      run's further offsets two iterations (16 slab reads) ahead
+            int li = wave * RPW + sg;
+            bool have = li < n;
+            int kk = have ? lead[li] : 0;
+            int q = qs[kk], cf = cfs[kk];
+            u4 m0 = *reinterpret_cast<gu4>(M0 + (size_t)q * W + f0);
+            u4 cur = lists[q * 16], nx1 = lists[q * 16 + 1];
+            while (have) {
+                const int li2 = li + NG;
+                const bool have2 = li2 < n;
+                const int kk2 = have2 ? lead[li2] : kk;
+                const int q2 = qs[kk2], cf2 = cfs[kk2];
+                const u4 m02 = *reinterpret_cast<gu4>(M0 + (size_t)q2 * W + f0);
+                const u4 cur2 = lists[q2 * 16], nx12 = lists[q2 * 16 + 1];
+                const int cnt = cf & 255, slow = cf & 256;
+                u4 best = m0;
+                if (!slow) {
+                    const gu4 lp = lists + q * 16;
+                    // the list is padded with its last entry to 128: reading past cnt repeats a member
+                    for (int j = 0; j < cnt; j += 8) {
+                        u4 nx2 = nx1;
+                        if (j + 16 < cnt) nx2 = lp[(j >> 3) + 2];
+                        const u4 a0 = *reinterpret_cast<const u4 *>(mine + (cur.x & 0xffffu)), a1 = *reinterpret_cast<const u4 *>(mine + (cur.x >> 16));
+                        const u4 a2 = *reinterpret_cast<const u4 *>(mine + (cur.y & 0xffffu)), a3 = *reinterpret_cast<const u4 *>(mine + (cur.y >> 16));
+                        if (j + 4 < cnt) {
+                            const u4 b0 = *reinterpret_cast<const u4 *>(mine + (cur.z & 0xffffu)), b1 = *reinterpret_cast<const u4 *>(mine + (cur.z >> 16));
+                            const u4 b2 = *reinterpret_cast<const u4 *>(mine + (cur.w & 0xffffu)), b3 = *reinterpret_cast<const u4 *>(mine + (cur.w >> 16));
+                            best = mx3(best, b0, b1); best = mx3(best, b2, b3);
+                        }
+                        best = mx3(best, a0, a1); best = mx3(best, a2, a3);
+                        cur = nx1; nx1 = nx2;
+                    }
+                }
+                int k2 = kk;
+                do {                                                           // every row of the run
+                    const int r = rid[k2];
+                    if (!slow) *reinterpret_cast<__attribute__((address_space(1))) u4 *>(out + (size_t)r * W + f0) = best;
+                    else if (chunk == 0 && fl == 0) p.todo[atomicAdd(p.todo_count, 1)] = (int)((int64_t)chain * p.R + r);
+                    ++k2;
+                } while (k2 < np && !(cfs[k2] & 512));
+                li = li2; have = have2; kk = kk2; q = q2; cf = cf2; m0 = m02; cur = cur2; nx1 = nx12;
+            }
         }
     }
 }
 
 template <bool BF16>
-__global__ __launch_bounds__(64 * XR_WAVES, 2) void xobj_rows_kernel(const XobjParams p) {
+__global__ __launch_bounds__(64 * XR_WAVES, 4) void xobj_rows_kernel(const XobjParams p) {
     extern __shared__ unsigned char xr_lds[];
-    // work item -> (chain, s1, chunk): chains own contiguous item ranges (item_base ascending)
-    const int item = blockIdx.x;
-    int lo = 0, hi = p.nchain - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (p.chains[mid].item_base <= item) lo = mid; else hi = mid - 1;
-    }
-    const int chain = lo;
+    // work item -> (chain, s1): N items per chain, the chains in the host's order (most crowded centres first: their workgroups
+    // run up to eight chunks and should not be the last to start)
+    const int N = p.group_N;
+    const int chain = p.chain_of_rank[blockIdx.x / N], s1 = blockIdx.x % N;
     const XobjChain ch = p.chains[chain];
-    const int nchunk = (BF16 ? 32 : 64) / ch.lpr;
-    const int rel = item - ch.item_base, s1 = rel / nchunk, chunk = rel % nchunk;
     switch (ch.lpr) {
-        case 64: if (!BF16) xobj_rows_body<BF16, (BF16 ? 32 : 64)>(p, ch, chain, s1, chunk, xr_lds); break;
-        case 32: xobj_rows_body<BF16, 32>(p, ch, chain, s1, chunk, xr_lds); break;
-        case 16: xobj_rows_body<BF16, 16>(p, ch, chain, s1, chunk, xr_lds); break;
-        default: xobj_rows_body<BF16, 8>(p, ch, chain, s1, chunk, xr_lds); break;
+        case 64: if (!BF16) xobj_rows_body<BF16, (BF16 ? 32 : 64)>(p, ch, chain, s1, xr_lds); break;
+        case 32: xobj_rows_body<BF16, 32>(p, ch, chain, s1, xr_lds); break;
+        case 16: xobj_rows_body<BF16, 16>(p, ch, chain, s1, xr_lds); break;
+        default: xobj_rows_body<BF16, 8>(p, ch, chain, s1, xr_lds); break;
     }
+}
+
+int pn_pcf(const int *fps1, const int *cnt2, const int *flags, int N, int *pcf, hipStream_t s) {
+    hipLaunchKernelGGL(pcf_kernel, dim3((unsigned)((N * 512 + 255) / 256)), dim3(256), 0, s, fps1, cnt2, flags, N, pcf);
+    DGDM_HIP_CHECK(hipGetLastError());
+    return DGDM_OK;
 }
 
 int pn_xobj_groups(const XobjParams &p, hipStream_t s) {
@@ -1122,7 +1147,7 @@ int pn_xobj_groups(const XobjParams &p, hipStream_t s) {
     // the rows it recorded (tie-flagged start points) run their own FPS
     XobjParams q = p;
     q.skip_fast = 1;
-    const int64_t cap = std::min<int64_t>(p.total_rows, p.todo_capacity);
+    const int64_t cap = std::min<int64_t>(std::min<int64_t>(p.total_rows, p.todo_capacity), 8192);
     if (p.xobj16) hipLaunchKernelGGL(xobj_kernel<true>, dim3((unsigned)((cap + 3) / 4)), dim3(256), 0, s, q);
     else hipLaunchKernelGGL(xobj_kernel<false>, dim3((unsigned)((cap + 3) / 4)), dim3(256), 0, s, q);
     DGDM_HIP_CHECK(hipGetLastError());
@@ -1578,10 +1603,10 @@ static int xobj_launch(XobjParams p, bool all_fast, hipStream_t s) {
         hipLaunchKernelGGL(xobj_fast_kernel<BF16>, dim3((unsigned)((p.total_rows + 3) / 4)), dim3(256), 0, s, p);
         DGDM_HIP_CHECK(hipGetLastError());
         if (all_fast) return DGDM_OK;               // no chain without tables, no start point with an order-dependent sequence
-        // the rows it recorded (a fraction of a percent: tie-flagged start points); the grid covers the worst case the caller
-        // allows for, surplus workgroups leave on the count
+        // the rows it recorded (a fraction of a percent: tie-flagged start points, or every row of a chain without tables): a
+        // bounded grid walks the list
         p.skip_fast = 1;
-        const int64_t cap = std::min<int64_t>(p.total_rows, p.todo_capacity);
+        const int64_t cap = std::min<int64_t>(std::min<int64_t>(p.total_rows, p.todo_capacity), 65536);
         hipLaunchKernelGGL(xobj_kernel<BF16>, dim3((unsigned)((cap + 3) / 4)), dim3(256), 0, s, p);
         DGDM_HIP_CHECK(hipGetLastError());
         return DGDM_OK;

@@ -239,13 +239,18 @@ class Guidance:
             lib().dgdm_guidance_destroy(self._h)
             self._h = None
 
-    def set_objects(self, objects: torch.Tensor, wait: bool = True) -> None:
-        """2-D: (n, V, 2); 3-D: (n, N, 3).  The table build (3-D) is enqueued on the current stream and the handle's build streams;
-        `wait=False` returns without waiting for it (the handle keeps the coordinates alive): a caller that knows its next objects can
-        build their tables on a side stream under the current batch's chains (bench.py does)."""
+    def set_objects(self, objects: torch.Tensor, wait: bool = False) -> None:
+        """2-D: (n, V, 2); 3-D: (n, N, 3).  The table build (3-D) is enqueued on the current stream and the handle's build streams and
+        the call returns: like every other call of the handle it is ordered by the stream - the coordinates are copied into the
+        handle's pool by a device copy on the current stream before anything else reads them (so `objects` is only needed by that
+        enqueued copy, the contract of any asynchronous call; torch's allocator keeps a freed block for work on the same stream), the
+        build streams start behind everything already enqueued on the current stream (chains still reading the previous tables
+        included), and whatever follows on the current stream waits for the build.  The host is then free to convert and sort the
+        next chains' FPS draws while the tables are being built (`dgdm_guided_chains_run` waits for the build's read-back only when
+        it needs it).  `wait=True` blocks until the tables exist."""
         o = _f32(objects)
         check(lib().dgdm_guidance_set_objects(self._h, dptr(o), o.shape[0], stream_ptr()))
-        self._objects_ref = o                            # `o` may be a temporary: it is read by kernels still in flight
+        self._objects_ref = o                            # `o` may be a temporary: it is read by the copy still in flight
         if wait:
             torch.cuda.current_stream().synchronize()
         self.n_objects = o.shape[0]
