@@ -17,7 +17,8 @@ Contract: `python bench.py --gpus N --steps K --warmup W`.  One rank per GPU.  U
 WORLD_SIZE in the environment) this process is one rank; without one and N > 1 it starts the N rank processes itself (fresh
 interpreters, before anything here touches a GPU) and waits for them.  W untimed steps, exactly K timed steps between
 barrier + synchronize, MAX over ranks; rank 0 prints ONE JSON line - the LAST line of stdout, compact (< 4 KB, scalars only:
-metric / value / config / roofline / stage_ms / cpu_baseline).  `--extra` additionally runs the secondary workloads and writes them,
+metric / value / config / roofline / stage_ms / cpu_baseline, and at N = 1 the metric's 2-D half - BASELINE configs[1], 10 steps run
+after the 3-D measurement - as value_2d / ms_per_step_2d / roofline_2d_frac / cpu_baseline_2d).  `--extra` additionally runs the secondary workloads and writes them,
 with the CPU legs' run lists, to gpurun_out/bench_extra.json; they are never part of the line.
 """
 import argparse
@@ -60,9 +61,12 @@ def parse():
                         "scaled by exact powers of two and split into two f16 pieces, three f16 MFMAs per product, float32 accumulation), "
                         "f32_bf16x6 (exact three-way bf16 split, six bf16 MFMAs per product), f32_mfma (the k-ordered float32 MFMA chain) or "
                         "bf16 (operands ROUNDED to bf16, float32 accumulation)")
-    p.add_argument("--cpu-baseline", choices=["sample", "full", "none"], default="sample",
-                   help="CPU oracle timed beside the GPU number (rank 0, N = 1): sample = ONE run of the bounded sample (about 15 s of CPU work, the "
-                        "default), full = median of 3 + an end-to-end reduced-grid chain + the CPU legs of every --extra workload, none = skip")
+    p.add_argument("--cpu-baseline", choices=["sample", "full", "none"], default="full",
+                   help="CPU oracle timed beside the GPU number (rank 0, N = 1): full = the SURVEY 8(d) protocol, median of 3 runs of the bounded sample + "
+                        "an end-to-end reduced-grid chain as a check of the extrapolation (about 75 s of CPU work; the default) + the CPU legs of every "
+                        "--extra workload, sample = ONE run of the bounded sample (about 15 s), none = skip")
+    p.add_argument("--no-2d", action="store_true", help="skip the second leg of the default run (BASELINE configs[1], the metric's 2-D half: "
+                   "10 steps after the 3-D measurement, reported as value_2d / ms_per_step_2d / roofline_2d_frac / cpu_baseline_2d)")
     p.add_argument("--no-cpu-baseline", action="store_true", help="same as --cpu-baseline none")
     p.add_argument("--extra", action="store_true", help="after the headline measurement also run the secondary workloads (the other BASELINE configs, the "
                    "other contraction modes, the training legs) and write them to --extra-out; never part of the headline line")
@@ -254,9 +258,25 @@ ARITHMETIC = {"f32_bf16x6": "float32-grade: every float32 product as six bf16 MF
                            "(per weight matrix, per tile row; float32 accumulation; 1.9e-7 rms of a 256-term contraction vs float64)",
               "f32_mfma": "float32 MFMA (v_mfma_f32_32x32x2_f32), a k-ordered fma chain",
               "bf16": "operands rounded to bf16, float32 accumulation"}
-# matrix pipe busy share from the recorded PMC passes (profiles/r04_pmc_kernels.md, r03 for the six-product kernel:
-# SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE); recorded, not live
-PIPE_BUSY_RECORDED = {("3d", "f32_f16x3"): 0.54, ("2d", "f32_f16x3"): 0.54, ("3d", "f32_bf16x6"): 0.71, ("2d", "f32_bf16x6"): 0.73, ("3d", "bf16"): 0.54}
+# matrix pipe busy share of the dominant kernel as RECORDED by the latest round's PMC passes (profiles/r0N_pmc_kernels.md, "Derived" table:
+# SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)); recorded, not live.  The six-product and bf16 kernels keep their last recording.
+PIPE_BUSY_FALLBACK = {("3d", "f32_bf16x6"): 0.71, ("2d", "f32_bf16x6"): 0.73, ("3d", "bf16"): 0.54}
+
+
+def pipe_busy_recorded(kind, form, kernel):
+    import glob
+    import re
+    if (kind, form) in PIPE_BUSY_FALLBACK:
+        return PIPE_BUSY_FALLBACK[(kind, form)], None
+    want = "`%s<%s>`" % (kernel, "3" if kind == "3d" else "2")
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_kernels.md")), reverse=True):
+        for line in open(f):
+            m = re.match(r"\|\s*%s\s*\|\s*([0-9.]+)\s*%%" % re.escape(want), line)
+            if m:
+                return float(m.group(1)) / 100.0, os.path.relpath(f, ROOT)
+    return None, None
+
+
 # algorithmic HBM bytes of ONE cond_fn's trunk launch per (pair, object): the xobj rows (1 KiB per replicated row, 3-D) or nothing of size R (2-D:
 # tables only) + the weights once (DESIGN_HISTORY.md 4.1)
 HBM_ALGORITHMIC_BYTES = {"3d": 36000 * 32 / 32 * 1024.0 + 7.2e6 / 32, "2d": 17e6 / 4}
@@ -268,7 +288,7 @@ def pmc_traffic(workload, contraction, kernel):
     FETCH_SIZE is the raw counter: on gfx950 it can under-count wide coalesced reads by 2x (MI355X_MICROARCH.md §HBM), so the
     true read traffic lies between 1x and 2x of `fetch_bytes_raw`.  None when no recording exists."""
     tag = workload + ("_bf16" if contraction == "bf16" else "")
-    f = next((c for c in (os.path.join(ROOT, "profiles", f"{r}_{tag}_pmc_hbm.json") for r in ("r05", "r04", "r03")) if os.path.exists(c)), None)
+    f = next((c for c in (os.path.join(ROOT, "profiles", f"{r}_{tag}_pmc_hbm.json") for r in ("r06", "r05", "r04", "r03")) if os.path.exists(c)), None)
     if f is None:
         return None
     d = json.load(open(f))
@@ -321,7 +341,7 @@ def stage_profile(wl, secs_per_step, contraction):
             "launches": n, "avg_launch_ms": ms / n,
             "algorithmic_flops_per_launch": flops / n, "issued_flops_per_algorithmic_flop": issued,
             "matrix_pipe_issue_frac": ach / peak, "frac_algorithmic_vs_f32_peak": alg / F32_MFMA_PEAK_TFLOPS,
-            "pipe_busy_recorded": PIPE_BUSY_RECORDED.get((wl.kind, form)),
+            "pipe_busy_recorded": pipe_busy_recorded(wl.kind, form, kname)[0], "pipe_busy_recorded_in": pipe_busy_recorded(wl.kind, form, kname)[1],
             "arithmetic": form,
             "share_of_step": (ms * 1e-3) / secs_per_step,
             "step_frac": (st["trunk"][2] + st["unet"][2]) / secs_per_step / 1e12 / peak,
@@ -356,12 +376,13 @@ def host_view(wl):
                                  unet_sd=wl.unet_sd, dyn_sd=wl.dyn_sd)
 
 
-def cpu_baseline(wl, full=False):
+def cpu_baseline(wl, full=False, median=None):
     """The CPU oracle (a restatement of the reference's as-written dataflow, pinned to the reference by tests/golden) on this
     box's host cores, on a bounded sample of the workload.  Default: ONE run of the sample (about 15 s of CPU work, so
     that the bench command stays mostly GPU time); `full`: median of 3 runs plus one end-to-end chain on a reduced grid as a sanity
     check of the extrapolation."""
-    med = _median3 if full else _once
+    median = full if median is None else median          # median of 3 without the end-to-end check: the 2-D leg of the default line
+    med = _median3 if median else _once
     from oracle import dgdm_oracle as orc
     # torch CPU kernels on these small/medium tensors get slower beyond a few dozen threads (256 threads: >10x slower
     # than 32 on the MI355X host), so the baseline uses at most 32 - the count is reported in `cores`
@@ -378,7 +399,7 @@ def cpu_baseline(wl, full=False):
             orc.unet1d_forward(wl.unet_sd, x, ts)
     t_unet, _ = _median3(unet)
     cells = wl.G * wl.P * wl.P
-    how = "median of 3 runs" if full else "1 run"
+    how = "median of 3 runs" if median else "1 run"
     check = None
     if wl.kind == "3d":
         # one full 512-row sub-batch of cond_fn (fwd + autograd), as generator/diffusion.py:495-498 runs 71 of per step
@@ -425,6 +446,8 @@ def cpu_baseline(wl, full=False):
                      "predicted_from_sample_s": wl.S * (t_c + t_unet)}
     out = {"value": B / chain, "unit": "samples/s", "cores": cores, "kind": "port", "sample": sample,
            "ms_per_denoise_step": chain / wl.S * 1e3, "cpu_seconds": sum(runs)}
+    if check:               # the reduced-grid end-to-end chain beside what the sample predicts for it
+        out["check_chain_s"], out["check_predicted_s"] = check["seconds"], check["predicted_from_sample_s"]
     detail = {"runs_s": runs, "end_to_end_check": check}
     return out, detail
 
@@ -731,8 +754,28 @@ def main():
             "workload": a.workload, "pairs": pairs, "B": wl.B, "S": wl.S, "rows": wl.rows, "n_obj": wl.n_obj, "draw_secs": draw_secs,
             "gloo": world > 1 and a.backend == "gloo", "unet_form": "%s%s" % ((lambda f: (f[0], " batched" if f[1] else ""))(wl.net.effective_form(wl.B * pairs, wl.L)))}
     cpu, detail = None, {}
+    second = None
+    if world == 1 and a.workload == "3d" and not a.no_2d and not a.force_group:
+        # the metric's 2-D half (BASELINE configs[1]) in the same line: 10 timed steps after 2 warm-up steps, its trunk's roofline fraction
+        # from HIP events, and (below, with the CPU legs) the oracle on a bounded sample of it
+        w2 = Workload("2d", DEFAULT_PAIRS["2d"], dev, rank, world, a.contraction)
+        n2 = 10
+        s2, _, _ = timed_loop(w2, n2, 2, None)
+        r2, sh2 = stage_profile(w2, s2 / n2, a.contraction)
+        second = {"value_2d": w2.B * w2.pairs * n2 / s2, "ms_per_step_2d": s2 / n2 * 1e3, "ms_per_denoise_step_2d": s2 / n2 / w2.S * 1e3,
+                  "steps_2d": n2, "pairs_per_step_2d": w2.pairs, "fingers_per_pair_2d": w2.B, "rows_per_cond_fn_2d": w2.rows,
+                  "roofline_2d_frac": r2["frac"] if r2 else None, "roofline_2d_achieved_tflops": r2["achieved"] if r2 else None,
+                  "roofline_2d_avg_launch_ms": r2["avg_launch_ms"] if r2 else None,
+                  "roofline_2d_issue_frac": r2["matrix_pipe_issue_frac"] if r2 else None, "trunk_share_of_step_2d": r2["share_of_step"] if r2 else None}
+        detail["second_leg_2d"] = {"roofline": r2, "stage_ms": sh2}
+        hv2 = host_view(w2)
+        del w2
+        torch.cuda.empty_cache()
     if world == 1 and a.cpu_baseline != "none":
         cpu, detail["cpu_baseline"] = cpu_baseline(host_view(wl), full=a.cpu_baseline == "full")
+        if second is not None:
+            c2, detail["cpu_baseline_2d"] = cpu_baseline(hv2, full=False, median=a.cpu_baseline == "full")
+            second["cpu_baseline_2d"], second["cpu_baseline_2d_cores"] = c2["value"], c2["cores"]
     if world == 1 and a.extra:
         kind = wl.kind
         del wl
@@ -742,7 +785,7 @@ def main():
         try:
             os.makedirs(os.path.dirname(a.extra_out), exist_ok=True)
             with open(a.extra_out, "w") as f:
-                json.dump({"headline": headline(meas, roof, shares, cpu), **detail}, f, indent=1)
+                json.dump({"headline": headline(meas, roof, shares, cpu, second), **detail}, f, indent=1)
             print(f"bench.py: details in {a.extra_out}", file=sys.stderr)
         except OSError as e:                                 # a read-only tree must not cost the headline
             print(f"bench.py: could not write {a.extra_out}: {e}", file=sys.stderr)
@@ -758,10 +801,10 @@ def main():
     except OSError:
         pass
     sys.stdout.flush()
-    print(json.dumps(headline(meas, roof, shares, cpu)), flush=True)
+    print(json.dumps(headline(meas, roof, shares, cpu, second)), flush=True)
 
 
-def headline(m, roof, shares, cpu):
+def headline(m, roof, shares, cpu, second=None):
     """The one JSON line of the bench contract, from plain numbers (tests/test_host_logic.py builds it from canned ones): kept far below
     4 KB so that a tail-capturing driver always holds all of it.  Prose about what the figures mean is in DESIGN.md §5, not here."""
     secs, steps = m["secs"], m["steps"]
@@ -782,6 +825,9 @@ def headline(m, roof, shares, cpu):
     if cpu:
         line["cpu_baseline"] = cpu
         line["speedup_vs_cpu_baseline"] = line["value"] / cpu["value"]
+    if second:
+        line.update(second)           # flat scalars: the 2-D half of the metric (BASELINE configs[1]), WORKLOAD_NAME["2d"]
+        line["config"]["workload_2d"] = WORKLOAD_NAME["2d"]
     return _round(line)
 
 

@@ -51,7 +51,10 @@ def build_info() -> dict:
         return {}
     with open(INFO) as f:
         info = json.load(f)
-    info["current"] = info.get("sources") == source_hashes()
+    # current = built from the sources the tree holds now AND still the file that build wrote (an experiment script that copies a
+    # variant library over it, or a partial build, must not be certified by the manifest of the last good one)
+    info["lib_intact"] = info.get("lib_sha256") == _sha([LIB])
+    info["current"] = info.get("sources") == source_hashes() and info["lib_intact"]
     return info
 
 
@@ -84,7 +87,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         for err in ex.map(run, jobs):
             if verbose and err.strip():
                 print(err)
-    linked = bool(force or jobs or not os.path.exists(LIB))
+    intact = os.path.exists(LIB) and os.path.exists(INFO) and json.load(open(INFO)).get("lib_sha256") == _sha([LIB])
+    linked = bool(force or jobs or not intact)
     if linked:
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
         with open(INFO, "w") as f:

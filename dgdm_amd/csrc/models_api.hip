@@ -417,7 +417,13 @@ std::vector<float> tfreqs(int half) {
 // checkpoint whose BatchNorm-folded per-channel gains span more than ~2^16 inside a matrix would leave its small rows below f16's
 // subnormal floor (an absolute error where float32 has a relative one).  e[l][j] lifts every row's largest |w| into the binade of the
 // matrix' largest (after the previous layer's column factors), so rows - and, through the column factors, the next layer's inputs - are
-// balanced whatever the checkpoint's gains.  tests/test_gpu_range.py.
+// balanced whatever the checkpoint's gains.  The BIAS counts as a weight on a constant input of the layer's input scale A (an
+// estimate: 1 for layer 1, then the largest scaled bias / (largest scaled weight x A) of the layer before): a BatchNorm channel with a
+// tiny gamma / sigma but an ordinary beta - a near-dead channel, common in trained nets - has an ordinary activation relu(beta + tiny),
+// and lifting its WEIGHTS to the top binade would make that activation 2^24 .. 2^60 times its neighbours', which share one f16 scale per
+// tile row in trunk_f16l.hip: everything else in the row would be pushed to or below the f16 floor.  With the bias in the row's
+// magnitude such a row is left where its bias is ordinary, and only its (irrelevant) tiny weights fall under the floor, as without
+// equilibration.  tests/test_gpu_range.py (gains on weight and bias together, on gamma alone, near-dead channels).
 struct TrunkEquil {
     std::vector<std::vector<int>> e;         // [layer 0 .. 7][unit]
     // units that are provably dead - a zero weight row and a bias <= 0, e.g. a BatchNorm channel with gamma = 0: relu gives exactly 0 for
@@ -433,27 +439,36 @@ struct TrunkEquil {
         W1 = W1_;
         e.assign(8, {});
         dead.assign(8, {});
+        double A = 1.0;                                      // magnitude of the layer's inputs in scaled units (encoder outputs: O(1))
         for (int l = 0; l < 8; ++l) {
             const int out = out_of(l), in = l == 0 ? IN1 : out_of(l - 1);
             Folded64 f;
             const int rc = fold_linear64(sd, lin(l), bn(l), out, in, &f);
             if (rc) return rc;
             std::vector<int> re(out, INT_MIN);
+            std::vector<double> mw(out, 0.0);                // a row's largest |w| after the previous layer's column factors
+            std::vector<char> zero_row(out, 1);
             int top = INT_MIN;
             for (int j = 0; j < out; ++j) {
-                double mx = 0.0;
                 for (int k = 0; k < in; ++k) {
                     const double w = std::fabs(f.w[(size_t)j * in + k]);
                     if (l && dead[l - 1][k]) continue;
-                    if (std::isfinite(w)) mx = std::max(mx, l ? std::ldexp(w, -e[l - 1][k]) : w);
+                    if (std::isfinite(w)) mw[j] = std::max(mw[j], l ? std::ldexp(w, -e[l - 1][k]) : w);
                 }
+                zero_row[j] = mw[j] == 0.0;
+                const double b = std::fabs(f.b[j]);
+                const double mx = std::max(mw[j], (A > 0.0 && std::isfinite(b)) ? b / A : 0.0);
                 if (mx > 0.0) { std::frexp(mx, &re[j]); top = std::max(top, re[j]); }
             }
             dead[l].assign(out, 0);
-            for (int j = 0; j < out; ++j) dead[l][j] = re[j] == INT_MIN && f.b[j] <= 0.0;
+            for (int j = 0; j < out; ++j) dead[l][j] = zero_row[j] && f.b[j] <= 0.0;
             e[l].assign(out, 0);
-            for (int j = 0; j < out; ++j)
-                if (re[j] != INT_MIN) e[l][j] = std::min(top - re[j], 60);      // >= 0: rows are only ever scaled up, to the top row's binade
+            double An = 0.0;
+            for (int j = 0; j < out; ++j) {
+                if (re[j] != INT_MIN && !dead[l][j]) e[l][j] = std::min(top - re[j], 60);      // >= 0: rows are only ever scaled up, to the top row's binade
+                if (!dead[l][j] && std::isfinite(f.b[j])) An = std::max(An, std::ldexp(std::max(std::fabs(f.b[j]), mw[j] * A), e[l][j]));
+            }
+            A = An;
         }
         return DGDM_OK;
     }

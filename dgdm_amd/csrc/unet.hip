@@ -1126,6 +1126,7 @@ static size_t ub_lds_bytes(int S, int Lin, int Lout, int cout) {
 int unet_batched_samples(const UnetParams &p, int L) {
     const int L2 = (L - 1) / 2 + 1;
     if (p.dsed > 32 || p.d0 != 128 || p.d1 != 256) return 0;       // the tilings above are written for the shipped widths (down_dims [128, 256])
+    if (2 * L2 != L) return 0;                                      // odd lengths: the per-sample kernel (selection, launch and effective_form agree)
     for (int S = 4; S >= 2; --S) {
         const bool fits = ub_lds_bytes(S, L, L, p.d0) <= 160 * 1024 && ub_lds_bytes(S, L2, L2, p.d1) <= 160 * 1024 && ub_lds_bytes(S, L2, L, p.d0) <= 160 * 1024 &&
                           ub_lds_bytes(S, L, L2, p.d0) <= 160 * 1024;

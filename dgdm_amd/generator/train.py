@@ -153,9 +153,13 @@ def fit(model: Diffusion, pts: np.ndarray, args, bounds, dev) -> Diffusion:
                 f = os.path.join(ckdir, "epoch=%04d.ckpt" % epoch)
                 torch.save(ck, f)
                 torch.save(ck, os.path.join(ckdir, "last.ckpt"))
+                if f in kept:                  # a run resumed from an older checkpoint re-saves epochs that are already on the list
+                    kept.remove(f)
                 kept.append(f)
                 while len(kept) > 10:          # save_top_k = 10, monitor = 'epoch', mode = 'max'
-                    os.remove(kept.pop(0))
+                    old = kept.pop(0)
+                    if os.path.exists(old):
+                        os.remove(old)
     model.sync_model()
     model.train_log = log
     if world > 1:

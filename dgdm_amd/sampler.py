@@ -375,7 +375,7 @@ def guided_chains(unet: Unet1d, guid: Guidance, sched: DDIMScheduler, mode: str,
             eps = unet.forward(x.reshape(nc * B, L, 1), ts).reshape(nc, B, L)
         g = guid.grad(x, t, objectives, rowcoef, step_starts[si].reshape(-1) if is3d else None)
         if trace is not None:
-            trace.append((eps.clone(), g.clone()))
+            trace.append((eps.clone(), g.clone(), x.clone()))          # eps, gradient and the step's INPUT x
         coef = sched.coefficients(t)
         if len(set(scales)) == 1:
             x = engine.ddim_guided_step(x, eps, g, 1, coef, scales[0])

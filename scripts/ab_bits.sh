@@ -1,6 +1,7 @@
 #!/bin/bash
 # Are two builds of the library bit-identical on the guidance gradient?  The tree's libdgdm_hip.so against dgdm_amd/csrc/alt_exp.so.
 cp dgdm_amd/csrc/libdgdm_hip.so /tmp/libA.so
+trap 'cp /tmp/libA.so dgdm_amd/csrc/libdgdm_hip.so' EXIT      # the shipped library is back in place however the script ends
 timeout 200 python3 scripts/dump_grad.py /tmp/gA.npz 2>/dev/null
 cp dgdm_amd/csrc/alt_exp.so dgdm_amd/csrc/libdgdm_hip.so
 timeout 200 python3 scripts/dump_grad.py /tmp/gB.npz 2>/dev/null

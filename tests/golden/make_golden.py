@@ -627,20 +627,32 @@ def g9_3d_dist(parts=None, B=2, tag=""):
     """The reference's own guided_sample / guided_sample_multi_object at the full per-finger grid of BASELINE configs[2] (G=45, P=5,
     sub_bs=512), free-running, with per-step traces and recorded FPS draws, for the chains of G9_3D_DIST (generator/diffusion.py:541-580,
     621-647).  One file per chain, written as soon as the chain is done; a chain whose file exists is skipped.  GOLDEN_THREADS sets the
-    CPU threads (default 8).  '<name>:eps' re-runs a chain with its eps-net output multiplied by (1 + 1e-6 N(0,1)) (as g9_3d_eps does):
-    the reference's own reproducibility under a perturbation of the size of any second float32 eps-net."""
+    CPU threads (default 8).  '<name>+eps' re-runs a chain with its eps-net output multiplied by (1 + 1e-6 N(0,1)) (as g9_3d_eps does):
+    the reference's own reproducibility under a perturbation of the size of any second float32 eps-net.  '<name>+arith' re-runs it
+    with the classifier trunk accumulating in float64 (as g9_3d_arith does): the reference's own reproducibility under a change of
+    the TRUNK's rounding pattern - what any second float32 implementation of the trunk is ('<name>_arith.npz': end point, arith_floor)."""
+    import copy
     import time
+
+    class In64(nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.m = copy.deepcopy(m).double()
+
+        def forward(self, x):
+            return self.m(x.double()).float()
+
     threads = int(os.environ.get("GOLDEN_THREADS", "8"))
     unet = make_unet()
     objs = torch.stack([synth.synth_object_3d(50 + i) for i in range(4)])
     G, P, L, T, S = 45, 5, 42, 15, 5
     noise = synth.synth_noise(0, B, L)
     for part in (parts or list(G9_3D_DIST)):
-        eps_run = part.endswith("+eps")
-        name = part[:-4] if eps_run else part
+        eps_run, arith_run = part.endswith("+eps"), part.endswith("+arith")
+        name = part[:-4] if eps_run else (part[:-6] if arith_run else part)
         o, gain, oi = G9_3D_DIST[name]
         multi = isinstance(oi, tuple)
-        path = os.path.join(OUT, f"g9_3d_{tag}{name}{'_eps' if eps_run else ''}.npz")
+        path = os.path.join(OUT, f"g9_3d_{tag}{name}{'_eps' if eps_run else ('_arith' if arith_run else '')}.npz")
         if os.path.exists(path):
             continue
         d = make_diffusion('point_3d', unet, _scaled_output(make_dyn3d(), gain), T, S, L, G, P, objs[:1], 512)
@@ -651,6 +663,10 @@ def g9_3d_dist(parts=None, B=2, tag=""):
         if eps_run:
             gen = torch.Generator().manual_seed(1)
             hook = d.noise_pred_net.register_forward_hook(lambda m, i, out_: out_ * (1.0 + 1e-6 * torch.randn(out_.shape, generator=gen)))
+        if arith_run:
+            dyn = d.classifier_model.module if hasattr(d.classifier_model, "module") else d.classifier_model
+            inner = dyn.m if hasattr(dyn, "m") else dyn                       # make_diffusion may wrap the model (see Wrapped)
+            inner.linears, inner.output = In64(inner.linears.eval()), In64(inner.output)
         torch.set_num_threads(threads)
         torch.manual_seed(0)
         t0 = time.time()
@@ -673,6 +689,13 @@ def g9_3d_dist(parts=None, B=2, tag=""):
             fl = _spread(end, ref["guided"])
             np.savez_compressed(path, guided=end, eps_floor=np.float64(fl), rel=np.float64(1e-6))
             print("  3d dist", part, f"{time.time() - t0:.0f}s eps spread (finger L2)", fl, flush=True)
+            continue
+        if arith_run:
+            ref = np.load(os.path.join(OUT, f"g9_3d_{tag}{name}.npz"))
+            assert np.array_equal(st, ref["starts"]), "the re-run must see the recorded FPS draws"
+            fl = _spread(end, ref["guided"])
+            np.savez_compressed(path, guided=end, arith_floor=np.float64(fl))
+            print("  3d dist", part, f"{time.time() - t0:.0f}s arith spread (finger L2)", fl, flush=True)
             continue
         tr.pack("trace", out)
         out["guided"], out["starts"], out["start_lens"] = end, st, ln

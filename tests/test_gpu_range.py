@@ -35,13 +35,22 @@ pytestmark = pytest.mark.gpu
 FLOOR = 1e-6
 
 
-def adversarial_dyn_sd(sd, seed, compensate=True, dead=0.05):
-    """See the module docstring.  Trunk layers only (linears.{3l} + BatchNorm linears.{3l+1}, l = 0 .. 7, then `output`)."""
+def adversarial_dyn_sd(sd, seed, compensate=True, dead=0.05, bias="scaled"):
+    """See the module docstring.  Trunk layers only (linears.{3l} + BatchNorm linears.{3l+1}, l = 0 .. 7, then `output`).
+    bias='scaled': the gain on gamma and beta together (the function is unchanged when compensated downstream); 'kept': on gamma ALONE
+    (beta as it was: another network, whose units' weights span 2^24 while their biases - and so their activations - do not);
+    'near_dead': 10 % of the units with gamma x 1e-12 and beta ~ 0.1 (a BatchNorm channel that has died in training but keeps its
+    offset: its activation is an ordinary constant, its weight row is 40 binades below its neighbours')."""
     rs = np.random.RandomState(seed)
     sd = {k: v.clone() for k, v in sd.items()}
     for l in range(8):
         lin, bn = f"linears.{3 * l}", f"linears.{3 * l + 1}"
         n = sd[bn + ".weight"].shape[0]
+        if bias == "near_dead":
+            nd = rs.uniform(size=n) < 0.10
+            sd[bn + ".weight"] = (sd[bn + ".weight"].double() * torch.from_numpy(np.where(nd, 1e-12, 1.0))).float()
+            sd[bn + ".bias"] = torch.from_numpy(np.where(nd, 0.1 * rs.uniform(0.5, 1.5, n), sd[bn + ".bias"].double().numpy())).float()
+            continue
         s = 2.0 ** (rs.uniform(-12, 12, n) if compensate else rs.uniform(-24, 0, n))
         kill = rs.uniform(size=n) < dead
         var_new = 10.0 ** rs.uniform(-6, 2, n)
@@ -50,7 +59,7 @@ def adversarial_dyn_sd(sd, seed, compensate=True, dead=0.05):
         gain = torch.from_numpy(np.where(kill, 0.0, s * keep))
         sd[bn + ".running_var"] = torch.from_numpy(var_new).float()
         sd[bn + ".weight"] = (sd[bn + ".weight"].double() * gain).float()
-        sd[bn + ".bias"] = (sd[bn + ".bias"].double() * torch.from_numpy(np.where(kill, 0.0, s))).float()
+        sd[bn + ".bias"] = (sd[bn + ".bias"].double() * torch.from_numpy(np.where(kill, 0.0, s if bias == "scaled" else 1.0))).float()
         if compensate:
             nxt = f"linears.{3 * (l + 1)}.weight" if l < 7 else "output.weight"
             sd[nxt] = (sd[nxt].double() / torch.from_numpy(s)[None, :]).float()
@@ -155,6 +164,48 @@ def test_f16x3_dynamic_range_3d(dev, compensate):      # noqa: F811
         _check(f"3-D {o} compensate={compensate}", errs)
         if compensate:
             assert errs["noeq"][0] > errs["f32"][0], errs
+
+
+@pytest.mark.parametrize("bias", ["kept", "near_dead"])
+def test_f16x3_bias_dominated_units(dev, bias):      # noqa: F811
+    """Units whose WEIGHT row is tiny against their bias (round-5 advisor): gains on gamma alone (beta unchanged), and near-dead BatchNorm
+    channels (gamma ~ 1e-12, beta ~ 0.1).  The equilibration must not lift such a row's weights - its activation, an ordinary
+    constant, would become 2^24 .. 2^60 times its neighbours' and take the tile row's f16 scale with it (models_api.hip TrunkEquil counts
+    the bias as a weight on the layer's input scale).  2-D and 3-D, against float64."""
+    T = 15
+    nv, B2, G2, P2, L2 = 100, 4, 8, 3, 14
+    sd = adversarial_dyn_sd(util.dyn2d_sd(97, nv), 12, True, bias=bias)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    obj = synth.synth_object_2d(5, nv)
+    x = synth.synth_noise(76, B2, L2).clamp(-1, 1)
+    s64 = util.setup('point', None, sd64, T, 5, L2, G2, P2)
+    for o in ("rotate", "shift_left"):
+        ref = orc.cond_fn(s64, x.double(), torch.full((B2,), 6, dtype=torch.int64), o, obj.double())
+        assert bool(torch.isfinite(ref).all()) and float(ref.norm()) > 0
+        errs = {}
+        for tag, mode in (("f32", "f32"), ("f32_mfma", "f32_mfma")):
+            gd = engine.Guidance(_dyn(2, sd, L2, nv), B2, G2, P2, (-1.0, 1.0), 1, T, nv, 0, max_objects=1, contraction_dtype=mode)
+            gd.set_objects(obj[None].to(dev))
+            gr = gd.grad(x.reshape(1, B2, L2).to(dev), 6, [engine.make_objective(o, 0)], None).cpu()
+            assert bool(torch.isfinite(gr).all()), (tag, o)
+            errs[tag] = _grad_err(gr.reshape(B2, L2, 1), ref)
+        _check(f"2-D {o} bias={bias}", errs)
+    B, G, P, L, sub = 2, 3, 2, 42, 7
+    sd = adversarial_dyn_sd(util.dyn3d_sd(98), 13, True, bias=bias)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    obj = synth.synth_object_3d(56)
+    x = synth.synth_noise(77, B, L).clamp(-1, 1)
+    calls = _starts_3d(B * G * P * P, sub, 11)
+    s64 = util.setup('point_3d', None, sd64, T, 5, L, G, P, sub)
+    for o in ("rotate", "shift_up"):
+        ref = orc.cond_fn(s64, x.double(), torch.full((B,), 9, dtype=torch.int64), o, obj.double(), (-1.0, 1.0), None, orc.StartLog([c.clone() for c in calls]))
+        assert bool(torch.isfinite(ref).all()) and float(ref.norm()) > 0
+        errs = {}
+        for tag, mode in (("f32", "f32"), ("f32_mfma", "f32_mfma")):
+            gr = _grad_3d(dev, sd, obj, x, 9, o, B, G, P, L, T, sub, calls, mode)
+            assert bool(torch.isfinite(gr).all()), (tag, o)
+            errs[tag] = _grad_err(gr.reshape(B, L, 1), ref)
+        _check(f"3-D {o} bias={bias}", errs)
 
 
 @pytest.mark.parametrize("scale", [1e-6, 1e-3, 1.0, 1e3, 1e6])
