@@ -64,10 +64,17 @@ __device__ __forceinline__ float mish(float x) {
     // torch.nn.functional.mish = x * tanh(softplus(x)).  With e = exp(x): tanh(log(1 + e)) = n / (n + 2), n = e (e + 2), which
     // needs one exp and one division instead of log1p + tanh.  torch's softplus returns x above its threshold 20, where
     // tanh(x) rounds to 1 in float32 - as does n / (n + 2) (n > 2e17) - so clamping the exponent at 20 reproduces that branch
-    // and keeps e*e finite.  Relative error ~2e-7 (one exp, one rounding per operation).
+    // and keeps e*e finite.  The division is v_rcp_f32 + one correction step (q = n r; q += (n - q d) r: the residual is exact in the
+    // fma, the quotient within an ulp of the correctly rounded one) instead of the IEEE sequence (v_div_scale x 2, v_rcp, four
+    // fma, v_div_fmas, v_div_fixup): d = n + 2 lies in [2, 2.4e17], where none of what that sequence guards against can happen.
+    // The GroupNorm + Mish passes of the eps-net are bound by VALU throughput.  Relative error ~2e-7.
     const float e = __expf(fminf(x, 20.f));
     const float n = e * (e + 2.f);
-    return x * (n / (n + 2.f));
+    const float d = n + 2.f;
+    const float r = __builtin_amdgcn_rcpf(d);
+    float q = n * r;
+    q = fmaf(fmaf(-q, d, n), r, q);
+    return x * q;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -807,6 +814,12 @@ __device__ void ub_conv(const UbPass &a, const int S, const int ns, const int b0
     const int j = lane & 15, q = lane >> 4;
     const int groups = __builtin_amdgcn_readfirstlane(a.cin >> 5), ntaps = __builtin_amdgcn_readfirstlane(a.ntaps);
     const int Rs = a.Lin + 4, R = S * Rs;
+    // Slab planes [channel group gg][piece][q] of Rp rows (16 B each), Rp a multiple of 16 rows (= all 64 banks): a B-operand read's lane
+    // groups hold positions j of plane q and j' of plane q + 1 (q even) that are 16-byte neighbours modulo the plane stride - with planes
+    // congruent modulo 256 B they cover the 64 banks exactly once (with R = 184 or 100 rows every read was a 2-way conflict: 12.9 % of the
+    // launch's cycles, profiles/r05_pmc_kernels.md).  The fill's stores put a lane's eight 16-byte pieces into the eight (gg, q) planes:
+    // one extra row of offset per (gg, q >> 1) spreads them over four bank quads (2-way, hidden under the store's own transfer time).
+    const int Rp = (R + 15) & ~15, Gp = 8 * Rp + 2;
     // SPLIT: waves 0-3 / 4-7 take the lower / upper NT position tiles and wave & 3 picks MT output tiles (both halves fetch the same weight
     // fragments); otherwise every wave holds all NT position tiles of its own MT output tiles (no fragment is fetched twice)
     const int half = SPLIT ? __builtin_amdgcn_readfirstlane(wave >> 2) : 0, tg = __builtin_amdgcn_readfirstlane(SPLIT ? (wave & 3) : wave);
@@ -818,7 +831,7 @@ __device__ void ub_conv(const UbPass &a, const int S, const int ns, const int b0
     for (int nt = 0; nt < NT; ++nt) {
         const int n = (half * NT + nt) * 16 + j, nn = min(n, npos - 1);
         const int sm = nn / Lp, l = nn - sm * Lp;
-        brow[nt] = q * R + sm * Rs + l * a.istride + a.ioff0 + 2;
+        brow[nt] = q * Rp + (q >> 1) + sm * Rs + l * a.istride + a.ioff0 + 2;
         srow[nt] = n < npos ? sm * (LoutS + 4) + 2 + l * a.ostride + a.ooff : -1;      // the stage keeps two halo rows around every sample, like the global buffers
         un[nt] = pow2_f(-kxs[sm]);
     }
@@ -875,8 +888,8 @@ __device__ void ub_conv(const UbPass &a, const int S, const int ns, const int b0
                     split2_f16(f32x2_u{hi[u][2], hi[u][3]} * f2, h3, l3);
                     H = u32x4_u{h0, h1, h2, h3}; Lw = u32x4_u{l0, l1, l2, l3};
                 }
-                slab[gg * 8 * R + qq * R + row] = H;
-                slab[gg * 8 * R + 4 * R + qq * R + row] = Lw;
+                slab[gg * Gp + qq * Rp + (qq >> 1) + row] = H;
+                slab[gg * Gp + 4 * Rp + qq * Rp + (qq >> 1) + row] = Lw;
             }
         }
         __syncthreads();
@@ -896,12 +909,12 @@ __device__ void ub_conv(const UbPass &a, const int S, const int ns, const int b0
             asm volatile("" : "+v"(pre));
 #pragma unroll
             for (int m = 0; m < MT; ++m) { n2h[m] = w[m][(size_t)pre * 128]; n2l[m] = w[m][(size_t)pre * 128 + 64]; }
-            const int ro = gg * 8 * R + t * a.iostep;
+            const int ro = gg * Gp + t * a.iostep;
             f16x8_u bh[NT], bl[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 bh[nt] = __builtin_bit_cast(f16x8_u, (u32x4_u)slab[brow[nt] + ro]);
-                bl[nt] = __builtin_bit_cast(f16x8_u, (u32x4_u)slab[4 * R + brow[nt] + ro]);
+                bl[nt] = __builtin_bit_cast(f16x8_u, (u32x4_u)slab[4 * Rp + brow[nt] + ro]);
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
@@ -1119,7 +1132,8 @@ __global__ __launch_bounds__(256) void ub_cond_kernel(const UnetParams *__restri
 }
 
 static size_t ub_lds_bytes(int S, int Lin, int Lout, int cout) {
-    return ((size_t)S * (Lout + 4) * (cout + UNET_ROW_PAD) + (size_t)S * 2 * cout + 16) * 4 + (size_t)2 * 8 * S * (std::max(Lin, Lout) + 4) * 16;
+    const size_t Rp = ((size_t)S * (std::max(Lin, Lout) + 4) + 15) & ~(size_t)15;        // rows per slab plane (ub_conv)
+    return ((size_t)S * (Lout + 4) * (cout + UNET_ROW_PAD) + (size_t)S * 2 * cout + 16) * 4 + (size_t)2 * (8 * Rp + 2) * 16;
 }
 
 // samples per workgroup: the most (<= 4) for which every launch fits the LDS and a half of the waves holds at most 6 position tiles
