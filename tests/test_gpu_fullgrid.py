@@ -182,6 +182,17 @@ def reference_floor(part):
     return (max(fl.values()) if fl else None), fl
 
 
+# chains whose free-running end point is farther from the reference than twice the reference's own re-run floors (round-6 rule): each
+# holds a ReLU tie that the HIP path resolves the other way than the reference - per-call gradients on the reference's trajectory stay
+# at tie level (asserted) and the deviation is confined to single tiles (test_fullgrid_3d_tiles, tests/test_gpu_fullgrid3d.py).  They
+# are xfail, not tolerated: DESIGN.md section 7 states the 3-D north star as NOT met on them.
+BEYOND_OWN_FLOORS = {
+    "rotate": "measured 1.60e-3 vs the reference, 1.57e-3 vs the float64 chain (the reference: 4.4e-4): the first call of every chain on object 0 "
+              "holds one tie in one tile that the HIP path resolves the other way than float64 (shared_first_call_events of the distribution report)",
+    "ccw_down": "measured 3.47e-4 vs the reference (bound 3.33e-4), 3.6e-4 vs the float64 chain (the reference: 1.7e-4)",
+}
+
+
 def tie_budget64(part, S, scale, n_obj, s):
     """How far the rows at risk of a float32 ReLU sign flip can push x over the chain's calls: call k's gradient enters x as
     sqrt(1 - abar_t) * scale * grad (/ n_obj in the ensemble).  0 when the fixture has no entry for the chain."""
@@ -212,8 +223,9 @@ def test_fullgrid_3d(dev, part):
         (without a tie: ~4e-7);
       * end point ``< 1e-4`` (north_star) when the chain is tie-free: the reference's own floors all below 3e-5 - zero included - AND no
         replayed call of the HIP path above rounding level;
-      * otherwise within the larger of twice the reference's own floor and what the rows AT RISK of a float32 sign flip explain, from
-        float64 evidence alone (tie_budget64), capped at 2e-3;
+      * otherwise within twice the largest of the reference's own re-run floors (thread / eps / arith), never above 1e-3; against the
+        float64 chain: within twice the reference's own distance from it (same cap).  Chains beyond that are xfail with their numbers
+        (BEYOND_OWN_FLOORS); what the rows AT RISK of a float32 sign flip could explain (tie_budget64, float64 evidence) is reported only;
       * the per-tile localisation of ``test_fullgrid_3d_tiles`` (a tie is one 32-row tile; anything systematic is all of them)."""
     g = _load3d(part)
     if g is None:
@@ -263,10 +275,16 @@ def test_fullgrid_3d(dev, part):
     # hold ties; a chain on which the reference does not move under any of its own rounding-level perturbations is held to the
     # north-star bound unconditionally, and tests/test_gpu_fullgrid3d.py::test_distribution is the primary statement.
     seen = tie_budget64(part, S, sampler.SCALE_3D if part.startswith("multi") else sampler.classifier_scale('point_3d', o), 2 if part.startswith("multi") else 1, s)
-    TOL_CAP = 2e-3
+    # Round 6: the end-point tolerance is TWICE the largest of the reference's own three re-run floors (thread, eps, arith) - how far the
+    # reference moves from itself under a rounding-level perturbation - and never above 1e-3 (ten north stars); the float64-side tie
+    # budget (an upper bound 100x above what flips) no longer buys tolerance, it is reported.  Chains that do not meet this bound are
+    # listed in BEYOND_OWN_FLOORS with what was measured and xfail: the statement is in the report, not in a wide bound.
+    TOL_CAP = 1e-3
+    three = [floors[k] for k in ("thread", "eps", "arith") if k in floors]
+    floor3 = max(three) if three else None
     tol = None
     if floor is not None:
-        tol = NORTH_STAR if floor < FLOOR_CLEAN else min(TOL_CAP, max(NORTH_STAR, 2.0 * floor, CHAIN_GAIN * seen))
+        tol = NORTH_STAR if floor < FLOOR_CLEAN else min(TOL_CAP, max(NORTH_STAR, 2.0 * (floor3 if floor3 is not None else floor)))
     c64 = chain64(f"3d/{part}")
     d_hip64 = finger_l2(out, c64) if c64 is not None else None
     _report({f"3d/{part}": dict(opt_obj=o, gain=gain, object=oi, reference_floors=floors, ties_seen_budget=seen, end_point_tolerance=tol,
@@ -281,9 +299,13 @@ def test_fullgrid_3d(dev, part):
     if hip64 is not None:                          # against float64: at rounding level like the reference, or one tie away from it
         assert hip64 <= max(ROUNDING, 1.5 * noise64) or hip64 < TIE_GRAD, (part, hip64, noise64)
     assert tol is not None, f"no reference floor recorded for {part} (make_golden.py g9_3d:{part}_alt / g9_3d_eps:{part})"
+    tol64 = min(TOL_CAP, max(NORTH_STAR, 2.0 * floors["f64chain"])) if d_hip64 is not None else None
+    if (err >= tol or (d_hip64 is not None and d_hip64 > tol64)) and part in BEYOND_OWN_FLOORS:
+        pytest.xfail(f"{part}: HIP vs reference {err:.2e} (bound {tol:.2e} = 2 x the reference's own floors {floors}), HIP vs the float64 chain {d_hip64} "
+                     f"(bound {tol64}); {BEYOND_OWN_FLOORS[part]}")
     assert err < tol, (part, err, floors, seen)
-    if d_hip64 is not None:       # against the chain in exact arithmetic: as close as the reference is (x 1.5), or what the seen ties explain
-        assert d_hip64 <= min(TOL_CAP, max(NORTH_STAR, 1.5 * floors["f64chain"], CHAIN_GAIN * seen)), (part, d_hip64, floors["f64chain"], seen)
+    if d_hip64 is not None:       # against the chain in exact arithmetic: within twice the reference's own distance from it
+        assert d_hip64 <= tol64, (part, d_hip64, floors["f64chain"], seen)
 
 
 @pytest.mark.parametrize("part", ["rotate", "convergence", "multi"])
