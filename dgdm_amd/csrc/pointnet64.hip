@@ -47,52 +47,87 @@ __device__ __forceinline__ void ring64_stream(wrsrc_t rs, int voff, int base_off
 constexpr int RING64 = 8;
 constexpr int PN64_GRID = 1024;       // workgroups of the launches whose item count is device data (two per CU resident, two rounds)
 
+// max(v, v of the lane a DPP pattern pairs this lane with): quad_perm [1,0,3,2] 0xB1, [2,3,0,1] 0x4E, row_half_mirror 0x141, row_mirror
+// 0x140 - four steps make the maximum over a row of 16 lanes on the VALU alone (a shuffle through LDS costs a round trip per step)
+template <int CTRL>
+__device__ __forceinline__ double dpp_max64(double v) {
+    const uint64_t b = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, 0xf, 0xf, false);
+    return fmax(v, __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo));
+}
+
 // ------------------------------------------------------------------------------------------------ T2
-// sa1 feature of every point as a centre (pointnet.hip sa1_kernel) -> F1 [N][128] doubles
-__global__ __launch_bounds__(128) void sa1_64_kernel(const float *xyz, int N, float r2, const double *__restrict__ w0t /*[3][64]*/,
+// sa1 feature of every point as a centre (pointnet.hip sa1_kernel) -> F1 [N][128] doubles.
+// One wave takes TWO centres: lane = (centre, one of its 32 neighbours) holds that row's 64 layer-0 values in registers, and the
+// 64 -> 128 layer runs feature by feature with the weight row as a wave-uniform operand: acc = b[f]; acc = fma(w[f][k], h[k], acc) for
+// k ascending - the same chain as ever, so F1 keeps its bits - then the group's maximum over the 32 lanes of the centre.  The weights
+// (64 KiB of doubles) are staged in LDS once per workgroup (persistent workgroups, two per CU, stride over all (object, centre pair)
+// tasks) and read as broadcasts, 32 ds_read_b128 per 64 FMAs: 0.5 LDS cycles per FMA cycle and CU.  (As scalar loads - s_load into
+// SGPRs, one per v_fma_f64 - the same loop ran 50x slower than its FMA count: every wave of the chip pulls the same 64 KiB through
+// 16 KiB scalar caches.  Round 5's form had the roles the other way round - lane = output feature, weights in registers, every
+// ACTIVATION a broadcast read, 2 KiB of them per centre and lane - at 35 cycles per v_fma_f64: 2.1 ms for the 32 objects of a bench
+// step, on the critical path of the table build.)
+constexpr int SA1_LDS_BYTES = (128 * 64 + 128) * 8;
+__global__ __launch_bounds__(256) void sa1_64_kernel(const float *xyz_all, int N, int nobj, float r2, const double *__restrict__ w0t /*[3][64]*/,
                                                      const double *__restrict__ b0, const double *__restrict__ w1 /*[128][64]*/,
-                                                     const double *__restrict__ b1, double *F1 /*[N][128]*/) {
-    __shared__ int nbr[32];
-    __shared__ double h1[32][64];
-    const int t = threadIdx.x, lane = t & 63;
-    xyz += (size_t)blockIdx.y * 3 * N; F1 += (size_t)blockIdx.y * N * 128;      // object of a batched launch
+                                                     const double *__restrict__ b1, double *F1_all /*[nobj][N][128]*/) {
+    extern __shared__ __attribute__((aligned(16))) double sa1_w[];      // [128][64] weights, [128] biases
+    __shared__ int nbr_all[4][2][32];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < 128 * 64; i += 256) sa1_w[i] = w1[i];
+    if (threadIdx.x < 128) sa1_w[128 * 64 + threadIdx.x] = b1[threadIdx.x];
+    __syncthreads();
+    int (*nbr)[32] = nbr_all[wave];
+    const int half = lane >> 5, sl = lane & 31;
+    const int ppo = (N + 1) / 2;                            // centre pairs per object
+    for (int task = blockIdx.x * 4 + wave; task < nobj * ppo; task += gridDim.x * 4) {
+        const int ob = task / ppo, pp = task - ob * ppo;
+        const float *xyz = xyz_all + (size_t)ob * 3 * N;
+        double *F1 = F1_all + (size_t)ob * N * 128;
+        const int p0 = 2 * pp, p1 = min(2 * pp + 1, N - 1);
 #ifdef DGDM_SA1_CLOCKS
-    long long tk[6]; int nk = 0;
-#define SA1_STAMP() do { if (nk < 6) tk[nk++] = __builtin_readcyclecounter(); } while (0)
-#else
-#define SA1_STAMP() do {} while (0)
+        const long long tk0 = __builtin_readcyclecounter();
 #endif
-    SA1_STAMP();
-    double wrow[64];
 #pragma unroll
-    for (int k = 0; k < 64; ++k) wrow[k] = w1[t * 64 + k];
-    const double bias1 = b1[t];
-    for (int p = blockIdx.x; p < N; p += gridDim.x) {
-        const float cx = xyz[3 * p], cy = xyz[3 * p + 1], cz = xyz[3 * p + 2];
-        SA1_STAMP();
-        if (t < 64) ball_first32(xyz, N, p, cx, cy, cz, sq3(cx, cy, cz), r2, nbr, lane);      // wave 0; float32 distances (index decision)
-        __syncthreads();
-        SA1_STAMP();
-        for (int i = t; i < 32 * 64; i += 128) {          // layer 0 on the relative coordinates (exact differences of float32 values)
-            const int s = i >> 6, c = i & 63, k = nbr[s];
-            const double dx = (double)xyz[3 * k] - (double)cx, dy = (double)xyz[3 * k + 1] - (double)cy, dz = (double)xyz[3 * k + 2] - (double)cz;
-            h1[s][c] = fmax(fma(w0t[128 + c], dz, fma(w0t[64 + c], dy, fma(w0t[c], dx, b0[c]))), 0.0);
+        for (int c = 0; c < 2; ++c) {                        // float32 distances (index decision), one centre after the other
+            const int pc = c ? p1 : p0;
+            const float cx = xyz[3 * pc], cy = xyz[3 * pc + 1], cz = xyz[3 * pc + 2];
+            ball_first32(xyz, N, pc, cx, cy, cz, sq3(cx, cy, cz), r2, nbr[c], lane);
         }
-        __syncthreads();
-        SA1_STAMP();
-        double best = 0.0;                                 // ReLU outputs are >= 0 and the group is never empty
-        for (int s = 0; s < 32; ++s) {
-            double acc = bias1;
+        __builtin_amdgcn_wave_barrier();
+        const int p = half ? p1 : p0, k = nbr[half][sl];
+        // layer 0 on the relative coordinates (exact differences of float32 values)
+        const double dx = (double)xyz[3 * k] - (double)xyz[3 * p], dy = (double)xyz[3 * k + 1] - (double)xyz[3 * p + 1],
+                     dz = (double)xyz[3 * k + 2] - (double)xyz[3 * p + 2];
+        double h[64];
 #pragma unroll
-            for (int k = 0; k < 64; ++k) acc = fma(wrow[k], h1[s][k], acc);
-            best = fmax(best, acc);
-        }
-        F1[(size_t)p * 128 + t] = best;
-        __syncthreads();
-        SA1_STAMP();
+        for (int c = 0; c < 64; ++c) h[c] = fmax(fma(w0t[128 + c], dz, fma(w0t[64 + c], dy, fma(w0t[c], dx, b0[c]))), 0.0);
+        double res[4] = {0.0, 0.0, 0.0, 0.0};
 #ifdef DGDM_SA1_CLOCKS
-        if (t == 0 && blockIdx.x == 100 && blockIdx.y == 3) printf("sa1: weights %lld ball %lld layer0 %lld layer1 %lld\n", tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2], tk[4] - tk[3]);
+        const long long tk1 = __builtin_readcyclecounter();
 #endif
+#pragma nounroll
+        for (int f = 0; f < 128; ++f) {
+            const double *wf = sa1_w + f * 64;               // wave-uniform: broadcast reads
+            double acc = sa1_w[128 * 64 + f];
+#pragma unroll
+            for (int kk = 0; kk < 64; ++kk) acc = fma(wf[kk], h[kk], acc);
+            // the group's maximum (32 lanes of one centre): four DPP steps inside the rows of 16, one exchange between the two rows
+            acc = dpp_max64<0xB1>(acc); acc = dpp_max64<0x4E>(acc); acc = dpp_max64<0x141>(acc); acc = dpp_max64<0x140>(acc);
+            acc = fmax(acc, __shfl_xor(acc, 16));
+            acc = fmax(acc, 0.0);                            // ReLU outputs are >= 0 and the group is never empty
+            if (sl == (f & 31)) res[f >> 5] = acc;
+        }
+#ifdef DGDM_SA1_CLOCKS
+        const long long tk2 = __builtin_readcyclecounter();
+        if (threadIdx.x == 0 && blockIdx.x == 100 && task < 4 * gridDim.x * 2) printf("sa1 task %d: ball + layer 0 %lld cycles, layer 1 %lld\n", task, tk1 - tk0, tk2 - tk1);
+#endif
+        if (half == 0 || 2 * pp + 1 < N) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) F1[(size_t)p * 128 + 32 * j + sl] = res[j];
+        }
+        __builtin_amdgcn_wave_barrier();                     // nbr is rewritten by the next task
     }
 }
 
@@ -224,7 +259,14 @@ __global__ __launch_bounds__(256, 2) void z64_kernel(const float *__restrict__ x
 
 // ------------------------------------------------------------------------------------------------ host side
 int pn_sa1_64(const float *xyz, int N, float r1sq, const PnWeights64 &w, double *F1_64, hipStream_t s, int nobj) {
-    hipLaunchKernelGGL(sa1_64_kernel, dim3(std::min(N, 1024), nobj), dim3(128), 0, s, xyz, N, r1sq, w.sa1_w0t, w.sa1_b0, w.sa1_w1, w.sa1_b1, F1_64);
+    static bool attr_set = false;
+    if (!attr_set) {
+        DGDM_HIP_CHECK(hipFuncSetAttribute((const void *)sa1_64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SA1_LDS_BYTES));
+        attr_set = true;
+    }
+    const int tasks = nobj * ((N + 1) / 2);
+    hipLaunchKernelGGL(sa1_64_kernel, dim3(std::min((tasks + 3) / 4, 512)), dim3(256), SA1_LDS_BYTES, s, xyz, N, nobj, r1sq, w.sa1_w0t, w.sa1_b0, w.sa1_w1,
+                       w.sa1_b1, F1_64);
     DGDM_HIP_CHECK(hipGetLastError());
     return DGDM_OK;
 }
