@@ -45,7 +45,7 @@ struct ObjectTables {       // 3-D, per object
     int *crowded = nullptr, *clist = nullptr;   // [N] int, [N + 1] int (clist[N] = count): centres whose ball query truncates (pointnet.hip crowd_kernel); pool slices
     DevBuf M0, cl2, cnt2;   // [N][256] float, [N][128] int, [N] int: variant-independent part of the sa3 max (pointnet.hip m0_kernel)
     DevBuf cl2s;            // [N][128] cl2 as positions in clist (xtab_kernel)
-    DevBuf cl2o;            // [N][128] u16: cl2 as byte offsets into xobj_rows_kernel's LDS slab (scaled for the build's mode: has16)
+    DevBuf cl2o;            // [N][2][128] u16: cl2 as byte offsets into xobj_rows_kernel's LDS slab (scaled for the build's mode: has16), even / odd slots first
     DevBuf pcf;             // [N][512] per (s1, s2): sa2's start point, its list length, its tie flag (pointnet.hip pcf_kernel)
     DevBuf X, X16;          // [N][N][256] float32 / [N][N][128] bf16 dwords: the finished embedding per (s1, start point) (pointnet.hip xtab_kernel)
     bool   has_x = false, has_x16 = false;
@@ -276,7 +276,7 @@ int DgdmGuidance::build_object(int oi, int slot, hipStream_t s) {
     int rc;
     if ((rc = t.Z.alloc((size_t)N * N * 256 * 4)) ||
         (rc = t.M0.alloc((size_t)N * 256 * 4)) || (rc = t.cl2.alloc((size_t)N * 128 * sizeof(int))) || (rc = t.cnt2.alloc((size_t)N * sizeof(int))) ||
-        (rc = t.cl2s.alloc((size_t)N * 128 * sizeof(int))) || (rc = t.cl2o.alloc((size_t)N * 128 * sizeof(unsigned short))) ||
+        (rc = t.cl2s.alloc((size_t)N * 128 * sizeof(int))) || (rc = t.cl2o.alloc((size_t)N * 256 * sizeof(unsigned short))) ||
         (rc = t.pcf.alloc((size_t)N * 512 * sizeof(int))))
         return rc;
     t.has16 = bf16;

@@ -45,7 +45,7 @@ struct XobjChain {
     // (chain, s1)-group kernel (xobj_group_kernel): the object's crowded centres, their slot in that list per fps2 sequence
     const int   *clist;           // [ncr] crowded centre point ids (crowd_kernel)
     const int   *cl2s;            // [N][128] cl2 as positions in clist (m0_kernel), padded like cl2
-    const unsigned short *cl2o;   // [N][128] the same as byte offsets into xobj_rows_kernel's LDS slab (position * lpr * 16)
+    const unsigned short *cl2o;   // [N][2][128] the same as byte offsets into xobj_rows_kernel's LDS slab (position * lpr * 16), even / odd positions first
     int          ncr;             // number of crowded centres (host copy)
     const int   *pcf;             // [N][512] q | cnt2[q] << 10 | (flags[q] != 0) << 18 with q = fps1[s1][s2] (pcf_kernel)
     int          lpr;             // lanes per row of the group kernel: 64 / 32 / 16 / 8  <=>  1 / 2 / 4 / 8 feature chunks

@@ -762,12 +762,28 @@ __global__ __launch_bounds__(256) void m0_kernel(const int *__restrict__ fps2 /*
         if (crB) ds[nA + __popcll(mB & below)] = slot_of[idB];
         const int ls = cnt > 0 ? slot_of[last] : 0;
         for (int j = cnt + lane; j < 128; j += 64) ds[j] = ls;
-        // the same list as byte offsets into xobj_rows_kernel's LDS slab (slot * lanes-per-row * 16 B; 0 when the slab does not fit)
+        // the same list as byte offsets into xobj_rows_kernel's LDS slab (slot * lanes-per-row * 16 B; 0 when the slab does not fit), in TWO
+        // orders (max does not care): members with an even slot first / with an odd slot first.  With 128-byte slab entries (lpr = 8:
+        // objects with more than 256 crowded centres) a slot's parity is the half of the 64 banks its entry lies in, and a ds_read_b128's
+        // 16-lane service group holds quarter-entries of two lane groups (0 & 3, 1 & 2 of every four): lane groups 0, 1 walk the
+        // even-first list and 2, 3 the odd-first one, so the two meet in the same bank half only where the halves of their lists overlap
+        // (the unsorted list: a 2-way conflict on every other read, +44 % LDS cycles in profiles/r06's first collection)
         const int sc = xobj_rows_lpr(*ncr, bf16 != 0) * 16;
-        unsigned short *dz = cl2o + (size_t)q * 128;
-        if (crA) dz[__popcll(mA & below)] = (unsigned short)(slot_of[idA] * sc);
-        if (crB) dz[nA + __popcll(mB & below)] = (unsigned short)(slot_of[idB] * sc);
-        for (int j = cnt + lane; j < 128; j += 64) dz[j] = (unsigned short)(ls * sc);
+        const int sA = crA ? slot_of[idA] : 0, sB = crB ? slot_of[idB] : 0;
+        const unsigned long long mAe = __ballot(crA && !(sA & 1)), mAo = __ballot(crA && (sA & 1)), mBe = __ballot(crB && !(sB & 1)), mBo = __ballot(crB && (sB & 1));
+        const int ne = __popcll(mAe) + __popcll(mBe), no = cnt - ne;
+        unsigned short *dz = cl2o + (size_t)q * 256;          // [2][128]
+        if (crA) {
+            const int pe = (sA & 1) ? ne + __popcll(mAo & below) : __popcll(mAe & below);                       // even-first position
+            dz[pe] = (unsigned short)(sA * sc);
+            dz[128 + ((sA & 1) ? pe - ne : no + pe)] = (unsigned short)(sA * sc);                                // odd-first position
+        }
+        if (crB) {
+            const int pe = (sB & 1) ? ne + __popcll(mAo) + __popcll(mBo & below) : __popcll(mAe) + __popcll(mBe & below);
+            dz[pe] = (unsigned short)(sB * sc);
+            dz[128 + ((sB & 1) ? pe - ne : no + pe)] = (unsigned short)(sB * sc);
+        }
+        for (int j = cnt + lane; j < 128; j += 64) { dz[j] = (unsigned short)(ls * sc); dz[128 + j] = (unsigned short)(ls * sc); }
     }
     // the non-crowded centres as a compact list (max is order-independent), padded to a multiple of eight with its first entry: eight
     // row loads in flight per wave instead of one behind a branch (the loop was a chain of 128 L2 round trips: 92 us per object)
@@ -999,7 +1015,8 @@ __device__ __forceinline__ void xobj_rows_body(const XobjParams &p, const XobjCh
     auto *out = as_global((BF16 ? p.xobj16 : reinterpret_cast<uint32_t *>(p.xobj)) + (size_t)chain * p.R * W + fl * 4);
     const unsigned char *mine = lds + fl * 16;                         // this lane's 16 bytes of a slab entry
     const auto *pcf = as_global(ch.pcf + (size_t)s1 * 512);
-    const gu4 lists = reinterpret_cast<gu4>(as_global(ch.cl2o));      // 16 x (8 offsets) per start point
+    // 2 x 16 x (8 offsets) per start point: the even-slots-first and the odd-slots-first order (m0_kernel)
+    const gu4 lists = reinterpret_cast<gu4>(as_global(ch.cl2o)) + (LPR == 8 ? ((sg >> 1) & 1) * 16 : 0);
     const int pieces = ch.ncr * LPR;
     auto mx3 = [](u4 a, u4 b, u4 c) {
         u4 o;
@@ -1072,18 +1089,18 @@ __device__ __forceinline__ void xobj_rows_body(const XobjParams &p, const XobjCh
             int kk = have ? lead[li] : 0;
             int q = qs[kk], cf = cfs[kk];
             u4 m0 = *reinterpret_cast<gu4>(M0 + (size_t)q * W + f0);
-            u4 cur = lists[q * 16], nx1 = lists[q * 16 + 1];
+            u4 cur = lists[q * 32], nx1 = lists[q * 32 + 1];
             while (have) {
                 const int li2 = li + NG;
                 const bool have2 = li2 < n;
                 const int kk2 = have2 ? lead[li2] : kk;
                 const int q2 = qs[kk2], cf2 = cfs[kk2];
                 const u4 m02 = *reinterpret_cast<gu4>(M0 + (size_t)q2 * W + f0);
-                const u4 cur2 = lists[q2 * 16], nx12 = lists[q2 * 16 + 1];
+                const u4 cur2 = lists[q2 * 32], nx12 = lists[q2 * 32 + 1];
                 const int cnt = cf & 255, slow = cf & 256;
                 u4 best = m0;
                 if (!slow) {
-                    const gu4 lp = lists + q * 16;
+                    const gu4 lp = lists + q * 32;
                     // the list is padded with its last entry to 128: reading past cnt repeats a member
                     for (int j = 0; j < cnt; j += 8) {
                         u4 nx2 = nx1;

@@ -7,7 +7,7 @@ R=$(pwd)
 OUT=$R/gpurun_out/kstats_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o k -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-extra "$@" > "$OUT/run.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o k -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-2d "$@" > "$OUT/run.log" 2>&1
 f=$(find "$OUT" -name '*kernel_stats.csv' | head -1)
 [ -n "$f" ] && cp "$f" "$OUT/kernel_stats.csv" && python3 "$R/scripts/prof_top.py" "$OUT/kernel_stats.csv" 30
 tail -n 1 "$OUT/run.log" | cut -c1-400

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Per-kernel PMC sums for one 3-D bench step (two passes; no --stats / sys-trace with --pmc).  usage: bash scripts/pmc_kernels.sh [extra bench args]
 R=$(pwd); OUT=$R/gpurun_out/pmck; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d $OUT/a -o p -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra "$@" > $OUT/a.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $OUT/b -o p -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra "$@" > $OUT/b.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d $OUT/a -o p -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra --no-2d "$@" > $OUT/a.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $OUT/b -o p -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra --no-2d "$@" > $OUT/b.log 2>&1
 python3 - <<PY
 import csv, glob, re
 from collections import defaultdict

@@ -11,7 +11,7 @@ R=$(pwd)
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT" "$R/profiles"
 cd /tmp && export TMPDIR=/tmp
-COMMON="--no-cpu-baseline --no-extra"
+COMMON="--no-cpu-baseline --no-extra --no-2d"
 HEAD_ID=${DGDM_HEAD:-unknown}
 for cfg in "3d f32" "2d f32" "3d bf16"; do
   set -- $cfg; wl=$1; ct=$2

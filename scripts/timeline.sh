@@ -6,5 +6,5 @@ R=$(pwd)
 OUT=$R/gpurun_out/timeline_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d "$OUT" -o k -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-extra "$@" > "$OUT/run.log" 2>&1
+rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d "$OUT" -o k -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-2d "$@" > "$OUT/run.log" 2>&1
 ls "$OUT"
