@@ -4,7 +4,7 @@
 OLD=${1:-_r04}
 for i in 1 2 3; do
   (cd $OLD && timeout 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1) > gpurun_out/rounds_old_$i.json
-  timeout 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/rounds_new_$i.json
+  timeout 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-2d 2>/dev/null | tail -1 > gpurun_out/rounds_new_$i.json
 done
 python3 - <<'PY'
 import json
