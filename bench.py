@@ -43,7 +43,6 @@ from dgdm_amd.dist import gather_pairs                     # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # same guide: v_mfma_f32_32x32x16_bf16, dense (not the 2:1-sparsity figure)
-SPLIT_TERMS = 6                   # csrc/trunk_split.hip: bf16 MFMA products issued per float32 product (operands split exactly in three)
 DEFAULT_PAIRS = {"3d": 32, "2d": 4, "3d_ensemble": 8}
 STREAM_SEED = 1234
 
@@ -56,10 +55,10 @@ def parse():
     p.add_argument("--workload", choices=["3d", "2d", "3d_ensemble"], default="3d")
     p.add_argument("--pairs", type=int, default=0, help="(object x objective) pairs per GPU per step (default 32 for 3d, 4 for 2d; "
                                                         "3d_ensemble: chains per GPU per step, default 8, each averaging 4 objects' gradients)")
-    p.add_argument("--contraction", choices=["f32", "f32_mfma", "bf16", "f32_f16x3", "f32_bf16x6"], default="f32",
+    p.add_argument("--contraction", choices=["f32", "f32_mfma", "bf16", "f32_f16x3"], default="f32",
                    help="arithmetic of the dynamics-trunk contractions: f32 (the parity path, the library default = f32_f16x3: float32 operands "
                         "scaled by exact powers of two and split into two f16 pieces, three f16 MFMAs per product, float32 accumulation), "
-                        "f32_bf16x6 (exact three-way bf16 split, six bf16 MFMAs per product), f32_mfma (the k-ordered float32 MFMA chain) or "
+                        "f32_mfma (the k-ordered float32 MFMA chain) or "
                         "bf16 (operands ROUNDED to bf16, float32 accumulation)")
     p.add_argument("--cpu-baseline", choices=["sample", "full", "none"], default="full",
                    help="CPU oracle timed beside the GPU number (rank 0, N = 1): full = the SURVEY 8(d) protocol, median of 3 runs of the bounded sample + "
@@ -251,16 +250,14 @@ def timed_loop(wl, steps, warmup, dist):
 # ---------------------------------------------------------------------------------------------------------------- roofline
 # what the JSON's `dtype` / roofline.arithmetic say about each contraction mode of the trunk (DESIGN_HISTORY.md 4.1 / 4.6 / 4.10)
 DEFAULT_F32_FORM = "f32_f16x3"           # what the library's DGDM_DTYPE_F32 selects (csrc/guidance_api.hip DGDM_DEFAULT_F16X3)
-DTYPE_LABEL = {"f32": "f32_split_f16x3", "f32_bf16x6": "f32_split_bf16x6", "f32_f16x3": "f32_split_f16x3", "f32_mfma": "f32", "bf16": "bf16"}
-ARITHMETIC = {"f32_bf16x6": "float32-grade: every float32 product as six bf16 MFMA products on exactly three-way-split operands (products exact, float32 "
-                     "accumulation; 1.6e-7 rms of a 256-term contraction vs float64, the v_mfma_f32 chain: 2.0e-7)",
-              "f32_f16x3": "float32-grade: every float32 product as three f16 MFMA products on two-way-split operands after exact power-of-two scaling "
+DTYPE_LABEL = {"f32": "f32_split_f16x3", "f32_f16x3": "f32_split_f16x3", "f32_mfma": "f32", "bf16": "bf16"}
+ARITHMETIC = {"f32_f16x3": "float32-grade: every float32 product as three f16 MFMA products on two-way-split operands after exact power-of-two scaling "
                            "(per weight matrix, per tile row; float32 accumulation; 1.9e-7 rms of a 256-term contraction vs float64)",
               "f32_mfma": "float32 MFMA (v_mfma_f32_32x32x2_f32), a k-ordered fma chain",
               "bf16": "operands rounded to bf16, float32 accumulation"}
 # matrix pipe busy share of the dominant kernel as RECORDED by the latest round's PMC passes (profiles/r0N_pmc_kernels.md, "Derived" table:
-# SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)); recorded, not live.  The six-product and bf16 kernels keep their last recording.
-PIPE_BUSY_FALLBACK = {("3d", "f32_bf16x6"): 0.71, ("2d", "f32_bf16x6"): 0.73, ("3d", "bf16"): 0.54}
+# SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)); recorded, not live.  The bf16 kernel keeps its last recording.
+PIPE_BUSY_FALLBACK = {("3d", "bf16"): 0.54}
 
 
 def pipe_busy_recorded(kind, form, kernel):
@@ -315,13 +312,13 @@ def stage_profile(wl, secs_per_step, contraction):
     n, ms, flops = st["trunk"]
     if not n:
         return None, None
-    # The trunk's arithmetic per mode (DESIGN_HISTORY.md 4.1 / 4.6 / 4.10).  'f32' (default): float32 contractions carried by the bf16 matrix
-    # pipe - SIX bf16 MFMA products are issued per algorithmic float32 product - so the kernel is priced against the bf16 dense peak
-    # with the ISSUED FLOPs (6 x algorithmic); the algorithmic float32 rate and what that is against the float32-MFMA peak (which the
-    # old k-ordered chain was bound by) are reported beside it.  'f32_mfma': that chain.  'bf16': operands rounded to bf16.
+    # The trunk's arithmetic per mode.  'f32' (default): float32 contractions carried by the f16 matrix pipe - THREE
+    # f16 MFMA products are issued per algorithmic float32 product - so the kernel is priced against the f16 dense peak: `frac` with the
+    # ALGORITHMIC FLOPs, `matrix_pipe_issue_frac` with the issued ones (3 x); what the algorithmic rate is against the float32-MFMA peak
+    # (which the k-ordered chain is bound by) is reported beside it.  'f32_mfma': that chain.  'bf16': operands rounded to bf16.
     form = DEFAULT_F32_FORM if contraction == "f32" else contraction
-    kname = {"bf16": "trunk_bf16_kernel", "f32_mfma": "trunk_kernel", "f32_f16x3": "trunk_f16l_kernel"}.get(form, "trunk_split_kernel")
-    issued = {"f32_bf16x6": SPLIT_TERMS, "f32_f16x3": 3}.get(form, 1)
+    kname = {"bf16": "trunk_bf16_kernel", "f32_mfma": "trunk_kernel"}.get(form, "trunk_f16l_kernel")
+    issued = {"f32_f16x3": 3}.get(form, 1)
     peak = F32_MFMA_PEAK_TFLOPS if contraction == "f32_mfma" else BF16_MFMA_PEAK_TFLOPS
     alg = flops / (ms * 1e-3) / 1e12
     ach = alg * issued
@@ -855,7 +852,7 @@ def extra_legs(dev, kind, rank, world, with_cpu):
     if with_cpu:
         cpu_jobs += [lambda: c0.update(config0(dev, cpu=True)), lambda: tl.update(cpu_baseline=train_leg_cpu()),
                      lambda: ul.update(cpu_baseline=unet_train_leg_cpu()), lambda: t3.update(cpu_baseline=train3d_leg_cpu())]
-    for k2, contraction in ((other, "f32"), ("3d", "f32_bf16x6"), ("3d", "f32_mfma"), ("3d", "bf16"), ("2d", "bf16"), ("3d_ensemble", "bf16")):
+    for k2, contraction in ((other, "f32"), ("3d", "f32_mfma"), ("3d", "bf16"), ("2d", "bf16"), ("3d_ensemble", "bf16")):
         w2 = Workload(k2, DEFAULT_PAIRS[k2], dev, rank, world, contraction)
         ns = 4
         s2, _, d2 = timed_loop(w2, ns, 1, None)

@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libdgdm_hip.so")
-SOURCES = ["host_util.hip", "smallnet.hip", "unet.hip", "trunk.hip", "trunk_bf16.hip", "trunk_split.hip", "trunk_f16l.hip", "pointnet.hip", "pointnet64.hip", "models_api.hip", "guidance_api.hip", "decode.hip", "debug.hip", "train2d.hip", "unet_train.hip", "train3d.hip", "torch_rng.hip"]
+SOURCES = ["host_util.hip", "smallnet.hip", "unet.hip", "trunk.hip", "trunk_bf16.hip", "trunk_f16l.hip", "pointnet.hip", "pointnet64.hip", "models_api.hip", "guidance_api.hip", "decode.hip", "debug.hip", "train2d.hip", "unet_train.hip", "train3d.hip", "torch_rng.hip"]
 # unet.hip: its block functions as real calls cost 200 VGPRs and a register save/restore through scratch at every call (152 MB of
 # scratch writes per 1024-sample launch in the round-2 PMC pass); fully inlined the kernel needs 126 VGPRs
 PER_FILE_FLAGS = {"unet.hip": ["-mllvm", "-amdgpu-function-calls=false"]}

@@ -1,7 +1,6 @@
 // Diffusion.cond_fn / get_convergence_centers (generator/diffusion.py:473-539) for batches of chains,
 // and the PointNet++-backed forward entry points.
 #ifndef DGDM_DEFAULT_F16X3
-#define DGDM_DEFAULT_F16X3 1      // which float32-grade form DGDM_DTYPE_F32 selects: 0 six bf16 products (trunk_split.hip), 1 three f16 products (trunk_f16l.hip)
 #endif
 #include "common.h"
 #include "models.h"
@@ -67,8 +66,7 @@ struct DgdmGuidance {
     DevBuf objpart;                              // 2-D: [max_objects][W1] doubles
     std::vector<std::unique_ptr<ObjectTables>> tables;   // 3-D
     bool bf16 = false;                           // contractions of the trunk on bf16 MFMA (dgdm_guidance_set_contraction_dtype)
-    bool f32_mfma = false;                       // float32 mode on the k-ordered float32 MFMA chain (trunk.hip) instead of the split form
-    bool f16x3 = DGDM_DEFAULT_F16X3 != 0;        // float32 mode: three f16 products on scaled two-way split operands (trunk_f16l.hip) instead of six bf16 ones
+    bool f32_mfma = false;                       // float32 mode on the k-ordered float32 MFMA chain (trunk.hip) instead of the f16x3 form (trunk_f16l.hip)
 #ifndef DGDM_NBUILD
 #define DGDM_NBUILD 3
 #endif
@@ -223,11 +221,10 @@ extern "C" void dgdm_guidance_destroy(DgdmGuidance *g) { delete g; }
 
 extern "C" int dgdm_guidance_set_contraction_dtype(DgdmGuidance *g, int dtype) {
     DGDM_REQUIRE(g, DGDM_EINVAL, "dgdm_guidance_set_contraction_dtype: null handle");
-    DGDM_REQUIRE(dtype >= DGDM_DTYPE_F32 && dtype <= DGDM_DTYPE_F32_BF16X6, DGDM_EINVAL,
-                 "contraction dtype %d unsupported (0 = f32 (default form), 1 = bf16, 2 = f32 on the float32 MFMA, 3 = f32 as 3 f16 products, 4 = f32 as 6 bf16 products)", dtype);
+    DGDM_REQUIRE(dtype >= DGDM_DTYPE_F32 && dtype <= DGDM_DTYPE_F32_F16X3, DGDM_EINVAL,
+                 "contraction dtype %d unsupported (0 = f32 (default form), 1 = bf16, 2 = f32 on the float32 MFMA, 3 = f32 as 3 f16 products = the default form)", dtype);
     g->bf16 = dtype == DGDM_DTYPE_BF16;
     g->f32_mfma = dtype == DGDM_DTYPE_F32_MFMA;
-    g->f16x3 = dtype == DGDM_DTYPE_F32_F16X3 || (dtype == DGDM_DTYPE_F32 && DGDM_DEFAULT_F16X3 != 0);
     return DGDM_OK;
 }
 
@@ -751,13 +748,10 @@ static int guidance_grad(DgdmGuidance *g, int kind, const float *x_dev, int time
         if ((rc = trunk_bf16_launch(kind, p, s))) return rc;
     } else if (g->f32_mfma) {
         if ((rc = trunk_launch(kind, false, false, p, s))) return rc;
-    } else if (g->f16x3) {
+    } else {
         TrunkF16Scales sc;
         g->m->fill_trunk_f16(&p, &sc);   // only the two weight streams differ (+ their scale exponents)
         if ((rc = trunk_f16l_launch(kind, p, sc, s))) return rc;
-    } else {
-        g->m->fill_trunk_split(&p);      // only the two weight streams differ
-        if ((rc = trunk_split_launch(kind, p, s))) return rc;
     }
 #ifdef DGDM_TRUNK_CLOCKS
     if (g->bf16) {      // mean cycles per phase over all waves (experiment build)

@@ -55,8 +55,6 @@ struct DgdmDynamics {
     dgdm::DevBuf ws2;
     dgdm::DevBuf w16;       // bf16 weight streams of the trunk (trunk_bf16.hip): forward then backward
     size_t fwd16_bytes = 0, bwd16_bytes = 0, sa3_16_offset = 0;     // sa3 bf16 image (z16_kernel) follows the two trunk streams
-    dgdm::DevBuf wsplit;    // split-float32 weight streams of the trunk (trunk_split.hip): forward then backward
-    size_t fwds_bytes = 0, bwds_bytes = 0;
     dgdm::DevBuf wf16;      // two-way f16 split streams of the trunk (trunk_f16l.hip): forward then backward
     size_t fwdh_bytes = 0, bwdh_bytes = 0;
     dgdm::TrunkF16Scales f16_scales{};
@@ -65,7 +63,6 @@ struct DgdmDynamics {
     void fill_trunk(dgdm::TrunkParams *p) const;
     void fill_trunk_f16(dgdm::TrunkParams *p, dgdm::TrunkF16Scales *sc) const;
     void fill_trunk_bf16(dgdm::TrunkParams *p) const;
-    void fill_trunk_split(dgdm::TrunkParams *p) const;
     dgdm::PnWeights pn() const;
     int gripper_forward(const float *x, int ldx, float *V, float *genc, int rows, hipStream_t s) const;
     int time_part(const float *t_dev, float t_scalar, float *tmp, float *out, int rows, hipStream_t s) const;

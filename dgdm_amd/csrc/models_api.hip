@@ -303,9 +303,8 @@ extern "C" int dgdm_unet1d_effective_form(const DgdmUnet1d *m, int B, int L) {
 
 extern "C" int dgdm_unet1d_set_contraction_dtype(DgdmUnet1d *m, int dtype) {
     DGDM_REQUIRE(m, DGDM_EINVAL, "dgdm_unet1d_set_contraction_dtype: null handle");
-    // DGDM_DTYPE_F32 (the default) and both split forms: float32-grade convolutions as three f16 MFMA products (the eps-net has one split
-    // form); DGDM_DTYPE_F32_MFMA: the float32 MFMA chain of rounds 1-3; DGDM_DTYPE_BF16: operands rounded to bf16
-    DGDM_REQUIRE(dtype >= DGDM_DTYPE_F32 && dtype <= DGDM_DTYPE_F32_BF16X6, DGDM_EINVAL, "contraction dtype %d unsupported", dtype);
+    // DGDM_DTYPE_F32 (the default) = DGDM_DTYPE_F32_F16X3: float32-grade convolutions as three f16 MFMA products; DGDM_DTYPE_F32_MFMA: the float32 MFMA chain of rounds 1-3; DGDM_DTYPE_BF16: operands rounded to bf16
+    DGDM_REQUIRE(dtype >= DGDM_DTYPE_F32 && dtype <= DGDM_DTYPE_F32_F16X3, DGDM_EINVAL, "contraction dtype %d unsupported", dtype);
     m->mode = dtype == DGDM_DTYPE_BF16 ? 1 : dtype == DGDM_DTYPE_F32_MFMA ? 0 : 2;
     return DGDM_OK;
 }
@@ -328,31 +327,6 @@ std::vector<double> cols64(const std::vector<double> &w, int rows, int ncols, in
     return o;
 }
 
-// ---- split-float32 weight streams (csrc/trunk_split.hip): a float32 matrix as three bf16 pieces, w = h + m + l exactly
-struct Split3 {
-    std::vector<float> p[3];
-    int K = 0;
-    Split3(const float *src, int M, int K_) : K(K_) {
-        auto bf = [](float x) { const uint32_t u = (uint32_t)f32_to_bf16(x) << 16; float y; memcpy(&y, &u, 4); return y; };
-        for (auto &v : p) v.resize((size_t)M * K_);
-        for (size_t i = 0; i < (size_t)M * K_; ++i) {
-            const float h = bf(src[i]), m = bf(src[i] - h), l = bf(src[i] - h - m);
-            p[0][i] = h; p[1][i] = m; p[2][i] = l;
-        }
-    }
-    // the three 1 KiB entries [h m l] of (output block op, input block ib, K-step s): lane (i, hh), slot j = P[32 op + i][32 ib + rho(8 s + j, hh)]
-    void emit(std::vector<uint16_t> &dst, int op, int ib, int s) const {
-        for (int q = 0; q < 3; ++q)
-            for (int lane = 0; lane < 64; ++lane) {
-                const int i = lane & 31, hh = lane >> 5;
-                for (int j = 0; j < 8; ++j) {
-                    const int rr = 8 * s + j, f = (rr & 3) + 8 * (rr >> 2) + 4 * hh;
-                    dst.push_back(f32_to_bf16(p[q][(size_t)(32 * op + i) * K + 32 * ib + f]));      // exact: the piece is a bf16 value
-                }
-            }
-    }
-};
-
 // ---- two-way f16 split streams (csrc/trunk_f16l.hip): w 2^ew = h + l, both f16, max |w 2^ew| in [2^12, 2^13)
 struct Split2 {
     std::vector<float> p[2];
@@ -371,7 +345,7 @@ struct Split2 {
             p[0][i] = h; p[1][i] = f16(w - h);
         }
     }
-    // the two 1 KiB entries [h l] of (output block op, input block ib, K-step s), operand layout of Split3::emit
+    // the two 1 KiB entries [h l] of (output block op, input block ib, K-step s): lane (i, hh), slot j = P[32 op + i][32 ib + rho(8 s + j, hh)]
     void emit(std::vector<uint16_t> &dst, int op, int ib, int s) const {
         for (int q = 0; q < 2; ++q)
             for (int lane = 0; lane < 64; ++lane) {
@@ -390,14 +364,6 @@ int f16_layer_stream(std::vector<uint16_t> &dst, const float *w /*[256][256]*/) 
         for (int pp = 0; pp < 4; ++pp)
             for (int blk = 2 * pp; blk < 2 * pp + 2; ++blk) sp.emit(dst, blk, ks / 2, ks % 2);
     return sp.ew;
-}
-
-// 256 -> 256 layer (trunk_split.hip stream_layer): 16 K-steps x 4 output-block pairs x [A.h A.m A.l B.h B.m B.l]
-void split_layer_stream(std::vector<uint16_t> &dst, const float *w /*[256][256]*/) {
-    const Split3 sp(w, 256, 256);
-    for (int ks = 0; ks < 16; ++ks)
-        for (int pp = 0; pp < 4; ++pp)
-            for (int blk = 2 * pp; blk < 2 * pp + 2; ++blk) sp.emit(dst, blk, ks / 2, ks % 2);
 }
 
 std::vector<float> tfreqs(int half) {
@@ -621,42 +587,6 @@ extern "C" int dgdm_dynamics_create(DgdmDynamics **out, int kind, const DgdmTens
         fwd16.insert(fwd16.end(), sa3_img16.begin(), sa3_img16.end());
         if ((rc = m->w16.upload(fwd16.data(), fwd16.size() * 2))) return rc;
     }
-    {   // split-float32 streams (trunk_split.hip), in consumption order
-        std::vector<uint16_t> fs, bs;
-        if (kind == 3) {
-            Folded l2;
-            if ((rc = eq.fold(sd, 1, W, W1, &l2))) return rc;
-            const std::vector<float> w1o3 = cols(l1.w, W1, IN1, 0, W);
-            const Split3 s1(w1o3.data(), W1, W), s2(l2.w.data(), W, W1);
-            for (int kb = 0; kb < 16; ++kb) {
-                for (int ks = 0; ks < 16; ++ks) s1.emit(fs, kb, ks / 2, ks % 2);                    // layer-1 block kb: 16 K-steps x [h m l]
-                for (int pp = 0; pp < 4; ++pp)                                                      // layer 2, input block kb
-                    for (int sx = 0; sx < 2; ++sx)
-                        for (int blk = 2 * pp; blk < 2 * pp + 2; ++blk) s2.emit(fs, blk, kb, sx);
-            }
-        }
-        std::vector<std::vector<uint16_t>> back;
-        for (int i = 0; i < m->n_mid; ++i) {
-            const int li = 3 * (first_mid + i);
-            Folded f;
-            if ((rc = eq.fold(sd, li / 3, W, W, &f))) return rc;
-            split_layer_stream(fs, f.w.data());
-            back.emplace_back();
-            split_layer_stream(back.back(), transpose(f.w.data(), W, W).data());
-        }
-        for (int i = m->n_mid - 1; i >= 0; --i) bs.insert(bs.end(), back[i].begin(), back[i].end());               // last layer first
-        if (kind == 3) {
-            Folded l2;
-            if ((rc = eq.fold(sd, 1, W, W1, &l2))) return rc;
-            const std::vector<float> w2t = transpose(l2.w.data(), W, W1);                                          // [512][256]
-            const Split3 st(w2t.data(), W1, W);
-            for (int kb = 0; kb < 16; ++kb)
-                for (int ks = 0; ks < 16; ++ks) st.emit(bs, kb, ks / 2, ks % 2);
-        }
-        m->fwds_bytes = fs.size() * 2; m->bwds_bytes = bs.size() * 2;
-        fs.insert(fs.end(), bs.begin(), bs.end());
-        if ((rc = m->wsplit.upload(fs.data(), fs.size() * 2))) return rc;
-    }
     {   // two-way f16 split streams (trunk_f16l.hip), in consumption order
         std::vector<uint16_t> fs, bs;
         TrunkF16Scales &sc = m->f16_scales;
@@ -781,11 +711,6 @@ void DgdmDynamics::fill_trunk_f16(TrunkParams *p, TrunkF16Scales *sc) const {   
     p->Wfwd = reinterpret_cast<const float4 *>(static_cast<const char *>(wf16.p)); p->fwd_bytes = (unsigned)fwdh_bytes;
     p->Wbwd = reinterpret_cast<const float4 *>(static_cast<const char *>(wf16.p) + fwdh_bytes); p->bwd_bytes = (unsigned)bwdh_bytes;
     *sc = f16_scales;
-}
-
-void DgdmDynamics::fill_trunk_split(TrunkParams *p) const {    // after fill_trunk: swaps the two weight streams only
-    p->Wfwd = reinterpret_cast<const float4 *>(static_cast<const char *>(wsplit.p)); p->fwd_bytes = (unsigned)fwds_bytes;
-    p->Wbwd = reinterpret_cast<const float4 *>(static_cast<const char *>(wsplit.p) + fwds_bytes); p->bwd_bytes = (unsigned)bwds_bytes;
 }
 
 PnWeights DgdmDynamics::pn() const {

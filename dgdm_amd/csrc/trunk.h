@@ -50,10 +50,6 @@ struct TrunkParams {
 // kind: 2 | 3.  rows_mode: first-layer pre-activations given per row (general forward API).
 int trunk_launch(int kind, bool rows_mode, bool fwd_only, const TrunkParams &p, hipStream_t s);
 
-// float32 contractions on the bf16 matrix pipe, operands split exactly into three bf16 pieces (trunk_split.hip): table mode, forward +
-// backward.  p.Wfwd / p.Wbwd point at the split streams (DgdmDynamics::fill_trunk_split).
-int trunk_split_launch(int kind, const TrunkParams &p, hipStream_t s);
-
 // float32 contractions as three f16 MFMA products on two-way split, power-of-two scaled operands (trunk_f16l.hip): table mode, forward +
 // backward.  p.Wfwd / p.Wbwd point at the f16 streams (DgdmDynamics::fill_trunk_f16), sc carries the weight matrices' scale exponents.
 struct TrunkF16Scales {

@@ -1,4 +1,4 @@
-// Fused dynamics trunk, forward + input-gradient backward (same contract as trunk_split_kernel, trunk_split.hip), float32-grade on the f16
+// Fused dynamics trunk, forward + input-gradient backward (same contract as trunk_kernel, trunk.hip), float32-grade on the f16
 // matrix pipe: the float32 trunk the library runs by default.
 //
 // Arithmetic.  Every float32 product as THREE f16 MFMAs instead of six bf16 ones:
@@ -18,8 +18,19 @@
 // bias is added as b 2^E, and E is taken out where true values are needed (the output layer, the folded tile sums).  Measured against
 // float64 (scripts/micro/split_mfma.hip, K = 256, He-init weights, post-ReLU inputs): rms error 1.9e-7 of the rms output, between the
 // 1.6e-7 of the six-product bf16 form and the 2.0e-7 of the v_mfma_f32 chain.  Half the matrix-pipe instructions and two thirds of the
-// weight bytes of trunk_split.hip.  Structure, register residency and sign-bit masks are those of trunk_split.hip (read that file's
-// header first); stream entries per (K-step, output-block pair): [A.h A.l B.h B.l], per block-out K-step: [h l].
+// weight bytes of the six-bf16-product form it replaced (rounds 3-5, retired in round 6; DESIGN_HISTORY.md 4.10).
+//
+// Structure.  One wave = one tile of 32 rows through all layers, forward and backward, in registers:
+//   Y [8] f32x16   a layer's output in the MFMA C/D layout (register r, lane (n, h)  <->  feature 32 o + rho(r, h) of row n)
+//   P / Act2       the layer's input as two sets of packed f16 B operands: K-step s of block o = registers 8s..8s+7 of Y[o], converted
+//                  pairwise (the weight images are images of the two pieces in the same operand order)
+// A 256 -> 256 layer is input-streaming (stream_layer): the K loop runs over the input blocks while all eight output blocks
+// accumulate, six MFMAs per (K-step, pair of output blocks), consecutive MFMAs never on the same accumulator; the previous layer's
+// epilogue - scale, ReLU + sign bits (exact float32 semantics, x > 0; bits kept in LDS for the backward pass), then the split of an
+// accumulator pair into its two pieces - is done just in time, one register pair per group of six MFMAs, in the shadow of the matrix
+// pipe.  The 512-wide first layers of the 3-D model and the last layer back are produced block by block (block_out).
+// Stream entries per (K-step, output-block pair): [A.h A.l B.h B.l], per block-out K-step: [h l] (host: Split2 / f16_layer_stream,
+// models_api.hip).
 //
 // The weight stream is SHARED by the workgroup's four waves through LDS.  Pulled through the CU's L1 once per wave (the ring form of
 // round 4's first version, 683 bytes per MFMA) it arrived at ~50 of the 85 B/clk/CU the MFMAs ask for: a 256 -> 256 layer took 22 k
@@ -81,21 +92,17 @@ __device__ __forceinline__ void split2(float lo, float hi, uint32_t &ph, uint32_
 }
 // The same values in three instructions instead of five (round 5): the residual and its conversion are ONE mixed-precision fma per value
 // (v_fma_mixlo/mixhi_f16: (-h) x 1.0 + v evaluated in float32 - exact - and rounded once to f16: bit for bit what convert-back, subtract,
-// convert give).  The work between the MFMAs is NOT free (removing it all: 7.12 -> 6.19 ms per 3-D launch, -DDGDM_EXP_NOITEM), so every
+// convert give).  The work between the MFMAs is NOT free (removing it all: 7.12 -> 6.19 ms per 3-D launch, a round-5 timing build), so every
 // instruction there counts.  Inline assembly (hipcc does not form the mix instructions from this pattern), and therefore ONLY where the
 // pieces are consumed many instructions later (the stack layers' items: at least four MFMA groups): the hazard recogniser does not see an
 // asm statement as a VALU write, so an MFMA reading the pieces right behind it gets no wait states - used in the 3-D front that way the
-// results were nondeterministic (scripts/det_bits.sh).  -DDGDM_F16_SPLIT_CVT: the five-instruction form everywhere.
+// results were nondeterministic (scripts/det_bits.sh).
 __device__ __forceinline__ void split2_mix(float lo, float hi, uint32_t &ph, uint32_t &pl) {
-#ifdef DGDM_F16_SPLIT_CVT
-    split2(lo, hi, ph, pl);
-#else
     uint32_t h, l;
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(lo), "v"(hi));
     asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(lo));
     asm("v_fma_mixhi_f16 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(hi));
     ph = h; pl = l;
-#endif
 }
 struct Act2 {
     hu32x4_t v[2][8][2];      // [piece][32-feature block][K-step]
@@ -137,9 +144,6 @@ struct LStream {
     // Unseen by the compiler the loads only make its own vmcnt waits longer than necessary (memory returns in order), never too short;
     // what makes a slot safe to read is advance()'s counted wait + barrier.
     __device__ __forceinline__ void issue(int c) {
-#ifdef DGDM_EXP_NODMA
-        if (c > 2) return;         // timing experiment (wrong results): no LDS-DMA traffic beside the reads
-#endif
         const int sl = c % NBUF;
 #pragma unroll
         for (int j = 0; j < CQ; ++j) {
@@ -177,12 +181,7 @@ struct LStream {
         slot = slot == NBUF - 1 ? 0 : slot + 1;
     }
     // entry e (0 .. 15) of chunk cur
-#ifdef DGDM_EXP_NOREAD
-    // timing experiment (wrong results): the operands are read once per stream and reused - what the kernel costs without its LDS operand reads
-    __device__ __forceinline__ v4f32 read(const int e) const { return buf[(e & 3) * 64 + lane]; }
-#else
     __device__ __forceinline__ v4f32 read(const int e) const { return buf[(slot * CH + e) * 64 + lane]; }
-#endif
 };
 
 // the three terms of one K-step for two accumulators (w: [A.h A.l B.h B.l]); small terms first
@@ -195,7 +194,7 @@ struct LStream {
         accA = hmfma(w[0], xh, accA);        \
         accB = hmfma(w[2], xh, accB);        \
     } while (0)
-// One 256 -> 256 layer, input-streaming (trunk_split.hip stream_layer).  Yp: the previous layer's accumulators = true values x 2^E per
+// One 256 -> 256 layer, input-streaming (see the file header).  Yp: the previous layer's accumulators = true values x 2^E per
 // row (E: this lane's row); on return Y = this layer's accumulators and E their scale.  ew: the weight matrix' scale exponent.
 // wn: the operands of the NEXT group to be consumed (read from LDS one group ahead); precondition of every consumer below: wn holds the
 // first group of the pass about to start, postcondition: the first group of the pass that follows in the stream.
@@ -228,19 +227,15 @@ __device__ __forceinline__ void stream_layer(LStream &ls, v4f32 (&wn)[4], const 
     HSTAMP(FWD ? 23 : 26);
     uint32_t mk = FWD ? 0u : smask[slot_in][tid];
     auto item = [&](const f32x16 &y, const int blk, const int d, const bool far) __attribute__((always_inline)) {
-#ifdef DGDM_EXP_NOITEM
-        // timing experiment (wrong results): no scaling / ReLU / mask / split work between the MFMAs
-        P[blk & 1][0][d / 4][d % 4] = __float_as_uint(y[2 * d]); P[blk & 1][1][d / 4][d % 4] = __float_as_uint(y[2 * d + 1]);
-        return;
-#endif
         // scale first (one packed multiply; exact, f is a power of two), then ReLU / mask: the same values as the other way round
         const int sh = 2 * d + 16 * (blk & 1);
         float lo, hi;
-#if !defined(DGDM_F16_MASK_CMP) && !defined(DGDM_F16_NO_NEGSCALE)
         if (FWD) {
             // forward: ONE packed fma makes -(y f) (+0 for a zero of either sign: y x (-f) + (+0)); its sign bit is (y > 0) - the mask bit,
-            // pushed through the alignbit shift register (see below) - and max(0, -that) is the scaled ReLU: the packed multiply and the
-            // packed 0 - y of the form below in one instruction, the same values bit for bit
+            // pushed through a shift register, one v_alignbit_b32 per value (mk = mk << 1 | sign) instead of compare + select + or: the
+            // 32 values of two blocks arrive in the order of their bit numbers, so the finished word is bitreverse(mk) (where it is
+            // stored) - and max(0, -that) is the scaled ReLU.  (Round 5's steps to this form, each bit-identical: DESIGN.md 4.1;
+            // what the kernel costs without this item at all, -13 %, and without its LDS operand reads, -1.7 %: measured there too.)
             const hf32x2_t nv = __builtin_elementwise_fma(hf32x2_t{y[2 * d], y[2 * d + 1]}, hf32x2_t{-f, -f}, hf32x2_t{0.f, 0.f});
             mk = __builtin_amdgcn_alignbit(mk, __float_as_uint(nv.x), 31);
             mk = __builtin_amdgcn_alignbit(mk, __float_as_uint(nv.y), 31);
@@ -251,29 +246,6 @@ __device__ __forceinline__ void stream_layer(LStream &ls, v4f32 (&wn)[4], const 
             lo = apply_bit(v.x, mk, sh);
             hi = apply_bit(v.y, mk, sh + 1);
         }
-#else
-        const hf32x2_t v = hf32x2_t{y[2 * d], y[2 * d + 1]} * hf32x2_t{f, f};
-        lo = v.x; hi = v.y;
-        if (FWD) {
-#ifdef DGDM_F16_MASK_CMP
-            mk |= (y[2 * d] > 0.f ? 1u : 0u) << sh;
-            mk |= (y[2 * d + 1] > 0.f ? 1u : 0u) << (sh + 1);
-#else
-            // (y > 0) as the SIGN of 0 - y (one packed subtract for the pair; +0 - +-0 = +0, so zeros of either sign and negative values give
-            // 0, positive values 1: exactly the comparison), pushed through a shift register - one v_alignbit_b32 per value (mk = mk << 1 |
-            // sign) instead of compare + select + or.  The 32 values of two blocks arrive in the order of their bit numbers, so the finished
-            // word is bitreverse(mk) (where it is stored).
-            const hf32x2_t ny = hf32x2_t{0.f, 0.f} - hf32x2_t{y[2 * d], y[2 * d + 1]};
-            mk = __builtin_amdgcn_alignbit(mk, __float_as_uint(ny.x), 31);
-            mk = __builtin_amdgcn_alignbit(mk, __float_as_uint(ny.y), 31);
-#endif
-            asm("v_max_f32 %0, 0, %1" : "=v"(lo) : "v"(lo));
-            asm("v_max_f32 %0, 0, %1" : "=v"(hi) : "v"(hi));
-        } else {
-            lo = apply_bit(lo, mk, sh);
-            hi = apply_bit(hi, mk, sh + 1);
-        }
-#endif
         uint32_t a, b;
         if (far) split2_mix(lo, hi, a, b);         // consumed at least four MFMA groups later (see split2_mix)
         else split2(lo, hi, a, b);
@@ -299,11 +271,7 @@ __device__ __forceinline__ void stream_layer(LStream &ls, v4f32 (&wn)[4], const 
                     const int q = sx * 4 + pp, nb = b + 1;
                     if (q == 0 && (nb & 1) == 0) mk = FWD ? 0u : smask[slot_in + nb / 2][tid];
                     item(Yp[nb], nb, q, true);
-#ifdef DGDM_F16_MASK_CMP
-                    if (FWD && q == 7 && (nb & 1) == 1) smask[slot_in + nb / 2][tid] = mk;
-#else
                     if (FWD && q == 7 && (nb & 1) == 1) smask[slot_in + nb / 2][tid] = __builtin_bitreverse32(mk);
-#endif
                 }
                 F16_STEP(Y[2 * pp], Y[2 * pp + 1], w, P[b & 1][0][sx], P[b & 1][1][sx]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -636,7 +604,7 @@ __global__ __launch_bounds__(256, 1) void trunk_f16l_kernel(const TrunkParams p,
             }
         }
     } else {
-        // 3-D: one more layer back (256 -> 512), block by block, straight into the fold (trunk_split.hip)
+        // 3-D: one more layer back (256 -> 512), block by block, straight into the fold
         HSTAMP(40);
         Act2 X;
         const int kt = split_rows(Y, X);

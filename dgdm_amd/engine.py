@@ -34,9 +34,8 @@ class Unet1d:
 
     def set_contraction_dtype(self, dtype: str) -> None:
         """Arithmetic of the multi-channel convolutions: 'f32' (default, the parity path: float32-grade, every product as three f16 MFMA
-        products on exactly scaled two-way split operands, csrc/unet.hip conv_mfma_f16x3; 'f32_f16x3' / 'f32_bf16x6' name the same form -
-        the eps-net has one split form), 'f32_mfma' (the float32 MFMA chain of rounds 1-3) or 'bf16' (operands ROUNDED to bf16)."""
-        codes = {"f32": 0, "bf16": 1, "f32_mfma": 2, "f32_f16x3": 3, "f32_bf16x6": 4}
+        products on exactly scaled two-way split operands, csrc/unet.hip conv_mfma_f16x3; 'f32_f16x3' names the same form), 'f32_mfma' (the float32 MFMA chain of rounds 1-3) or 'bf16' (operands ROUNDED to bf16)."""
+        codes = {"f32": 0, "bf16": 1, "f32_mfma": 2, "f32_f16x3": 3}
         if dtype not in codes:
             raise ValueError(f"contraction dtype {dtype!r} not supported")
         check(lib().dgdm_unet1d_set_contraction_dtype(self._h, codes[dtype]))
@@ -225,10 +224,9 @@ class Guidance:
 
     def set_contraction_dtype(self, dtype: str) -> None:
         """Arithmetic of the trunk of cond_fn: 'f32' (default, = 'f32_f16x3': float32 operands as two exactly scaled f16 pieces, three f16
-        MFMAs per product, float32 accumulation - float32-grade, csrc/trunk_f16l.hip), 'f32_bf16x6' (float32 operands split exactly into
-        three bf16 pieces, six bf16 MFMAs per product, csrc/trunk_split.hip), 'f32_mfma' (the k-ordered float32 MFMA chain,
+        MFMAs per product, float32 accumulation - float32-grade, csrc/trunk_f16l.hip), 'f32_mfma' (the k-ordered float32 MFMA chain,
         csrc/trunk.hip) or 'bf16' (operands ROUNDED to bf16, float32 accumulation)."""
-        codes = {"f32": 0, "bf16": 1, "f32_mfma": 2, "f32_f16x3": 3, "f32_bf16x6": 4}
+        codes = {"f32": 0, "bf16": 1, "f32_mfma": 2, "f32_f16x3": 3}
         if dtype not in codes:
             raise ValueError(f"contraction dtype {dtype!r} not supported")
         check(lib().dgdm_guidance_set_contraction_dtype(self._h, codes[dtype]))

@@ -99,7 +99,7 @@ class Diffusion(nn.Module):
                  pts_z_dim: int = 3, render_video: bool = False, seed: int = 0, contraction_dtype: str = "f32", simulator=None,
                  render_plots: bool = True, table_logger=None):
         super().__init__()
-        if contraction_dtype not in ("f32", "bf16", "f32_mfma", "f32_f16x3", "f32_bf16x6"):
+        if contraction_dtype not in ("f32", "bf16", "f32_mfma", "f32_f16x3"):
             raise ValueError(f"contraction dtype {contraction_dtype!r} not supported")
         # not a reference argument: 'bf16' runs the trunk / eps-net / sa3 contractions with bf16 operands (DESIGN_HISTORY.md 4.6)
         self.contraction_dtype = contraction_dtype

@@ -36,7 +36,7 @@ extern "C" {
 
 /* One host tensor of a reference-format state_dict (torch layout, contiguous). */
 /* contraction dtypes of dgdm_unet1d_set_contraction_dtype / dgdm_guidance_set_contraction_dtype */
-enum { DGDM_DTYPE_F32 = 0, DGDM_DTYPE_BF16 = 1, DGDM_DTYPE_F32_MFMA = 2, DGDM_DTYPE_F32_F16X3 = 3, DGDM_DTYPE_F32_BF16X6 = 4 };
+enum { DGDM_DTYPE_F32 = 0, DGDM_DTYPE_BF16 = 1, DGDM_DTYPE_F32_MFMA = 2, DGDM_DTYPE_F32_F16X3 = 3 };      /* (4, the six-bf16-product form of rounds 3-5, is retired: DGDM_EINVAL) */
 
 typedef struct DgdmTensor {
     const char *name;     /* e.g. "linears.3.weight", "module."-prefix already stripped     */
@@ -82,8 +82,8 @@ int dgdm_unet1d_forward(DgdmUnet1d *m, const float *sample_dev, const int32_t *t
 /* Arithmetic of the convolutions with more than one input and output channel.  DGDM_DTYPE_F32 (default, the parity path):
  * float32-grade on the f16 matrix pipe - every float32 product as three f16 MFMA products on operands scaled by exact powers of two
  * (per convolution's weights, per sample and convolution input) and split in two f16 pieces, float32 accumulation (DESIGN_HISTORY.md 4.2;
- * closer to float64 than the float32 MFMA chain).  DGDM_DTYPE_F32_F16X3 / DGDM_DTYPE_F32_BF16X6 select the same form (the eps-net has
- * one split form); DGDM_DTYPE_F32_MFMA the float32 MFMA chain (also used where the split form's LDS slabs do not fit: L = 44, 46);
+ * closer to float64 than the float32 MFMA chain).  DGDM_DTYPE_F32_F16X3 selects the same form; DGDM_DTYPE_F32_MFMA the float32 MFMA
+ * chain (also used where the split form's LDS slabs do not fit: L = 44, 46);
  * DGDM_DTYPE_BF16: weights and activations entering those convolutions rounded to bf16, float32 accumulation (BASELINE configs[4]).
  * GroupNorm, Mish, FiLM, residual adds, the Linear layers and the single-channel first/last convolutions are float32 in every mode.   */
 int dgdm_unet1d_set_contraction_dtype(DgdmUnet1d *m, int dtype);
@@ -177,9 +177,8 @@ int  dgdm_guidance_create(DgdmGuidance **out, DgdmDynamics *model, const DgdmGui
 void dgdm_guidance_destroy(DgdmGuidance *g);
 /* Arithmetic of the trunk contractions inside dgdm_dyn{2,3}d_guidance_grad.  DGDM_DTYPE_F32 (default, the parity path) =
  * DGDM_DTYPE_F32_F16X3: float32 operands as two f16 pieces each after exact power-of-two scaling (per weight matrix, per tile row),
- * three f16 MFMAs per product with float32 accumulation (csrc/trunk_f16l.hip: 1.9e-7 rms of a 256-term contraction vs float64; half the
- * matrix-pipe instructions of the six-product form; DESIGN_HISTORY.md 4.12).  DGDM_DTYPE_F32_BF16X6: float32 operands split EXACTLY into three
- * bf16 pieces each, six bf16 MFMAs per product (csrc/trunk_split.hip, round 3's default; 1.6e-7).  DGDM_DTYPE_F32_MFMA: the k-ordered
+ * three f16 MFMAs per product with float32 accumulation (csrc/trunk_f16l.hip: 1.9e-7 rms of a 256-term contraction vs float64;
+ * DESIGN_HISTORY.md 4.12).  DGDM_DTYPE_F32_MFMA: the k-ordered
  * float32 fma chain itself (v_mfma_f32_32x32x2_f32; 2.0e-7).  DGDM_DTYPE_BF16 (BASELINE configs[4]: "bf16 contractions, f32
  * accumulate"): weights and the activations/gradients entering a contraction rounded to bf16 (nearest even), float32 accumulation;
  * first-layer tables, biases, objective and row sums stay float32.  The reference has no such switch (it calls

@@ -1,5 +1,5 @@
 #!/bin/bash
-# one wave's cycle stamps per phase of trunk_f16l_kernel (3-D); EXPS: extra -D flags per run, e.g. EXPS="- -DDGDM_EXP_NODMA" (timing
+# one wave's cycle stamps per phase of trunk_f16l_kernel (3-D); EXPS: extra -D flags per run, e.g. EXPS="- -DDGDM_F16_SLOTS=5" (timing
 # experiment with wrong results: no LDS-DMA traffic after a stream's first chunks - measured: the tile's 419 k cycles become 394 k)
 for e in ${EXPS:--}; do
   [ "$e" = "-" ] && e=""

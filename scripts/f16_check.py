@@ -13,7 +13,7 @@ for part in ("rotate", "convergence_b", "shift_left_b", "ccw_down"):
     o, gain = str(g["opt_obj"]), float(g["gain"]); oi = int(g["obj"]) if "obj" in g.files else 0
     dyn = engine.Dynamics(3, synth.scale_output(util.dyn3d_sd(g["dyn3d_seed"]), gain), L)
     res = {}
-    for mode in ("f32_bf16x6", "f32_f16x3", "f32_mfma"):
+    for mode in ("f32_f16x3", "f32_mfma"):
         gd = engine.Guidance(dyn, B, G, P, (-1.0, 1.0), 2, T, N, 512, max_objects=2, contraction_dtype=mode)
         gd.set_objects(torch.from_numpy(g["objs"]).to(dev))
         st = sampler.StartStream(N, 512, util.unpack_starts(g["starts"].astype(np.int64), g["start_lens"]))
@@ -36,5 +36,5 @@ for part in ("rotate", "convergence_b", "shift_left_b", "ccw_down"):
 # timing: 3-D 32 pairs, 2-D 4 pairs
 import subprocess
 for wl in ("3d", "2d"):
-    for mode in ("f32_bf16x6", "f32_f16x3"):
+    for mode in ("f32_f16x3",):
         pass
