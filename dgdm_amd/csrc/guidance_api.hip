@@ -818,17 +818,21 @@ extern "C" int dgdm_guided_chains_run(DgdmUnet1d *unet, DgdmGuidance *g, const f
     // 3-D: the embeddings of the rows depend on the draws and the objects, not on x, so those of ALL the steps are made before the
     // first one, in one upload and one gather launch: the (chain, s1) groups then hold n_steps times the rows per slab staged (and
     // per slab read from HBM), and more of them are equal rows computed once.  The host's conversion and sort of the draws runs
-    // while the objects' tables are still being built (embed() waits for them only after the host work).
+    // while the objects' tables are still being built (embed() waits for them only after the host work).  (A gather launch holds
+    // fewer than 2^22 rows per chain - the sorted row list packs s2 beside the row id - so a longer run is embedded in groups of
+    // `cpe` calls, each before its first step.)
     DgdmGuidance::Embedded emb;
     std::vector<int> oidx(n_chains * n_grad);
     const int64_t call_stride = (int64_t)n_chains * n_grad * spc;
-    if (kind == 3) {
+    int cpe = kind == 3 ? (int)std::min<int64_t>(n_steps, std::max<int64_t>(1, (((int64_t)1 << 22) - 1) / std::max<int64_t>(1, g->R))) : n_steps;
+    if (const char *e = getenv("DGDM_EMBED_CALLS")) cpe = std::max(1, std::min(cpe, atoi(e)));      // test hook: calls per gather launch
+    if (kind == 3)
         for (int i = 0; i < n_chains * n_grad; ++i) oidx[i] = objectives[i].object;
-        if ((rc = g->embed(oidx.data(), n_chains * n_grad, starts_host, n_steps, call_stride, &emb, s))) return rc;
-    }
     for (int si = 0; si < n_steps; ++si) {
         float *x = g->loopx[si & 1].as<float>(), *xn = (si + 1 == n_steps) ? x_out_dev : g->loopx[(si + 1) & 1].as<float>();
         const int t = timesteps[si];
+        if (kind == 3 && si % cpe == 0 &&
+            (rc = g->embed(oidx.data(), n_chains * n_grad, starts_host + (size_t)si * call_stride, std::min(cpe, n_steps - si), call_stride, &emb, s))) return rc;
         // eps-net: at the first step all chains hold the same B fingers - one evaluation, replicated (same input, same bits)
         const int nb = (si == 0 && n_chains > 1) ? B : n_chains * B;
         hipLaunchKernelGGL(fill_i32_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, g->loopts.as<int>(), t, nb);
@@ -845,7 +849,7 @@ extern "C" int dgdm_guided_chains_run(DgdmUnet1d *unet, DgdmGuidance *g, const f
             xg = g->loopxrep.as<float>();
         }
         if ((rc = guidance_grad(g, kind, xg, t, objectives, rowcoef_dev, nullptr, n_chains * n_grad, g->loopgrad.as<float>(), s,
-                                kind == 3 ? &emb : nullptr, si))) return rc;
+                                kind == 3 ? &emb : nullptr, si % cpe))) return rc;
         const float *cf = coef + 4 * si;
         if (same_scale) {
             if ((rc = dgdm_ddim_guided_step(x, g->loopeps.as<float>(), g->loopgrad.as<float>(), n_grad, xn, (int64_t)nx, cf[0], cf[1], cf[2], cf[3], scales[0], s))) return rc;

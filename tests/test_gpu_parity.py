@@ -473,6 +473,17 @@ def test_native_loop_equals_step_by_step(dev):
         torch.manual_seed(4)
         b = sampler.guided_chains(net, gd, s, mode, noise, chains, unguided=ug, trace=[])
         assert torch.equal(a, b), mode
+        if mode == 'point_3d':
+            # the library embeds all calls of a run in one gather launch unless their rows pass the packed-row limit (2^22 per chain): then in
+            # groups of calls, each before its first step - forced here (test hook), same bits
+            for cpe in ("2", "1"):
+                os.environ["DGDM_EMBED_CALLS"] = cpe
+                try:
+                    torch.manual_seed(4)
+                    c = sampler.guided_chains(net, gd, s, mode, noise, chains, unguided=ug)
+                finally:
+                    os.environ.pop("DGDM_EMBED_CALLS", None)
+                assert torch.equal(a, c), (mode, cpe)
         torch.manual_seed(5)
         a = sampler.guided_multi_object(net, gd, s, mode, noise, [0, 1, 2, 3], 'shift_left')
         torch.manual_seed(5)
