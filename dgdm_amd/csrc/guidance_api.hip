@@ -125,7 +125,6 @@ struct DgdmGuidance {
     int upload_starts(const int64_t *starts_host, int n_chains, int64_t rows, hipStream_t s, bool need_order = true, int n_calls = 1,
                       int64_t call_stride = 0);
     int ensure_rows(int n_chains, int64_t rows_per_chain);      // grows the per-row device buffers and the pinned staging area
-    size_t xobj_reserve_rows = 0;                                // rows run_xobj sizes xobj / xobj16 for at least (see there)
     // true + p filled when every chain's object has its embedding table in the wanted format: then no per-step gather runs at all
     int use_xtab(const int *objidx_host, int n_chains, int64_t rows, bool want16, dgdm::TrunkParams *p, bool *ok, hipStream_t s);
     int build_object(int oi, int slot, hipStream_t s);
@@ -613,9 +612,8 @@ int DgdmGuidance::run_xobj(const int *objidx_host, int n_chains, int64_t rows, b
         ch[i].Z16 = t.has16 ? t.Z16.as<uint32_t>() : nullptr; ch[i].M0_16 = t.has16 ? t.M0_16.as<uint32_t>() : nullptr;
         want16 = want16 && t.has16;          // bf16 rows only if every chain's object was built with its bf16 tables
     }
-    {   // grow-only buffers: sized for the largest embed of the run in progress (xobj_reserve_rows, set by dgdm_guided_chains_run before its
-        // first embed) so that the second, larger embed of a run does not reallocate - hipFree would wait for step 0's kernels
-        const size_t nrows = std::max<size_t>((size_t)n_chains * rows, xobj_reserve_rows);
+    {   // grow-only buffers (a run's embeds have the same size, or shrink at its tail: no reallocation under kernels in flight)
+        const size_t nrows = (size_t)n_chains * rows;
         int rc = want16 ? xobj16.alloc(nrows * 512) : xobj.alloc(nrows * 256 * 4);
         if (rc) return rc;
     }
