@@ -220,7 +220,7 @@ def timed_loop(wl, steps, warmup, dist):
         draw_s[k] = time.perf_counter() - t
         return r
 
-    out, t0, fut = None, None, None
+    out, t0, fut, pending = None, None, None, None
     for k in range(total):
         if k == warmup:
             torch.cuda.synchronize()
@@ -234,8 +234,14 @@ def timed_loop(wl, steps, warmup, dist):
         fut = drawer.submit(draw, k + 1) if (k + 1 < total and k + 1 != warmup) else None
         out = wl.run(k, objs.pop(k), pre)
         if dist is not None and (dist.get_world_size() > 1 or FORCE_GROUP):
-            # the path's only collective: final samples; RCCL on device tensors, or host tensors for the gloo test mode
-            out = gather_pairs(out, wl.pairs * dist.get_world_size())
+            # the path's only collective: final samples; RCCL on device tensors, or host tensors for the gloo test mode.
+            # Asynchronous: RCCL gathers step k's samples on its own stream, behind the chains that made them, while this stream goes on
+            # with step k + 1's tables; the previous step's handle is completed here, the last one before the clock stops
+            if pending is not None:
+                pending.wait()
+            pending = gather_pairs(out, wl.pairs * dist.get_world_size(), async_op=True)
+    if pending is not None:
+        out = pending.wait()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

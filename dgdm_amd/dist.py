@@ -23,10 +23,26 @@ def shard_range(n_items: int, rank: int, world: int) -> range:
     return range(lo, lo + q + (1 if rank < r else 0))
 
 
-def gather_pairs(local: torch.Tensor, n_items: int, group=None) -> torch.Tensor:
-    """all_gather of per-rank results [n_local, ...] (block partition of `n_items`) -> [n_items, ...] on every rank."""
+class _Gathered:
+    """An all_gather in flight (gather_pairs(..., async_op=True)): wait() returns the gathered tensor.  Until then the collective
+    runs on the backend's own stream behind what produced `local`, beside whatever the caller enqueues next."""
+
+    def __init__(self, work, finish):
+        self._work, self._finish = work, finish
+
+    def wait(self) -> torch.Tensor:
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        return self._finish()
+
+
+def gather_pairs(local: torch.Tensor, n_items: int, group=None, async_op: bool = False):
+    """all_gather of per-rank results [n_local, ...] (block partition of `n_items`) -> [n_items, ...] on every rank.
+    async_op=True: returns a handle whose wait() gives the tensor - the gather then overlaps the caller's next kernels (RCCL runs it on
+    its own stream behind the producer of `local`; bench.py gathers a step's samples while the next step's tables are being built)."""
     if not dist.is_available() or not dist.is_initialized():
-        return local
+        return _Gathered(None, lambda: local) if async_op else local
     # an initialised group of ONE rank still goes through the collective (RCCL on the device tensor): that is how the 1-GPU box
     # exercises this branch (tests/test_gpu_dist.py)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -38,9 +54,14 @@ def gather_pairs(local: torch.Tensor, n_items: int, group=None) -> torch.Tensor:
     pad = torch.zeros((most,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
     pad[:src.shape[0]] = src
     bufs = [torch.empty_like(pad) for _ in range(world)]
+
+    def finish():
+        out = torch.cat([bufs[r][:len(shard_range(n_items, r, world))] for r in range(world)], dim=0)
+        return out.to(dev) if via_host else out
+    if async_op and not via_host:
+        return _Gathered(dist.all_gather(bufs, pad, group=group, async_op=True), finish)
     dist.all_gather(bufs, pad, group=group)
-    out = torch.cat([bufs[r][:len(shard_range(n_items, r, world))] for r in range(world)], dim=0)
-    return out.to(dev) if via_host else out
+    return _Gathered(None, finish) if async_op else finish()
 
 
 def run_sharded(pairs: Sequence[Tuple[int, str]], run_local: Callable[[List[Tuple[int, str]]], torch.Tensor], group=None) -> torch.Tensor:
