@@ -64,6 +64,7 @@ struct DgdmGuidance {
     DevBuf ptab_t, ptab_sweep_t;                 // the same tables tiled for the trunk kernels (smallnet.h tile_table)
     DevBuf pmax;                                 // [C] largest magnitude of a cell's row of ptab (trunk_f16l.hip: f16 scale of 3-D layer 2's input)
     DevBuf objpart;                              // 2-D: [max_objects][W1] doubles
+    DevBuf objtmp;                               // 2-D: scratch of set_objects (the object encoder's hidden layer, [n_objects][512] doubles)
     std::vector<std::unique_ptr<ObjectTables>> tables;   // 3-D
     bool bf16 = false;                           // contractions of the trunk on bf16 MFMA (dgdm_guidance_set_contraction_dtype)
     bool f32_mfma = false;                       // float32 mode on the k-ordered float32 MFMA chain (trunk.hip) instead of the f16x3 form (trunk_f16l.hip)
@@ -337,11 +338,11 @@ extern "C" int dgdm_guidance_set_objects(DgdmGuidance *g, const float *objects_d
     host_stamp("set_objects: enter");
     prof_begin(s, DGDM_STAGE_TABLES);
     if (g->m->kind == 2) {
-        DevBuf tmp;
-        if ((rc = tmp.alloc((size_t)n_objects * 512 * 8))) return rc;
-        if ((rc = g->m->object_part_2d64(objects_dev, tmp.as<double>(), g->objpart.as<double>(), n_objects, s))) return rc;
+        // (a grow-only member, not a local: a local's hipFree - and the synchronize that had to precede it - stalled the host behind
+        //  the previous batch's chains at every call)
+        if ((rc = g->objtmp.alloc((size_t)n_objects * 512 * 8))) return rc;
+        if ((rc = g->m->object_part_2d64(objects_dev, g->objtmp.as<double>(), g->objpart.as<double>(), n_objects, s))) return rc;
         prof_end(s, DGDM_STAGE_TABLES, 0.0);
-        DGDM_HIP_CHECK(hipStreamSynchronize(s));
     } else {
         while ((int)g->tables.size() < n_objects) g->tables.emplace_back(new ObjectTables());
         const int N = g->cfg.num_object_points;
