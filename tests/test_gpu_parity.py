@@ -536,23 +536,25 @@ def test_unet_batched_equals_per_sample(dev):
 def test_xobj_rows_large_groups(dev):
     """xobj_rows_kernel takes a (chain, s1) group in passes of 1024 rows: clouds of 128 points give 128 groups per chain, i.e. ~1400 rows per
     group for the five calls of a configs[2]-sized chain (B = 32, G = 45, P = 5) - two passes, runs cut at the pass boundary - against the
-    per-row table kernel (test hook mode 2): bit-identical gradients at every step, 3 chains, objects with and without crowded centres."""
+    per-row table kernel (test hook mode 2): bit-identical end points, 3 chains, objects with and without crowded centres, float32 and
+    bf16 table formats."""
     B, G, P, L, T, sub, N = 32, 45, 5, 42, 15, 512, 128
     dyn = engine.Dynamics(3, util.dyn3d_sd(45), L)
     objs = torch.stack([synth.synth_object_3d(s, N) for s in (1, 8, 2)])
-    net = engine.Unet1d(util.unet_sd(11))
     s = sched(T, 5)
     noise = synth.synth_noise(3, B, L).to(dev)
     chains = [(0, 'rotate'), (1, 'shift_up'), (2, 'clockwise_left')]
-    out = {}
-    for mode in (0, 2):
-        gd = engine.Guidance(dyn, B, G, P, (-1.0, 1.0), 3, T, N, sub, max_objects=3)
-        gd.debug_fps_path(mode)
-        gd.set_objects(objs.to(dev))
-        torch.manual_seed(6)
-        if mode == 0:
-            out[mode] = sampler.guided_chains(net, gd, s, 'point_3d', noise, chains).cpu()      # one gather launch for the five calls: the large groups
-        else:
-            out[mode] = sampler.guided_chains(net, gd, s, 'point_3d', noise, chains, trace=[]).cpu()      # step by step, per-row kernel
-    assert torch.equal(out[0], out[2])
-    assert bool(torch.isfinite(out[0]).all()) and float(out[0].abs().max()) > 0
+    for dtype in ("f32", "bf16"):
+        net = engine.Unet1d(util.unet_sd(11), contraction_dtype=dtype)
+        out = {}
+        for mode in (0, 2):
+            gd = engine.Guidance(dyn, B, G, P, (-1.0, 1.0), 3, T, N, sub, max_objects=3, contraction_dtype=dtype)
+            gd.debug_fps_path(mode)
+            gd.set_objects(objs.to(dev))
+            torch.manual_seed(6)
+            if mode == 0:
+                out[mode] = sampler.guided_chains(net, gd, s, 'point_3d', noise, chains).cpu()      # one gather launch for the five calls: the large groups
+            else:
+                out[mode] = sampler.guided_chains(net, gd, s, 'point_3d', noise, chains, trace=[]).cpu()      # step by step, per-row kernel
+        assert torch.equal(out[0], out[2]), dtype
+        assert bool(torch.isfinite(out[0]).all()) and float(out[0].abs().max()) > 0
