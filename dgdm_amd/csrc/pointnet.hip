@@ -433,8 +433,17 @@ __device__ __forceinline__ void l2c_reduce(const uint32_t *ych, const unsigned c
         u4 v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = *reinterpret_cast<const u4 *>(ych + ((size_t)((four >> (8 * e)) & 255u) * LPR + fl) * 4);
+        if (BF16) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) best = vmax4(best, v[e]);
+            for (int e = 0; e < 4; ++e) best = vmax4(best, v[e]);
+        } else {
+            // Y >= 0: the unsigned maximum is the float maximum, and three operands go into one v_max3_u32 (bit-identical to the fmaxf chain)
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                best.x = max(max(best.x, v[e].x), v[e + 1].x); best.y = max(max(best.y, v[e].y), v[e + 1].y);
+                best.z = max(max(best.z, v[e].z), v[e + 1].z); best.w = max(max(best.w, v[e].w), v[e + 1].w);
+            }
+        }
     }
     if (RPW > 1) {
 #pragma unroll
