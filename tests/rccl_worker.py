@@ -22,7 +22,8 @@ def main():
     res = {"backend": dist.get_backend(), "world": dist.get_world_size()}
     x = torch.arange(5 * 2 * 42, dtype=torch.float32, device=dev).reshape(5, 2, 42, 1)
     g = ddist.gather_pairs(x, 5)
-    res["gather_pairs"] = bool(g.is_cuda and torch.equal(g, x))
+    h = ddist.gather_pairs(x, 5, async_op=True)                 # the asynchronous form: RCCL's stream, completed by wait()
+    res["gather_pairs"] = bool(g.is_cuda and torch.equal(g, x) and torch.equal(h.wait(), x))
     t = torch.linspace(-1, 1, 1200, device=dev)
     r = ddist.all_reduce_sum(t.clone())
     res["all_reduce_sum"] = bool(r.is_cuda and torch.equal(r, t))

@@ -31,7 +31,9 @@ def _worker(rank, world, port, n_pairs, q):
     out = run_sharded(pairs, run_local)
     ok = out.shape == (n_pairs, 2, 3, 1) and torch.equal(out[:, 0, 0, 0], torch.arange(n_pairs, dtype=torch.float32))
     again = gather_pairs(run_local([pairs[i] for i in shard_range(n_pairs, rank, world)]), n_pairs)
-    q.put((rank, bool(ok and torch.equal(again, out))))
+    # the asynchronous form (bench.py: a step's gather beside the next step's kernels): the handle's wait() gives the same tensor
+    later = gather_pairs(run_local([pairs[i] for i in shard_range(n_pairs, rank, world)]), n_pairs, async_op=True)
+    q.put((rank, bool(ok and torch.equal(again, out) and torch.equal(later.wait(), out) and torch.equal(later.wait(), out))))
     dist.destroy_process_group()
 
 
